@@ -1,0 +1,212 @@
+"""Seeded synthetic weights / images / boxes for the SAM box->mask hot path.
+
+There is no SAM checkpoint and no dataset on the build or GPU machines, so every test,
+the smoke run and ``bench.py`` use inputs generated here.  The generators are pure
+torch-CPU / numpy so that the same seed gives bit-identical tensors in the authoring
+container (where golden vectors are produced with the real reference) and on the GPU box.
+
+Shapes follow the reference's ``state_dict`` contract:
+  image encoder  : Generate Dataset/segment_anything/modeling/image_encoder.py:17-104
+  prompt encoder : Generate Dataset/segment_anything/modeling/prompt_encoder.py:16-60,176-188
+  mask decoder   : Generate Dataset/segment_anything/modeling/mask_decoder.py:16-69
+  two-way xfmr   : Generate Dataset/segment_anything/modeling/transformer.py:16-60,109-149,185-216
+  registry       : Generate Dataset/segment_anything/build_sam.py:14-107
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+
+@dataclass(frozen=True)
+class SamConfig:
+    """Hyper-parameters of one SAM variant (build_sam.py:14-21,37-44,55-98)."""
+
+    name: str
+    embed_dim: int
+    depth: int
+    num_heads: int
+    global_attn_indexes: Tuple[int, ...]
+    img_size: int = 1024
+    patch_size: int = 16
+    window_size: int = 14
+    out_chans: int = 256          # == prompt_embed_dim == decoder transformer_dim
+    mlp_ratio: int = 4
+    mask_in_chans: int = 16
+    dec_depth: int = 2
+    dec_heads: int = 8
+    dec_mlp_dim: int = 2048
+    num_mask_tokens: int = 4      # 3 multimask outputs + 1
+    iou_hidden: int = 256
+
+    @property
+    def grid(self) -> int:        # 64 tokens per side
+        return self.img_size // self.patch_size
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+
+CONFIGS: Dict[str, SamConfig] = {
+    "vit_h": SamConfig("vit_h", 1280, 32, 16, (7, 15, 23, 31)),
+    "vit_l": SamConfig("vit_l", 1024, 24, 16, (5, 11, 17, 23)),
+    "vit_b": SamConfig("vit_b", 768, 12, 12, (2, 5, 8, 11)),
+    # Not in the reference registry: a 2-block encoder with the same 1024^2 / 64x64 geometry,
+    # small enough that the CPU oracle finishes in ~1 s.  Used by fast parity tests and smoke().
+    # Block 0 is windowed, block 1 is global, so both attention kernels are exercised.
+    "vit_tiny": SamConfig("vit_tiny", 128, 2, 2, (1,)),
+    # head_dim 80 like ViT-H (the awkward MFMA K size) at toy width.
+    "vit_tiny80": SamConfig("vit_tiny80", 160, 2, 2, (1,)),
+}
+
+
+def _uniform(gen: torch.Generator, shape, bound: float) -> torch.Tensor:
+    return (torch.rand(shape, generator=gen, dtype=torch.float32) * 2.0 - 1.0) * bound
+
+
+def _linear(sd, gen, prefix: str, out_f: int, in_f: int, bias: bool = True) -> None:
+    bound = 1.0 / math.sqrt(in_f)
+    sd[prefix + ".weight"] = _uniform(gen, (out_f, in_f), bound)
+    if bias:
+        sd[prefix + ".bias"] = _uniform(gen, (out_f,), bound)
+
+
+def _norm(sd, gen, prefix: str, n: int) -> None:
+    # LayerNorm affine: near (1, 0) but not exactly, so gamma/beta paths are exercised.
+    sd[prefix + ".weight"] = 1.0 + 0.1 * torch.randn(n, generator=gen)
+    sd[prefix + ".bias"] = 0.05 * torch.randn(n, generator=gen)
+
+
+def _dec_attention(sd, gen, prefix: str, dim: int, internal: int) -> None:
+    _linear(sd, gen, prefix + ".q_proj", internal, dim)
+    _linear(sd, gen, prefix + ".k_proj", internal, dim)
+    _linear(sd, gen, prefix + ".v_proj", internal, dim)
+    _linear(sd, gen, prefix + ".out_proj", dim, internal)
+
+
+def make_state_dict(cfg: SamConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """A full SAM ``state_dict`` (fp32, CPU) with the reference's key names and shapes.
+
+    Every tensor is random, including the ones the reference zero-initialises
+    (``pos_embed``, ``rel_pos_h/w`` -- image_encoder.py:68-70,221-222) so that the rel-pos and
+    abs-pos paths are never tested against zeros.
+    """
+    gen = torch.Generator().manual_seed(1234567 + seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    D, g, hd = cfg.embed_dim, cfg.grid, cfg.head_dim
+    P, C = cfg.patch_size, cfg.out_chans
+
+    # ---- image encoder -------------------------------------------------------------
+    sd["image_encoder.pos_embed"] = 0.02 * torch.randn(1, g, g, D, generator=gen)
+    fan = 3 * P * P
+    sd["image_encoder.patch_embed.proj.weight"] = _uniform(gen, (D, 3, P, P), 1.0 / math.sqrt(fan))
+    sd["image_encoder.patch_embed.proj.bias"] = _uniform(gen, (D,), 1.0 / math.sqrt(fan))
+    for i in range(cfg.depth):
+        p = f"image_encoder.blocks.{i}"
+        s = g if i in cfg.global_attn_indexes else cfg.window_size
+        _norm(sd, gen, p + ".norm1", D)
+        sd[p + ".attn.rel_pos_h"] = 0.02 * torch.randn(2 * s - 1, hd, generator=gen)
+        sd[p + ".attn.rel_pos_w"] = 0.02 * torch.randn(2 * s - 1, hd, generator=gen)
+        _linear(sd, gen, p + ".attn.qkv", 3 * D, D)
+        _linear(sd, gen, p + ".attn.proj", D, D)
+        _norm(sd, gen, p + ".norm2", D)
+        _linear(sd, gen, p + ".mlp.lin1", cfg.mlp_ratio * D, D)
+        _linear(sd, gen, p + ".mlp.lin2", D, cfg.mlp_ratio * D)
+    sd["image_encoder.neck.0.weight"] = _uniform(gen, (C, D, 1, 1), 1.0 / math.sqrt(D))
+    _norm(sd, gen, "image_encoder.neck.1", C)
+    sd["image_encoder.neck.2.weight"] = _uniform(gen, (C, C, 3, 3), 1.0 / math.sqrt(9 * C))
+    _norm(sd, gen, "image_encoder.neck.3", C)
+
+    # ---- prompt encoder ------------------------------------------------------------
+    sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"] = torch.randn(2, C // 2, generator=gen)
+    for i in range(4):
+        sd[f"prompt_encoder.point_embeddings.{i}.weight"] = torch.randn(1, C, generator=gen)
+    sd["prompt_encoder.not_a_point_embed.weight"] = torch.randn(1, C, generator=gen)
+    m4, m = cfg.mask_in_chans // 4, cfg.mask_in_chans
+    sd["prompt_encoder.mask_downscaling.0.weight"] = _uniform(gen, (m4, 1, 2, 2), 0.5)
+    sd["prompt_encoder.mask_downscaling.0.bias"] = _uniform(gen, (m4,), 0.5)
+    _norm(sd, gen, "prompt_encoder.mask_downscaling.1", m4)
+    sd["prompt_encoder.mask_downscaling.3.weight"] = _uniform(gen, (m, m4, 2, 2), 1.0 / math.sqrt(4 * m4))
+    sd["prompt_encoder.mask_downscaling.3.bias"] = _uniform(gen, (m,), 1.0 / math.sqrt(4 * m4))
+    _norm(sd, gen, "prompt_encoder.mask_downscaling.4", m)
+    sd["prompt_encoder.mask_downscaling.6.weight"] = _uniform(gen, (C, m, 1, 1), 1.0 / math.sqrt(m))
+    sd["prompt_encoder.mask_downscaling.6.bias"] = _uniform(gen, (C,), 1.0 / math.sqrt(m))
+    sd["prompt_encoder.no_mask_embed.weight"] = torch.randn(1, C, generator=gen)
+
+    # ---- mask decoder --------------------------------------------------------------
+    for i in range(cfg.dec_depth):
+        p = f"mask_decoder.transformer.layers.{i}"
+        _dec_attention(sd, gen, p + ".self_attn", C, C)
+        _norm(sd, gen, p + ".norm1", C)
+        _dec_attention(sd, gen, p + ".cross_attn_token_to_image", C, C // 2)
+        _norm(sd, gen, p + ".norm2", C)
+        _linear(sd, gen, p + ".mlp.lin1", cfg.dec_mlp_dim, C)
+        _linear(sd, gen, p + ".mlp.lin2", C, cfg.dec_mlp_dim)
+        _norm(sd, gen, p + ".norm3", C)
+        _norm(sd, gen, p + ".norm4", C)
+        _dec_attention(sd, gen, p + ".cross_attn_image_to_token", C, C // 2)
+    _dec_attention(sd, gen, "mask_decoder.transformer.final_attn_token_to_image", C, C // 2)
+    _norm(sd, gen, "mask_decoder.transformer.norm_final_attn", C)
+    sd["mask_decoder.iou_token.weight"] = torch.randn(1, C, generator=gen)
+    sd["mask_decoder.mask_tokens.weight"] = torch.randn(cfg.num_mask_tokens, C, generator=gen)
+    sd["mask_decoder.output_upscaling.0.weight"] = _uniform(gen, (C, C // 4, 2, 2), 1.0 / math.sqrt(C))
+    sd["mask_decoder.output_upscaling.0.bias"] = _uniform(gen, (C // 4,), 1.0 / math.sqrt(C))
+    _norm(sd, gen, "mask_decoder.output_upscaling.1", C // 4)
+    sd["mask_decoder.output_upscaling.3.weight"] = _uniform(gen, (C // 4, C // 8, 2, 2), 1.0 / math.sqrt(C // 4))
+    sd["mask_decoder.output_upscaling.3.bias"] = _uniform(gen, (C // 8,), 1.0 / math.sqrt(C // 4))
+    for i in range(cfg.num_mask_tokens):
+        p = f"mask_decoder.output_hypernetworks_mlps.{i}.layers"
+        _linear(sd, gen, p + ".0", C, C)
+        _linear(sd, gen, p + ".1", C, C)
+        _linear(sd, gen, p + ".2", C // 8, C)
+    p = "mask_decoder.iou_prediction_head.layers"
+    _linear(sd, gen, p + ".0", cfg.iou_hidden, C)
+    _linear(sd, gen, p + ".1", cfg.iou_hidden, cfg.iou_hidden)
+    _linear(sd, gen, p + ".2", cfg.num_mask_tokens, cfg.iou_hidden)
+    return sd
+
+
+def make_image(index: int, h: int = 1024, w: int = 1024) -> np.ndarray:
+    """uint8 HWC "blob" tile: 40 random filled discs + N(0, 8) noise."""
+    rng = np.random.default_rng(1000 + index)
+    img = np.full((h, w, 3), rng.integers(40, 200, size=3), dtype=np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(40):
+        cy, cx = rng.uniform(0, h), rng.uniform(0, w)
+        r = rng.uniform(8, 160)
+        col = rng.integers(0, 256, size=3).astype(np.float32)
+        img[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = col
+    img += rng.normal(0.0, 8.0, size=img.shape).astype(np.float32)
+    return np.clip(img + 0.5, 0, 255).astype(np.uint8)
+
+
+def make_noise_image(index: int, h: int = 1024, w: int = 1024) -> np.ndarray:
+    """Cheap white-noise tile (throughput runs; generation cost matters there)."""
+    rng = np.random.default_rng(1000 + index)
+    return rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+
+
+def make_boxes(index: int, n: int = 32, h: int = 1024, w: int = 1024, n_classes: int = 18):
+    """``n`` xyxy float32 hboxes + integer labels (DOTA-v2 has 18 classes, GD/mapping.py:46-50)."""
+    rng = np.random.default_rng(2000 + index)
+    cx, cy = rng.uniform(0, w, n), rng.uniform(0, h, n)
+    bw = np.exp(rng.uniform(np.log(8), np.log(512), n))
+    bh = np.exp(rng.uniform(np.log(8), np.log(512), n))
+    x0, x1 = np.clip(cx - bw / 2, 0, w - 1), np.clip(cx + bw / 2, 0, w - 1)
+    y0, y1 = np.clip(cy - bh / 2, 0, h - 1), np.clip(cy + bh / 2, 0, h - 1)
+    boxes = np.stack([x0, y0, x1, y1], axis=1).astype(np.float32)
+    labels = rng.integers(0, n_classes, n).astype(np.int64)
+    return boxes, labels
+
+
+# BASELINE.json configs[0]: ViT-B, one tile, 4 hboxes (SURVEY.md 8d "C1").
+C1_BOXES = np.array(
+    [[100, 100, 300, 300], [10, 20, 500, 400], [600, 600, 900, 1000], [0, 0, 1023, 1023]],
+    dtype=np.float32,
+)

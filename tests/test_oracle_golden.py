@@ -1,0 +1,73 @@
+"""CPU: pin ``oracle/sam_oracle.py`` against fixtures produced by the REAL reference
+(``oracle/make_golden.py``; Generate Dataset/segment_anything/predictor.py driven as in
+main_sam_hbox_semantic.py:148-206 and main_sam_*_mask_instance.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from samrs_amd import synth
+from oracle import sam_oracle as so
+from oracle.make_golden import cases, run_predictor
+
+LOGIT_ATOL = 2e-4      # fp32 op-order noise between reference modules and the functional restatement
+
+
+def _check(name, golden_dir, shapes):
+    path = os.path.join(golden_dir, name + ".npz")
+    g = np.load(path)
+    cfg = synth.CONFIGS[name]
+    sd = synth.make_state_dict(cfg, 0)
+    pred = so.OraclePredictor(sd, cfg)
+    for si, (h, w) in enumerate(shapes):
+        pred.set_image(synth.make_image(si, h, w))
+        f = pred.features
+        np.testing.assert_allclose(f[0, ::16, ::4, ::4].numpy(), g[f"s{si}_emb_sample"], atol=2e-4, rtol=0)
+        assert abs(f.double().norm().item() - float(g[f"s{si}_emb_norm"])) < 1e-3 * float(g[f"s{si}_emb_norm"])
+        for tag, kw, labels in cases(name):
+            kw = dict(kw)
+            if (h, w) != (1024, 1024):
+                for key in ("boxes", "point_coords"):
+                    if key in kw:
+                        kw[key] = kw[key] * np.float32(min(h, w) / 1024.0)
+            masks, iou, low = run_predictor(pred, so.apply_boxes, so.apply_coords, (h, w), kw)
+            k = f"s{si}_{tag}"
+            np.testing.assert_allclose(low[:, :, ::4, ::4].numpy(), g[k + "_low"], atol=LOGIT_ATOL, rtol=0)
+            np.testing.assert_allclose(iou.numpy(), g[k + "_iou"], atol=LOGIT_ATOL, rtol=0)
+            area = masks.flatten(2).sum(-1).numpy().astype(np.int64)
+            # a pixel whose logit is within fp32 noise of 0 may flip: allow a handful per mask
+            assert np.abs(area - g[k + "_area"]).max() <= 8, (tag, area, g[k + "_area"])
+            if labels is not None:
+                seg, _ = so.paint_semantic(masks[:, 0].numpy(), labels, (h, w))
+                assert (seg != g[k + "_seg"]).sum() <= 16
+
+
+@pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80"])
+def test_oracle_matches_reference_tiny(name, golden_dir):
+    _check(name, golden_dir, [(1024, 1024), (600, 800)])
+
+
+@pytest.mark.slow
+def test_oracle_matches_reference_vit_b(golden_dir):
+    _check("vit_b", golden_dir, [(1024, 1024)])
+
+
+def test_box_chunking_matches_driver():
+    # main_sam_hbox_semantic.py:157-181: part_num = n // 20 + 1, empty tail skipped
+    assert so.box_chunks(32) == [(0, 20), (20, 32)]
+    assert so.box_chunks(40) == [(0, 20), (20, 40)]
+    assert so.box_chunks(5) == [(0, 5)]
+    assert so.box_chunks(0) == []
+
+
+def test_paint_order_and_statistics():
+    m = np.zeros((3, 4, 4), bool)
+    m[0, :2] = True
+    m[1, 1:3] = True          # overwrites row 1 of box 0
+    labels = np.array([5, 7, 2])
+    seg, areas = so.paint_semantic(m, labels, (4, 4))
+    assert (seg[0] == 5).all() and (seg[1] == 7).all() and (seg[2] == 7).all() and (seg[3] == 255).all()
+    assert areas.tolist() == [8, 8, 0]
+    pix, ins = so.class_statistics(areas, labels, 18)
+    assert pix[5] == 8 and pix[7] == 8 and ins[2] == 0 and ins.sum() == 2

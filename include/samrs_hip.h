@@ -1,0 +1,160 @@
+/*
+ * samrs_hip.h -- C ABI of libsamrs_hip.so, the MI355X (gfx950) SAM box->mask engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of ViTAE-Transformer/SAMRS: what
+ * `SamPredictor.set_image()` / `predict_torch()` compute
+ * (reference: Generate Dataset/segment_anything/predictor.py:34-90,168-245).
+ * Plain pointers + sizes only; no torch types.  All data pointers are DEVICE pointers unless a
+ * parameter says otherwise; every entry point that launches work takes the HIP stream to launch
+ * on (`hipStream_t` passed as `void*`; NULL = the legacy default stream) and does NOT
+ * synchronise -- exactly like the reference, where the sync happens at the caller's `.cpu()`
+ * (Generate Dataset/main_sam_hbox_semantic.py:189).
+ *
+ * One engine handle per GPU per process; a handle is not thread-safe (neither is the
+ * reference's stateful SamPredictor, predictor.py:84-90).
+ *
+ * Return convention: 0 = OK, negative = error code below; `samrs_last_error()` returns the
+ * message.  The Python wrapper re-raises the reference's exception types / messages
+ * (predictor.py:133-134,213-214: RuntimeError "An image must be set ...").
+ */
+#ifndef SAMRS_HIP_H
+#define SAMRS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAMRS_ABI_VERSION 1
+
+enum samrs_status {
+    SAMRS_OK = 0,
+    SAMRS_ERR_NOT_SET = -1,      /* predict before set_images (predictor.py:213-214)            */
+    SAMRS_ERR_BAD_SHAPE = -2,    /* e.g. long side != 1024 (predictor.py:79-83)                 */
+    SAMRS_ERR_BAD_ARG = -3,      /* points without labels (predictor.py:139-141), null ptrs ... */
+    SAMRS_ERR_HIP = -4,          /* a HIP runtime call failed                                   */
+    SAMRS_ERR_BAD_WEIGHTS = -5,  /* unknown / missing / mis-shaped tensor (strict load,
+                                    build_sam.py:103-106)                                       */
+    SAMRS_ERR_CAPACITY = -6      /* more images / prompts than the handle was created for       */
+};
+
+/* MFMA operand type.  Accumulation, residual stream, LayerNorm / softmax statistics and the
+ * whole token side of the decoder are always fp32. */
+enum samrs_precision {
+    SAMRS_PREC_BF16 = 0,
+    SAMRS_PREC_F16 = 1
+};
+
+/* Model hyper-parameters: Generate Dataset/segment_anything/build_sam.py:14-21,37-44,55-98. */
+typedef struct samrs_config {
+    int32_t embed_dim;               /* 1280 (vit_h) / 1024 (vit_l) / 768 (vit_b)            */
+    int32_t depth;                   /* 32 / 24 / 12                                          */
+    int32_t num_heads;               /* 16 / 16 / 12                                          */
+    int32_t n_global;                /* number of valid entries in global_attn_indexes        */
+    int32_t global_attn_indexes[8];  /* blocks that use global attention                      */
+    int32_t img_size;                /* 1024                                                  */
+    int32_t patch_size;              /* 16                                                    */
+    int32_t window_size;             /* 14                                                    */
+    int32_t out_chans;               /* 256 (== prompt / decoder width)                       */
+    int32_t max_images;              /* encoder batch == number of embedding slots            */
+    int32_t max_prompts;             /* max prompts (boxes) per samrs_predict call            */
+    int32_t max_points;              /* max points per prompt                                 */
+    int32_t precision;               /* enum samrs_precision                                  */
+} samrs_config;
+
+typedef struct samrs_engine samrs_engine_t;
+
+/* -- lifetime ------------------------------------------------------------------------------
+ * replaces: sam_model_registry[...](checkpoint) + sam.to(device) + SamPredictor(sam)
+ * (main_sam_hbox_semantic.py:87-89).  `device` is the HIP device ordinal.  Returns NULL on
+ * failure and writes a message into err (if non-NULL). */
+samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int err_len);
+void samrs_destroy(samrs_engine_t* e);
+const char* samrs_last_error(const samrs_engine_t* e);
+int samrs_abi_version(void);
+
+/* -- weights -------------------------------------------------------------------------------
+ * replaces: sam.load_state_dict(state_dict) (build_sam.py:103-106).  One call per tensor with
+ * the reference's key name, fp32, contiguous, HOST memory.  The engine
+ * repacks into its MFMA operand layouts.  samrs_finalize_weights() fails with
+ * SAMRS_ERR_BAD_WEIGHTS if any tensor is missing (strict). */
+int samrs_load_weight(samrs_engine_t* e, const char* name, const float* host_data,
+                      const int64_t* shape, int ndim);
+int samrs_finalize_weights(samrs_engine_t* e, void* stream);
+
+/* -- image side ----------------------------------------------------------------------------
+ * replaces: SamPredictor.set_image / set_torch_image (predictor.py:34-90) incl.
+ * Sam.preprocess (modeling/sam.py:164-174) and ImageEncoderViT.forward
+ * (modeling/image_encoder.py:106-116).
+ * `images`: n_images contiguous uint8 HWC RGB tiles of identical size in_h x in_w, ALREADY
+ * resized so that max(in_h, in_w) == img_size (ResizeLongestSide.apply_image,
+ * utils/transforms.py:26-31, stays on the host).  Embeddings land in slots
+ * slot0 .. slot0+n_images-1. */
+int samrs_set_images(samrs_engine_t* e, const uint8_t* images, int n_images, int in_h, int in_w,
+                     int slot0, void* stream);
+/* SamPredictor.get_image_embedding (predictor.py:247-258): fp32 [out_chans, 64, 64] (NCHW). */
+int samrs_get_embedding(samrs_engine_t* e, int slot, float* out_chw, void* stream);
+/* Install a precomputed embedding (fp32 NCHW) into a slot; marks it set. */
+int samrs_set_embedding(samrs_engine_t* e, int slot, const float* emb_chw, void* stream);
+/* SamPredictor.reset_image (predictor.py:264-271). */
+int samrs_reset_image(samrs_engine_t* e, int slot);
+
+/* -- prompt side ---------------------------------------------------------------------------
+ * replaces: SamPredictor.predict_torch (predictor.py:168-245) = PromptEncoder.forward
+ * (modeling/prompt_encoder.py:128-173) + MaskDecoder.forward (modeling/mask_decoder.py:71-174)
+ * + Sam.postprocess_masks (modeling/sam.py:133-162) + `> mask_threshold` (predictor.py:242-243).
+ *
+ *  boxes        [n_prompts,4] fp32 xyxy in the INPUT frame (after apply_boxes_torch) or NULL
+ *  point_coords [n_prompts,n_points,2] fp32 input frame, or NULL
+ *  point_labels [n_prompts,n_points] int32 (1 fg, 0 bg, -1 pad), required iff point_coords
+ *  mask_input   [n_prompts,1,256,256] fp32 or NULL
+ *  multimask    0 -> C = 1 (mask token 0), 1 -> C = 3 (tokens 1..3) (mask_decoder.py:102-107)
+ *  return_logits 0 -> masks_out is uint8 {0,1} [n_prompts,C,orig_h,orig_w];
+ *                1 -> masks_out is fp32 logits of the same shape
+ *  in_h,in_w    size of the image handed to samrs_set_images (predictor.input_size)
+ *  orig_h,orig_w size of the original image (predictor.original_size)
+ *  masks_out / iou_out [n_prompts,C] / lowres_out [n_prompts,C,256,256]: caller-owned device
+ *  buffers; any of them may be NULL to skip that output. */
+int samrs_predict(samrs_engine_t* e, int slot, int n_prompts,
+                  const float* boxes, const float* point_coords, const int32_t* point_labels,
+                  int n_points, const float* mask_input, int multimask, int return_logits,
+                  int in_h, int in_w, int orig_h, int orig_w,
+                  void* masks_out, float* iou_out, float* lowres_out, void* stream);
+
+/* -- "next row" N1: ordered painting + areas + class statistics on device --------------------
+ * replaces the host loop of main_sam_hbox_semantic.py:195-206 and the sums of
+ * statistic.py:15-21.  masks: uint8 [n,orig_h,orig_w] (the C = 1 output of samrs_predict),
+ * labels: int32 [n] on device.  seg_mask (uint8 [orig_h,orig_w], caller initialises to 255,
+ * :162) is overwritten in box order (later box wins).  areas_out int64 [n] = pixels per mask.
+ * class_pixels / class_instances int64 [n_classes] are ACCUMULATED (area > 0 only); either may
+ * be NULL. */
+int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, int n,
+                int orig_h, int orig_w, uint8_t* seg_mask, int64_t* areas_out,
+                int64_t* class_pixels, int64_t* class_instances, int n_classes, void* stream);
+
+/* -- kernel-level entry points (used by the parity tests to check each kernel alone) --------
+ * All pointers are device pointers.  `prec` is enum samrs_precision; "et" = MFMA operand type
+ * (bf16 or f16 bit patterns in uint16). */
+int samrs_k_gemm(int prec, const void* A_et, const void* B_et, void* C, const float* bias,
+                 const float* add2d, int add2d_period, int M, int N, int K,
+                 int out_f32, int gelu, int accumulate, void* stream);
+int samrs_k_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C, int ldc,
+                     int M, int N, int K, int relu, int accumulate, void* stream);
+int samrs_k_convert(int prec, const float* in, void* out_et, int64_t n, void* stream);
+int samrs_k_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
+                      void* out_et, float* out_f32, int rows_out, int D, int window_mode,
+                      int n_images, int grid, int window, void* stream);
+int samrs_k_window_attention(int prec, const void* qkv_et, const float* rel_h, const float* rel_w,
+                             void* out_et, int n_images, int grid, int window, int heads,
+                             int head_dim, void* stream);
+int samrs_k_global_attention(int prec, const void* qkv_et, const float* rel_h, const float* rel_w,
+                             void* out_et, int n_images, int grid, int heads, int head_dim,
+                             void* stream);
+int samrs_k_postprocess(const float* lowres, int n_masks, int in_h, int in_w, int orig_h,
+                        int orig_w, int img_size, int return_logits, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAMRS_HIP_H */

@@ -1,0 +1,101 @@
+// common.h -- shared device helpers for libsamrs_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define SAMRS_WAVE 64
+
+enum { PREC_BF16 = 0, PREC_F16 = 1 };
+
+// ---------------------------------------------------------------------------------------------
+// MFMA operand element type ("ET"): bf16 or f16, carried around as raw uint16 bit patterns so
+// that LDS / global traffic is type-agnostic 16-byte vectors.
+// ---------------------------------------------------------------------------------------------
+template <int PREC>
+struct ET;
+
+template <>
+struct ET<PREC_BF16> {
+    static __device__ __forceinline__ uint16_t from_float(float f) {
+        __bf16 b = (__bf16)f;  // RNE, v_cvt_pk_bf16_f32 on gfx950
+        return __builtin_bit_cast(uint16_t, b);
+    }
+    static __device__ __forceinline__ float to_float(uint16_t u) {
+        return __builtin_bit_cast(float, (uint32_t)u << 16);
+    }
+    static __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                       __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                       __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+template <>
+struct ET<PREC_F16> {
+    static __device__ __forceinline__ uint16_t from_float(float f) {
+        // saturate instead of producing inf: fp16 max is 65504
+        f = __builtin_fminf(__builtin_fmaxf(f, -65504.0f), 65504.0f);
+        _Float16 h = (_Float16)f;  // RNE
+        return __builtin_bit_cast(uint16_t, h);
+    }
+    static __device__ __forceinline__ float to_float(uint16_t u) {
+        return (float)__builtin_bit_cast(_Float16, u);
+    }
+    static __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                      __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16_t mfma32(uint4 a, uint4 b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a),
+                                                      __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    }
+};
+
+template <int PREC>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)ET<PREC>::from_float(lo) | ((uint32_t)ET<PREC>::from_float(hi) << 16);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-level reductions (64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// exact-erf GELU (nn.GELU default; Generate Dataset/segment_anything/modeling/common.py:18-26)
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// XCD-aware, bijective remap of a linear block id (cdna_hip_programming.md T1): the hardware
+// dispatches block b to XCD b % 8; give every XCD a contiguous chunk of the logical grid so
+// that neighbouring tiles (which share operand panels) hit the same L2.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int NX = 8;
+    int q = nwg / NX, r = nwg % NX;
+    int xcd = bid % NX, idx = bid / NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+#define HIP_CHECK_RET(expr)                                                     \
+    do {                                                                        \
+        hipError_t _e = (expr);                                                 \
+        if (_e != hipSuccess) return _e;                                        \
+    } while (0)

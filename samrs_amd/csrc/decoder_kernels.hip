@@ -1,0 +1,609 @@
+// decoder_kernels.hip -- prompt encoder, two-way transformer glue, upscaler tail, postprocess,
+// painting (gfx950).  The GEMM-shaped parts run through gemm.hip; everything here is the
+// HBM-/latency-bound remainder, fp32 except where it feeds an MFMA GEMM.
+//
+// Reference semantics (paths under Generate Dataset/segment_anything/):
+//   prompt tokens / PE : modeling/prompt_encoder.py:73-100,176-219 ; mask_decoder.py:127-129
+//   mask prompt embed  : modeling/prompt_encoder.py:51-59,102-105
+//   attention          : modeling/transformer.py:218-240 (softmax(QK^T / sqrt(d)) V)
+//   upscaler tail      : modeling/mask_decoder.py:53-59,154-167
+//   postprocess        : modeling/sam.py:133-162, predictor.py:242-243
+//   painting / stats   : Generate Dataset/main_sam_hbox_semantic.py:195-206, statistic.py:15-21
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr float TWO_PI = 6.283185307179586f;
+
+// random-Fourier positional encoding of a point in [0,1]^2 (prompt_encoder.py:190-197):
+// channel ch < 128 -> sin(2pi * ((2c-1) . G[:, ch])), ch >= 128 -> cos(... G[:, ch-128])
+__device__ __forceinline__ float pe_channel(const float* __restrict__ gauss, float cx01, float cy01, int ch, int half) {
+    const int f = ch < half ? ch : ch - half;
+    const float vx = 2.0f * cx01 - 1.0f, vy = 2.0f * cy01 - 1.0f;
+    const float a = TWO_PI * (vx * gauss[f] + vy * gauss[half + f]);
+    return ch < half ? sinf(a) : cosf(a);
+}
+
+// grid: (T, n_prompts); block: C threads (one per channel)
+__global__ void prompt_tokens_kernel(PromptParams p, float* __restrict__ tokens, int T, int C) {
+    const int j = blockIdx.x, b = blockIdx.y, ch = threadIdx.x;
+    const int half = C / 2;
+    const bool has_pts = p.point_coords != nullptr;
+    const bool has_box = p.boxes != nullptr;
+    const int npt = has_pts ? p.n_points + (has_box ? 0 : 1) : 0;
+    float v;
+    if (j == 0) {
+        v = p.iou_token[ch];
+    } else if (j < 5) {
+        v = p.mask_tokens[(j - 1) * C + ch];
+    } else if (j < 5 + npt) {
+        const int k = j - 5;
+        int label = -1;
+        float x = 0.f, y = 0.f;
+        if (k < p.n_points) {
+            label = p.point_labels[b * p.n_points + k];
+            x = p.point_coords[(b * p.n_points + k) * 2 + 0] + 0.5f;
+            y = p.point_coords[(b * p.n_points + k) * 2 + 1] + 0.5f;
+        }
+        if (label == -1) {
+            v = p.not_a_point[ch];
+        } else {
+            v = pe_channel(p.gauss, x / p.img_size, y / p.img_size, ch, half);
+            if (label == 0) v += p.point_emb[0][ch];
+            else if (label == 1) v += p.point_emb[1][ch];
+        }
+    } else {
+        const int corner = j - 5 - npt;  // 0 or 1
+        const float x = p.boxes[b * 4 + 2 * corner + 0] + 0.5f;
+        const float y = p.boxes[b * 4 + 2 * corner + 1] + 0.5f;
+        v = pe_channel(p.gauss, x / p.img_size, y / p.img_size, ch, half) + p.point_emb[2 + corner][ch];
+    }
+    tokens[((size_t)b * T + j) * C + ch] = v;
+}
+
+// grid: g*g blocks; block: C threads.  pe[(y*g + x)][ch] at ((x+.5)/g, (y+.5)/g)
+__global__ void dense_pe_kernel(const float* __restrict__ gauss, float* __restrict__ pe, int g, int C) {
+    const int t = blockIdx.x, ch = threadIdx.x;
+    const int y = t / g, x = t % g;
+    pe[(size_t)t * C + ch] = pe_channel(gauss, ((float)x + 0.5f) / (float)g, ((float)y + 0.5f) / (float)g, ch, C / 2);
+}
+
+// mask prompt -> dense embedding.  Block = 256 threads = 16 tokens x 16 mid channels in phase 1,
+// 256 output channels in phase 2.
+__global__ __launch_bounds__(256) void mask_embed_kernel(MaskEmbedParams p, const float* __restrict__ mask_in,
+                                                         float* __restrict__ dense, int grid) {
+    __shared__ float act2[16][16];
+    const int t = threadIdx.x;
+    const int b = blockIdx.y;
+    const int tok0 = blockIdx.x * 16;
+    {
+        const int tl = t >> 4, c2 = t & 15;
+        const int tok = tok0 + tl;
+        const int ty = tok / grid, tx = tok % grid;
+        const int S = 4 * grid;
+        const float* in = mask_in + (size_t)b * S * S + (size_t)(4 * ty) * S + 4 * tx;
+        float out2 = p.b3[c2];
+#pragma unroll
+        for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                float a[4];
+                float mean = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float s = p.b0[c];
+#pragma unroll
+                    for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 2; ++kx)
+                            s += p.w0[c * 4 + ky * 2 + kx] * in[(size_t)(2 * sy + ky) * S + 2 * sx + kx];
+                    a[c] = s;
+                    mean += s;
+                }
+                mean *= 0.25f;
+                float var = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) var += (a[c] - mean) * (a[c] - mean);
+                const float rstd = 1.0f / sqrtf(var * 0.25f + 1e-6f);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float g = gelu_erf((a[c] - mean) * rstd * p.ln1w[c] + p.ln1b[c]);
+                    out2 += p.w3[((c2 * 4 + c) * 2 + sy) * 2 + sx] * g;
+                }
+            }
+        // LayerNorm2d over the 16 channels = the 16 lanes of this token's group
+        float s = out2;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s * (1.0f / 16.0f);
+        float d = (out2 - mean) * (out2 - mean);
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) d += __shfl_xor(d, off, 64);
+        const float rstd = 1.0f / sqrtf(d * (1.0f / 16.0f) + 1e-6f);
+        act2[tl][c2] = gelu_erf((out2 - mean) * rstd * p.ln4w[c2] + p.ln4b[c2]);
+    }
+    __syncthreads();
+    float w[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) w[c] = p.w6[t * 16 + c];
+    const float bb = p.b6[t];
+    for (int tl = 0; tl < 16; ++tl) {
+        float s = bb;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) s += w[c] * act2[tl][c];
+        dense[((size_t)b * grid * grid + tok0 + tl) * 256 + t] = s;
+    }
+}
+
+template <int PREC>
+__global__ void make_keys_kernel(const float* __restrict__ emb, const float* __restrict__ dense,
+                                 const float* __restrict__ vec, float* __restrict__ out_f32,
+                                 uint16_t* __restrict__ out_et, long per_batch4, long total4, int C4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const long r = i % per_batch4;
+    float4 e = reinterpret_cast<const float4*>(emb)[r];
+    const float4 d = dense ? reinterpret_cast<const float4*>(dense)[i] : reinterpret_cast<const float4*>(vec)[r % C4];
+    e.x += d.x; e.y += d.y; e.z += d.z; e.w += d.w;
+    reinterpret_cast<float4*>(out_f32)[i] = e;
+    uint2 o;
+    o.x = pack2<PREC>(e.x, e.y);
+    o.y = pack2<PREC>(e.z, e.w);
+    reinterpret_cast<uint2*>(out_et)[i] = o;
+}
+
+__global__ void add_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
+// token self attention, one block per prompt.  Thread (h, i) -> query token i of head h.
+constexpr int TOK_MAX = 16;
+template <int DH>
+__global__ __launch_bounds__(256) void token_self_attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, float* __restrict__ o, int T,
+                                                              int C, int heads) {
+    extern __shared__ float sm[];  // q | k | v, each [T][C]
+    float* sq = sm;
+    float* sk = sm + T * C;
+    float* sv = sm + 2 * T * C;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < T * C; i += blockDim.x) {
+        sq[i] = q[(size_t)b * T * C + i];
+        sk[i] = k[(size_t)b * T * C + i];
+        sv[i] = v[(size_t)b * T * C + i];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)DH);
+    for (int w = threadIdx.x; w < heads * T; w += blockDim.x) {
+        const int h = w / T, i = w % T;
+        float qi[DH], acc[DH];
+#pragma unroll
+        for (int c = 0; c < DH; ++c) {
+            qi[c] = sq[i * C + h * DH + c];
+            acc[c] = 0.f;
+        }
+        float m = -INFINITY, l = 0.f;
+        for (int j = 0; j < T; ++j) {
+            const float* kr = sk + j * C + h * DH;
+            const float* vr = sv + j * C + h * DH;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) s += qi[c] * kr[c];
+            s *= scale;
+            const float mn = fmaxf(m, s);
+            const float corr = expf(m - mn), pj = expf(s - mn);
+            l = l * corr + pj;
+#pragma unroll
+            for (int c = 0; c < DH; ++c) acc[c] = acc[c] * corr + pj * vr[c];
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+        float* orow = o + ((size_t)b * T + i) * C + h * DH;
+#pragma unroll
+        for (int c = 0; c < DH; ++c) orow[c] = acc[c] * inv;
+    }
+}
+
+// tokens -> image attention (head dim 16).  grid (heads, n_prompts), 4 waves; wave w owns tokens
+// w, w+4, ...; lanes stride over the image keys with a per-lane online softmax, merged at the end.
+template <int PREC, int TPW>
+__global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restrict__ qp, const uint16_t* __restrict__ kp,
+                                                            const uint16_t* __restrict__ vp, int ld, long bstride,
+                                                            float* __restrict__ o, int T, int tokens, int Ci) {
+    constexpr int HD = 16;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float qv[TPW][HD], m[TPW], l[TPW], acc[TPW][HD];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wave + 4 * i;
+        m[i] = -INFINITY;
+        l[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+            qv[i][c] = (t < T) ? qp[((size_t)b * T + t) * Ci + h * HD + c] * 0.25f : 0.f;  // 1/sqrt(16)
+            acc[i][c] = 0.f;
+        }
+    }
+    const uint16_t* kb = kp + (size_t)b * bstride * ld + h * HD;
+    const uint16_t* vb = vp + (size_t)b * bstride * ld + h * HD;
+    for (int key = lane; key < tokens; key += 64) {
+        const uint4 k0 = *reinterpret_cast<const uint4*>(kb + (size_t)key * ld);
+        const uint4 k1 = *reinterpret_cast<const uint4*>(kb + (size_t)key * ld + 8);
+        const uint4 v0 = *reinterpret_cast<const uint4*>(vb + (size_t)key * ld);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(vb + (size_t)key * ld + 8);
+        float kf[HD], vf[HD];
+        const uint32_t kw[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+        const uint32_t vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            kf[2 * c] = ET<PREC>::to_float((uint16_t)(kw[c] & 0xffffu));
+            kf[2 * c + 1] = ET<PREC>::to_float((uint16_t)(kw[c] >> 16));
+            vf[2 * c] = ET<PREC>::to_float((uint16_t)(vw[c] & 0xffffu));
+            vf[2 * c + 1] = ET<PREC>::to_float((uint16_t)(vw[c] >> 16));
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) s += qv[i][c] * kf[c];
+            const float mn = fmaxf(m[i], s);
+            const float corr = __expf(m[i] - mn);
+            const float pj = __expf(s - mn);
+            l[i] = l[i] * corr + pj;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) acc[i][c] = acc[i][c] * corr + pj * vf[c];
+            m[i] = mn;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int t = wave + 4 * i;
+        const float mall = wave_max(m[i]);
+        const float f = __expf(m[i] - mall);
+        const float lsum = wave_sum(l[i] * f);
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+            const float a = wave_sum(acc[i][c] * f);
+            if (lane == 0 && t < T) o[((size_t)b * T + t) * Ci + h * HD + c] = a / lsum;
+        }
+    }
+}
+
+// image -> tokens attention (head dim 16).  Thread = (image token, head); keys/values are the T
+// prompt tokens (LDS).  grid (tokens/32, n_prompts).
+template <int PREC>
+__global__ __launch_bounds__(256) void i2t_attention_kernel(const uint16_t* __restrict__ qi, int ld, long bstride,
+                                                            const float* __restrict__ kt, const float* __restrict__ vt,
+                                                            uint16_t* __restrict__ out, int T, int tokens, int Ci) {
+    constexpr int HD = 16;
+    extern __shared__ float sm[];  // kt | vt, each [T][Ci]
+    float* sk = sm;
+    float* sv = sm + T * Ci;
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < T * Ci; i += 256) {
+        sk[i] = kt[(size_t)b * T * Ci + i];
+        sv[i] = vt[(size_t)b * T * Ci + i];
+    }
+    __syncthreads();
+    const int heads = Ci / HD;                  // 8
+    const int tok = blockIdx.x * (256 / heads) + threadIdx.x / heads;
+    const int h = threadIdx.x % heads;
+    if (tok >= tokens) return;
+    const uint16_t* qrow = qi + ((size_t)b * bstride + tok) * ld + h * HD;
+    const uint4 q0 = *reinterpret_cast<const uint4*>(qrow);
+    const uint4 q1 = *reinterpret_cast<const uint4*>(qrow + 8);
+    const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    float qf[HD];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        qf[2 * c] = ET<PREC>::to_float((uint16_t)(qw[c] & 0xffffu)) * 0.25f;
+        qf[2 * c + 1] = ET<PREC>::to_float((uint16_t)(qw[c] >> 16)) * 0.25f;
+    }
+    float m = -INFINITY, l = 0.f, acc[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) acc[c] = 0.f;
+    for (int j = 0; j < T; ++j) {
+        const float* kr = sk + j * Ci + h * HD;
+        const float* vr = sv + j * Ci + h * HD;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) s += qf[c] * kr[c];
+        const float mn = fmaxf(m, s);
+        const float corr = __expf(m - mn), pj = __expf(s - mn);
+        l = l * corr + pj;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) acc[c] = acc[c] * corr + pj * vr[c];
+        m = mn;
+    }
+    const float inv = 1.0f / l;
+    uint4 o0, o1;
+    o0.x = pack2<PREC>(acc[0] * inv, acc[1] * inv);   o0.y = pack2<PREC>(acc[2] * inv, acc[3] * inv);
+    o0.z = pack2<PREC>(acc[4] * inv, acc[5] * inv);   o0.w = pack2<PREC>(acc[6] * inv, acc[7] * inv);
+    o1.x = pack2<PREC>(acc[8] * inv, acc[9] * inv);   o1.y = pack2<PREC>(acc[10] * inv, acc[11] * inv);
+    o1.z = pack2<PREC>(acc[12] * inv, acc[13] * inv); o1.w = pack2<PREC>(acc[14] * inv, acc[15] * inv);
+    uint16_t* orow = out + ((size_t)b * tokens + tok) * Ci + h * HD;
+    *reinterpret_cast<uint4*>(orow) = o0;
+    *reinterpret_cast<uint4*>(orow + 8) = o1;
+}
+
+// rows of 256 floats = 4 groups of 64: LayerNorm2d(64) (eps) + GELU per group -> ET.
+// One wave per row; lane holds 4 consecutive values; a group = 16 lanes.
+template <int PREC>
+__global__ __launch_bounds__(256) void group_ln_gelu_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps,
+                                                            uint16_t* __restrict__ out, long rows) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4 v = reinterpret_cast<const float4*>(in + row * 256)[lane];
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s * (1.0f / 64.0f);
+    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+    float q = (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + eps);
+    const int c0 = (lane & 15) * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c0);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + c0);
+    uint2 o;
+    o.x = pack2<PREC>(gelu_erf(a * rstd * g.x + bt.x), gelu_erf(b * rstd * g.y + bt.y));
+    o.y = pack2<PREC>(gelu_erf(c * rstd * g.z + bt.z), gelu_erf(d * rstd * g.w + bt.w));
+    reinterpret_cast<uint2*>(out + row * 256)[lane] = o;
+}
+
+// low[b][c][Y][X] = hyper[b][sel0 + c] . up2[b][pixel(Y, X)][0..31]
+// up2 rows are ordered (token y, x)(dy, dx)(dy2, dx2); Y = 4y + 2dy + dy2, X = 4x + 2dx + dx2.
+template <int PREC>
+__global__ __launch_bounds__(256) void mask_product_kernel(const uint16_t* __restrict__ up2, const float* __restrict__ hyper,
+                                                           float* __restrict__ low, int grid, int n_mask_tokens,
+                                                           int sel0, int n_sel) {
+    __shared__ float hy[4][32];
+    const int b = blockIdx.y;
+    if (threadIdx.x < n_sel * 32)
+        hy[threadIdx.x / 32][threadIdx.x % 32] = hyper[((size_t)b * n_mask_tokens + sel0 + threadIdx.x / 32) * 32 + threadIdx.x % 32];
+    __syncthreads();
+    const int S = 4 * grid;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int Y = pix / S, X = pix % S;
+    const int y = Y >> 2, dy = (Y >> 1) & 1, dy2 = Y & 1;
+    const int x = X >> 2, dx = (X >> 1) & 1, dx2 = X & 1;
+    const size_t prow = (((size_t)b * grid * grid + (size_t)y * grid + x) * 4 + dy * 2 + dx) * 4 + dy2 * 2 + dx2;
+    const uint4* src = reinterpret_cast<const uint4*>(up2 + prow * 32);
+    float u[32];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 w = src[i];
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u[i * 8 + 2 * e] = ET<PREC>::to_float((uint16_t)(ww[e] & 0xffffu));
+            u[i * 8 + 2 * e + 1] = ET<PREC>::to_float((uint16_t)(ww[e] >> 16));
+        }
+    }
+    for (int c = 0; c < n_sel; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += hy[c][k] * u[k];
+        low[(((size_t)b * n_sel + c) * S + Y) * S + X] = s;
+    }
+}
+
+// ---- postprocess ------------------------------------------------------------------------
+// PyTorch upsample_bilinear2d, align_corners=False: src = scale*(dst+0.5)-0.5 clamped at 0,
+// scale = in/out; out = wy0*(wx0*v00 + wx1*v01) + wy1*(wx0*v10 + wx1*v11).
+struct Lin {
+    int i0, i1;
+    float w0, w1;
+};
+__device__ __forceinline__ Lin lin_coord(int dst, float scale, int in_size) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    Lin r;
+    r.i0 = (int)src;
+    r.i0 = r.i0 < in_size - 1 ? r.i0 : in_size - 1;
+    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+    r.w1 = src - (float)r.i0;
+    r.w0 = 1.0f - r.w1;
+    return r;
+}
+// stage 1: value of the img_size^2 upsampled map at integer (Y1, X1), from the 256^2 logits
+__device__ __forceinline__ float stage1(const float* __restrict__ low, int LS, float s1, int Y1, int X1) {
+    const Lin ly = lin_coord(Y1, s1, LS), lx = lin_coord(X1, s1, LS);
+    const float* r0 = low + (size_t)ly.i0 * LS;
+    const float* r1 = low + (size_t)ly.i1 * LS;
+    return ly.w0 * (lx.w0 * r0[lx.i0] + lx.w1 * r0[lx.i1]) + ly.w1 * (lx.w0 * r1[lx.i0] + lx.w1 * r1[lx.i1]);
+}
+
+// One thread = 4 horizontally adjacent output pixels.  grid (ceil(W/4 * H / 256), n_masks).
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ low_all, int LS, int in_h, int in_w,
+                                                          int H, int W, int img_size, int return_logits,
+                                                          void* __restrict__ out) {
+    const int W4 = (W + 3) / 4;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)W4 * H) return;
+    const int Y = (int)(t / W4), X0 = (int)(t % W4) * 4;
+    const int mi = blockIdx.y;
+    const float* low = low_all + (size_t)mi * LS * LS;
+    const float s1 = (float)LS / (float)img_size;
+    const bool identity = (H == in_h) && (W == in_w);
+    float v[4];
+    if (identity) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (X0 + e < W) ? stage1(low, LS, s1, Y, X0 + e) : 0.f;
+    } else {
+        const float sy = (float)in_h / (float)H, sx = (float)in_w / (float)W;
+        const Lin ly = lin_coord(Y, sy, in_h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (X0 + e < W) {
+                const Lin lx = lin_coord(X0 + e, sx, in_w);
+                const float a = lx.w0 * stage1(low, LS, s1, ly.i0, lx.i0) + lx.w1 * stage1(low, LS, s1, ly.i0, lx.i1);
+                const float b = lx.w0 * stage1(low, LS, s1, ly.i1, lx.i0) + lx.w1 * stage1(low, LS, s1, ly.i1, lx.i1);
+                v[e] = ly.w0 * a + ly.w1 * b;
+            } else {
+                v[e] = 0.f;
+            }
+        }
+    }
+    const size_t obase = ((size_t)mi * H + Y) * W + X0;
+    if (return_logits) {
+        float* o = reinterpret_cast<float*>(out) + obase;
+        for (int e = 0; e < 4 && X0 + e < W; ++e) o[e] = v[e];
+    } else {
+        uint8_t* o = reinterpret_cast<uint8_t*>(out) + obase;
+        if ((W & 3) == 0) {
+            const uint32_t pk = (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 1u << 8 : 0u) | (v[2] > 0.f ? 1u << 16 : 0u) |
+                                (v[3] > 0.f ? 1u << 24 : 0u);
+            *reinterpret_cast<uint32_t*>(o) = pk;
+        } else {
+            for (int e = 0; e < 4 && X0 + e < W; ++e) o[e] = v[e] > 0.f ? 1 : 0;
+        }
+    }
+}
+
+// ---- painting -----------------------------------------------------------------------------
+// seg[p] = label of the LAST mask (in box order) covering p; untouched otherwise.
+__global__ void paint_kernel(const uint8_t* __restrict__ masks, const int32_t* __restrict__ labels, int n, long hw,
+                             uint8_t* __restrict__ seg) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    for (int j = n - 1; j >= 0; --j) {
+        if (masks[(size_t)j * hw + p]) {
+            seg[p] = (uint8_t)labels[j];
+            return;
+        }
+    }
+}
+// areas[j] += popcount(mask j); grid (chunks, n)
+__global__ void area_kernel(const uint8_t* __restrict__ masks, long hw, unsigned long long* __restrict__ areas) {
+    const int j = blockIdx.y;
+    const uint8_t* m = masks + (size_t)j * hw;
+    unsigned int cnt = 0;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < hw; p += (long)gridDim.x * blockDim.x) cnt += m[p] ? 1u : 0u;
+    float c = (float)cnt;  // <= hw / (gridDim*blockDim) + 1, exact in fp32
+    c = wave_sum(c);
+    if ((threadIdx.x & 63) == 0 && c > 0.f) atomicAdd(&areas[j], (unsigned long long)c);
+}
+__global__ void class_stats_kernel(const unsigned long long* __restrict__ areas, const int32_t* __restrict__ labels, int n,
+                                   unsigned long long* __restrict__ cpix, unsigned long long* __restrict__ cins, int n_classes) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int j = 0; j < n; ++j) {
+        const int l = labels[j];
+        if (areas[j] > 0 && l >= 0 && l < n_classes) {   // statistic.py:18-21 (area > 0 only)
+            if (cpix) cpix[l] += areas[j];
+            if (cins) cins[l] += 1ull;
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_prompt_tokens(const PromptParams& p, float* tokens, int T, hipStream_t s) {
+    dim3 g(T, p.n_prompts), b(256);
+    prompt_tokens_kernel<<<g, b, 0, s>>>(p, tokens, T, 256);
+    return hipGetLastError();
+}
+hipError_t launch_dense_pe(const float* gauss, float* pe, int grid, hipStream_t s) {
+    dense_pe_kernel<<<grid * grid, 256, 0, s>>>(gauss, pe, grid, 256);
+    return hipGetLastError();
+}
+hipError_t launch_mask_embed(const MaskEmbedParams& p, const float* mask_in, float* dense, int n, int grid, hipStream_t s) {
+    dim3 g(grid * grid / 16, n);
+    mask_embed_kernel<<<g, 256, 0, s>>>(p, mask_in, dense, grid);
+    return hipGetLastError();
+}
+hipError_t launch_make_keys(int prec, const float* emb, const float* dense, const float* vec, float* out_f32,
+                            void* out_et, int n_batches, int tokens, int C, hipStream_t s) {
+    const long per4 = (long)tokens * C / 4, tot4 = per4 * n_batches;
+    const int blocks = (int)((tot4 + 255) / 256);
+    if (prec == PREC_BF16)
+        make_keys_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(emb, dense, vec, out_f32, (uint16_t*)out_et, per4, tot4, C / 4);
+    else
+        make_keys_kernel<PREC_F16><<<blocks, 256, 0, s>>>(emb, dense, vec, out_f32, (uint16_t*)out_et, per4, tot4, C / 4);
+    return hipGetLastError();
+}
+hipError_t launch_add_f32(const float* a, const float* b, float* out, long n, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    add_f32_kernel<<<(int)((n / 4 + 255) / 256), 256, 0, s>>>(a, b, out, n / 4);
+    return hipGetLastError();
+}
+hipError_t launch_token_self_attn(const float* q, const float* k, const float* v, float* o, int n, int T, int C,
+                                  int heads, hipStream_t s) {
+    if (C / heads != 32 || T > TOK_MAX) return hipErrorInvalidValue;
+    token_self_attn_kernel<32><<<n, 256, 3 * T * C * sizeof(float), s>>>(q, k, v, o, T, C, heads);
+    return hipGetLastError();
+}
+hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const void* vp, int ld, long bstride,
+                                float* o, int n, int T, int tokens, int Ci, int heads, hipStream_t s) {
+    if (Ci / heads != 16 || T > TOK_MAX) return hipErrorInvalidValue;
+    dim3 g(heads, n), b(256);
+    const uint16_t* k = (const uint16_t*)kp;
+    const uint16_t* v = (const uint16_t*)vp;
+    if (T <= 8) {
+        if (prec == PREC_BF16) t2i_attention_kernel<PREC_BF16, 2><<<g, b, 0, s>>>(qp, k, v, ld, bstride, o, T, tokens, Ci);
+        else t2i_attention_kernel<PREC_F16, 2><<<g, b, 0, s>>>(qp, k, v, ld, bstride, o, T, tokens, Ci);
+    } else {
+        if (prec == PREC_BF16) t2i_attention_kernel<PREC_BF16, 4><<<g, b, 0, s>>>(qp, k, v, ld, bstride, o, T, tokens, Ci);
+        else t2i_attention_kernel<PREC_F16, 4><<<g, b, 0, s>>>(qp, k, v, ld, bstride, o, T, tokens, Ci);
+    }
+    return hipGetLastError();
+}
+hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long bstride, const float* kt, const float* vt,
+                                void* out, int n, int T, int tokens, int Ci, int heads, hipStream_t s) {
+    if (Ci / heads != 16 || 256 % heads) return hipErrorInvalidValue;
+    const int per = 256 / heads;
+    dim3 g((tokens + per - 1) / per, n), b(256);
+    const size_t sh = 2 * (size_t)T * Ci * sizeof(float);
+    if (prec == PREC_BF16)
+        i2t_attention_kernel<PREC_BF16><<<g, b, sh, s>>>((const uint16_t*)qi, ld, bstride, kt, vt, (uint16_t*)out, T, tokens, Ci);
+    else
+        i2t_attention_kernel<PREC_F16><<<g, b, sh, s>>>((const uint16_t*)qi, ld, bstride, kt, vt, (uint16_t*)out, T, tokens, Ci);
+    return hipGetLastError();
+}
+hipError_t launch_group_ln_gelu(int prec, const float* in, const float* gamma, const float* beta, float eps,
+                                void* out, long rows, int groups, int gsize, hipStream_t s) {
+    if (groups != 4 || gsize != 64) return hipErrorInvalidValue;
+    const int blocks = (int)((rows + 3) / 4);
+    if (prec == PREC_BF16) group_ln_gelu_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(in, gamma, beta, eps, (uint16_t*)out, rows);
+    else group_ln_gelu_kernel<PREC_F16><<<blocks, 256, 0, s>>>(in, gamma, beta, eps, (uint16_t*)out, rows);
+    return hipGetLastError();
+}
+hipError_t launch_mask_product(int prec, const void* up2, const float* hyper, float* low, int n, int grid,
+                               int n_mask_tokens, int sel0, int n_sel, hipStream_t s) {
+    if (n_sel > 4 || n_sel < 1) return hipErrorInvalidValue;
+    const int S = 4 * grid;
+    dim3 g(S * S / 256, n), b(256);
+    if (prec == PREC_BF16) mask_product_kernel<PREC_BF16><<<g, b, 0, s>>>((const uint16_t*)up2, hyper, low, grid, n_mask_tokens, sel0, n_sel);
+    else mask_product_kernel<PREC_F16><<<g, b, 0, s>>>((const uint16_t*)up2, hyper, low, grid, n_mask_tokens, sel0, n_sel);
+    return hipGetLastError();
+}
+hipError_t launch_postprocess(const float* low, int n_masks, int in_h, int in_w, int orig_h, int orig_w,
+                              int img_size, int return_logits, void* out, hipStream_t s) {
+    const long work = (long)((orig_w + 3) / 4) * orig_h;
+    dim3 g((unsigned)((work + 255) / 256), n_masks), b(256);
+    postprocess_kernel<<<g, b, 0, s>>>(low, img_size / 4, in_h, in_w, orig_h, orig_w, img_size, return_logits, out);
+    return hipGetLastError();
+}
+hipError_t launch_paint(const uint8_t* masks, const int32_t* labels, int n, int h, int w, uint8_t* seg,
+                        unsigned long long* areas, unsigned long long* class_pixels,
+                        unsigned long long* class_instances, int n_classes, hipStream_t s) {
+    const long hw = (long)h * w;
+    if (seg) paint_kernel<<<(int)((hw + 255) / 256), 256, 0, s>>>(masks, labels, n, hw, seg);
+    if (areas) {
+        HIP_CHECK_RET(hipMemsetAsync(areas, 0, sizeof(unsigned long long) * n, s));
+        dim3 g(64, n);
+        area_kernel<<<g, 256, 0, s>>>(masks, hw, areas);
+        if (class_pixels || class_instances)
+            class_stats_kernel<<<1, 64, 0, s>>>(areas, labels, n, class_pixels, class_instances, n_classes);
+    }
+    return hipGetLastError();
+}

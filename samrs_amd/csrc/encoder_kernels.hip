@@ -1,0 +1,720 @@
+// encoder_kernels.hip -- non-GEMM kernels of the ViT image encoder (gfx950).
+//
+// Reference semantics (paths under Generate Dataset/segment_anything/):
+//   preprocess + patch im2col : modeling/sam.py:164-174, modeling/image_encoder.py:364-395
+//   LayerNorm (+window gather): modeling/image_encoder.py:168-172,243-264 (zero pad AFTER norm1)
+//   windowed attention        : modeling/image_encoder.py:224-240,325-361,267-289
+//   global attention          : same with window_size == 0
+//   neck im2col / transposes  : modeling/image_encoder.py:88-104,114
+//
+// Attention formulation (both kernels).  Everything is computed TRANSPOSED so that one lane owns
+// one query: S^T = K * Q^T with v_mfma_f32_32x32x16 (first operand = 32 keys x 16 d, second =
+// 16 d x 32 queries).  In the 32x32 accumulator layout lane l holds column q = l & 31 and rows
+// key = (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15, so the softmax row-reduction is in-lane plus one
+// xor-32 shuffle.  The un-normalised probabilities feed the PV MFMA (O^T = V^T * P^T) straight
+// from registers: MFMA sums over k in any order, so the k-slot <-> key assignment is chosen to be
+// exactly the accumulator layout (slot (half, jj) of MFMA u of tile t <-> key
+// 32t + 16u + 8*(jj>>2) + 4*half + (jj&3)); V^T fragments are gathered with the same assignment
+// (two 8-byte LDS reads).  No permutes, no P round-trip through LDS.
+//
+// Decomposed rel-pos (image_encoder.py:325-361) uses the UNSCALED q: T = Q * [rel_h; rel_w]^T is
+// computed with the same MFMA (table rows play the role of keys), bounced through a per-wave LDS
+// scratch [q][row] and gathered as bias(q, k) = T_h[q][qh - kh + S-1] + T_w[q][qw - kw + S-1].
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__constant__ float c_mean[3] = {123.675f, 116.28f, 103.53f};  // modeling/sam.py:27
+__constant__ float c_std[3] = {58.395f, 57.12f, 57.375f};     // modeling/sam.py:28
+
+// -----------------------------------------------------------------------------------------
+// preprocess + im2col for the 16x16/16 patch conv.  A[row = (img, py, px)][k = c*256 + ky*16 + kx]
+// One thread = 8 horizontally adjacent pixels (24 bytes of HWC input) -> three 16-byte chunks.
+// -----------------------------------------------------------------------------------------
+template <int PREC>
+__global__ void patch_im2col_kernel(const uint8_t* __restrict__ img, uint16_t* __restrict__ A,
+                                    int n_images, int in_h, int in_w, int grid, int patch) {
+    const int P2 = patch * patch;            // 256
+    const int halves = patch / 8;            // 2
+    const long total = (long)n_images * grid * grid * patch * halves;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int half = t % halves;
+    long u = t / halves;
+    const int ky = u % patch; u /= patch;
+    const int px = u % grid; u /= grid;
+    const int py = u % grid;
+    const int im = u / grid;
+    const int y = py * patch + ky, x0 = px * patch + half * 8;
+    float v[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int x = x0 + e;
+        const bool in = (y < in_h) && (x < in_w);
+        const uint8_t* p = img + ((size_t)im * in_h * in_w + (size_t)y * in_w + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c][e] = in ? ((float)p[c] - c_mean[c]) / c_std[c] : 0.f;
+    }
+    const size_t row = ((size_t)im * grid + py) * grid + px;
+    uint16_t* out = A + row * (3 * P2) + ky * patch + half * 8;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        uint4 o;
+        o.x = pack2<PREC>(v[c][0], v[c][1]);
+        o.y = pack2<PREC>(v[c][2], v[c][3]);
+        o.z = pack2<PREC>(v[c][4], v[c][5]);
+        o.w = pack2<PREC>(v[c][6], v[c][7]);
+        *reinterpret_cast<uint4*>(out + c * P2) = o;
+    }
+}
+
+template <int PREC>
+__global__ void convert_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    uint2 o;
+    o.x = pack2<PREC>(v.x, v.y);
+    o.y = pack2<PREC>(v.z, v.w);
+    reinterpret_cast<uint2*>(out)[i] = o;
+}
+
+// -----------------------------------------------------------------------------------------
+// LayerNorm over the last dim, one wave per OUTPUT row.  window_mode: output rows are in window
+// order [(img, wy, wx), (iy, ix)] and rows that fall in the bottom/right padding are ZERO (the
+// reference pads after norm1, image_encoder.py:168-172,256-259).
+// -----------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
+
+template <int PREC>
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const float* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, uint16_t* __restrict__ out_et, float* __restrict__ out_f32, int rows_out, int D,
+    int window_mode, int grid, int window) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_out) return;
+    long src = row;
+    bool valid = true;
+    if (window_mode) {
+        const int nw = (grid + window - 1) / window;
+        const int w2 = window * window;
+        int t = row % w2;
+        int win = (row / w2) % (nw * nw);
+        int im = row / (w2 * nw * nw);
+        const int y = (win / nw) * window + t / window;
+        const int x = (win % nw) * window + t % window;
+        valid = (y < grid) && (x < grid);
+        src = ((long)im * grid + y) * grid + x;
+    }
+    const int nv = D >> 2;
+    if (!valid) {
+        for (int i = lane; i < nv; i += 64) {
+            if (out_et) reinterpret_cast<uint2*>(out_et + (size_t)row * D)[i] = make_uint2(0u, 0u);
+            if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const float4* xr = reinterpret_cast<const float4*>(X + (size_t)src * D);
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            v[i] = xr[idx];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int idx = lane + 64 * i;
+        if (idx < nv) {
+            const float4 g = reinterpret_cast<const float4*>(gamma)[idx];
+            const float4 b = reinterpret_cast<const float4*>(beta)[idx];
+            const float o0 = (v[i].x - mean) * rstd * g.x + b.x;
+            const float o1 = (v[i].y - mean) * rstd * g.y + b.y;
+            const float o2 = (v[i].z - mean) * rstd * g.z + b.z;
+            const float o3 = (v[i].w - mean) * rstd * g.w + b.w;
+            if (out_et) {
+                uint2 o;
+                o.x = pack2<PREC>(o0, o1);
+                o.y = pack2<PREC>(o2, o3);
+                reinterpret_cast<uint2*>(out_et + (size_t)row * D)[idx] = o;
+            }
+            if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[idx] = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+// shared attention pieces
+// -----------------------------------------------------------------------------------------
+// e-th 16-bit element of a 16-byte vector, without taking its address (keeps it in registers)
+__device__ __forceinline__ uint16_t elem16(const uint4& v, int e) {
+    const uint32_t w = (e < 2) ? v.x : (e < 4) ? v.y : (e < 6) ? v.z : v.w;
+    return (uint16_t)((e & 1) ? (w >> 16) : (w & 0xffffu));
+}
+
+// key (row) index of accumulator register r for lane-half hh within a 32x32 tile
+__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// Q fragments straight from global: lane (q = l&31, hh = l>>5) holds Q[q][16*ks + 8*hh .. +7].
+template <int KS>
+__device__ __forceinline__ void load_q_frags(const uint16_t* qrow /* &Q[q][0] or nullptr */, int hh,
+                                             uint4 (&qf)[KS]) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = qrow ? *reinterpret_cast<const uint4*>(qrow + 16 * ks + 8 * hh) : make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// One 32-row tile of  M * Q^T : rows come from an LDS matrix [rows][HD] (ET, row stride HD).
+template <int PREC, int HD>
+__device__ __forceinline__ f32x16_t tile_times_qT(const uint16_t* lds_rows /* row 0 of the tile */,
+                                                  int lane, const uint4 (&qf)[HD / 16]) {
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const uint16_t* p = lds_rows + (lane & 31) * HD + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p + 16 * ks);
+        acc = ET<PREC>::mfma32(a, qf[ks], acc);
+    }
+    return acc;
+}
+
+// V^T fragment for PV MFMA `u` of a 32-key tile: lane (dd = l&31, hh) holds keys
+// base + 4hh + {0..3} and base + 8 + 4hh + {0..3}, base = 16u, of row d = dd.
+__device__ __forceinline__ uint4 load_vt_frag(const uint16_t* vt_row /* &Vt[d][tile key 0] */, int u, int hh) {
+    const uint2 lo = *reinterpret_cast<const uint2*>(vt_row + 16 * u + 4 * hh);
+    const uint2 hi = *reinterpret_cast<const uint2*>(vt_row + 16 * u + 8 + 4 * hh);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+template <int PREC>
+__device__ __forceinline__ uint4 pack_p(const f32x16_t& p, int u) {
+    uint4 o;
+    o.x = pack2<PREC>(p[8 * u + 0], p[8 * u + 1]);
+    o.y = pack2<PREC>(p[8 * u + 2], p[8 * u + 3]);
+    o.z = pack2<PREC>(p[8 * u + 4], p[8 * u + 5]);
+    o.w = pack2<PREC>(p[8 * u + 6], p[8 * u + 7]);
+    return o;
+}
+
+// =========================================================================================
+// windowed attention: one block per (window, head); 4 waves; each wave owns 32-query strips.
+// qkv rows are in WINDOW order (written by the window-gather LayerNorm + qkv GEMM).
+// =========================================================================================
+template <int HD>
+struct WinCfg {
+    static constexpr int WS = 14, N = WS * WS, NT = 7, NP = NT * 32;  // 196 tokens -> 7 tiles of 32
+    static constexpr int DT = (HD + 31) / 32;                          // d tiles for PV
+    static constexpr int VSTR = 228;                                   // V^T row stride (elements)
+    static constexpr int TSTR = 65;                                    // scratch row stride (floats)
+    static constexpr int K_BYTES = NP * HD * 2;
+    static constexpr int VT_BYTES = DT * 32 * VSTR * 2;
+    static constexpr int RT_BYTES = 64 * HD * 2;
+    static constexpr int T_BYTES = 4 * 32 * TSTR * 4;
+    static constexpr int LDS_BYTES = K_BYTES + VT_BYTES + RT_BYTES + T_BYTES;
+};
+
+template <int PREC, int HD>
+__global__ __launch_bounds__(256) void window_attention_kernel(
+    const uint16_t* __restrict__ qkv, const float* __restrict__ rel_h, const float* __restrict__ rel_w,
+    uint16_t* __restrict__ out, int grid, int heads) {
+    using C = WinCfg<HD>;
+    constexpr int KS = HD / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* Vt = reinterpret_cast<uint16_t*>(smem + C::K_BYTES);
+    uint16_t* Rt = reinterpret_cast<uint16_t*>(smem + C::K_BYTES + C::VT_BYTES);
+    float* Tq = reinterpret_cast<float*>(smem + C::K_BYTES + C::VT_BYTES + C::RT_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, ql = lane & 31;
+    const int wi = blockIdx.x;            // global window index = img * nw*nw + win
+    const int head = blockIdx.y;
+    const int D = heads * HD;
+    const int nw = (grid + C::WS - 1) / C::WS;
+    const int win = wi % (nw * nw), im = wi / (nw * nw);
+    const int wy = win / nw, wx = win % nw;
+    const size_t row0 = (size_t)wi * C::N;
+    const uint16_t* base = qkv + row0 * (3 * D) + head * HD;
+
+    // ---- stage K (row-major), V^T, rel tables -------------------------------------------
+    for (int i = tid; i < (C::VT_BYTES / 16); i += 256) reinterpret_cast<uint4*>(Vt)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    constexpr int CH = HD / 8;  // 16-byte chunks per row
+    for (int c = tid; c < C::NP * CH; c += 256) {
+        const int r = c / CH, ch = c % CH;
+        uint4 kv = make_uint4(0u, 0u, 0u, 0u);
+        if (r < C::N) {
+            kv = *reinterpret_cast<const uint4*>(base + (size_t)r * (3 * D) + D + ch * 8);
+            const uint4 vv = *reinterpret_cast<const uint4*>(base + (size_t)r * (3 * D) + 2 * D + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * C::VSTR + r] = elem16(vv, e);
+        }
+        *reinterpret_cast<uint4*>(Ks + r * HD + ch * 8) = kv;
+    }
+    for (int i = tid; i < 64 * HD; i += 256) {
+        const int r = i / HD, d = i % HD;
+        float v = 0.f;
+        if (r < 2 * C::WS - 1) v = rel_h[r * HD + d];
+        else if (r >= 32 && r < 32 + 2 * C::WS - 1) v = rel_w[(r - 32) * HD + d];
+        Rt[i] = ET<PREC>::from_float(v);
+    }
+    __syncthreads();
+
+    const float scale = rsqrtf((float)HD);
+    float* tq = Tq + wave * 32 * C::TSTR;
+
+    for (int s = wave; s < C::NT; s += 4) {
+        const int q = 32 * s + ql;                 // query index inside the window
+        const bool qin = q < C::N;
+        uint4 qf[KS];
+        load_q_frags<KS>(qin ? base + (size_t)q * (3 * D) : nullptr, hh, qf);
+
+        // rel-pos tiles -> scratch [q][row]
+        {
+            const f32x16_t th = tile_times_qT<PREC, HD>(Rt, lane, qf);
+            const f32x16_t tw = tile_times_qT<PREC, HD>(Rt + 32 * HD, lane, qf);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                tq[ql * C::TSTR + acc_row(r, hh)] = th[r];
+                tq[ql * C::TSTR + 32 + acc_row(r, hh)] = tw[r];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const int qc = qin ? q : C::N - 1;
+        const int qh = qc / C::WS, qw = qc % C::WS;
+        const float* trow = tq + ql * C::TSTR;
+
+        f32x16_t S[C::NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            S[t] = tile_times_qT<PREC, HD>(Ks + t * 32 * HD, lane, qf);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + acc_row(r, hh);
+                float v = -INFINITY;
+                if (key < C::N) {
+                    const int kh = key / C::WS, kw = key % C::WS;
+                    v = S[t][r] * scale + trow[qh - kh + C::WS - 1] + trow[32 + qw - kw + C::WS - 1];
+                }
+                S[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(S[t][r] - mx);
+                S[t][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+
+        // PV: O^T[d][q]
+        f32x16_t O[C::DT];
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint4 pb = pack_p<PREC>(S[t], u);
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) {
+                    const uint4 va = load_vt_frag(Vt + (dt * 32 + ql) * C::VSTR + 32 * t, u, hh);
+                    O[dt] = ET<PREC>::mfma32(va, pb, O[dt]);
+                }
+            }
+
+        // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
+        const int y = wy * C::WS + q / C::WS, x = wx * C::WS + q % C::WS;
+        if (qin && y < grid && x < grid) {
+            const float inv = 1.0f / sum;
+            uint16_t* orow = out + ((size_t)im * grid * grid + (size_t)y * grid + x) * D + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 32 * dt + 8 * g + 4 * hh;
+                    if (d0 < HD) {
+                        uint2 o;
+                        o.x = pack2<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
+                        o.y = pack2<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
+                        *reinterpret_cast<uint2*>(orow + d0) = o;
+                    }
+                }
+        }
+        __builtin_amdgcn_wave_barrier();  // scratch is rewritten by the next strip
+    }
+}
+
+// =========================================================================================
+// global attention (grid x grid tokens, flash-style online softmax).
+// Block = 128 queries of one (image, head): 4 waves x 32-query strips.  A strip lies inside one
+// image row half, so qh is wave-uniform and qw = qw0 + lane.  Keys are streamed one image row
+// (64 keys) per tile: kh = tile index, kw = position in the tile.
+// =========================================================================================
+template <int HD>
+struct GlbCfg {
+    static constexpr int G = 64, KT = 64;                 // grid side, keys per tile
+    static constexpr int DT = (HD + 31) / 32;
+    static constexpr int VSTR = KT + 4;                   // 68: 8-byte aligned, conflict-light
+    static constexpr int TAB_ROWS = 128;                  // 2*G-1 = 127 rows (+1 zero row)
+    static constexpr int TAB_BYTES = 2 * TAB_ROWS * HD * 2;      // rel_h | rel_w as ET
+    static constexpr int TW_STR = 97;                     // per-wave scratch row stride (floats)
+    static constexpr int TW_BYTES = 4 * 32 * TW_STR * 4;
+    static constexpr int K_BYTES = KT * HD * 2;
+    static constexpr int VT_BYTES = DT * 32 * VSTR * 2;
+    static constexpr int KV_BYTES = 2 * (K_BYTES + VT_BYTES);    // double buffered
+    static constexpr int UNION_BYTES = (TAB_BYTES + TW_BYTES) > KV_BYTES ? (TAB_BYTES + TW_BYTES) : KV_BYTES;
+    static constexpr int RH_STR = 65;
+    static constexpr int RH_BYTES = 4 * 32 * RH_STR * 4;
+    static constexpr int LDS_BYTES = UNION_BYTES + RH_BYTES;
+};
+
+template <int PREC, int HD>
+__global__ __launch_bounds__(256) void global_attention_kernel(
+    const uint16_t* __restrict__ qkv, const float* __restrict__ rel_h, const float* __restrict__ rel_w,
+    uint16_t* __restrict__ out, int heads) {
+    using C = GlbCfg<HD>;
+    constexpr int KS = HD / 16;
+    constexpr int G = C::G, NTOK = G * G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // setup view
+    uint16_t* Tab = reinterpret_cast<uint16_t*>(smem);                       // [2][128][HD]
+    float* TW = reinterpret_cast<float*>(smem + C::TAB_BYTES);               // [4][32][TW_STR]
+    // main-loop view (aliases the setup view)
+    // buffer b: K tile at b*(K_BYTES+VT_BYTES), V^T tile right after it (computed, not an array
+    // of pointers: runtime-indexed arrays end up in scratch)
+    auto Kb = [&](int b) { return reinterpret_cast<uint16_t*>(smem + b * (C::K_BYTES + C::VT_BYTES)); };
+    auto Vb = [&](int b) { return reinterpret_cast<uint16_t*>(smem + b * (C::K_BYTES + C::VT_BYTES) + C::K_BYTES); };
+    float* RH = reinterpret_cast<float*>(smem + C::UNION_BYTES);             // [4][32][RH_STR]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, ql = lane & 31;
+    const int qb = blockIdx.x, head = blockIdx.y, im = blockIdx.z;
+    const int D = heads * HD;
+    const uint16_t* base = qkv + (size_t)im * NTOK * (3 * D) + head * HD;
+
+    const int q = qb * 128 + wave * 32 + ql;
+    const int qh = q / G;                       // wave-uniform
+    const int qw0 = (qb * 128 + wave * 32) % G; // 0 or 32
+    uint4 qf[KS];
+    load_q_frags<KS>(base + (size_t)q * (3 * D), hh, qf);
+
+    // ---- setup: rel tables -> LDS (ET), T_h / T_w tiles -> scratch -> RH (LDS) / rw (regs) ----
+    for (int i = tid; i < 2 * C::TAB_ROWS * HD; i += 256) {
+        const int tsel = i / (C::TAB_ROWS * HD);
+        const int r = (i / HD) % C::TAB_ROWS, d = i % HD;
+        float v = 0.f;
+        if (r < 2 * G - 1) v = (tsel ? rel_w : rel_h)[r * HD + d];
+        Tab[i] = ET<PREC>::from_float(v);
+    }
+    __syncthreads();
+    float* rh = RH + wave * 32 * C::RH_STR + ql * C::RH_STR;
+    float* tw = TW + wave * 32 * C::TW_STR;
+    {
+        // T_h'[i'][q] = Q[q] . rel_h[qh + i'],  i' = 63 - kh  -> RH[q][kh]
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x16_t th = tile_times_qT<PREC, HD>(Tab + (qh + 32 * t) * HD, lane, qf);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rh[(G - 1) - (32 * t + acc_row(r, hh))] = th[r];
+        }
+        // T_w'[i'][q] = Q[q] . rel_w[qw0 + i'],  i' = ql - kw + 63  in [0, 94]
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const f32x16_t tt = tile_times_qT<PREC, HD>(Tab + (C::TAB_ROWS + qw0 + 32 * t) * HD, lane, qf);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tw[ql * C::TW_STR + 32 * t + acc_row(r, hh)] = tt[r];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float rw[2][16];  // rw[a][r] = RW[q][kw = 32a + acc_row(r, hh)]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rw[a][r] = tw[ql * C::TW_STR + ql - (32 * a + acc_row(r, hh)) + (G - 1)];
+    __syncthreads();  // everyone is done with Tab / TW before K/V tiles overwrite them
+
+    // ---- main loop over key tiles -----------------------------------------------------------
+    constexpr int CH = HD / 8;
+    constexpr int NCH = C::KT * CH;                 // 16-byte chunks per K (or V) tile
+    constexpr int PER = (NCH + 255) / 256;
+    uint4 rk[PER], rv[PER];
+    // straight-line, unconditional global loads (out-of-range chunk ids are clamped and simply
+    // not stored): conditionals / lambdas around these arrays push them into scratch.
+#define GLB_GLOAD(kt_)                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < PER; ++i_) {                                       \
+        int c_ = tid + 256 * i_;                                                                \
+        c_ = c_ < NCH ? c_ : NCH - 1;                                                           \
+        const int r_ = c_ / CH, ch_ = c_ % CH;                                                  \
+        const uint16_t* p_ = base + (size_t)((kt_) * C::KT + r_) * (3 * D) + ch_ * 8;           \
+        rk[i_] = *reinterpret_cast<const uint4*>(p_ + D);                                       \
+        rv[i_] = *reinterpret_cast<const uint4*>(p_ + 2 * D);                                   \
+    }
+#define GLB_LSTORE(buf_)                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < PER; ++i_) {                                       \
+        const int c_ = tid + 256 * i_;                                                          \
+        if (c_ < NCH) {                                                                         \
+            const int r_ = c_ / CH, ch_ = c_ % CH;                                              \
+            *reinterpret_cast<uint4*>(Kb(buf_) + r_ * HD + ch_ * 8) = rk[i_];                   \
+            _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_)                                    \
+                Vb(buf_)[(ch_ * 8 + e_) * C::VSTR + r_] = elem16(rv[i_], e_);                   \
+        }                                                                                       \
+    }
+    // rows d >= HD of V^T must be zero in both buffers (only when HD is not a multiple of 32)
+    if (C::DT * 32 > HD) {
+        for (int b = 0; b < 2; ++b)
+            for (int i = tid; i < (C::DT * 32 - HD) * C::VSTR; i += 256) Vb(b)[HD * C::VSTR + i] = 0;
+    }
+    GLB_GLOAD(0)
+    GLB_LSTORE(0)
+    __syncthreads();
+
+    const float scale = rsqrtf((float)HD);
+    f32x16_t O[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nkt = NTOK / C::KT;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        GLB_GLOAD(kt + 1 < nkt ? kt + 1 : kt)
+        const float bh = rh[kt];  // RH[q][kh = kt]
+
+        f32x16_t S[2];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            S[a] = tile_times_qT<PREC, HD>(Kb(buf) + a * 32 * HD, lane, qf);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = S[a][r] * scale + bh + rw[a][r];
+                S[a][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float sum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(S[a][r] - m_new);
+                S[a][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint4 pb = pack_p<PREC>(S[a], u);
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) {
+                    const uint4 va = load_vt_frag(Vb(buf) + (dt * 32 + ql) * C::VSTR + 32 * a, u, hh);
+                    O[dt] = ET<PREC>::mfma32(va, pb, O[dt]);
+                }
+            }
+        GLB_LSTORE(buf ^ 1)
+        __syncthreads();
+    }
+
+    const float inv = 1.0f / l_run;
+    uint16_t* orow = out + ((size_t)im * NTOK + q) * D + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 32 * dt + 8 * g + 4 * hh;
+            if (d0 < HD) {
+                uint2 o;
+                o.x = pack2<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
+                o.y = pack2<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + d0) = o;
+            }
+        }
+}
+
+// -----------------------------------------------------------------------------------------
+// neck: im2col for the 3x3 / pad 1 conv on a channels-last [img][g][g][C] ET tensor.
+// A[row = (img, y, x)][k = (ky*3 + kx)*C + c]; one thread per 16-byte chunk.
+// -----------------------------------------------------------------------------------------
+__global__ void neck_im2col_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ A, int n_images,
+                                   int grid, int C) {
+    const int cpr = 9 * C / 8;  // chunks per output row
+    const long total = (long)n_images * grid * grid * cpr;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int ch = t % cpr;
+    const long row = t / cpr;
+    const int tap = (ch * 8) / C, c0 = (ch * 8) % C;
+    const int x = row % grid, y = (row / grid) % grid;
+    const long im = row / ((long)grid * grid);
+    const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (yy >= 0 && yy < grid && xx >= 0 && xx < grid)
+        v = *reinterpret_cast<const uint4*>(in + ((im * grid + yy) * grid + xx) * C + c0);
+    *reinterpret_cast<uint4*>(A + row * (9L * C) + ch * 8) = v;
+}
+
+// [tokens][C] <-> [C][tokens] fp32 (embedding hand-over in the reference's NCHW layout)
+__global__ void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = by + j, c = bx + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = in[(size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+template <typename K>
+hipError_t set_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_patch_im2col(int prec, const uint8_t* img, void* A, int n_images, int in_h, int in_w,
+                               int grid, int patch, hipStream_t s) {
+    if (patch % 8) return hipErrorInvalidValue;
+    const long total = (long)n_images * grid * grid * patch * (patch / 8);
+    const int blocks = (int)((total + 255) / 256);
+    if (prec == PREC_BF16)
+        patch_im2col_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(img, (uint16_t*)A, n_images, in_h, in_w, grid, patch);
+    else
+        patch_im2col_kernel<PREC_F16><<<blocks, 256, 0, s>>>(img, (uint16_t*)A, n_images, in_h, in_w, grid, patch);
+    return hipGetLastError();
+}
+
+hipError_t launch_convert(int prec, const float* in, void* out, long n, hipStream_t s) {
+    if (n % 4) return hipErrorInvalidValue;
+    const long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256);
+    if (prec == PREC_BF16) convert_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(in, (uint16_t*)out, n4);
+    else convert_kernel<PREC_F16><<<blocks, 256, 0, s>>>(in, (uint16_t*)out, n4);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
+                            void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
+                            int window, hipStream_t s) {
+    if (D % 4 || D > LN_MAXV * 256) return hipErrorInvalidValue;
+    const int blocks = (rows_out + 3) / 4;
+    if (prec == PREC_BF16)
+        layernorm_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window);
+    else
+        layernorm_kernel<PREC_F16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window);
+    return hipGetLastError();
+}
+
+template <int PREC, int HD>
+static hipError_t launch_win(const void* qkv, const float* rh, const float* rw, void* out, int n_images,
+                             int grid, int heads, hipStream_t s) {
+    using C = WinCfg<HD>;
+    auto k = window_attention_kernel<PREC, HD>;
+    HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
+    const int nw = (grid + C::WS - 1) / C::WS;
+    dim3 g(n_images * nw * nw, heads), b(256);
+    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, rh, rw, (uint16_t*)out, grid, heads);
+    return hipGetLastError();
+}
+
+hipError_t launch_window_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
+                                   int n_images, int grid, int window, int heads, int head_dim, hipStream_t s) {
+    if (window != 14) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) {
+        if (head_dim == 64) return launch_win<PREC_BF16, 64>(qkv, rel_h, rel_w, out, n_images, grid, heads, s);
+        if (head_dim == 80) return launch_win<PREC_BF16, 80>(qkv, rel_h, rel_w, out, n_images, grid, heads, s);
+    } else if (prec == PREC_F16) {
+        if (head_dim == 64) return launch_win<PREC_F16, 64>(qkv, rel_h, rel_w, out, n_images, grid, heads, s);
+        if (head_dim == 80) return launch_win<PREC_F16, 80>(qkv, rel_h, rel_w, out, n_images, grid, heads, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int PREC, int HD>
+static hipError_t launch_glb(const void* qkv, const float* rh, const float* rw, void* out, int n_images,
+                             int heads, hipStream_t s) {
+    using C = GlbCfg<HD>;
+    auto k = global_attention_kernel<PREC, HD>;
+    HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
+    dim3 g(C::G * C::G / 128, heads, n_images), b(256);
+    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, rh, rw, (uint16_t*)out, heads);
+    return hipGetLastError();
+}
+
+hipError_t launch_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
+                                   int n_images, int grid, int heads, int head_dim, hipStream_t s) {
+    if (grid != 64) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) {
+        if (head_dim == 64) return launch_glb<PREC_BF16, 64>(qkv, rel_h, rel_w, out, n_images, heads, s);
+        if (head_dim == 80) return launch_glb<PREC_BF16, 80>(qkv, rel_h, rel_w, out, n_images, heads, s);
+    } else if (prec == PREC_F16) {
+        if (head_dim == 64) return launch_glb<PREC_F16, 64>(qkv, rel_h, rel_w, out, n_images, heads, s);
+        if (head_dim == 80) return launch_glb<PREC_F16, 80>(qkv, rel_h, rel_w, out, n_images, heads, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_neck_im2col(const void* in, void* A, int n_images, int grid, int C, hipStream_t s) {
+    if (C % 8) return hipErrorInvalidValue;
+    const long total = (long)n_images * grid * grid * (9 * C / 8);
+    neck_im2col_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>((const uint16_t*)in, (uint16_t*)A, n_images, grid, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t s) {
+    dim3 g((cols + 31) / 32, (rows + 31) / 32), b(32, 8);
+    transpose_f32_kernel<<<g, b, 0, s>>>(in, out, rows, cols);
+    return hipGetLastError();
+}

@@ -1,0 +1,699 @@
+// engine.hip -- the C ABI of libsamrs_hip.so (include/samrs_hip.h): engine handle, strict weight
+// loading + repacking, the encoder / decoder launch sequences.
+//
+// Launch sequences follow the reference graph, restated for this kernel set:
+//   set_images : modeling/sam.py:164-174 -> modeling/image_encoder.py:106-116,166-182,88-104
+//   predict    : modeling/prompt_encoder.py:128-173 -> modeling/mask_decoder.py:71-174 with
+//                modeling/transformer.py:62-106,151-182 -> modeling/sam.py:133-162
+// (paths under Generate Dataset/segment_anything/).  Image-side work shared by all prompts of a
+// call (layer-0 key/value/query projections when there is no mask prompt) is computed once.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/samrs_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+struct DevTensor {
+    float* p = nullptr;           // fp32 on device
+    std::vector<int64_t> shape;
+    size_t numel = 0;
+};
+
+struct DecAttn {
+    const float *qw, *qb, *kw, *kb, *vw, *vb, *ow, *ob;
+};
+
+struct DecLayer {
+    DecAttn self, t2i, i2t;
+    const float *n1w, *n1b, *n2w, *n2b, *n3w, *n3b, *n4w, *n4b;
+    const float *m1w, *m1b, *m2w, *m2b;
+    uint16_t* kvq_w = nullptr;    // ET [384][256] = [Wk_t2i; Wv_t2i; Wq_i2t]
+    float* kvq_b = nullptr;       // [384]
+    float* kvq_pe = nullptr;      // [tokens][384] = [PE Wk^T | 0 | PE Wq^T]
+    uint16_t* i2t_ow = nullptr;   // ET [256][128]
+};
+
+struct EncBlock {
+    bool global = false;
+    const float *ln1w, *ln1b, *ln2w, *ln2b, *qkv_b, *proj_b, *lin1_b, *lin2_b, *rel_h, *rel_w;
+    uint16_t *qkv_w = nullptr, *proj_w = nullptr, *lin1_w = nullptr, *lin2_w = nullptr;
+};
+
+}  // namespace
+
+struct samrs_engine {
+    samrs_config cfg{};
+    int device = 0;
+    int prec = 0;
+    bool finalized = false;
+    std::string err;
+    std::map<std::string, DevTensor> w;        // fp32 device copies keyed by reference name
+    std::vector<void*> owned;                   // everything hipMalloc'ed by the engine
+
+    // derived sizes
+    int grid = 64, tokens = 4096, D = 0, C = 256, hd = 0, nwin = 5;
+    int T_max = 0;
+
+    // encoder weights / workspaces
+    std::vector<EncBlock> blocks;
+    uint16_t *patch_w = nullptr, *neck0_w = nullptr, *neck2_w = nullptr;
+    float* X = nullptr;            // residual stream fp32 [Bi*tokens, D]
+    uint16_t* Y = nullptr;         // LN out (ET) [Mw_pad, D]
+    uint16_t* QKV = nullptr;       // [Mw_pad, 3D]
+    uint16_t* AO = nullptr;        // attention out [Bi*tokens, D]
+    uint16_t* H = nullptr;         // MLP hidden [Bi*tokens, 4D]  (also patch im2col / neck im2col)
+    float* N1 = nullptr;           // neck fp32 [Bi*tokens, C]
+    uint16_t* N1e = nullptr;       // [Bi*tokens, C]
+    float* EMB = nullptr;          // [slots][tokens][C] fp32 (token-major)
+    std::vector<char> slot_set;
+
+    // decoder weights
+    std::vector<DecLayer> layers;
+    DecAttn fin{};
+    uint16_t* fin_kv_w = nullptr;  // ET [256][256] = [Wk; Wv]
+    float *fin_kv_b = nullptr, *fin_pe = nullptr;
+    uint16_t *up1_w = nullptr, *up2_w = nullptr;
+    float *up1_b = nullptr, *up2_b = nullptr;
+    float* PE = nullptr;           // dense PE [tokens][C]
+
+    // decoder workspaces
+    float *TOK0 = nullptr, *Q = nullptr, *TA = nullptr, *TQ = nullptr, *TK = nullptr, *TV = nullptr, *TO = nullptr;
+    float *MH = nullptr, *QP = nullptr, *KT = nullptr, *VT = nullptr, *O128 = nullptr;
+    float *K0F = nullptr;          // shared layer-0 keys fp32 [tokens][C]
+    uint16_t* K0E = nullptr;
+    float* KF = nullptr;           // per-prompt keys fp32 [Bb*tokens][C]
+    uint16_t* KE = nullptr;
+    float* DENSE = nullptr;        // mask-prompt dense embedding (allocated on first use)
+    uint16_t* KVQ = nullptr;       // [Bb*tokens][384]
+    uint16_t* OI = nullptr;        // [Bb*tokens][128]
+    float* U1raw = nullptr;        // [Bb*tokens][256]
+    uint16_t* U1 = nullptr;        // [Bb*tokens][256]
+    uint16_t* U2 = nullptr;        // [Bb*tokens*4][128]
+    float *HY1 = nullptr, *HY2 = nullptr, *HYPER = nullptr, *IOU = nullptr, *LOW = nullptr;
+};
+
+namespace {
+
+int fail(samrs_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf;
+    return code;
+}
+
+#define CK(e, expr)                                                                                    \
+    do {                                                                                               \
+        hipError_t _err = (expr);                                                                      \
+        if (_err != hipSuccess)                                                                        \
+            return fail((e), SAMRS_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_err)); \
+    } while (0)
+
+template <typename T>
+hipError_t dalloc(samrs_engine* e, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t r = hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 16);
+    if (r != hipSuccess) return r;
+    e->owned.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return hipSuccess;
+}
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+bool is_global(const samrs_config& c, int i) {
+    for (int k = 0; k < c.n_global; ++k)
+        if (c.global_attn_indexes[k] == i) return true;
+    return false;
+}
+
+// ---- the strict name/shape contract -----------------------------------
+void required_tensors(const samrs_engine* e, std::vector<std::pair<std::string, std::vector<int64_t>>>& out) {
+    const samrs_config& c = e->cfg;
+    const int64_t D = c.embed_dim, g = e->grid, hd = e->hd, C = c.out_chans, P = c.patch_size;
+    auto add = [&](const std::string& n, std::vector<int64_t> s) { out.emplace_back(n, std::move(s)); };
+    add("image_encoder.pos_embed", {1, g, g, D});
+    add("image_encoder.patch_embed.proj.weight", {D, 3, P, P});
+    add("image_encoder.patch_embed.proj.bias", {D});
+    for (int i = 0; i < c.depth; ++i) {
+        const std::string p = "image_encoder.blocks." + std::to_string(i);
+        const int64_t s = is_global(c, i) ? g : c.window_size;
+        add(p + ".norm1.weight", {D}); add(p + ".norm1.bias", {D});
+        add(p + ".attn.rel_pos_h", {2 * s - 1, hd}); add(p + ".attn.rel_pos_w", {2 * s - 1, hd});
+        add(p + ".attn.qkv.weight", {3 * D, D}); add(p + ".attn.qkv.bias", {3 * D});
+        add(p + ".attn.proj.weight", {D, D}); add(p + ".attn.proj.bias", {D});
+        add(p + ".norm2.weight", {D}); add(p + ".norm2.bias", {D});
+        add(p + ".mlp.lin1.weight", {4 * D, D}); add(p + ".mlp.lin1.bias", {4 * D});
+        add(p + ".mlp.lin2.weight", {D, 4 * D}); add(p + ".mlp.lin2.bias", {D});
+    }
+    add("image_encoder.neck.0.weight", {C, D, 1, 1});
+    add("image_encoder.neck.1.weight", {C}); add("image_encoder.neck.1.bias", {C});
+    add("image_encoder.neck.2.weight", {C, C, 3, 3});
+    add("image_encoder.neck.3.weight", {C}); add("image_encoder.neck.3.bias", {C});
+    add("prompt_encoder.pe_layer.positional_encoding_gaussian_matrix", {2, C / 2});
+    for (int i = 0; i < 4; ++i) add("prompt_encoder.point_embeddings." + std::to_string(i) + ".weight", {1, C});
+    add("prompt_encoder.not_a_point_embed.weight", {1, C});
+    add("prompt_encoder.no_mask_embed.weight", {1, C});
+    add("prompt_encoder.mask_downscaling.0.weight", {4, 1, 2, 2}); add("prompt_encoder.mask_downscaling.0.bias", {4});
+    add("prompt_encoder.mask_downscaling.1.weight", {4}); add("prompt_encoder.mask_downscaling.1.bias", {4});
+    add("prompt_encoder.mask_downscaling.3.weight", {16, 4, 2, 2}); add("prompt_encoder.mask_downscaling.3.bias", {16});
+    add("prompt_encoder.mask_downscaling.4.weight", {16}); add("prompt_encoder.mask_downscaling.4.bias", {16});
+    add("prompt_encoder.mask_downscaling.6.weight", {C, 16, 1, 1}); add("prompt_encoder.mask_downscaling.6.bias", {C});
+    auto attn = [&](const std::string& p, int64_t internal) {
+        add(p + ".q_proj.weight", {internal, C}); add(p + ".q_proj.bias", {internal});
+        add(p + ".k_proj.weight", {internal, C}); add(p + ".k_proj.bias", {internal});
+        add(p + ".v_proj.weight", {internal, C}); add(p + ".v_proj.bias", {internal});
+        add(p + ".out_proj.weight", {C, internal}); add(p + ".out_proj.bias", {C});
+    };
+    for (int i = 0; i < 2; ++i) {
+        const std::string p = "mask_decoder.transformer.layers." + std::to_string(i);
+        attn(p + ".self_attn", C);
+        attn(p + ".cross_attn_token_to_image", C / 2);
+        attn(p + ".cross_attn_image_to_token", C / 2);
+        for (int k = 1; k <= 4; ++k) {
+            add(p + ".norm" + std::to_string(k) + ".weight", {C});
+            add(p + ".norm" + std::to_string(k) + ".bias", {C});
+        }
+        add(p + ".mlp.lin1.weight", {2048, C}); add(p + ".mlp.lin1.bias", {2048});
+        add(p + ".mlp.lin2.weight", {C, 2048}); add(p + ".mlp.lin2.bias", {C});
+    }
+    attn("mask_decoder.transformer.final_attn_token_to_image", C / 2);
+    add("mask_decoder.transformer.norm_final_attn.weight", {C}); add("mask_decoder.transformer.norm_final_attn.bias", {C});
+    add("mask_decoder.iou_token.weight", {1, C});
+    add("mask_decoder.mask_tokens.weight", {4, C});
+    add("mask_decoder.output_upscaling.0.weight", {C, C / 4, 2, 2}); add("mask_decoder.output_upscaling.0.bias", {C / 4});
+    add("mask_decoder.output_upscaling.1.weight", {C / 4}); add("mask_decoder.output_upscaling.1.bias", {C / 4});
+    add("mask_decoder.output_upscaling.3.weight", {C / 4, C / 8, 2, 2}); add("mask_decoder.output_upscaling.3.bias", {C / 8});
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "mask_decoder.output_hypernetworks_mlps." + std::to_string(i) + ".layers";
+        add(p + ".0.weight", {C, C}); add(p + ".0.bias", {C});
+        add(p + ".1.weight", {C, C}); add(p + ".1.bias", {C});
+        add(p + ".2.weight", {C / 8, C}); add(p + ".2.bias", {C / 8});
+    }
+    const std::string p = "mask_decoder.iou_prediction_head.layers";
+    add(p + ".0.weight", {C, C}); add(p + ".0.bias", {C});
+    add(p + ".1.weight", {C, C}); add(p + ".1.bias", {C});
+    add(p + ".2.weight", {4, C}); add(p + ".2.bias", {4});
+}
+
+const float* W(samrs_engine* e, const std::string& n) { return e->w.at(n).p; }
+
+DecAttn dec_attn(samrs_engine* e, const std::string& p) {
+    return DecAttn{W(e, p + ".q_proj.weight"), W(e, p + ".q_proj.bias"), W(e, p + ".k_proj.weight"),
+                   W(e, p + ".k_proj.bias"),   W(e, p + ".v_proj.weight"), W(e, p + ".v_proj.bias"),
+                   W(e, p + ".out_proj.weight"), W(e, p + ".out_proj.bias")};
+}
+
+// fp32 device tensor -> new ET device tensor; optionally frees the fp32 copy
+int to_et(samrs_engine* e, const std::string& name, uint16_t** out, bool free_f32, hipStream_t s) {
+    DevTensor& t = e->w.at(name);
+    CK(e, dalloc(e, out, t.numel));
+    CK(e, launch_convert(e->prec, t.p, *out, (long)t.numel, s));
+    if (free_f32) {
+        CK(e, hipStreamSynchronize(s));
+        for (auto it = e->owned.begin(); it != e->owned.end(); ++it)
+            if (*it == t.p) { e->owned.erase(it); break; }
+        CK(e, hipFree(t.p));
+        t.p = nullptr;
+    }
+    return SAMRS_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int samrs_abi_version(void) { return SAMRS_ABI_VERSION; }
+
+const char* samrs_last_error(const samrs_engine_t* e) { return e ? e->err.c_str() : "null engine"; }
+
+samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int err_len) {
+    auto bad = [&](const char* m) -> samrs_engine_t* {
+        if (err && err_len > 0) snprintf(err, err_len, "%s", m);
+        return nullptr;
+    };
+    if (!cfg) return bad("null config");
+    if (cfg->img_size != 1024 || cfg->patch_size != 16 || cfg->window_size != 14 || cfg->out_chans != 256)
+        return bad("only img_size 1024 / patch 16 / window 14 / out_chans 256 are supported (build_sam.py:62-80)");
+    if (cfg->embed_dim % 128 || cfg->embed_dim % cfg->num_heads) return bad("embed_dim must be a multiple of 128 and of num_heads");
+    const int hd = cfg->embed_dim / cfg->num_heads;
+    if (hd != 64 && hd != 80) return bad("head_dim must be 64 or 80");
+    if (cfg->precision != SAMRS_PREC_BF16 && cfg->precision != SAMRS_PREC_F16) return bad("bad precision");
+    if (cfg->max_images < 1 || cfg->max_prompts < 1 || cfg->max_points < 0 || cfg->n_global < 0 || cfg->n_global > 8)
+        return bad("bad capacity / n_global");
+    if (5 + cfg->max_points + 1 + 2 > 16) return bad("max_points too large (token count must stay <= 16)");
+    if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed (no HIP device? this library has no CPU fallback)");
+    samrs_engine* e = new samrs_engine();
+    e->cfg = *cfg;
+    e->device = device;
+    e->prec = cfg->precision;
+    e->grid = cfg->img_size / cfg->patch_size;
+    e->tokens = e->grid * e->grid;
+    e->D = cfg->embed_dim;
+    e->C = cfg->out_chans;
+    e->hd = hd;
+    e->nwin = (e->grid + cfg->window_size - 1) / cfg->window_size;
+    e->T_max = 5 + cfg->max_points + 1 + 2;
+    e->slot_set.assign(cfg->max_images, 0);
+    return e;
+}
+
+void samrs_destroy(samrs_engine_t* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    for (void* p : e->owned) (void)hipFree(p);
+    delete e;
+}
+
+int samrs_load_weight(samrs_engine_t* e, const char* name, const float* host, const int64_t* shape, int ndim) {
+    if (!e || !name || !host || !shape || ndim < 1 || ndim > 4) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_load_weight: bad argument");
+    if (e->finalized) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "weights already finalized");
+    CK(e, hipSetDevice(e->device));
+    DevTensor t;
+    t.shape.assign(shape, shape + ndim);
+    t.numel = 1;
+    for (int i = 0; i < ndim; ++i) t.numel *= (size_t)shape[i];
+    const std::string n(name);
+    std::vector<float> tmp;
+    const float* src = host;
+    if (n == "image_encoder.neck.2.weight" && ndim == 4) {
+        // [co][ci][ky][kx] -> [co][(ky*3+kx)*Ci + ci]  (k order of neck_im2col_kernel)
+        const int64_t Co = shape[0], Ci = shape[1], KH = shape[2], KW = shape[3];
+        tmp.resize(t.numel);
+        for (int64_t co = 0; co < Co; ++co)
+            for (int64_t ci = 0; ci < Ci; ++ci)
+                for (int64_t ky = 0; ky < KH; ++ky)
+                    for (int64_t kx = 0; kx < KW; ++kx)
+                        tmp[(co * KH * KW + ky * KW + kx) * Ci + ci] = host[((co * Ci + ci) * KH + ky) * KW + kx];
+        src = tmp.data();
+    } else if ((n == "mask_decoder.output_upscaling.0.weight" || n == "mask_decoder.output_upscaling.3.weight") && ndim == 4) {
+        // ConvTranspose2d [ci][co][dy][dx] -> GEMM B [(dy*2+dx)*Co + co][ci]   (mask_decoder.py:53-59)
+        const int64_t Ci = shape[0], Co = shape[1];
+        tmp.resize(t.numel);
+        for (int64_t ci = 0; ci < Ci; ++ci)
+            for (int64_t co = 0; co < Co; ++co)
+                for (int64_t s = 0; s < 4; ++s) tmp[(s * Co + co) * Ci + ci] = host[(ci * Co + co) * 4 + s];
+        src = tmp.data();
+    }
+    auto it = e->w.find(n);
+    if (it != e->w.end()) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "duplicate tensor %s", name);
+    CK(e, dalloc(e, &t.p, t.numel));
+    CK(e, hipMemcpy(t.p, src, t.numel * sizeof(float), hipMemcpyHostToDevice));
+    e->w.emplace(n, std::move(t));
+    return SAMRS_OK;
+}
+
+int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
+    if (!e) return SAMRS_ERR_BAD_ARG;
+    if (e->finalized) return SAMRS_OK;
+    hipStream_t s = (hipStream_t)stream;
+    CK(e, hipSetDevice(e->device));
+    // ---- strict check (build_sam.py:106 load_state_dict raises on any mismatch) ----
+    std::vector<std::pair<std::string, std::vector<int64_t>>> req;
+    required_tensors(e, req);
+    for (auto& r : req) {
+        auto it = e->w.find(r.first);
+        if (it == e->w.end()) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "missing tensor %s", r.first.c_str());
+        if (it->second.shape != r.second) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "shape mismatch for %s", r.first.c_str());
+    }
+    if (e->w.size() != req.size()) {
+        for (auto& kv : e->w) {
+            bool found = false;
+            for (auto& r : req) if (r.first == kv.first) { found = true; break; }
+            if (!found) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "unexpected tensor %s", kv.first.c_str());
+        }
+    }
+    const samrs_config& c = e->cfg;
+    const int D = e->D, C = e->C, tokens = e->tokens;
+    int rc;
+    // ---- encoder weights -> ET ----
+    if ((rc = to_et(e, "image_encoder.patch_embed.proj.weight", &e->patch_w, true, s))) return rc;
+    if ((rc = to_et(e, "image_encoder.neck.0.weight", &e->neck0_w, true, s))) return rc;
+    if ((rc = to_et(e, "image_encoder.neck.2.weight", &e->neck2_w, true, s))) return rc;
+    e->blocks.resize(c.depth);
+    for (int i = 0; i < c.depth; ++i) {
+        const std::string p = "image_encoder.blocks." + std::to_string(i);
+        EncBlock& b = e->blocks[i];
+        b.global = is_global(c, i);
+        if ((rc = to_et(e, p + ".attn.qkv.weight", &b.qkv_w, true, s))) return rc;
+        if ((rc = to_et(e, p + ".attn.proj.weight", &b.proj_w, true, s))) return rc;
+        if ((rc = to_et(e, p + ".mlp.lin1.weight", &b.lin1_w, true, s))) return rc;
+        if ((rc = to_et(e, p + ".mlp.lin2.weight", &b.lin2_w, true, s))) return rc;
+        b.ln1w = W(e, p + ".norm1.weight"); b.ln1b = W(e, p + ".norm1.bias");
+        b.ln2w = W(e, p + ".norm2.weight"); b.ln2b = W(e, p + ".norm2.bias");
+        b.qkv_b = W(e, p + ".attn.qkv.bias"); b.proj_b = W(e, p + ".attn.proj.bias");
+        b.lin1_b = W(e, p + ".mlp.lin1.bias"); b.lin2_b = W(e, p + ".mlp.lin2.bias");
+        b.rel_h = W(e, p + ".attn.rel_pos_h"); b.rel_w = W(e, p + ".attn.rel_pos_w");
+    }
+    // ---- decoder: dense PE, fused image-side projection weights, PE projections ----
+    CK(e, dalloc(e, &e->PE, (size_t)tokens * C));
+    CK(e, launch_dense_pe(W(e, "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"), e->PE, e->grid, s));
+    const int Ci = C / 2;  // 128
+    float* tmpw = nullptr;
+    CK(e, dalloc(e, &tmpw, (size_t)3 * Ci * C));
+    e->layers.resize(2);
+    for (int i = 0; i < 2; ++i) {
+        const std::string p = "mask_decoder.transformer.layers." + std::to_string(i);
+        DecLayer& L = e->layers[i];
+        L.self = dec_attn(e, p + ".self_attn");
+        L.t2i = dec_attn(e, p + ".cross_attn_token_to_image");
+        L.i2t = dec_attn(e, p + ".cross_attn_image_to_token");
+        L.n1w = W(e, p + ".norm1.weight"); L.n1b = W(e, p + ".norm1.bias");
+        L.n2w = W(e, p + ".norm2.weight"); L.n2b = W(e, p + ".norm2.bias");
+        L.n3w = W(e, p + ".norm3.weight"); L.n3b = W(e, p + ".norm3.bias");
+        L.n4w = W(e, p + ".norm4.weight"); L.n4b = W(e, p + ".norm4.bias");
+        L.m1w = W(e, p + ".mlp.lin1.weight"); L.m1b = W(e, p + ".mlp.lin1.bias");
+        L.m2w = W(e, p + ".mlp.lin2.weight"); L.m2b = W(e, p + ".mlp.lin2.bias");
+        // [Wk_t2i; Wv_t2i; Wq_i2t]
+        CK(e, hipMemcpyAsync(tmpw, L.t2i.kw, sizeof(float) * Ci * C, hipMemcpyDeviceToDevice, s));
+        CK(e, hipMemcpyAsync(tmpw + Ci * C, L.t2i.vw, sizeof(float) * Ci * C, hipMemcpyDeviceToDevice, s));
+        CK(e, hipMemcpyAsync(tmpw + 2 * Ci * C, L.i2t.qw, sizeof(float) * Ci * C, hipMemcpyDeviceToDevice, s));
+        CK(e, dalloc(e, &L.kvq_w, (size_t)3 * Ci * C));
+        CK(e, launch_convert(e->prec, tmpw, L.kvq_w, (long)3 * Ci * C, s));
+        CK(e, dalloc(e, &L.kvq_b, (size_t)3 * Ci));
+        CK(e, hipMemcpyAsync(L.kvq_b, L.t2i.kb, sizeof(float) * Ci, hipMemcpyDeviceToDevice, s));
+        CK(e, hipMemcpyAsync(L.kvq_b + Ci, L.t2i.vb, sizeof(float) * Ci, hipMemcpyDeviceToDevice, s));
+        CK(e, hipMemcpyAsync(L.kvq_b + 2 * Ci, L.i2t.qb, sizeof(float) * Ci, hipMemcpyDeviceToDevice, s));
+        CK(e, dalloc(e, &L.kvq_pe, (size_t)tokens * 3 * Ci));
+        CK(e, hipMemsetAsync(L.kvq_pe, 0, sizeof(float) * tokens * 3 * Ci, s));
+        CK(e, launch_gemm_f32(e->PE, C, L.t2i.kw, nullptr, L.kvq_pe, 3 * Ci, tokens, Ci, C, false, false, s));
+        CK(e, launch_gemm_f32(e->PE, C, L.i2t.qw, nullptr, L.kvq_pe + 2 * Ci, 3 * Ci, tokens, Ci, C, false, false, s));
+        if ((rc = to_et(e, p + ".cross_attn_image_to_token.out_proj.weight", &L.i2t_ow, false, s))) return rc;
+    }
+    e->fin = dec_attn(e, "mask_decoder.transformer.final_attn_token_to_image");
+    CK(e, hipMemcpyAsync(tmpw, e->fin.kw, sizeof(float) * Ci * C, hipMemcpyDeviceToDevice, s));
+    CK(e, hipMemcpyAsync(tmpw + Ci * C, e->fin.vw, sizeof(float) * Ci * C, hipMemcpyDeviceToDevice, s));
+    CK(e, dalloc(e, &e->fin_kv_w, (size_t)2 * Ci * C));
+    CK(e, launch_convert(e->prec, tmpw, e->fin_kv_w, (long)2 * Ci * C, s));
+    CK(e, dalloc(e, &e->fin_kv_b, (size_t)2 * Ci));
+    CK(e, hipMemcpyAsync(e->fin_kv_b, e->fin.kb, sizeof(float) * Ci, hipMemcpyDeviceToDevice, s));
+    CK(e, hipMemcpyAsync(e->fin_kv_b + Ci, e->fin.vb, sizeof(float) * Ci, hipMemcpyDeviceToDevice, s));
+    CK(e, dalloc(e, &e->fin_pe, (size_t)tokens * 2 * Ci));
+    CK(e, hipMemsetAsync(e->fin_pe, 0, sizeof(float) * tokens * 2 * Ci, s));
+    CK(e, launch_gemm_f32(e->PE, C, e->fin.kw, nullptr, e->fin_pe, 2 * Ci, tokens, Ci, C, false, false, s));
+    // upscaler: weights were reordered at load to GEMM-B layout; biases are tiled over the 4 sub-pixels
+    if ((rc = to_et(e, "mask_decoder.output_upscaling.0.weight", &e->up1_w, false, s))) return rc;
+    if ((rc = to_et(e, "mask_decoder.output_upscaling.3.weight", &e->up2_w, false, s))) return rc;
+    CK(e, dalloc(e, &e->up1_b, (size_t)C));
+    CK(e, dalloc(e, &e->up2_b, (size_t)C / 2));
+    for (int k = 0; k < 4; ++k) {
+        CK(e, hipMemcpyAsync(e->up1_b + k * (C / 4), W(e, "mask_decoder.output_upscaling.0.bias"), sizeof(float) * C / 4, hipMemcpyDeviceToDevice, s));
+        CK(e, hipMemcpyAsync(e->up2_b + k * (C / 8), W(e, "mask_decoder.output_upscaling.3.bias"), sizeof(float) * C / 8, hipMemcpyDeviceToDevice, s));
+    }
+
+    // ---- workspaces ----
+    const size_t Bi = c.max_images, Bb = c.max_prompts;
+    const size_t M = Bi * tokens;
+    const size_t Mw = round_up(Bi * e->nwin * e->nwin * c.window_size * c.window_size, 128);
+    const size_t Mmax = Mw > M ? Mw : M;
+    CK(e, dalloc(e, &e->X, M * D));
+    CK(e, dalloc(e, &e->Y, Mmax * D));
+    CK(e, hipMemsetAsync(e->Y, 0, Mmax * D * 2, s));
+    CK(e, dalloc(e, &e->QKV, Mmax * 3 * D));
+    CK(e, dalloc(e, &e->AO, M * D));
+    size_t hsz = M * 4 * D;
+    if (M * 9 * C > hsz) hsz = M * 9 * C;
+    if (M * 768 > hsz) hsz = M * 768;
+    CK(e, dalloc(e, &e->H, hsz));
+    CK(e, dalloc(e, &e->N1, M * C));
+    CK(e, dalloc(e, &e->N1e, M * C));
+    CK(e, dalloc(e, &e->EMB, M * C));
+    const size_t BT = Bb * e->T_max;
+    CK(e, dalloc(e, &e->TOK0, BT * C)); CK(e, dalloc(e, &e->Q, BT * C)); CK(e, dalloc(e, &e->TA, BT * C));
+    CK(e, dalloc(e, &e->TQ, BT * C)); CK(e, dalloc(e, &e->TK, BT * C)); CK(e, dalloc(e, &e->TV, BT * C));
+    CK(e, dalloc(e, &e->TO, BT * C)); CK(e, dalloc(e, &e->MH, BT * 2048));
+    CK(e, dalloc(e, &e->QP, BT * Ci)); CK(e, dalloc(e, &e->KT, BT * Ci)); CK(e, dalloc(e, &e->VT, BT * Ci));
+    CK(e, dalloc(e, &e->O128, BT * Ci));
+    CK(e, dalloc(e, &e->K0F, (size_t)tokens * C)); CK(e, dalloc(e, &e->K0E, (size_t)tokens * C));
+    CK(e, dalloc(e, &e->KF, Bb * tokens * C)); CK(e, dalloc(e, &e->KE, Bb * tokens * C));
+    CK(e, dalloc(e, &e->KVQ, Bb * tokens * 3 * Ci)); CK(e, dalloc(e, &e->OI, Bb * tokens * Ci));
+    CK(e, dalloc(e, &e->U1raw, Bb * tokens * C)); CK(e, dalloc(e, &e->U1, Bb * tokens * C));
+    CK(e, dalloc(e, &e->U2, Bb * tokens * 4 * (C / 2)));
+    CK(e, dalloc(e, &e->HY1, Bb * C)); CK(e, dalloc(e, &e->HY2, Bb * C));
+    CK(e, dalloc(e, &e->HYPER, Bb * 4 * (C / 8))); CK(e, dalloc(e, &e->IOU, Bb * 4));
+    CK(e, dalloc(e, &e->LOW, Bb * 3 * 256 * 256));
+    CK(e, hipStreamSynchronize(s));
+    e->finalized = true;
+    return SAMRS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int samrs_set_images(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int in_w, int slot0, void* stream) {
+    if (!e || !images) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_set_images: null argument");
+    if (!e->finalized) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "weights not finalized");
+    const samrs_config& c = e->cfg;
+    if (n < 1 || slot0 < 0 || slot0 + n > c.max_images) return fail(e, SAMRS_ERR_CAPACITY, "n_images/slot out of range (max_images=%d)", c.max_images);
+    if (in_h < 1 || in_w < 1 || in_h > c.img_size || in_w > c.img_size || (in_h != c.img_size && in_w != c.img_size))
+        return fail(e, SAMRS_ERR_BAD_SHAPE, "set_torch_image input must be BCHW with long side %d.", c.img_size);
+    hipStream_t s = (hipStream_t)stream;
+    CK(e, hipSetDevice(e->device));
+    const int D = e->D, C = e->C, g = e->grid, tokens = e->tokens, prec = e->prec;
+    const int M = n * tokens;
+    const int Mw = n * e->nwin * e->nwin * c.window_size * c.window_size;
+    const int Mw_pad = (int)round_up(Mw, 128);
+    for (int i = 0; i < n; ++i) e->slot_set[slot0 + i] = 0;
+
+    // patch embed: im2col (normalise + zero pad) -> GEMM (+bias +pos_embed) -> X
+    CK(e, launch_patch_im2col(prec, images, e->H, n, in_h, in_w, g, c.patch_size, s));
+    CK(e, launch_gemm_et(prec, e->H, e->patch_w, e->X, W(e, "image_encoder.patch_embed.proj.bias"),
+                         W(e, "image_encoder.pos_embed"), tokens, M, D, 3 * c.patch_size * c.patch_size, true, false, false, s));
+    for (int i = 0; i < c.depth; ++i) {
+        const EncBlock& b = e->blocks[i];
+        if (!b.global) {
+            CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, Mw, D, 1, g, c.window_size, s));
+            CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, Mw_pad, 3 * D, D, false, false, false, s));
+            CK(e, launch_window_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s));
+        } else {
+            CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
+            CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
+            CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, s));
+        }
+        CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
+        CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
+        CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
+        CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
+    }
+    // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d   (all channels-last)
+    CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s));
+    CK(e, launch_gemm_et(prec, e->Y, e->neck0_w, e->N1, nullptr, nullptr, 0, M, C, D, true, false, false, s));
+    CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.1.weight"), W(e, "image_encoder.neck.1.bias"), 1e-6f,
+                           e->N1e, nullptr, M, C, 0, g, 0, s));
+    CK(e, launch_neck_im2col(e->N1e, e->H, n, g, C, s));
+    CK(e, launch_gemm_et(prec, e->H, e->neck2_w, e->N1, nullptr, nullptr, 0, M, C, 9 * C, true, false, false, s));
+    CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.3.weight"), W(e, "image_encoder.neck.3.bias"), 1e-6f,
+                           nullptr, e->EMB + (size_t)slot0 * tokens * C, M, C, 0, g, 0, s));
+    for (int i = 0; i < n; ++i) e->slot_set[slot0 + i] = 1;
+    return SAMRS_OK;
+}
+
+int samrs_get_embedding(samrs_engine_t* e, int slot, float* out_chw, void* stream) {
+    if (!e || !out_chw) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_get_embedding: null argument");
+    if (slot < 0 || slot >= e->cfg.max_images) return fail(e, SAMRS_ERR_CAPACITY, "slot out of range");
+    if (!e->slot_set[slot]) return fail(e, SAMRS_ERR_NOT_SET, "An image must be set with .set_image(...) to generate an embedding.");
+    CK(e, hipSetDevice(e->device));
+    CK(e, launch_transpose_f32(e->EMB + (size_t)slot * e->tokens * e->C, out_chw, e->tokens, e->C, (hipStream_t)stream));
+    return SAMRS_OK;
+}
+
+int samrs_set_embedding(samrs_engine_t* e, int slot, const float* emb_chw, void* stream) {
+    if (!e || !emb_chw) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_set_embedding: null argument");
+    if (!e->finalized) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "weights not finalized");
+    if (slot < 0 || slot >= e->cfg.max_images) return fail(e, SAMRS_ERR_CAPACITY, "slot out of range");
+    CK(e, hipSetDevice(e->device));
+    CK(e, launch_transpose_f32(emb_chw, e->EMB + (size_t)slot * e->tokens * e->C, e->C, e->tokens, (hipStream_t)stream));
+    e->slot_set[slot] = 1;
+    return SAMRS_OK;
+}
+
+int samrs_reset_image(samrs_engine_t* e, int slot) {
+    if (!e) return SAMRS_ERR_BAD_ARG;
+    if (slot < 0 || slot >= e->cfg.max_images) return fail(e, SAMRS_ERR_CAPACITY, "slot out of range");
+    e->slot_set[slot] = 0;
+    return SAMRS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const float* point_coords,
+                  const int32_t* point_labels, int n_points, const float* mask_input, int multimask,
+                  int return_logits, int in_h, int in_w, int orig_h, int orig_w, void* masks_out, float* iou_out,
+                  float* lowres_out, void* stream) {
+    if (!e) return SAMRS_ERR_BAD_ARG;
+    if (!e->finalized) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "weights not finalized");
+    const samrs_config& c = e->cfg;
+    if (slot < 0 || slot >= c.max_images) return fail(e, SAMRS_ERR_CAPACITY, "slot out of range");
+    if (!e->slot_set[slot]) return fail(e, SAMRS_ERR_NOT_SET, "An image must be set with .set_image(...) before mask prediction.");
+    if (n < 1 || n > c.max_prompts) return fail(e, SAMRS_ERR_CAPACITY, "n_prompts=%d exceeds max_prompts=%d", n, c.max_prompts);
+    if (point_coords && !point_labels) return fail(e, SAMRS_ERR_BAD_ARG, "point_labels must be supplied if point_coords is supplied.");
+    if (point_coords && (n_points < 1 || n_points > c.max_points)) return fail(e, SAMRS_ERR_CAPACITY, "n_points=%d exceeds max_points=%d", n_points, c.max_points);
+    if (in_h < 1 || in_w < 1 || in_h > c.img_size || in_w > c.img_size || orig_h < 1 || orig_w < 1)
+        return fail(e, SAMRS_ERR_BAD_SHAPE, "bad input/original size");
+    hipStream_t s = (hipStream_t)stream;
+    CK(e, hipSetDevice(e->device));
+    const int C = e->C, Ci = C / 2, tokens = e->tokens, prec = e->prec, g = e->grid;
+    const int npt = point_coords ? n_points + (boxes ? 0 : 1) : 0;
+    const int T = 5 + npt + (boxes ? 2 : 0);
+    const int BT = n * T;
+    const int Mi = n * tokens;
+    auto lin = [&](const float* A, int lda, const float* Wt, const float* b, float* Cout, int ldc, int M, int N, int K,
+                   bool relu, bool acc) { return launch_gemm_f32(A, lda, Wt, b, Cout, ldc, M, N, K, relu, acc, s); };
+    auto ln_tok = [&](const float* gw, const float* gb) {
+        return launch_layernorm(prec, e->Q, gw, gb, 1e-5f, nullptr, e->Q, BT, C, 0, g, 0, s);
+    };
+
+    // ---- prompt encoder (prompt_encoder.py:128-173) ----
+    PromptParams pp{};
+    pp.boxes = boxes; pp.point_coords = point_coords; pp.point_labels = point_labels;
+    pp.n_prompts = n; pp.n_points = point_coords ? n_points : 0;
+    pp.img_size = (float)c.img_size;
+    pp.gauss = W(e, "prompt_encoder.pe_layer.positional_encoding_gaussian_matrix");
+    for (int i = 0; i < 4; ++i) pp.point_emb[i] = W(e, "prompt_encoder.point_embeddings." + std::to_string(i) + ".weight");
+    pp.not_a_point = W(e, "prompt_encoder.not_a_point_embed.weight");
+    pp.iou_token = W(e, "mask_decoder.iou_token.weight");
+    pp.mask_tokens = W(e, "mask_decoder.mask_tokens.weight");
+    CK(e, launch_prompt_tokens(pp, e->TOK0, T, s));
+    CK(e, hipMemcpyAsync(e->Q, e->TOK0, sizeof(float) * BT * C, hipMemcpyDeviceToDevice, s));
+
+    const float* emb = e->EMB + (size_t)slot * tokens * C;
+    const bool shared0 = (mask_input == nullptr);
+    if (shared0) {
+        CK(e, launch_make_keys(prec, emb, nullptr, W(e, "prompt_encoder.no_mask_embed.weight"), e->K0F, e->K0E, 1, tokens, C, s));
+    } else {
+        if (!e->DENSE) CK(e, dalloc(e, &e->DENSE, (size_t)c.max_prompts * tokens * C));
+        MaskEmbedParams mp{W(e, "prompt_encoder.mask_downscaling.0.weight"), W(e, "prompt_encoder.mask_downscaling.0.bias"),
+                           W(e, "prompt_encoder.mask_downscaling.1.weight"), W(e, "prompt_encoder.mask_downscaling.1.bias"),
+                           W(e, "prompt_encoder.mask_downscaling.3.weight"), W(e, "prompt_encoder.mask_downscaling.3.bias"),
+                           W(e, "prompt_encoder.mask_downscaling.4.weight"), W(e, "prompt_encoder.mask_downscaling.4.bias"),
+                           W(e, "prompt_encoder.mask_downscaling.6.weight"), W(e, "prompt_encoder.mask_downscaling.6.bias")};
+        CK(e, launch_mask_embed(mp, mask_input, e->DENSE, n, g, s));
+        CK(e, launch_make_keys(prec, emb, e->DENSE, nullptr, e->KF, e->KE, n, tokens, C, s));
+    }
+
+    // ---- two-way transformer (transformer.py:62-106,151-182) ----
+    for (int li = 0; li < 2; ++li) {
+        const DecLayer& L = e->layers[li];
+        const bool sh = shared0 && li == 0;     // image side still identical for every prompt
+        // (1) token self attention
+        const float* qin = e->Q;
+        if (li > 0) { CK(e, launch_add_f32(e->Q, e->TOK0, e->TA, (long)BT * C, s)); qin = e->TA; }
+        CK(e, lin(qin, C, L.self.qw, L.self.qb, e->TQ, C, BT, C, C, false, false));
+        CK(e, lin(qin, C, L.self.kw, L.self.kb, e->TK, C, BT, C, C, false, false));
+        CK(e, lin(e->Q, C, L.self.vw, L.self.vb, e->TV, C, BT, C, C, false, false));
+        CK(e, launch_token_self_attn(e->TQ, e->TK, e->TV, e->TO, n, T, C, 8, s));
+        CK(e, lin(e->TO, C, L.self.ow, L.self.ob, e->Q, C, BT, C, C, false, li > 0));
+        CK(e, ln_tok(L.n1w, L.n1b));
+        // image-side projections for this layer: K_t2i | V_t2i | Q_i2t  (PE folded in as add2d)
+        const uint16_t* keys_et = sh ? e->K0E : e->KE;
+        const long bstride = sh ? 0 : tokens;
+        CK(e, launch_gemm_et(prec, keys_et, L.kvq_w, e->KVQ, L.kvq_b, L.kvq_pe, tokens, sh ? tokens : Mi, 3 * Ci, C, false, false, false, s));
+        // (2) tokens -> image
+        CK(e, launch_add_f32(e->Q, e->TOK0, e->TA, (long)BT * C, s));
+        CK(e, lin(e->TA, C, L.t2i.qw, L.t2i.qb, e->QP, Ci, BT, Ci, C, false, false));
+        CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 3 * Ci, bstride, e->O128, n, T, tokens, Ci, 8, s));
+        CK(e, lin(e->O128, Ci, L.t2i.ow, L.t2i.ob, e->Q, C, BT, C, Ci, false, true));
+        CK(e, ln_tok(L.n2w, L.n2b));
+        // (3) MLP (ReLU)
+        CK(e, lin(e->Q, C, L.m1w, L.m1b, e->MH, 2048, BT, 2048, C, true, false));
+        CK(e, lin(e->MH, 2048, L.m2w, L.m2b, e->Q, C, BT, C, 2048, false, true));
+        CK(e, ln_tok(L.n3w, L.n3b));
+        // (4) image -> tokens
+        CK(e, launch_add_f32(e->Q, e->TOK0, e->TA, (long)BT * C, s));
+        CK(e, lin(e->TA, C, L.i2t.kw, L.i2t.kb, e->KT, Ci, BT, Ci, C, false, false));
+        CK(e, lin(e->Q, C, L.i2t.vw, L.i2t.vb, e->VT, Ci, BT, Ci, C, false, false));
+        CK(e, launch_i2t_attention(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, e->OI, n, T, tokens, Ci, 8, s));
+        if (sh)
+            CK(e, launch_gemm_et(prec, e->OI, L.i2t_ow, e->KF, L.i2t.ob, e->K0F, tokens, Mi, C, Ci, true, false, false, s));
+        else
+            CK(e, launch_gemm_et(prec, e->OI, L.i2t_ow, e->KF, L.i2t.ob, nullptr, 0, Mi, C, Ci, true, false, true, s));
+        CK(e, launch_layernorm(prec, e->KF, L.n4w, L.n4b, 1e-5f, e->KE, e->KF, Mi, C, 0, g, 0, s));
+    }
+    // final tokens -> image attention (transformer.py:98-104)
+    CK(e, launch_add_f32(e->Q, e->TOK0, e->TA, (long)BT * C, s));
+    CK(e, lin(e->TA, C, e->fin.qw, e->fin.qb, e->QP, Ci, BT, Ci, C, false, false));
+    CK(e, launch_gemm_et(prec, e->KE, e->fin_kv_w, e->KVQ, e->fin_kv_b, e->fin_pe, tokens, Mi, 2 * Ci, C, false, false, false, s));
+    CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 2 * Ci, tokens, e->O128, n, T, tokens, Ci, 8, s));
+    CK(e, lin(e->O128, Ci, e->fin.ow, e->fin.ob, e->Q, C, BT, C, Ci, false, true));
+    CK(e, ln_tok(W(e, "mask_decoder.transformer.norm_final_attn.weight"), W(e, "mask_decoder.transformer.norm_final_attn.bias")));
+
+    // ---- heads (mask_decoder.py:156-172) ----
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "mask_decoder.output_hypernetworks_mlps." + std::to_string(i) + ".layers";
+        CK(e, lin(e->Q + (size_t)(1 + i) * C, T * C, W(e, p + ".0.weight"), W(e, p + ".0.bias"), e->HY1, C, n, C, C, true, false));
+        CK(e, lin(e->HY1, C, W(e, p + ".1.weight"), W(e, p + ".1.bias"), e->HY2, C, n, C, C, true, false));
+        CK(e, lin(e->HY2, C, W(e, p + ".2.weight"), W(e, p + ".2.bias"), e->HYPER + i * (C / 8), 4 * (C / 8), n, C / 8, C, false, false));
+    }
+    {
+        const std::string p = "mask_decoder.iou_prediction_head.layers";
+        CK(e, lin(e->Q, T * C, W(e, p + ".0.weight"), W(e, p + ".0.bias"), e->HY1, C, n, C, C, true, false));
+        CK(e, lin(e->HY1, C, W(e, p + ".1.weight"), W(e, p + ".1.bias"), e->HY2, C, n, C, C, true, false));
+        CK(e, lin(e->HY2, C, W(e, p + ".2.weight"), W(e, p + ".2.bias"), e->IOU, 4, n, 4, C, false, false));
+    }
+    // ---- upscaler (mask_decoder.py:53-59,154-155) as two GEMMs + fused tail ----
+    CK(e, launch_gemm_et(prec, e->KE, e->up1_w, e->U1raw, e->up1_b, nullptr, 0, Mi, C, C, true, false, false, s));
+    CK(e, launch_group_ln_gelu(prec, e->U1raw, W(e, "mask_decoder.output_upscaling.1.weight"),
+                               W(e, "mask_decoder.output_upscaling.1.bias"), 1e-6f, e->U1, (long)Mi, 4, C / 4, s));
+    CK(e, launch_gemm_et(prec, e->U1, e->up2_w, e->U2, e->up2_b, nullptr, 0, Mi * 4, C / 2, C / 4, false, true, false, s));
+    const int sel0 = multimask ? 1 : 0, nsel = multimask ? 3 : 1;     // mask_decoder.py:102-107
+    float* low = lowres_out ? lowres_out : e->LOW;
+    CK(e, launch_mask_product(prec, e->U2, e->HYPER, low, n, g, 4, sel0, nsel, s));
+    if (iou_out)
+        CK(e, hipMemcpy2DAsync(iou_out, sizeof(float) * nsel, e->IOU + sel0, sizeof(float) * 4, sizeof(float) * nsel, n,
+                               hipMemcpyDeviceToDevice, s));
+    // ---- postprocess (sam.py:133-162) + threshold (predictor.py:242-243) ----
+    if (masks_out)
+        CK(e, launch_postprocess(low, n * nsel, in_h, in_w, orig_h, orig_w, c.img_size, return_logits, masks_out, s));
+    return SAMRS_OK;
+}
+
+int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, int n, int h, int w, uint8_t* seg,
+                int64_t* areas, int64_t* cpix, int64_t* cins, int n_classes, void* stream) {
+    if (!e || !masks || !labels || n < 1 || h < 1 || w < 1) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_paint: bad argument");
+    if ((cpix || cins) && !areas) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_paint: class statistics need areas_out");
+    CK(e, hipSetDevice(e->device));
+    CK(e, launch_paint(masks, labels, n, h, w, seg, (unsigned long long*)areas, (unsigned long long*)cpix,
+                       (unsigned long long*)cins, n_classes, (hipStream_t)stream));
+    return SAMRS_OK;
+}
+
+// ---- kernel-level entry points -------------------------------------------------------------------
+#define KRET(expr) do { hipError_t _e = (expr); return _e == hipSuccess ? SAMRS_OK : SAMRS_ERR_HIP; } while (0)
+
+int samrs_k_gemm(int prec, const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
+                 int M, int N, int K, int out_f32, int gelu, int accumulate, void* stream) {
+    KRET(launch_gemm_et(prec, A, B, C, bias, add2d, period, M, N, K, out_f32 != 0, gelu != 0, accumulate != 0, (hipStream_t)stream));
+}
+int samrs_k_gemm_f32(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M, int N, int K,
+                     int relu, int accumulate, void* stream) {
+    KRET(launch_gemm_f32(A, lda, Wt, bias, C, ldc, M, N, K, relu != 0, accumulate != 0, (hipStream_t)stream));
+}
+int samrs_k_convert(int prec, const float* in, void* out, int64_t n, void* stream) {
+    KRET(launch_convert(prec, in, out, (long)n, (hipStream_t)stream));
+}
+int samrs_k_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps, void* out_et,
+                      float* out_f32, int rows_out, int D, int window_mode, int n_images, int grid, int window, void* stream) {
+    (void)n_images;
+    KRET(launch_layernorm(prec, X, gamma, beta, eps, out_et, out_f32, rows_out, D, window_mode, grid, window, (hipStream_t)stream));
+}
+int samrs_k_window_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out, int n_images,
+                             int grid, int window, int heads, int head_dim, void* stream) {
+    KRET(launch_window_attention(prec, qkv, rel_h, rel_w, out, n_images, grid, window, heads, head_dim, (hipStream_t)stream));
+}
+int samrs_k_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out, int n_images,
+                             int grid, int heads, int head_dim, void* stream) {
+    KRET(launch_global_attention(prec, qkv, rel_h, rel_w, out, n_images, grid, heads, head_dim, (hipStream_t)stream));
+}
+int samrs_k_postprocess(const float* low, int n_masks, int in_h, int in_w, int orig_h, int orig_w, int img_size,
+                        int return_logits, void* out, void* stream) {
+    KRET(launch_postprocess(low, n_masks, in_h, in_w, orig_h, orig_w, img_size, return_logits, out, (hipStream_t)stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// kernels.h -- host-side launchers of every HIP kernel in libsamrs_hip (internal header).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- gemm.hip -------------------------------------------------------------------------------
+hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const float* bias,
+                          const float* add2d, int add2d_period, int M, int N, int K, bool out_f32,
+                          bool gelu, bool accumulate, hipStream_t s);
+hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
+                           int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s);
+
+// ---- encoder_kernels.hip --------------------------------------------------------------------
+hipError_t launch_patch_im2col(int prec, const uint8_t* img, void* A, int n_images, int in_h, int in_w,
+                               int grid, int patch, hipStream_t s);
+hipError_t launch_convert(int prec, const float* in, void* out, long n, hipStream_t s);
+hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
+                            void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
+                            int window, hipStream_t s);
+hipError_t launch_window_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
+                                   int n_images, int grid, int window, int heads, int head_dim, hipStream_t s);
+hipError_t launch_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
+                                   int n_images, int grid, int heads, int head_dim, hipStream_t s);
+hipError_t launch_neck_im2col(const void* in, void* A, int n_images, int grid, int C, hipStream_t s);
+hipError_t launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t s);
+
+// ---- decoder_kernels.hip --------------------------------------------------------------------
+struct PromptParams {
+    const float* boxes;          // [n,4] or null
+    const float* point_coords;   // [n,np,2] or null
+    const int32_t* point_labels; // [n,np] or null
+    int n_prompts, n_points;
+    float img_size;
+    const float* gauss;          // [2,128]
+    const float* point_emb[4];   // 4 x [256]
+    const float* not_a_point;    // [256]
+    const float* iou_token;      // [256]
+    const float* mask_tokens;    // [4,256]
+};
+// tokens [n, T, 256], T = 5 + n_points (+1 pad point when there is no box) + 2*(boxes != null)
+hipError_t launch_prompt_tokens(const PromptParams& p, float* tokens, int T, hipStream_t s);
+hipError_t launch_dense_pe(const float* gauss, float* pe /*[g*g,256]*/, int grid, hipStream_t s);
+// mask prompt -> dense embedding [n, 4096, 256] (prompt_encoder.py:51-59)
+struct MaskEmbedParams {
+    const float *w0, *b0, *ln1w, *ln1b, *w3, *b3, *ln4w, *ln4b, *w6, *b6;
+};
+hipError_t launch_mask_embed(const MaskEmbedParams& p, const float* mask_in, float* dense, int n, int grid, hipStream_t s);
+// out_f32[b, t, :] = emb[t, :] + (dense ? dense[b, t, :] : vec[:]) and its ET copy
+hipError_t launch_make_keys(int prec, const float* emb, const float* dense, const float* vec, float* out_f32,
+                            void* out_et, int n_batches, int tokens, int C, hipStream_t s);
+hipError_t launch_add_f32(const float* a, const float* b, float* out, long n, hipStream_t s);
+// token self attention: q,k,v [n*T, C] -> o [n*T, C]; heads of dim C/heads
+hipError_t launch_token_self_attn(const float* q, const float* k, const float* v, float* o, int n, int T, int C,
+                                  int heads, hipStream_t s);
+// tokens -> image attention. qp [n*T, Ci] fp32; kp/vp ET rows of `ld` elements, batch stride in rows
+// (0 = shared by all prompts); o [n*T, Ci] fp32.
+hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const void* vp, int ld, long batch_stride_rows,
+                                float* o, int n, int T, int tokens, int Ci, int heads, hipStream_t s);
+// image -> tokens attention. qi ET rows of `ld` elements (batch stride in rows, 0 = shared);
+// kt, vt [n*T, Ci] fp32; out ET [n*tokens, Ci].
+hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long batch_stride_rows, const float* kt,
+                                const float* vt, void* out, int n, int T, int tokens, int Ci, int heads, hipStream_t s);
+// per row of `in` [rows, groups*gsize]: +0, LN over each group (eps), GELU -> ET
+hipError_t launch_group_ln_gelu(int prec, const float* in, const float* gamma, const float* beta, float eps,
+                                void* out, long rows, int groups, int gsize, hipStream_t s);
+// low[b, c, Y, X] = sum_ch hyper[b, sel0 + c, ch] * up2[b, y, x, dy, dx, dy2, dx2, ch]
+hipError_t launch_mask_product(int prec, const void* up2, const float* hyper, float* low, int n, int grid,
+                               int n_mask_tokens, int sel0, int n_sel, hipStream_t s);
+hipError_t launch_postprocess(const float* low, int n_masks, int in_h, int in_w, int orig_h, int orig_w,
+                              int img_size, int return_logits, void* out, hipStream_t s);
+hipError_t launch_paint(const uint8_t* masks, const int32_t* labels, int n, int h, int w, uint8_t* seg,
+                        unsigned long long* areas, unsigned long long* class_pixels,
+                        unsigned long long* class_instances, int n_classes, hipStream_t s);

@@ -133,6 +133,12 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
                 int orig_h, int orig_w, uint8_t* seg_mask, int64_t* areas_out,
                 int64_t* class_pixels, int64_t* class_instances, int n_classes, void* stream);
 
+/* -- test hook: run preprocess + patch embed + the first n_blocks encoder blocks for n_images
+ * tiles and copy the fp32 residual stream [n_images*4096, embed_dim] (channels-last,
+ * image_encoder.py:107-112) to x_out.  Invalidates the embedding slots. */
+int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_images, int in_h,
+                               int in_w, int n_blocks, float* x_out, void* stream);
+
 /* -- kernel-level entry points (used by the parity tests to check each kernel alone) --------
  * All pointers are device pointers.  `prec` is enum samrs_precision; "et" = MFMA operand type
  * (bf16 or f16 bit patterns in uint16). */

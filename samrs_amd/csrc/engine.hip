@@ -448,7 +448,8 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
 }
 
 // -------------------------------------------------------------------------------------------------
-int samrs_set_images(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int in_w, int slot0, void* stream) {
+static int encode(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int in_w, int slot0, void* stream,
+                  int n_blocks, bool do_neck) {
     if (!e || !images) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_set_images: null argument");
     if (!e->finalized) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "weights not finalized");
     const samrs_config& c = e->cfg;
@@ -467,7 +468,7 @@ int samrs_set_images(samrs_engine_t* e, const uint8_t* images, int n, int in_h, 
     CK(e, launch_patch_im2col(prec, images, e->H, n, in_h, in_w, g, c.patch_size, s));
     CK(e, launch_gemm_et(prec, e->H, e->patch_w, e->X, W(e, "image_encoder.patch_embed.proj.bias"),
                          W(e, "image_encoder.pos_embed"), tokens, M, D, 3 * c.patch_size * c.patch_size, true, false, false, s));
-    for (int i = 0; i < c.depth; ++i) {
+    for (int i = 0; i < c.depth && i < n_blocks; ++i) {
         const EncBlock& b = e->blocks[i];
         if (!b.global) {
             CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, Mw, D, 1, g, c.window_size, s));
@@ -483,6 +484,7 @@ int samrs_set_images(samrs_engine_t* e, const uint8_t* images, int n, int in_h, 
         CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
         CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
     }
+    if (!do_neck) return SAMRS_OK;
     // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d   (all channels-last)
     CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s));
     CK(e, launch_gemm_et(prec, e->Y, e->neck0_w, e->N1, nullptr, nullptr, 0, M, C, D, true, false, false, s));
@@ -493,6 +495,19 @@ int samrs_set_images(samrs_engine_t* e, const uint8_t* images, int n, int in_h, 
     CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.3.weight"), W(e, "image_encoder.neck.3.bias"), 1e-6f,
                            nullptr, e->EMB + (size_t)slot0 * tokens * C, M, C, 0, g, 0, s));
     for (int i = 0; i < n; ++i) e->slot_set[slot0 + i] = 1;
+    return SAMRS_OK;
+}
+
+int samrs_set_images(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int in_w, int slot0, void* stream) {
+    return encode(e, images, n, in_h, in_w, slot0, stream, 1 << 30, true);
+}
+
+int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int in_w, int n_blocks,
+                               float* x_out, void* stream) {
+    if (!x_out) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_debug_encoder_prefix: null output");
+    const int rc = encode(e, images, n, in_h, in_w, 0, stream, n_blocks, false);
+    if (rc) return rc;
+    CK(e, hipMemcpyAsync(x_out, e->X, sizeof(float) * (size_t)n * e->tokens * e->D, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SAMRS_OK;
 }
 

@@ -1,0 +1,238 @@
+"""ctypes binding of ``libsamrs_hip.so`` (C ABI: ``include/samrs_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every computation happens in
+the library.  There is NO fallback: if the shared library is missing, or there is no HIP device,
+importing / constructing fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .synth import SamConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsamrs_hip.so")
+
+PREC_BF16, PREC_F16 = 0, 1
+PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16}
+
+OK, ERR_NOT_SET, ERR_BAD_SHAPE, ERR_BAD_ARG, ERR_HIP, ERR_BAD_WEIGHTS, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
+
+
+class samrs_config(C.Structure):
+    _fields_ = [
+        ("embed_dim", C.c_int32), ("depth", C.c_int32), ("num_heads", C.c_int32),
+        ("n_global", C.c_int32), ("global_attn_indexes", C.c_int32 * 8),
+        ("img_size", C.c_int32), ("patch_size", C.c_int32), ("window_size", C.c_int32),
+        ("out_chans", C.c_int32), ("max_images", C.c_int32), ("max_prompts", C.c_int32),
+        ("max_points", C.c_int32), ("precision", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Loads the in-tree shared library; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C samrs_amd/csrc` (or __graft_entry__.build()). "
+            "samrs_amd has no CPU / PyTorch fallback by design.")
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.c_int, C.c_float
+    lib.samrs_abi_version.restype = ip
+    lib.samrs_create.restype = vp
+    lib.samrs_create.argtypes = [C.POINTER(samrs_config), ip, C.c_char_p, ip]
+    lib.samrs_destroy.argtypes = [vp]
+    lib.samrs_destroy.restype = None
+    lib.samrs_last_error.argtypes = [vp]
+    lib.samrs_last_error.restype = C.c_char_p
+    lib.samrs_load_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), ip]
+    lib.samrs_finalize_weights.argtypes = [vp, vp]
+    lib.samrs_set_images.argtypes = [vp, vp, ip, ip, ip, ip, vp]
+    lib.samrs_get_embedding.argtypes = [vp, ip, vp, vp]
+    lib.samrs_set_embedding.argtypes = [vp, ip, vp, vp]
+    lib.samrs_reset_image.argtypes = [vp, ip]
+    lib.samrs_predict.argtypes = [vp, ip, ip, vp, vp, vp, ip, vp, ip, ip, ip, ip, ip, ip, vp, vp, vp, vp]
+    lib.samrs_paint.argtypes = [vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, ip, vp]
+    lib.samrs_debug_encoder_prefix.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp]
+    lib.samrs_debug_encoder_prefix.restype = ip
+    lib.samrs_k_gemm.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
+    lib.samrs_k_gemm_f32.argtypes = [vp, ip, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
+    lib.samrs_k_convert.argtypes = [ip, vp, vp, C.c_int64, vp]
+    lib.samrs_k_layernorm.argtypes = [ip, vp, vp, vp, fp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
+    lib.samrs_k_window_attention.argtypes = [ip, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
+    lib.samrs_k_global_attention.argtypes = [ip, vp, vp, vp, vp, ip, ip, ip, ip, vp]
+    lib.samrs_k_postprocess.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, vp, vp]
+    for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_get_embedding",
+                 "samrs_set_embedding", "samrs_reset_image", "samrs_predict", "samrs_paint", "samrs_k_gemm",
+                 "samrs_k_gemm_f32", "samrs_k_convert", "samrs_k_layernorm", "samrs_k_window_attention",
+                 "samrs_k_global_attention", "samrs_k_postprocess"):
+        getattr(lib, name).restype = ip
+    if lib.samrs_abi_version() != 1:
+        raise ImportError("libsamrs_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    """One engine handle = one GPU's weights + workspaces (``samrs_engine_t``)."""
+
+    def __init__(self, cfg: SamConfig, device: torch.device, precision: str = "f16", max_images: int = 1,
+                 max_prompts: int = 64, max_points: int = 4):
+        if device.type != "cuda":
+            raise EngineError("samrs_amd runs on a HIP device only (torch device type 'cuda'); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise EngineError("no HIP device visible to PyTorch")
+        self.lib = load_library()
+        self.cfg = cfg
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        self.precision = precision
+        self.max_images, self.max_prompts, self.max_points = max_images, max_prompts, max_points
+        c = samrs_config()
+        c.embed_dim, c.depth, c.num_heads = cfg.embed_dim, cfg.depth, cfg.num_heads
+        c.n_global = len(cfg.global_attn_indexes)
+        for i, g in enumerate(cfg.global_attn_indexes):
+            c.global_attn_indexes[i] = g
+        c.img_size, c.patch_size, c.window_size, c.out_chans = cfg.img_size, cfg.patch_size, cfg.window_size, cfg.out_chans
+        c.max_images, c.max_prompts, c.max_points = max_images, max_prompts, max_points
+        c.precision = PRECISIONS[precision]
+        err = C.create_string_buffer(512)
+        self.handle = self.lib.samrs_create(C.byref(c), self.device.index, err, 512)
+        if not self.handle:
+            raise EngineError("samrs_create failed: " + err.value.decode())
+
+    # -- error mapping: same exception types / messages as the reference (predictor.py:133-134 ...)
+    def _check(self, rc: int) -> None:
+        if rc == OK:
+            return
+        msg = self.lib.samrs_last_error(self.handle).decode()
+        if rc == ERR_NOT_SET:
+            raise RuntimeError(msg)
+        if rc in (ERR_BAD_SHAPE, ERR_BAD_ARG):
+            raise AssertionError(msg)
+        raise EngineError(f"libsamrs_hip error {rc}: {msg}")
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.samrs_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Strict load (build_sam.py:103-106): every key / shape of the reference state_dict."""
+        for name, t in sd.items():
+            a = np.ascontiguousarray(t.detach().to(torch.float32).cpu().numpy())
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._check(self.lib.samrs_load_weight(self.handle, name.encode(), a.ctypes.data, shape, a.ndim))
+        with torch.cuda.device(self.device):
+            self._check(self.lib.samrs_finalize_weights(self.handle, _stream()))
+
+    def set_images(self, images_u8: torch.Tensor, slot0: int = 0) -> None:
+        """images_u8: uint8 [n, H, W, 3] on this device, long side == img_size."""
+        assert images_u8.dtype == torch.uint8 and images_u8.dim() == 4 and images_u8.shape[-1] == 3
+        assert images_u8.is_cuda and images_u8.is_contiguous()
+        n, h, w, _ = images_u8.shape
+        with torch.cuda.device(self.device):
+            self._check(self.lib.samrs_set_images(self.handle, images_u8.data_ptr(), n, h, w, slot0, _stream()))
+
+    def debug_encoder_prefix(self, images_u8: torch.Tensor, n_blocks: int) -> torch.Tensor:
+        """Test hook: residual stream [n, 64, 64, D] after patch embed + the first n_blocks blocks."""
+        n, h, w, _ = images_u8.shape
+        out = torch.empty(n, self.cfg.grid, self.cfg.grid, self.cfg.embed_dim, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.samrs_debug_encoder_prefix(self.handle, images_u8.data_ptr(), n, h, w, n_blocks,
+                                                            out.data_ptr(), _stream()))
+        return out
+
+    def get_embedding(self, slot: int = 0) -> torch.Tensor:
+        out = torch.empty(1, self.cfg.out_chans, self.cfg.grid, self.cfg.grid, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.samrs_get_embedding(self.handle, slot, out.data_ptr(), _stream()))
+        return out
+
+    def set_embedding(self, emb: torch.Tensor, slot: int = 0) -> None:
+        emb = emb.to(self.device, torch.float32).contiguous()
+        assert emb.numel() == self.cfg.out_chans * self.cfg.grid ** 2
+        with torch.cuda.device(self.device):
+            self._check(self.lib.samrs_set_embedding(self.handle, slot, emb.data_ptr(), _stream()))
+
+    def reset_image(self, slot: int = 0) -> None:
+        self._check(self.lib.samrs_reset_image(self.handle, slot))
+
+    def predict(self, slot: int, boxes: Optional[torch.Tensor], point_coords: Optional[torch.Tensor],
+                point_labels: Optional[torch.Tensor], mask_input: Optional[torch.Tensor], multimask_output: bool,
+                return_logits: bool, input_size: Tuple[int, int], original_size: Tuple[int, int],
+                want_masks: bool = True) -> Tuple[Optional[torch.Tensor], torch.Tensor, torch.Tensor]:
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        if point_coords is not None and point_labels is None:
+            raise AssertionError("point_labels must be supplied if point_coords is supplied.")
+        n = None
+        if point_coords is not None:
+            point_coords = point_coords.to(**f32).contiguous()
+            point_labels = point_labels.to(dtype=torch.int32, device=dev).contiguous()
+            n = point_coords.shape[0]
+        if boxes is not None:
+            boxes = boxes.to(**f32).reshape(-1, 4).contiguous()
+            n = boxes.shape[0] if n is None else n
+        if mask_input is not None:
+            mask_input = mask_input.to(**f32).contiguous()
+            n = mask_input.shape[0] if n is None else n
+        if n is None:
+            raise AssertionError("at least one prompt (points, boxes or mask_input) is required")
+        npts = 0 if point_coords is None else point_coords.shape[1]
+        c = 3 if multimask_output else 1
+        oh, ow = int(original_size[0]), int(original_size[1])
+        masks = None
+        if want_masks:
+            masks = torch.empty(n, c, oh, ow, dtype=torch.float32 if return_logits else torch.uint8, device=dev)
+        iou = torch.empty(n, c, **f32)
+        low = torch.empty(n, c, 256, 256, **f32)
+        with torch.cuda.device(dev):
+            self._check(self.lib.samrs_predict(
+                self.handle, slot, n, _ptr(boxes), _ptr(point_coords), _ptr(point_labels), npts, _ptr(mask_input),
+                int(bool(multimask_output)), int(bool(return_logits)), int(input_size[0]), int(input_size[1]), oh, ow,
+                _ptr(masks), iou.data_ptr(), low.data_ptr(), _stream()))
+        if masks is not None and not return_logits:
+            masks = masks.view(torch.bool)
+        return masks, iou, low
+
+    def paint(self, masks: torch.Tensor, labels: torch.Tensor, seg: torch.Tensor,
+              class_pixels: Optional[torch.Tensor] = None, class_instances: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Ordered painting + areas (+ class statistics) on device; see samrs_paint in samrs_hip.h."""
+        m = masks.view(torch.uint8) if masks.dtype == torch.bool else masks
+        m = m.reshape(-1, m.shape[-2], m.shape[-1]).contiguous()
+        n, h, w = m.shape
+        labels = labels.to(dtype=torch.int32, device=self.device).contiguous()
+        areas = torch.empty(n, dtype=torch.int64, device=self.device)
+        ncls = 0 if class_pixels is None else class_pixels.numel()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.samrs_paint(self.handle, m.data_ptr(), labels.data_ptr(), n, h, w, seg.data_ptr(),
+                                             areas.data_ptr(), _ptr(class_pixels), _ptr(class_instances), ncls, _stream()))
+        return areas

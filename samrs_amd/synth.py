@@ -61,8 +61,8 @@ CONFIGS: Dict[str, SamConfig] = {
     # small enough that the CPU oracle finishes in ~1 s.  Used by fast parity tests and smoke().
     # Block 0 is windowed, block 1 is global, so both attention kernels are exercised.
     "vit_tiny": SamConfig("vit_tiny", 128, 2, 2, (1,)),
-    # head_dim 80 like ViT-H (the awkward MFMA K size) at toy width.
-    "vit_tiny80": SamConfig("vit_tiny80", 160, 2, 2, (1,)),
+    # head_dim 80 like ViT-H (the awkward MFMA K size); width 640 keeps every GEMM dim a multiple of 128.
+    "vit_tiny80": SamConfig("vit_tiny80", 640, 2, 8, (1,)),
 }
 
 

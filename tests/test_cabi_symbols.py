@@ -1,0 +1,63 @@
+"""CPU: the C-ABI shared library builds for gfx950, loads without a GPU and exports every symbol
+that include/samrs_hip.h declares (no compute is called here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    import __graft_entry__ as ge
+    ge.build_library()
+    from samrs_amd import engine
+    assert os.path.exists(engine.LIB_PATH)
+    return engine.LIB_PATH
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "samrs_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(samrs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    names = declared_functions()
+    for must in ["samrs_create", "samrs_destroy", "samrs_load_weight", "samrs_finalize_weights", "samrs_set_images",
+                 "samrs_predict", "samrs_get_embedding", "samrs_set_embedding", "samrs_reset_image", "samrs_paint",
+                 "samrs_last_error"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, f"declared in samrs_hip.h but not exported: {missing}"
+    lib.samrs_abi_version.restype = ctypes.c_int
+    assert lib.samrs_abi_version() == 1
+
+
+def test_config_struct_layout_matches_header(lib_path):
+    from samrs_amd import engine
+    # 4 + 8 + 8 int32 fields
+    assert ctypes.sizeof(engine.samrs_config) == 4 * (4 + 8 + 8)
+
+
+def test_create_fails_loudly_without_gpu(lib_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from samrs_amd import engine, synth
+    lib = engine.load_library()
+    c = engine.samrs_config()
+    cfg = synth.CONFIGS["vit_tiny"]
+    c.embed_dim, c.depth, c.num_heads, c.n_global = cfg.embed_dim, cfg.depth, cfg.num_heads, 1
+    c.global_attn_indexes[0] = 1
+    c.img_size, c.patch_size, c.window_size, c.out_chans = 1024, 16, 14, 256
+    c.max_images, c.max_prompts, c.max_points, c.precision = 1, 4, 1, 1
+    err = ctypes.create_string_buffer(256)
+    h = lib.samrs_create(ctypes.byref(c), 0, err, 256)
+    assert not h and b"no CPU fallback" in err.value

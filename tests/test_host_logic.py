@@ -1,0 +1,63 @@
+"""CPU: host-side mirror of the reference interface (no GPU, no compute in the library)."""
+import numpy as np
+import pytest
+import torch
+
+import samrs_amd
+from samrs_amd import driver, synth
+from samrs_amd.transforms import ResizeLongestSide
+from oracle import sam_oracle as so
+
+
+def test_registry_names_match_reference():
+    # Generate Dataset/segment_anything/build_sam.py:47-52
+    for k in ("default", "vit_h", "vit_l", "vit_b"):
+        assert k in samrs_amd.sam_model_registry
+    assert samrs_amd.sam_model_registry["default"] is samrs_amd.sam_model_registry["vit_h"]
+
+
+def test_sam_refuses_cpu_device():
+    sam = samrs_amd.sam_model_registry["vit_tiny"]()
+    assert sam.image_encoder.img_size == 1024 and sam.mask_threshold == 0.0 and sam.image_format == "RGB"
+    with pytest.raises(RuntimeError):
+        sam.to("cpu")
+    with pytest.raises(RuntimeError):
+        samrs_amd.SamPredictor(sam)          # not on a device yet -> loud failure, no fallback
+
+
+@pytest.mark.parametrize("hw", [(1024, 1024), (800, 800), (600, 800), (1500, 1000), (333, 1024)])
+def test_resize_longest_side_matches_oracle(hw):
+    t = ResizeLongestSide(1024)
+    assert t.get_preprocess_shape(hw[0], hw[1], 1024) == so.get_preprocess_shape(hw[0], hw[1], 1024)
+    g = torch.Generator().manual_seed(1)
+    boxes = torch.rand(7, 4, generator=g, dtype=torch.float64) * min(hw)      # DOTA loader yields float64
+    keep = boxes.clone()
+    out = t.apply_boxes_torch(boxes, hw)
+    assert out.dtype == torch.float32 and torch.equal(out, so.apply_boxes(boxes, hw))
+    assert torch.equal(boxes, keep)                                            # inputs are not mutated
+    pts = np.random.default_rng(0).uniform(0, min(hw), (5, 2))
+    np.testing.assert_allclose(t.apply_coords(pts, hw), so.apply_coords(torch.from_numpy(pts), hw).numpy(), rtol=1e-6)
+    img = synth.make_noise_image(0, *hw)
+    np.testing.assert_array_equal(t.apply_image(img), so.apply_image(img))
+
+
+def test_state_dict_factory_matches_contract():
+    sd = synth.make_state_dict(synth.CONFIGS["vit_b"], 0)
+    assert sd["image_encoder.blocks.2.attn.rel_pos_h"].shape == (127, 64)      # global block
+    assert sd["image_encoder.blocks.0.attn.rel_pos_h"].shape == (27, 64)       # windowed block
+    assert sd["mask_decoder.output_upscaling.0.weight"].shape == (256, 64, 2, 2)
+    assert sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].shape == (2, 128)
+    n_enc = sum(v.numel() for k, v in sd.items() if k.startswith("image_encoder"))
+    n_dec = sum(v.numel() for k, v in sd.items() if k.startswith("mask_decoder"))
+    assert n_enc == 89_670_912 and n_dec == 4_058_340                          # SURVEY.md section 8 [measured]
+    sd2 = synth.make_state_dict(synth.CONFIGS["vit_b"], 0)
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd)                         # reproducible
+
+
+def test_driver_chunking_and_sharding():
+    assert driver.box_chunks(32, 20) == so.box_chunks(32, 20) == [(0, 20), (20, 32)]
+    assert driver.box_chunks(40, 20) == so.box_chunks(40, 20)
+    assert driver.box_chunks(0, 20) == []
+    files = [f"P{i:04d}.png" for i in (5, 3, 9, 1, 7, 2, 8, 0, 6, 4)]
+    parts = [driver.shard(files, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == sorted(files) and parts[0] == ["P0000.png", "P0004.png", "P0008.png"]

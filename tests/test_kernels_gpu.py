@@ -1,0 +1,249 @@
+"""GPU: every HIP kernel alone, through the C ABI's kernel-level entry points, against a plain
+torch fp32/fp64 CPU statement of the same op on the same (already rounded) operands.
+
+Tolerances: MFMA operands are bf16 / f16, accumulation is fp32.  With operands pre-rounded on the
+host the only differences left are fp32 summation order and the rounding of ET outputs
+(one ulp: 2^-8 relative for bf16, 2^-11 for f16).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+PRECS = [("f16", 1, torch.float16, 2.0 ** -10), ("bf16", 0, torch.bfloat16, 2.0 ** -7)]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from samrs_amd import engine
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return engine.load_library()
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def et_bits(x, dt):
+    """fp32 tensor -> (rounded fp32 values, int16 bit-pattern tensor)"""
+    r = x.to(dt)
+    return r.to(torch.float32), r.view(torch.int16)
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp(min=1e-30)).item(), (a - b).abs().max().item()
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_convert_bit_exact(lib, name, prec, dt, ulp):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4096 * 8, generator=g) * torch.logspace(-6, 4, 4096 * 8)
+    x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, 70000.0, -70000.0, 1e-8])
+    out = torch.empty(x.numel(), dtype=torch.int16, device="cuda")
+    xd = dev(x)
+    assert lib.samrs_k_convert(prec, xd.data_ptr(), out.data_ptr(), x.numel(), stream()) == 0
+    ref = x.clamp(-65504, 65504).to(dt).view(torch.int16) if dt == torch.float16 else x.to(dt).view(torch.int16)
+    assert torch.equal(out.cpu(), ref), f"{name}: {(out.cpu() != ref).sum().item()} mismatching bit patterns"
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (384, 128, 640), (128, 256, 2304)])
+def test_gemm_et_variants(lib, name, prec, dt, ulp, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    A, Ab = et_bits(torch.randn(M, K, generator=g), dt)
+    B, Bb = et_bits(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
+    bias = torch.randn(N, generator=g)
+    add2d = torch.randn(64, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    ref = A.double() @ B.double().t()
+    Ad, Bd, biasd, add2dd = dev(Ab), dev(Bb), dev(bias), dev(add2d)
+    # (a) plain fp32 out, no bias
+    out = torch.empty(M, N, device="cuda")
+    assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), out.data_ptr(), None, None, 0, M, N, K, 1, 0, 0, stream()) == 0
+    r, mx = rel_err(out.cpu(), ref)
+    print(f"gemm {name} {M}x{N}x{K} plain: rel {r:.2e} max {mx:.2e}")
+    assert r < 2e-6, "transposed / permuted output?" if r > 0.1 else "accumulation error too large"
+    # (b) bias + add2d(period 64) + accumulate into existing fp32 C
+    out = dev(C0.clone())
+    assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), out.data_ptr(), biasd.data_ptr(), add2dd.data_ptr(), 64,
+                            M, N, K, 1, 0, 1, stream()) == 0
+    ref_b = ref + bias.double() + add2d.double().repeat(M // 64, 1) + C0.double()
+    r, mx = rel_err(out.cpu(), ref_b)
+    print(f"gemm {name} {M}x{N}x{K} bias+add2d+acc: rel {r:.2e}")
+    assert r < 2e-6
+    # (c) ET out with bias + GELU
+    out = torch.empty(M, N, dtype=torch.int16, device="cuda")
+    assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), out.data_ptr(), biasd.data_ptr(), None, 0, M, N, K, 0, 1, 0, stream()) == 0
+    ref_c = F.gelu((ref + bias.double()).float())
+    got = out.cpu().view(dt).float()
+    err = (got - ref_c).abs() / ref_c.abs().clamp(min=1e-2)
+    print(f"gemm {name} {M}x{N}x{K} gelu->ET: max rel {err.max().item():.2e}")
+    assert err.max().item() < 1.5 * ulp
+
+
+def test_gemm_f32_exact_class(lib):
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K, lda_pad, relu, acc) in [(7, 32, 256, 0, 0, 0), (224, 2048, 256, 0, 1, 0), (224, 256, 2048, 0, 0, 1),
+                                          (32, 4, 256, 1792 - 256, 0, 0), (4096, 128, 256, 0, 0, 0), (100, 70, 128, 0, 1, 1)]:
+        lda = K + lda_pad
+        A = torch.randn(M, lda, generator=g)
+        Wt = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b = torch.randn(N, generator=g)
+        C0 = torch.randn(M, N + 8, generator=g)
+        ref = A[:, :K].double() @ Wt.double().t() + b.double()
+        if relu:
+            ref = ref.clamp(min=0)
+        if acc:
+            ref = ref + C0[:, :N].double()
+        Ad, Wd, bd, Cd = dev(A), dev(Wt), dev(b), dev(C0.clone())
+        assert lib.samrs_k_gemm_f32(Ad.data_ptr(), lda, Wd.data_ptr(), bd.data_ptr(), Cd.data_ptr(), N + 8, M, N, K, relu, acc, stream()) == 0
+        out = Cd.cpu()
+        r, mx = rel_err(out[:, :N], ref)
+        print(f"gemm_f32 {M}x{N}x{K} lda={lda} relu={relu} acc={acc}: rel {r:.2e} max {mx:.2e}")
+        assert r < 3e-6
+        assert torch.equal(out[:, N:], C0[:, N:]), "wrote outside the [M, N] window"
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_layernorm_plain_and_window(lib, name, prec, dt, ulp):
+    g = torch.Generator().manual_seed(9)
+    for D in (128, 256, 768, 1280):
+        n_img, grid, win = 2, 64, 14
+        X = torch.randn(n_img * grid * grid, D, generator=g) * 3 + 0.5
+        gam = 1 + 0.1 * torch.randn(D, generator=g)
+        bet = 0.1 * torch.randn(D, generator=g)
+        ref = F.layer_norm(X, (D,), gam, bet, eps=1e-6)
+        Xd, gd, bd = dev(X), dev(gam), dev(bet)
+        # plain: fp32 + ET outputs
+        oe = torch.empty(X.shape, dtype=torch.int16, device="cuda")
+        of = torch.empty(X.shape, device="cuda")
+        assert lib.samrs_k_layernorm(prec, Xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-6, oe.data_ptr(), of.data_ptr(),
+                                     X.shape[0], D, 0, n_img, grid, win, stream()) == 0
+        r, mx = rel_err(of.cpu(), ref)
+        assert mx < 2e-5, (D, mx)
+        assert (oe.cpu().view(dt).float() - ref).abs().max().item() < 8 * ulp
+        # window gather (image_encoder.py:243-264): 25 windows of 14x14, zero rows in the padding
+        nw = 5
+        rows = n_img * nw * nw * win * win
+        oe = torch.empty(rows, D, dtype=torch.int16, device="cuda")
+        assert lib.samrs_k_layernorm(prec, Xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-6, oe.data_ptr(), None,
+                                     rows, D, 1, n_img, grid, win, stream()) == 0
+        y = F.pad(ref.view(n_img, grid, grid, D), (0, 0, 0, 6, 0, 6))
+        y = y.view(n_img, nw, win, nw, win, D).permute(0, 1, 3, 2, 4, 5).reshape(rows, D)
+        got = oe.cpu().view(dt).float()
+        assert (got - y).abs().max().item() < 8 * ulp
+        assert (got[y.abs().sum(1) == 0] == 0).all()
+
+
+def _attention_ref(qkv, rel_h, rel_w, heads, S):
+    """fp32 attention on [B, S*S, 3D] (already rounded) with decomposed rel-pos
+    (image_encoder.py:224-240,325-361)."""
+    B, N, D3 = qkv.shape
+    D = D3 // 3
+    d = D // heads
+    t = qkv.reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4).reshape(3, B * heads, N, d).double()
+    q, k, v = t[0], t[1], t[2]
+    attn = (q * d ** -0.5) @ k.transpose(1, 2)
+    idx = torch.arange(S)[:, None] - torch.arange(S)[None, :] + (S - 1)
+    Rh, Rw = rel_h.double()[idx], rel_w.double()[idx]
+    rq = q.reshape(B * heads, S, S, d)
+    rh = torch.einsum("bhwc,hkc->bhwk", rq, Rh)
+    rw = torch.einsum("bhwc,wkc->bhwk", rq, Rw)
+    attn = (attn.view(-1, S, S, S, S) + rh[..., :, None] + rw[..., None, :]).view(-1, N, N)
+    o = attn.softmax(-1) @ v
+    return o.view(B, heads, N, d).permute(0, 2, 1, 3).reshape(B, N, D).float()
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("hd,heads", [(64, 2), (80, 2)])
+def test_window_attention(lib, name, prec, dt, ulp, hd, heads):
+    g = torch.Generator().manual_seed(hd)
+    n_img, grid, win, nw = 1, 64, 14, 5
+    D = hd * heads
+    nwin = n_img * nw * nw
+    qkv, qkvb = et_bits(torch.randn(nwin, win * win, 3 * D, generator=g), dt)
+    rel_h, _ = et_bits(0.3 * torch.randn(2 * win - 1, hd, generator=g), dt)   # pre-rounded: the kernel rounds tables to ET
+    rel_w, _ = et_bits(0.3 * torch.randn(2 * win - 1, hd, generator=g), dt)
+    ref_w = _attention_ref(qkv, rel_h, rel_w, heads, win)                     # [nwin, 196, D]
+    # un-partition + crop (image_encoder.py:267-289)
+    ref = ref_w.view(n_img, nw, nw, win, win, D).permute(0, 1, 3, 2, 4, 5).reshape(n_img, nw * win, nw * win, D)[:, :grid, :grid]
+    out = torch.full((n_img * grid * grid, D), 0x7E00, dtype=torch.int16, device="cuda")  # NaN canary
+    qd, rhd, rwd = dev(qkvb), dev(rel_h), dev(rel_w)
+    assert lib.samrs_k_window_attention(prec, qd.data_ptr(), rhd.data_ptr(), rwd.data_ptr(), out.data_ptr(), n_img, grid, win,
+                                        heads, hd, stream()) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().view(dt).float().view(n_img, grid, grid, D)
+    assert torch.isfinite(got).all(), "some output rows were never written"
+    r, mx = rel_err(got, ref)
+    print(f"window attention {name} hd={hd}: rel {r:.2e} max {mx:.2e}")
+    assert r < (3e-3 if name == "f16" else 2e-2)
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("hd,heads", [(64, 2), (80, 1)])
+def test_global_attention(lib, name, prec, dt, ulp, hd, heads):
+    g = torch.Generator().manual_seed(100 + hd)
+    n_img, grid = 1, 64
+    D = hd * heads
+    qkv, qkvb = et_bits(torch.randn(n_img, grid * grid, 3 * D, generator=g), dt)
+    rel_h, _ = et_bits(0.3 * torch.randn(2 * grid - 1, hd, generator=g), dt)
+    rel_w, _ = et_bits(0.3 * torch.randn(2 * grid - 1, hd, generator=g), dt)
+    ref = _attention_ref(qkv, rel_h, rel_w, heads, grid)
+    out = torch.full((n_img * grid * grid, D), 0x7E00, dtype=torch.int16, device="cuda")
+    qd, rhd, rwd = dev(qkvb), dev(rel_h), dev(rel_w)
+    assert lib.samrs_k_global_attention(prec, qd.data_ptr(), rhd.data_ptr(), rwd.data_ptr(), out.data_ptr(), n_img, grid,
+                                        heads, hd, stream()) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().view(dt).float().view(n_img, grid * grid, D)
+    assert torch.isfinite(got).all()
+    r, mx = rel_err(got, ref)
+    print(f"global attention {name} hd={hd}: rel {r:.2e} max {mx:.2e}")
+    assert r < (3e-3 if name == "f16" else 2e-2)
+
+
+def test_global_attention_online_softmax_rescale(lib):
+    """Force the running-max rescale branch: one key late in the sequence dominates."""
+    hd, heads, grid, dt, prec = 64, 1, 64, torch.float16, 1
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(1, grid * grid, 3 * hd, generator=g)
+    x[0, 3000, hd:2 * hd] *= 12.0            # a spiky key far into the stream
+    x[0, 100, hd:2 * hd] *= 8.0
+    qkv, qkvb = et_bits(x, dt)
+    rel_h = torch.zeros(2 * grid - 1, hd)
+    rel_w = torch.zeros(2 * grid - 1, hd)
+    ref = _attention_ref(qkv, rel_h, rel_w, heads, grid)
+    out = torch.empty(grid * grid, hd, dtype=torch.int16, device="cuda")
+    qd, rhd, rwd = dev(qkvb), dev(rel_h), dev(rel_w)
+    assert lib.samrs_k_global_attention(prec, qd.data_ptr(), rhd.data_ptr(), rwd.data_ptr(), out.data_ptr(), 1, grid, heads, hd, stream()) == 0
+    got = out.cpu().view(dt).float().view(1, grid * grid, hd)
+    r, mx = rel_err(got, ref)
+    print(f"global attention spiky keys: rel {r:.2e} max {mx:.2e}")
+    assert r < 3e-3
+
+
+@pytest.mark.parametrize("in_hw,orig_hw", [((1024, 1024), (1024, 1024)), ((768, 1024), (600, 800)), ((1024, 683), (1500, 1000))])
+def test_postprocess_matches_interpolate(lib, in_hw, orig_hw):
+    g = torch.Generator().manual_seed(3)
+    low = torch.randn(3, 256, 256, generator=g)
+    ref = F.interpolate(low[None], (1024, 1024), mode="bilinear", align_corners=False)
+    ref = ref[..., : in_hw[0], : in_hw[1]]
+    ref = F.interpolate(ref, orig_hw, mode="bilinear", align_corners=False)[0]
+    lowd = dev(low)
+    outf = torch.empty(3, *orig_hw, device="cuda")
+    assert lib.samrs_k_postprocess(lowd.data_ptr(), 3, in_hw[0], in_hw[1], orig_hw[0], orig_hw[1], 1024, 1, outf.data_ptr(), stream()) == 0
+    d = (outf.cpu() - ref).abs().max().item()
+    print(f"postprocess {in_hw}->{orig_hw}: logits max abs diff {d:.2e}")
+    assert d < 1e-5
+    outm = torch.empty(3, *orig_hw, dtype=torch.uint8, device="cuda")
+    assert lib.samrs_k_postprocess(lowd.data_ptr(), 3, in_hw[0], in_hw[1], orig_hw[0], orig_hw[1], 1024, 0, outm.data_ptr(), stream()) == 0
+    mism = (outm.cpu().bool() != (ref > 0)).sum().item()
+    assert mism <= 3, mism      # only pixels whose logit is within fp32 noise of zero

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): each test group in its own process with its own timeout, so a
+# fault in one kernel does not hide the others.  Logs land in gpurun_out/.
+set -u
+mkdir -p gpurun_out
+cd "${GRAFT_REPO_ROOT:-.}"
+export PYTHONDONTWRITEBYTECODE=1
+rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 > gpurun_out/gpu.txt
+run() { # name timeout cmd...
+  local name=$1; shift; local t=$1; shift
+  echo "=== $name" | tee -a gpurun_out/summary.txt
+  timeout "$t" "$@" > "gpurun_out/$name.log" 2>&1
+  local rc=$?
+  echo "rc=$rc" | tee -a gpurun_out/summary.txt
+  grep -E "passed|failed|error" "gpurun_out/$name.log" | tail -3 | tee -a gpurun_out/summary.txt
+}
+: > gpurun_out/summary.txt
+PT="python -m pytest -m gpu -q -s -rA -p no:cacheprovider"
+for grp in "$@"; do
+  case $grp in
+    k_basic)  run k_basic 600 $PT tests/test_kernels_gpu.py -k "convert or gemm or layernorm or postprocess" ;;
+    k_win)    run k_win 600 $PT tests/test_kernels_gpu.py -k "window_attention" ;;
+    k_glb)    run k_glb 600 $PT tests/test_kernels_gpu.py -k "global_attention" ;;
+    p_enc)    run p_enc 900 $PT tests/test_parity_gpu.py -k "encoder_blockwise" ;;
+    p_dec)    run p_dec 900 $PT tests/test_parity_gpu.py -k "decoder_alone" ;;
+    p_e2e)    run p_e2e 900 $PT tests/test_parity_gpu.py -k "embedding_and_masks or paint or error or batch_equals" ;;
+    p_gold)   run p_gold 1500 $PT tests/test_parity_gpu.py -k "golden or c1_config" ;;
+    all)      run all 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider ;;
+    smoke)    run smoke 600 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    bench)    run bench 1200 python bench.py --steps 3 --warmup 1 ;;
+    benchq)   run benchq 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;
+    prof)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
+              run prof 1200 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;
+  esac
+done
+tail -5 gpurun_out/*.log 2>/dev/null | tail -120
+cat gpurun_out/summary.txt

@@ -126,6 +126,8 @@ def main() -> None:
     dt = timed(step, args.steps, args.warmup)
     images = world * args.batch * args.steps
     value = images / dt
+    if rank == 0:
+        print(f"[bench] {args.dtype}: {value:.2f} images/s over {world} GPU(s), {dt / args.steps * 1e3:.1f} ms/step", file=sys.stderr, flush=True)
     F = flops_per_image(cfg, args.boxes)
 
     # ---- roofline of the dominant kernel: the MLP lin1 GEMM (57.6 % of encoder FLOPs with lin2) ----
@@ -162,6 +164,7 @@ def main() -> None:
 
     # ---- the one collective of the path: class statistics all-reduce (outside the timed step) ----
     gen = driver.SemanticGenerator(samrs_amd.SamPredictor(sam), n_classes=18, box_batch=args.boxes)
+    eng.set_images(tiles[:1].contiguous(), 0)       # constructing a SamPredictor resets its slot (predictor.py:30-32)
     _, labels = synth.make_boxes(rank * 100, args.boxes)
     m, _, _ = eng.predict(0, boxes[0], None, None, None, False, False, (1024, 1024), (1024, 1024))
     seg = torch.full((1024, 1024), 255, dtype=torch.uint8, device=dev)

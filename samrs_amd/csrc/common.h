@@ -78,9 +78,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// exact-erf GELU (nn.GELU default; Generate Dataset/segment_anything/modeling/common.py:18-26)
+// exact-erf GELU (nn.GELU default; Generate Dataset/segment_anything/modeling/common.py:18-26).
+// erfc(z) for z >= 0 from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32-epsilon class):
+//   erfc(z) = t*(a1 + t*(a2 + t*(a3 + t*(a4 + t*a5)))) * exp(-z^2),  t = 1/(1 + p z)
+// and gelu(x) = x - 0.5*x*erfc(z) for x >= 0, 0.5*x*erfc(z) for x < 0, z = |x|/sqrt(2): no
+// cancellation in the negative tail, ~12 VALU ops instead of libm erff's two-branch ~35.
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float hxe = 0.5f * x * poly * __expf(-z * z);     // 0.5 * x * erfc(z)
+    return x >= 0.f ? x - hxe : hxe;
 }
 
 // XCD-aware, bijective remap of a linear block id (cdna_hip_programming.md T1): the hardware

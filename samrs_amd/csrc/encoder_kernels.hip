@@ -256,19 +256,28 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     const uint16_t* base = qkv + row0 * (3 * D) + head * HD;
 
     // ---- stage K (row-major), V^T, rel tables -------------------------------------------
-    for (int i = tid; i < (C::VT_BYTES / 16); i += 256) reinterpret_cast<uint4*>(Vt)[i] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
     constexpr int CH = HD / 8;  // 16-byte chunks per row
+    // rows d >= HD of V^T feed the padded part of the last d-tile: must be zero, nothing else is
+    // read uninitialised (keys >= N are written as zeros below).
+    for (int i = tid; i < (C::DT * 32 - HD) * C::VSTR; i += 256) Vt[HD * C::VSTR + i] = 0;
     for (int c = tid; c < C::NP * CH; c += 256) {
         const int r = c / CH, ch = c % CH;
         uint4 kv = make_uint4(0u, 0u, 0u, 0u);
-        if (r < C::N) {
-            kv = *reinterpret_cast<const uint4*>(base + (size_t)r * (3 * D) + D + ch * 8);
-            const uint4 vv = *reinterpret_cast<const uint4*>(base + (size_t)r * (3 * D) + 2 * D + ch * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) Vt[(ch * 8 + e) * C::VSTR + r] = elem16(vv, e);
-        }
+        if (r < C::N) kv = *reinterpret_cast<const uint4*>(base + (size_t)r * (3 * D) + D + ch * 8);
         *reinterpret_cast<uint4*>(Ks + r * HD + ch * 8) = kv;
+    }
+    // V^T[d][key]: a thread takes one 8-wide d chunk of TWO adjacent keys and writes eight 4-byte
+    // words; consecutive lanes take consecutive key pairs -> consecutive banks (conflict-free),
+    // instead of 2-byte scatters that pile onto two banks.
+    for (int c = tid; c < (C::NP / 2) * CH; c += 256) {
+        const int kp = c % (C::NP / 2), ch = c / (C::NP / 2);
+        const int r0 = 2 * kp;
+        uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = v0;
+        if (r0 < C::N) v0 = *reinterpret_cast<const uint4*>(base + (size_t)r0 * (3 * D) + 2 * D + ch * 8);
+        if (r0 + 1 < C::N) v1 = *reinterpret_cast<const uint4*>(base + (size_t)(r0 + 1) * (3 * D) + 2 * D + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + e) * C::VSTR + r0) = (uint32_t)elem16(v0, e) | ((uint32_t)elem16(v1, e) << 16);
     }
     for (int i = tid; i < 64 * HD; i += 256) {
         const int r = i / HD, d = i % HD;
@@ -419,7 +428,22 @@ __global__ __launch_bounds__(256) void global_attention_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, ql = lane & 31;
-    const int qb = blockIdx.x, head = blockIdx.y, im = blockIdx.z;
+    // 1-D grid.  All 32 query blocks of one (image, head) re-read the same 1.3 MB of K/V, so put
+    // them on ONE XCD (hardware: block b -> XCD b % 8) to keep that working set in its 4 MB L2.
+    const int QB = NTOK / 128;
+    int qb, P;
+    {
+        const int L = blockIdx.x, npairs = gridDim.x / QB;
+        if (npairs % 8 == 0) {
+            const int xcd = L % 8, idx = L / 8;
+            qb = idx % QB;
+            P = (idx / QB) * 8 + xcd;
+        } else {
+            qb = L % QB;
+            P = L / QB;
+        }
+    }
+    const int head = P % heads, im = P / heads;
     const int D = heads * HD;
     const uint16_t* base = qkv + (size_t)im * NTOK * (3 * D) + head * HD;
 
@@ -468,28 +492,40 @@ __global__ __launch_bounds__(256) void global_attention_kernel(
 
     // ---- main loop over key tiles -----------------------------------------------------------
     constexpr int CH = HD / 8;
-    constexpr int NCH = C::KT * CH;                 // 16-byte chunks per K (or V) tile
+    constexpr int NCH = C::KT * CH;                 // 16-byte chunks per K tile
     constexpr int PER = (NCH + 255) / 256;
-    uint4 rk[PER], rv[PER];
-    // straight-line, unconditional global loads (out-of-range chunk ids are clamped and simply
+    constexpr int NVP = (C::KT / 2) * CH;           // (key pair, d chunk) items per V tile
+    constexpr int PERV = (NVP + 255) / 256;
+    uint4 rk[PER], rv0[PERV], rv1[PERV];
+    // straight-line, unconditional global loads (out-of-range item ids are clamped and simply
     // not stored): conditionals / lambdas around these arrays push them into scratch.
 #define GLB_GLOAD(kt_)                                                                         \
     _Pragma("unroll") for (int i_ = 0; i_ < PER; ++i_) {                                       \
         int c_ = tid + 256 * i_;                                                                \
         c_ = c_ < NCH ? c_ : NCH - 1;                                                           \
         const int r_ = c_ / CH, ch_ = c_ % CH;                                                  \
-        const uint16_t* p_ = base + (size_t)((kt_) * C::KT + r_) * (3 * D) + ch_ * 8;           \
-        rk[i_] = *reinterpret_cast<const uint4*>(p_ + D);                                       \
-        rv[i_] = *reinterpret_cast<const uint4*>(p_ + 2 * D);                                   \
+        rk[i_] = *reinterpret_cast<const uint4*>(base + (size_t)((kt_) * C::KT + r_) * (3 * D) + D + ch_ * 8); \
+    }                                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < PERV; ++i_) {                                      \
+        int c_ = tid + 256 * i_;                                                                \
+        c_ = c_ < NVP ? c_ : NVP - 1;                                                           \
+        const int kp_ = c_ % (C::KT / 2), ch_ = c_ / (C::KT / 2);                               \
+        const uint16_t* p_ = base + (size_t)((kt_) * C::KT + 2 * kp_) * (3 * D) + 2 * D + ch_ * 8; \
+        rv0[i_] = *reinterpret_cast<const uint4*>(p_);                                          \
+        rv1[i_] = *reinterpret_cast<const uint4*>(p_ + 3 * D);                                  \
     }
 #define GLB_LSTORE(buf_)                                                                       \
     _Pragma("unroll") for (int i_ = 0; i_ < PER; ++i_) {                                       \
         const int c_ = tid + 256 * i_;                                                          \
-        if (c_ < NCH) {                                                                         \
-            const int r_ = c_ / CH, ch_ = c_ % CH;                                              \
-            *reinterpret_cast<uint4*>(Kb(buf_) + r_ * HD + ch_ * 8) = rk[i_];                   \
+        if (c_ < NCH) *reinterpret_cast<uint4*>(Kb(buf_) + (c_ / CH) * HD + (c_ % CH) * 8) = rk[i_]; \
+    }                                                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < PERV; ++i_) {                                      \
+        const int c_ = tid + 256 * i_;                                                          \
+        if (c_ < NVP) {                                                                         \
+            const int kp_ = c_ % (C::KT / 2), ch_ = c_ / (C::KT / 2);                           \
             _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_)                                    \
-                Vb(buf_)[(ch_ * 8 + e_) * C::VSTR + r_] = elem16(rv[i_], e_);                   \
+                *reinterpret_cast<uint32_t*>(Vb(buf_) + (ch_ * 8 + e_) * C::VSTR + 2 * kp_) =   \
+                    (uint32_t)elem16(rv0[i_], e_) | ((uint32_t)elem16(rv1[i_], e_) << 16);      \
         }                                                                                       \
     }
     // rows d >= HD of V^T must be zero in both buffers (only when HD is not a multiple of 32)
@@ -688,7 +724,7 @@ static hipError_t launch_glb(const void* qkv, const float* rh, const float* rw, 
     using C = GlbCfg<HD>;
     auto k = global_attention_kernel<PREC, HD>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
-    dim3 g(C::G * C::G / 128, heads, n_images), b(256);
+    dim3 g((C::G * C::G / 128) * heads * n_images), b(256);
     k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, rh, rw, (uint16_t*)out, heads);
     return hipGetLastError();
 }

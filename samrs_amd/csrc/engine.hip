@@ -679,6 +679,8 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
     return SAMRS_OK;
 }
 
+void samrs_debug_set_gemm_variant(int v) { set_gemm_variant(v); }
+
 // ---- kernel-level entry points -------------------------------------------------------------------
 #define KRET(expr) do { hipError_t _e = (expr); return _e == hipSuccess ? SAMRS_OK : SAMRS_ERR_HIP; } while (0)
 

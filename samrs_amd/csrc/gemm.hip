@@ -28,7 +28,13 @@ constexpr int GEMM_THREADS = 256;
 // physical 16-byte chunk of logical chunk c in row r of a [rows][64] ET tile
 __device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 1) & 7); }
 
-template <int PREC, bool OUT_F32, bool GELU>
+// LDS-DMA helper: 16 bytes per lane, global (per-lane address) -> LDS (wave-uniform base + lane*16).
+__device__ __forceinline__ void glds16(const uint16_t* gsrc, uint16_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int PREC, bool OUT_F32, bool GELU, bool GLDS>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_et_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
@@ -95,8 +101,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_et_kernel(
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    GEMM_LOAD_TILE(0);
-    GEMM_STORE_TILE(0);
+    // GLDS staging (cdna_hip_programming.md section 5, rule 21): the DMA writes LDS linearly
+    // (wave-uniform base + lane*16 B), so wave w's i-th instruction fills rows 32i + 8w .. +7
+    // (lane l -> row +(l>>3), physical chunk l&7) and the swizzle goes on the SOURCE address:
+    // the lane fetches logical chunk (l&7) ^ swz(row).  swz(row) does not depend on i.
+    const int g_row = 8 * wave + (lane >> 3);
+    const int g_chunk = (lane & 7) ^ ((g_row >> 1) & 7);
+    const uint16_t* gAg = A + (size_t)(m0 + g_row) * K + g_chunk * 8;
+    const uint16_t* gBg = B + (size_t)(n0 + g_row) * K + g_chunk * 8;
+#define GEMM_GLDS_TILE(kt_, buf_)                                                              \
+    do {                                                                                       \
+        const size_t koff_ = (size_t)(kt_) * BK;                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                     \
+            glds16(gAg + (size_t)(32 * i_) * K + koff_, &lds[buf_][0][(32 * i_ + 8 * wave) * BK]); \
+            glds16(gBg + (size_t)(32 * i_) * K + koff_, &lds[buf_][1][(32 * i_ + 8 * wave) * BK]); \
+        }                                                                                      \
+    } while (0)
+
+    if (GLDS) {
+        GEMM_GLDS_TILE(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        GEMM_LOAD_TILE(0);
+        GEMM_STORE_TILE(0);
+    }
     __syncthreads();
 
     const int fr = lane & 15;   // fragment row within a 16-row tile
@@ -104,8 +132,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_et_kernel(
 
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        // unconditional prefetch (the last iteration re-reads the last tile; nobody consumes it)
-        GEMM_LOAD_TILE(kt + 1 < nk ? kt + 1 : kt);
+        if (GLDS) {
+            if (kt + 1 < nk) GEMM_GLDS_TILE(kt + 1, buf ^ 1);
+        } else {
+            // unconditional prefetch (the last iteration re-reads the last tile; nobody consumes it)
+            GEMM_LOAD_TILE(kt + 1 < nk ? kt + 1 : kt);
+        }
 
         const uint16_t* la = &lds[buf][0][0];
         const uint16_t* lb = &lds[buf][1][0];
@@ -128,7 +160,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_et_kernel(
                 for (int j = 0; j < 4; ++j) acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]);
         }
 
-        GEMM_STORE_TILE(buf ^ 1);
+        if (GLDS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile has landed in LDS
+        } else {
+            GEMM_STORE_TILE(buf ^ 1);
+        }
         __syncthreads();
     }
 
@@ -168,7 +204,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_et_kernel(
     }
 }
 
-template <int PREC>
+int g_gemm_variant = 1;   // 0 = register-staged, 1 = LDS-DMA (global_load_lds)
+
+template <int PREC, bool GLDS>
 hipError_t launch_gemm_prec(const void* A, const void* B, void* C, const float* bias,
                             const float* add2d, int period, int M, int N, int K, bool out_f32,
                             bool gelu, bool accumulate, hipStream_t s) {
@@ -178,14 +216,14 @@ hipError_t launch_gemm_prec(const void* A, const void* B, void* C, const float* 
     const int acc = accumulate ? 1 : 0;
     if (out_f32) {
         if (gelu)
-            gemm_et_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+            gemm_et_kernel<PREC, true, true, GLDS><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
         else
-            gemm_et_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+            gemm_et_kernel<PREC, true, false, GLDS><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
     } else {
         if (gelu)
-            gemm_et_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+            gemm_et_kernel<PREC, false, true, GLDS><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
         else
-            gemm_et_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+            gemm_et_kernel<PREC, false, false, GLDS><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
     }
     return hipGetLastError();
 }
@@ -267,12 +305,17 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
                           bool gelu, bool accumulate, hipStream_t s) {
     if (M % BM || N % BN || K % BK || M <= 0 || N <= 0 || K <= 0) return hipErrorInvalidValue;
     if (add2d && add2d_period <= 0) return hipErrorInvalidValue;
+    const bool glds = g_gemm_variant == 1;
     if (prec == PREC_BF16)
-        return launch_gemm_prec<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        return glds ? launch_gemm_prec<PREC_BF16, true>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s)
+                    : launch_gemm_prec<PREC_BF16, false>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
     if (prec == PREC_F16)
-        return launch_gemm_prec<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        return glds ? launch_gemm_prec<PREC_F16, true>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s)
+                    : launch_gemm_prec<PREC_F16, false>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
     return hipErrorInvalidValue;
 }
+
+void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s) {

@@ -7,6 +7,7 @@
 hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const float* bias,
                           const float* add2d, int add2d_period, int M, int N, int K, bool out_f32,
                           bool gelu, bool accumulate, hipStream_t s);
+void set_gemm_variant(int v);   // 0 = register-staged tiles, 1 = LDS-DMA staging (default)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s);
 

@@ -1,0 +1,57 @@
+"""GPU micro-benchmark of gemm_et variants on the encoder's hot shapes (run via gpurun).
+Interleaved rounds in ONE process (cdna_hip_programming.md 5.4 rule 24); random operands."""
+import sys, os, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from samrs_amd import engine
+
+lib = engine.load_library()
+lib.samrs_debug_set_gemm_variant.argtypes = [__import__("ctypes").c_int]
+lib.samrs_debug_set_gemm_variant.restype = None
+dev = torch.device("cuda")
+s = torch.cuda.current_stream().cuda_stream
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "1"])]
+prec_name = sys.argv[2] if len(sys.argv) > 2 else "f16"
+prec = engine.PRECISIONS[prec_name]
+dt = torch.float16 if prec_name == "f16" else torch.bfloat16
+shapes = [("lin1+gelu", 32768, 5120, 1280, 0, 1, 0), ("lin2+res", 32768, 1280, 5120, 1, 0, 1),
+          ("qkv(win)", 39296, 3840, 1280, 0, 0, 0), ("proj+res", 32768, 1280, 1280, 1, 0, 1),
+          ("lin1 b=1", 4096, 5120, 1280, 0, 1, 0)]
+g = torch.Generator().manual_seed(0)
+for name, M, N, K, of32, gelu, acc in shapes:
+    A = torch.randn(M, K, generator=g).to(dev).to(dt)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(dt)
+    bias = torch.randn(N, generator=g).to(dev)
+    C = torch.zeros(M, N, dtype=torch.float32 if of32 else torch.int16, device=dev)
+    ref = A[:2048].float() @ W.float().t() + bias
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    res = {}
+    for v in variants:
+        lib.samrs_debug_set_gemm_variant(v)
+        C.zero_()
+        lib.samrs_k_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), None, 0, M, N, K, of32, gelu, acc, s)
+        got = C[:2048].float() if of32 else C[:2048].view(dt).float()
+        err = ((got - ref).norm() / ref.norm()).item()
+        res[v] = {"err": err, "ms": []}
+    for rnd in range(5):
+        for v in variants:
+            lib.samrs_debug_set_gemm_variant(v)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                lib.samrs_k_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), None, 0, M, N, K, of32, gelu, acc, s)
+            e1.record(); torch.cuda.synchronize()
+            res[v]["ms"].append(e0.elapsed_time(e1) / 10)
+    # vendor reference point (hipBLASLt through torch), same operands, no epilogue
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = torch.empty(M, N, dtype=dt, device=dev)
+    for _ in range(3): torch.matmul(A, W.t(), out=out)
+    e0.record()
+    for _ in range(10): torch.matmul(A, W.t(), out=out)
+    e1.record(); torch.cuda.synchronize()
+    lib_ms = e0.elapsed_time(e1) / 10
+    fl = 2.0 * M * N * K
+    line = f"{name:10s} M={M} N={N} K={K}: " + " | ".join(
+        f"v{v}: {min(r['ms'])*1e3:7.1f}us {fl/min(r['ms'])/1e9:7.1f}TF (med {sorted(r['ms'])[2]*1e3:.1f}us) err {r['err']:.1e}" for v, r in res.items())
+    print(line + f" | torch.matmul {lib_ms*1e3:.1f}us {fl/lib_ms/1e9:.1f}TF", flush=True)

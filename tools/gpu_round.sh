@@ -28,6 +28,7 @@ for grp in "$@"; do
     all)      run all 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider ;;
     smoke)    run smoke 600 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)    run bench 1200 python bench.py --steps 3 --warmup 1 ;;
+    gemmb)    run gemmb 600 python tools/gemm_bench.py ${GEMM_VARIANTS:-0,1} f16 ;;
     benchq)   run benchq 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;
     prof)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
               run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;

@@ -414,7 +414,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     // ---- workspaces ----
     const size_t Bi = c.max_images, Bb = c.max_prompts;
     const size_t M = Bi * tokens;
-    const size_t Mw = round_up(Bi * e->nwin * e->nwin * c.window_size * c.window_size, 128);
+    const size_t Mw = round_up(Bi * e->nwin * e->nwin * c.window_size * c.window_size, 256);
     const size_t Mmax = Mw > M ? Mw : M;
     CK(e, dalloc(e, &e->X, M * D));
     CK(e, dalloc(e, &e->Y, Mmax * D));
@@ -461,7 +461,7 @@ static int encode(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int
     const int D = e->D, C = e->C, g = e->grid, tokens = e->tokens, prec = e->prec;
     const int M = n * tokens;
     const int Mw = n * e->nwin * e->nwin * c.window_size * c.window_size;
-    const int Mw_pad = (int)round_up(Mw, 128);
+    const int Mw_pad = (int)round_up(Mw, 256);   // multiple of the 256-row GEMM tile
     for (int i = 0; i < n; ++i) e->slot_set[slot0 + i] = 0;
 
     // patch embed: im2col (normalise + zero pad) -> GEMM (+bias +pos_embed) -> X

@@ -34,7 +34,7 @@ __device__ __forceinline__ void glds16(const uint16_t* gsrc, uint16_t* lds_wave_
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int PREC, bool OUT_F32, bool GELU, bool GLDS>
+template <int PREC, bool OUT_F32, bool GELU, bool GLDS, int GROUP_M>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_et_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
@@ -46,10 +46,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_et_kernel(
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int tiles_n = N / BN;
+    // Tile order.  (1) xcd_remap gives every XCD a contiguous range of logical ids (blocks that
+    // run together share one 4 MB L2).  (2) Inside that range ids walk GROUP_M tile rows fastest,
+    // then tile columns: the ~64 blocks resident on an XCD form a ~8x8 super-tile, so each A and B
+    // panel fetched into L2 is reused 8 times instead of streaming the whole weight matrix through
+    // L2 once per tile row.
+    const int tiles_n = N / BN, tiles_m = M / BM;
     const int nwg = gridDim.x;
     const int bid = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    int tile_m, tile_n;
+    if (GROUP_M > 1) {
+        const int per_group = GROUP_M * tiles_n;
+        const int group = bid / per_group, first_m = group * GROUP_M;
+        const int gsz = (tiles_m - first_m) < GROUP_M ? (tiles_m - first_m) : GROUP_M;
+        const int in_g = bid - group * per_group;
+        tile_m = first_m + in_g % gsz;
+        tile_n = in_g / gsz;
+    } else {
+        tile_m = bid / tiles_n;
+        tile_n = bid % tiles_n;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // --- staging map: thread t moves chunks (row = (t>>3) + 32*i, chunk = t&7), i = 0..3 ---
@@ -204,9 +220,354 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_et_kernel(
     }
 }
 
-int g_gemm_variant = 1;   // 0 = register-staged, 1 = LDS-DMA (global_load_lds)
 
-template <int PREC, bool GLDS>
+// ---------------------------------------------------------------------------------------------
+// gemm_et_pipe_kernel: 256x128x64 block tile, 512 threads = 8 waves (4 along M x 2 along N, each
+// a 64x64 sub-tile exactly as above), THREE-stage LDS ring filled by LDS-DMA with a COUNTED
+// s_waitcnt vmcnt: the loads of tile t+2 are issued before computing tile t and only tile t+1 is
+// waited for at the (raw) barrier, so DMA traffic stays in flight across barriers instead of
+// draining every K step (rocprofv3 on the 2-stage kernel: 47 % of wave cycles parked in
+// s_waitcnt/s_barrier, MFMA busy 30 %).  144 KiB LDS -> one block (8 waves) per CU.
+// ---------------------------------------------------------------------------------------------
+constexpr int PBM = 256, PBN = 128, PTHREADS = 512, PSTAGES = 3;
+constexpr int PSTAGE_ELEMS = (PBM + PBN) * BK;          // A rows then B rows, 64 ET each
+constexpr int P_GLDS_PER_TILE = (PBM + PBN) * BK * 2 / (PTHREADS * 16);   // 6 per thread
+
+// LDS-DMA issued from inline asm so that hipcc's s_waitcnt insertion does not know about it (it
+// would otherwise put vmcnt(0) in front of every ds_read).  M0 = LDS byte address of the wave's
+// 1 KiB destination; M0 is compiler-reserved, so it is saved / restored inside the statement, and
+// the SALU-write -> LDS-DMA hazard gets its s_nop (cdna_hip_programming.md 5.7).  The caller
+// counts vmcnt by hand.
+template <int OFF>
+__device__ __forceinline__ void glds16_asm(const uint16_t* gsrc, uint32_t wave_lds_base) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_add_u32 m0, %2, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(wave_lds_base), "n"(OFF)
+        : "memory", "scc");
+}
+
+template <int PREC, bool OUT_F32, bool GELU>
+__global__ __launch_bounds__(PTHREADS) void gemm_et_pipe_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
+    int M, int N, int K, int accumulate) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[PSTAGES * PSTAGE_ELEMS];   // 144 KiB, ONE object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;               // 0..7
+    const int wm = wave >> 1, wn = wave & 1;
+
+    constexpr int GROUP = 8;
+    const int tiles_n = N / PBN, tiles_m = M / PBM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_group = GROUP * tiles_n;
+    const int group = bid / per_group, first_m = group * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = bid - group * per_group;
+    const int tile_m = first_m + in_g % gsz, tile_n = in_g / gsz;
+    const int m0 = tile_m * PBM, n0 = tile_n * PBN;
+
+    // DMA map: one glds round = 512 lanes x 16 B = 64 rows; wave w fills rows 64*i + 8w .. +7.
+    const int g_row = 8 * wave + (lane >> 3);
+    const int g_chunk = (lane & 7) ^ ((g_row >> 1) & 7);         // swizzle on the SOURCE (rule 21)
+    const uint16_t* gAg = A + (size_t)(m0 + g_row) * K + g_chunk * 8;
+    const uint16_t* gBg = B + (size_t)(n0 + g_row) * K + g_chunk * 8;
+    // LDS byte address of this wave's first 8-row group in stage 0 / operand A
+    const uint32_t wave_lds_base = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)(tid >> 6) * (8 * BK * 2));
+    const size_t rs64 = (size_t)64 * K;      // 64 rows further down in A / B
+#define PIPE_ISSUE(kt_, stage_)                                                                 \
+    do {                                                                                         \
+        const size_t koff_ = (size_t)(kt_) * BK;                                                 \
+        constexpr int SB_ = (stage_) * PSTAGE_ELEMS * 2;                                         \
+        glds16_asm<SB_ + 0 * 64 * BK * 2>(gAg + koff_, wave_lds_base);                           \
+        glds16_asm<SB_ + 1 * 64 * BK * 2>(gAg + rs64 + koff_, wave_lds_base);                    \
+        glds16_asm<SB_ + 2 * 64 * BK * 2>(gAg + 2 * rs64 + koff_, wave_lds_base);                \
+        glds16_asm<SB_ + 3 * 64 * BK * 2>(gAg + 3 * rs64 + koff_, wave_lds_base);                \
+        glds16_asm<SB_ + PBM * BK * 2 + 0 * 64 * BK * 2>(gBg + koff_, wave_lds_base);            \
+        glds16_asm<SB_ + PBM * BK * 2 + 1 * 64 * BK * 2>(gBg + rs64 + koff_, wave_lds_base);     \
+    } while (0)
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    PIPE_ISSUE(0, 0);
+    if (nk > 1) {
+        PIPE_ISSUE(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_GLDS_PER_TILE) : "memory");   // tile 0 landed
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // The ring is unrolled by its depth so that every stage offset is a compile-time constant:
+    // with a run-time stage index hipcc cannot prove that the in-flight DMA (slot t+2) does not
+    // alias the slot being read (t) and drains vmcnt to 0 in front of the first ds_read of every
+    // K step, which serialises the whole pipeline.
+#define PIPE_STEP(kt_, S_)                                                                       \
+    if ((kt_) < nk) {                                                                            \
+        if ((kt_) + 2 < nk) PIPE_ISSUE((kt_) + 2, ((S_) + 2) % PSTAGES);                         \
+        const uint16_t* la = lds + (S_) * PSTAGE_ELEMS;                                          \
+        const uint16_t* lb = la + PBM * BK;                                                      \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                       \
+            uint4 fa[4], fb[4];                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                      \
+                const int r = wm * 64 + j * 16 + fr;                                             \
+                fa[j] = *reinterpret_cast<const uint4*>(la + r * BK + swz(r, ks * 4 + fq) * 8);  \
+            }                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
+                const int r = wn * 64 + i * 16 + fr;                                             \
+                fb[i] = *reinterpret_cast<const uint4*>(lb + r * BK + swz(r, ks * 4 + fq) * 8);  \
+            }                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                    \
+                    acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]);                       \
+        }                                                                                        \
+        /* tile kt+1 must be in LDS for EVERY wave before the next step reads it; the tile     */\
+        /* issued in this step may stay in flight.  Raw barrier: __syncthreads() would drain.  */\
+        if ((kt_) + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_GLDS_PER_TILE) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+        __builtin_amdgcn_s_barrier();                                                            \
+    }
+    for (int kt = 0; kt < nk; kt += PSTAGES) {
+        PIPE_STEP(kt, 0)
+        PIPE_STEP(kt + 1, 1)
+        PIPE_STEP(kt + 2, 2)
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * fq;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + fr;
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y;
+            float v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (add2d) {
+                const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
+                v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
+            }
+            if (GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            if (OUT_F32) {
+                float* C = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
+                if (accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(C);
+                    v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
+                }
+                *reinterpret_cast<float4*>(C) = make_float4(v0, v1, v2, v3);
+            } else {
+                uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)m * N + n;
+                uint2 o;
+                o.x = pack2<PREC>(v0, v1);
+                o.y = pack2<PREC>(v2, v3);
+                *reinterpret_cast<uint2*>(C) = o;
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// gemm_et_stag_kernel: same tile / ring / DMA as gemm_et_pipe_kernel, but the two waves that share
+// a SIMD (waves w and w+4) run STAGGERED by one barrier interval.  Every K step is cut into four
+// segments separated by raw barriers -- L0 (fragment reads, k 0..31 + DMA issue), C0 (16 MFMAs),
+// L1 (reads, k 32..63), C1 (16 MFMAs) -- and group 1 (waves 4..7) executes one extra barrier up
+// front, so while group 0 is in a C segment group 1 is in an L segment and vice versa: the matrix
+// pipe of every SIMD always has one wave feeding it while its partner waits on LDS (rocprofv3 on the
+// lock-step kernel: 48 % of wave cycles parked, MFMA busy 37 %).  s_setprio(1) around the MFMA
+// segments lets the computing wave win issue arbitration (cdna_hip_programming.md T5).
+//
+// Ring safety with the stagger (interval numbering 4*kt + {0,1,2,3} for group 0, +1 for group 1):
+//  WAR  the slot of tile kt-1 is last read by group 1 in interval 4kt-1; its refill (tile kt+2) is
+//       issued in an L0 segment, i.e. interval 4kt (group 0) / 4kt+1 (group 1): after that barrier.
+//  RAW  tile kt+1 is first read in interval 4kt+4; every wave waits vmcnt for its own share at the
+//       end of BOTH its L1 and C1 segments (interval 4kt+3 for either group) and then passes the
+//       barrier that opens interval 4kt+4.
+// Both groups execute exactly 2 + 4*nk barriers.
+// ---------------------------------------------------------------------------------------------
+template <int PREC, bool OUT_F32, bool GELU>
+__global__ __launch_bounds__(PTHREADS) void gemm_et_stag_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
+    int M, int N, int K, int accumulate) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[PSTAGES * PSTAGE_ELEMS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int grp = wave >> 2;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    constexpr int GROUP = 8;
+    const int tiles_n = N / PBN, tiles_m = M / PBM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_group = GROUP * tiles_n;
+    const int group = bid / per_group, first_m = group * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = bid - group * per_group;
+    const int tile_m = first_m + in_g % gsz, tile_n = in_g / gsz;
+    const int m0 = tile_m * PBM, n0 = tile_n * PBN;
+
+    const int g_row = 8 * wave + (lane >> 3);
+    const int g_chunk = (lane & 7) ^ ((g_row >> 1) & 7);
+    const uint16_t* gAg = A + (size_t)(m0 + g_row) * K + g_chunk * 8;
+    const uint16_t* gBg = B + (size_t)(n0 + g_row) * K + g_chunk * 8;
+    const uint32_t wave_lds_base = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * (8 * BK * 2));
+    const size_t rs64 = (size_t)64 * K;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    PIPE_ISSUE(0, 0);
+    if (nk > 1) {
+        PIPE_ISSUE(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_GLDS_PER_TILE) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one interval behind
+
+    const int fr = lane & 15, fq = lane >> 4;
+#define STAG_LOAD(S_, KS_)                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+        const int r = wm * 64 + j * 16 + fr;                                                      \
+        fa[j] = *reinterpret_cast<const uint4*>(lds + (S_) * PSTAGE_ELEMS + r * BK + swz(r, (KS_) * 4 + fq) * 8); \
+    }                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+        const int r = wn * 64 + i * 16 + fr;                                                      \
+        fb[i] = *reinterpret_cast<const uint4*>(lds + (S_) * PSTAGE_ELEMS + PBM * BK + r * BK + swz(r, (KS_) * 4 + fq) * 8); \
+    }
+#define STAG_MMA()                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]); \
+    __builtin_amdgcn_s_setprio(0);
+#define STAG_WAIT_NEXT(kt_)                                                                       \
+    if ((kt_) + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_GLDS_PER_TILE) : "memory");    \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define STAG_STEP(kt_, S_)                                                                        \
+    if ((kt_) < nk) {                                                                             \
+        uint4 fa[4], fb[4];                                                                       \
+        /* L0 */                                                                                  \
+        if ((kt_) + 2 < nk) PIPE_ISSUE((kt_) + 2, ((S_) + 2) % PSTAGES);                          \
+        STAG_LOAD(S_, 0)                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        __builtin_amdgcn_s_barrier();                                                             \
+        /* C0 */                                                                                  \
+        STAG_MMA()                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        __builtin_amdgcn_s_barrier();                                                             \
+        /* L1 */                                                                                  \
+        STAG_LOAD(S_, 1)                                                                          \
+        STAG_WAIT_NEXT(kt_)                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        __builtin_amdgcn_s_barrier();                                                             \
+        /* C1 */                                                                                  \
+        STAG_MMA()                                                                                \
+        STAG_WAIT_NEXT(kt_)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        __builtin_amdgcn_s_barrier();                                                             \
+    }
+    for (int kt = 0; kt < nk; kt += PSTAGES) {
+        STAG_STEP(kt, 0)
+        STAG_STEP(kt + 1, 1)
+        STAG_STEP(kt + 2, 2)
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // group 0 finishes one interval early
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * fq;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + fr;
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y;
+            float v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (add2d) {
+                const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
+                v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
+            }
+            if (GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            if (OUT_F32) {
+                float* C = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
+                if (accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(C);
+                    v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
+                }
+                *reinterpret_cast<float4*>(C) = make_float4(v0, v1, v2, v3);
+            } else {
+                uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)m * N + n;
+                uint2 o;
+                o.x = pack2<PREC>(v0, v1);
+                o.y = pack2<PREC>(v2, v3);
+                *reinterpret_cast<uint2*>(C) = o;
+            }
+        }
+    }
+}
+
+template <int PREC>
+hipError_t launch_gemm_stag(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
+                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
+    dim3 grid((M / PBM) * (N / PBN)), block(PTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (out_f32) {
+        if (gelu) gemm_et_stag_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_stag_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    } else {
+        if (gelu) gemm_et_stag_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_stag_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    }
+    return hipGetLastError();
+}
+
+template <int PREC>
+hipError_t launch_gemm_pipe(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
+                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
+    dim3 grid((M / PBM) * (N / PBN)), block(PTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (out_f32) {
+        if (gelu) gemm_et_pipe_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_pipe_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    } else {
+        if (gelu) gemm_et_pipe_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_pipe_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    }
+    return hipGetLastError();
+}
+
+int g_gemm_variant = 5;   // 0 reg-staged, 1 LDS-DMA, 2 LDS-DMA+grouped, 3 reg+grouped, 4 256x128 3-stage pipe, 5 = 4 + staggered wave groups
+
+template <int PREC, bool GLDS, int GROUP_M>
 hipError_t launch_gemm_prec(const void* A, const void* B, void* C, const float* bias,
                             const float* add2d, int period, int M, int N, int K, bool out_f32,
                             bool gelu, bool accumulate, hipStream_t s) {
@@ -216,14 +577,14 @@ hipError_t launch_gemm_prec(const void* A, const void* B, void* C, const float* 
     const int acc = accumulate ? 1 : 0;
     if (out_f32) {
         if (gelu)
-            gemm_et_kernel<PREC, true, true, GLDS><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+            gemm_et_kernel<PREC, true, true, GLDS, GROUP_M><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
         else
-            gemm_et_kernel<PREC, true, false, GLDS><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+            gemm_et_kernel<PREC, true, false, GLDS, GROUP_M><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
     } else {
         if (gelu)
-            gemm_et_kernel<PREC, false, true, GLDS><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+            gemm_et_kernel<PREC, false, true, GLDS, GROUP_M><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
         else
-            gemm_et_kernel<PREC, false, false, GLDS><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+            gemm_et_kernel<PREC, false, false, GLDS, GROUP_M><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
     }
     return hipGetLastError();
 }
@@ -305,13 +666,25 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
                           bool gelu, bool accumulate, hipStream_t s) {
     if (M % BM || N % BN || K % BK || M <= 0 || N <= 0 || K <= 0) return hipErrorInvalidValue;
     if (add2d && add2d_period <= 0) return hipErrorInvalidValue;
-    const bool glds = g_gemm_variant == 1;
-    if (prec == PREC_BF16)
-        return glds ? launch_gemm_prec<PREC_BF16, true>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s)
-                    : launch_gemm_prec<PREC_BF16, false>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
-    if (prec == PREC_F16)
-        return glds ? launch_gemm_prec<PREC_F16, true>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s)
-                    : launch_gemm_prec<PREC_F16, false>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+#define GEMM_DISPATCH(P)                                                                                         \
+    switch (g_gemm_variant) {                                                                                    \
+        case 0: return launch_gemm_prec<P, false, 1>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
+        case 1: return launch_gemm_prec<P, true, 1>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);  \
+        case 3: return launch_gemm_prec<P, false, 8>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
+        default: return launch_gemm_prec<P, true, 8>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
+    }
+    if (g_gemm_variant == 5 && M % PBM == 0) {   // staggered-group pipelined kernel
+        if (prec == PREC_BF16) return launch_gemm_stag<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_stag<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        return hipErrorInvalidValue;
+    }
+    if (g_gemm_variant == 4 && M % PBM == 0) {   // pipelined 256x128 kernel (default when M allows)
+        if (prec == PREC_BF16) return launch_gemm_pipe<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_pipe<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        return hipErrorInvalidValue;
+    }
+    if (prec == PREC_BF16) { GEMM_DISPATCH(PREC_BF16) }
+    if (prec == PREC_F16) { GEMM_DISPATCH(PREC_F16) }
     return hipErrorInvalidValue;
 }
 

@@ -56,7 +56,8 @@ def test_convert_bit_exact(lib, name, prec, dt, ulp):
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (384, 128, 640), (128, 256, 2304)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (384, 128, 640), (128, 256, 2304),
+                                   (256, 128, 64), (256, 256, 192), (512, 256, 640), (768, 128, 1280)])
 def test_gemm_et_variants(lib, name, prec, dt, ulp, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A, Ab = et_bits(torch.randn(M, K, generator=g), dt)

@@ -29,6 +29,11 @@ for grp in "$@"; do
     smoke)    run smoke 600 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench)    run bench 1200 python bench.py --steps 3 --warmup 1 ;;
     gemmb)    run gemmb 600 python tools/gemm_bench.py ${GEMM_VARIANTS:-0,1} f16 ;;
+    pmc)      cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
+              run pmc1 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc1 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 2 f16}
+              run pmc2 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/pmc2 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 2 f16}
+              run pmc3 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc3 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 2 f16}
+              run pmc4 600 rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAIT_INST_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc4 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 2 f16} ;;
     benchq)   run benchq 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;
     prof)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
               run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;

@@ -59,9 +59,26 @@ struct ET<PREC_F16> {
     }
 };
 
+typedef float float2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bfloat2_t __attribute__((ext_vector_type(2)));
+
+// two floats -> one packed ET word, RNE, NO saturation (v_cvt_pk_{f16,bf16}_f32): for values known
+// to be in range (softmax probabilities, normalised attention outputs).
+template <int PREC>
+__device__ __forceinline__ uint32_t pack2_fast(float lo, float hi) {
+    const float2_t f = {lo, hi};
+    if (PREC == PREC_F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, half2_t));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bfloat2_t));
+}
+// general version: f16 saturates at +-65504 instead of overflowing to inf
 template <int PREC>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)ET<PREC>::from_float(lo) | ((uint32_t)ET<PREC>::from_float(hi) << 16);
+    if (PREC == PREC_F16) {
+        lo = __builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f);
+        hi = __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f);
+    }
+    return pack2_fast<PREC>(lo, hi);
 }
 
 // ---------------------------------------------------------------------------------------------

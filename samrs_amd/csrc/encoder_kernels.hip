@@ -162,14 +162,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
 // -----------------------------------------------------------------------------------------
 // shared attention pieces
 // -----------------------------------------------------------------------------------------
-// e-th 16-bit element of a 16-byte vector, without taking its address (keeps it in registers)
-__device__ __forceinline__ uint16_t elem16(const uint4& v, int e) {
-    const uint32_t w = (e < 2) ? v.x : (e < 4) ? v.y : (e < 6) ? v.z : v.w;
-    return (uint16_t)((e & 1) ? (w >> 16) : (w & 0xffffu));
-}
+#define LOG2E_F 1.4426950408889634f
 
 // key (row) index of accumulator register r for lane-half hh within a 32x32 tile
-__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+__device__ __forceinline__ constexpr int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
 
 // Q fragments straight from global: lane (q = l&31, hh = l>>5) holds Q[q][16*ks + 8*hh .. +7].
 template <int KS>
@@ -197,6 +193,32 @@ __device__ __forceinline__ f32x16_t tile_times_qT(const uint16_t* lds_rows /* ro
     return acc;
 }
 
+// Same, rows = rows [row0, row0+32) of an fp32 rel-pos table in GLOBAL memory (rows >= nrows are
+// zero): the table is only touched once per block, so it is not worth an LDS copy.
+template <int PREC, int HD>
+__device__ __forceinline__ f32x16_t table_times_qT(const float* __restrict__ tab, int row0, int nrows, int lane,
+                                                   const uint4 (&qf)[HD / 16]) {
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int row = row0 + (lane & 31);
+    const bool ok = row < nrows;
+    const float* p = tab + (size_t)(ok ? row : 0) * HD + 8 * (lane >> 5);
+#pragma unroll
+    for (int ks = 0; ks < HD / 16; ++ks) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+        if (ok) {
+            x = *reinterpret_cast<const float4*>(p + 16 * ks);
+            y = *reinterpret_cast<const float4*>(p + 16 * ks + 4);
+        }
+        uint4 a;
+        a.x = pack2<PREC>(x.x, x.y); a.y = pack2<PREC>(x.z, x.w);
+        a.z = pack2<PREC>(y.x, y.y); a.w = pack2<PREC>(y.z, y.w);
+        acc = ET<PREC>::mfma32(a, qf[ks], acc);
+    }
+    return acc;
+}
+
 // V^T fragment for PV MFMA `u` of a 32-key tile: lane (dd = l&31, hh) holds keys
 // base + 4hh + {0..3} and base + 8 + 4hh + {0..3}, base = 16u, of row d = dd.
 __device__ __forceinline__ uint4 load_vt_frag(const uint16_t* vt_row /* &Vt[d][tile key 0] */, int u, int hh) {
@@ -206,34 +228,79 @@ __device__ __forceinline__ uint4 load_vt_frag(const uint16_t* vt_row /* &Vt[d][t
 }
 
 template <int PREC>
-__device__ __forceinline__ uint4 pack_p(const f32x16_t& p, int u) {
+__device__ __forceinline__ uint4 pack_p(const f32x16_t& p, int u) {   // probabilities in [0,1]: no saturation
     uint4 o;
-    o.x = pack2<PREC>(p[8 * u + 0], p[8 * u + 1]);
-    o.y = pack2<PREC>(p[8 * u + 2], p[8 * u + 3]);
-    o.z = pack2<PREC>(p[8 * u + 4], p[8 * u + 5]);
-    o.w = pack2<PREC>(p[8 * u + 6], p[8 * u + 7]);
+    o.x = pack2_fast<PREC>(p[8 * u + 0], p[8 * u + 1]);
+    o.y = pack2_fast<PREC>(p[8 * u + 2], p[8 * u + 3]);
+    o.z = pack2_fast<PREC>(p[8 * u + 4], p[8 * u + 5]);
+    o.w = pack2_fast<PREC>(p[8 * u + 6], p[8 * u + 7]);
     return o;
 }
 
+// word w (0..3) of a uint4
+__device__ __forceinline__ uint32_t word_of(const uint4& v, int w) { return w == 0 ? v.x : w == 1 ? v.y : w == 2 ? v.z : v.w; }
+// V^T staging: element e (0..7) of two adjacent keys' 16-byte d-chunks -> one word {v0[e], v1[e]}
+__device__ __forceinline__ uint32_t pair_elem(const uint4& v0, const uint4& v1, int e) {
+    return __builtin_amdgcn_perm(word_of(v1, e >> 1), word_of(v0, e >> 1), (e & 1) ? 0x07060302u : 0x05040100u);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// one online-softmax step on a 32-key S^T tile held in `S` (already = log2-domain logits WITHOUT the
+// per-tile constant `bh2`): updates running max / sum, rescales O only when some lane's max moved,
+// leaves the probabilities in S.
+template <int DT>
+__device__ __forceinline__ void online_softmax_step(f32x16_t* S, int ntiles, float mx, float bh2, float& m_run, float& l_run,
+                                                    f32x16_t (&O)[DT]) {
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx + bh2);
+    if (__any(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+    }
+    m_run = m_new;
+    const float off = m_new - bh2;
+    float sum = 0.f;
+    for (int a = 0; a < ntiles; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(S[a][r] - off);
+            S[a][r] = p;
+            sum += p;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    l_run += sum;
+}
+
 // =========================================================================================
-// windowed attention: one block per (window, head); 4 waves; each wave owns 32-query strips.
-// qkv rows are in WINDOW order (written by the window-gather LayerNorm + qkv GEMM).
+// windowed attention: one block (8 waves) per (window, head); wave w < 7 owns the 32-query strip w
+// (7 strips cover the 196 window tokens), keys are visited tile by tile with an online softmax so
+// that a wave needs ~130 registers and two waves fit per SIMD.  qkv rows are in WINDOW order
+// (written by the window-gather LayerNorm + qkv GEMM).
 // =========================================================================================
 template <int HD>
 struct WinCfg {
     static constexpr int WS = 14, N = WS * WS, NT = 7, NP = NT * 32;  // 196 tokens -> 7 tiles of 32
     static constexpr int DT = (HD + 31) / 32;                          // d tiles for PV
     static constexpr int VSTR = 228;                                   // V^T row stride (elements)
-    static constexpr int TSTR = 65;                                    // scratch row stride (floats)
+    static constexpr int NW = 8, THREADS = NW * 64;
+    static constexpr int SSTR = 33;                                    // scratch row stride (floats)
     static constexpr int K_BYTES = NP * HD * 2;
     static constexpr int VT_BYTES = DT * 32 * VSTR * 2;
-    static constexpr int RT_BYTES = 64 * HD * 2;
-    static constexpr int T_BYTES = 4 * 32 * TSTR * 4;
-    static constexpr int LDS_BYTES = K_BYTES + VT_BYTES + RT_BYTES + T_BYTES;
+    static constexpr int S_BYTES = NW * 32 * SSTR * 4;
+    static constexpr int LDS_BYTES = K_BYTES + VT_BYTES + S_BYTES;
 };
 
 template <int PREC, int HD>
-__global__ __launch_bounds__(256) void window_attention_kernel(
+__global__ __launch_bounds__(512) void window_attention_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ rel_h, const float* __restrict__ rel_w,
     uint16_t* __restrict__ out, int grid, int heads) {
     using C = WinCfg<HD>;
@@ -241,8 +308,7 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vt = reinterpret_cast<uint16_t*>(smem + C::K_BYTES);
-    uint16_t* Rt = reinterpret_cast<uint16_t*>(smem + C::K_BYTES + C::VT_BYTES);
-    float* Tq = reinterpret_cast<float*>(smem + C::K_BYTES + C::VT_BYTES + C::RT_BYTES);
+    float* Scr = reinterpret_cast<float*>(smem + C::K_BYTES + C::VT_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, ql = lane & 31;
@@ -255,21 +321,18 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
     const size_t row0 = (size_t)wi * C::N;
     const uint16_t* base = qkv + row0 * (3 * D) + head * HD;
 
-    // ---- stage K (row-major), V^T, rel tables -------------------------------------------
+    // ---- stage K (row-major) and V^T ---------------------------------------------------------
     constexpr int CH = HD / 8;  // 16-byte chunks per row
-    // rows d >= HD of V^T feed the padded part of the last d-tile: must be zero, nothing else is
-    // read uninitialised (keys >= N are written as zeros below).
-    for (int i = tid; i < (C::DT * 32 - HD) * C::VSTR; i += 256) Vt[HD * C::VSTR + i] = 0;
-    for (int c = tid; c < C::NP * CH; c += 256) {
+    for (int i = tid; i < (C::DT * 32 - HD) * C::VSTR; i += C::THREADS) Vt[HD * C::VSTR + i] = 0;
+    for (int c = tid; c < C::NP * CH; c += C::THREADS) {
         const int r = c / CH, ch = c % CH;
         uint4 kv = make_uint4(0u, 0u, 0u, 0u);
         if (r < C::N) kv = *reinterpret_cast<const uint4*>(base + (size_t)r * (3 * D) + D + ch * 8);
         *reinterpret_cast<uint4*>(Ks + r * HD + ch * 8) = kv;
     }
     // V^T[d][key]: a thread takes one 8-wide d chunk of TWO adjacent keys and writes eight 4-byte
-    // words; consecutive lanes take consecutive key pairs -> consecutive banks (conflict-free),
-    // instead of 2-byte scatters that pile onto two banks.
-    for (int c = tid; c < (C::NP / 2) * CH; c += 256) {
+    // words; consecutive lanes take consecutive key pairs -> consecutive banks.
+    for (int c = tid; c < (C::NP / 2) * CH; c += C::THREADS) {
         const int kp = c % (C::NP / 2), ch = c / (C::NP / 2);
         const int r0 = 2 * kp;
         uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = v0;
@@ -277,110 +340,90 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
         if (r0 + 1 < C::N) v1 = *reinterpret_cast<const uint4*>(base + (size_t)(r0 + 1) * (3 * D) + 2 * D + ch * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-            *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + e) * C::VSTR + r0) = (uint32_t)elem16(v0, e) | ((uint32_t)elem16(v1, e) << 16);
-    }
-    for (int i = tid; i < 64 * HD; i += 256) {
-        const int r = i / HD, d = i % HD;
-        float v = 0.f;
-        if (r < 2 * C::WS - 1) v = rel_h[r * HD + d];
-        else if (r >= 32 && r < 32 + 2 * C::WS - 1) v = rel_w[(r - 32) * HD + d];
-        Rt[i] = ET<PREC>::from_float(v);
+            *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + e) * C::VSTR + r0) = pair_elem(v0, v1, e);
     }
     __syncthreads();
+    if (wave >= C::NT) return;            // no block-level barrier below this point
 
-    const float scale = rsqrtf((float)HD);
-    float* tq = Tq + wave * 32 * C::TSTR;
+    const int q = 32 * wave + ql;         // query index inside the window
+    const bool qin = q < C::N;
+    uint4 qf[KS];
+    load_q_frags<KS>(qin ? base + (size_t)q * (3 * D) : nullptr, hh, qf);
 
-    for (int s = wave; s < C::NT; s += 4) {
-        const int q = 32 * s + ql;                 // query index inside the window
-        const bool qin = q < C::N;
-        uint4 qf[KS];
-        load_q_frags<KS>(qin ? base + (size_t)q * (3 * D) : nullptr, hh, qf);
-
-        // rel-pos tiles -> scratch [q][row]
-        {
-            const f32x16_t th = tile_times_qT<PREC, HD>(Rt, lane, qf);
-            const f32x16_t tw = tile_times_qT<PREC, HD>(Rt + 32 * HD, lane, qf);
+    // ---- decomposed rel-pos: RH[j] = q . rel_h[qh - j + 13], RW[j] = q . rel_w[qw - j + 13] -----
+    // (log2 domain; image_encoder.py:325-361 uses the UNSCALED q)
+    const int qc = qin ? q : C::N - 1;
+    const int qh = qc / C::WS, qw = qc % C::WS;
+    float* scr = Scr + wave * 32 * C::SSTR + ql * C::SSTR;
+    float RH[C::WS], RW[C::WS];
+    {
+        const f32x16_t th = table_times_qT<PREC, HD>(rel_h, 0, 2 * C::WS - 1, lane, qf);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                tq[ql * C::TSTR + acc_row(r, hh)] = th[r];
-                tq[ql * C::TSTR + 32 + acc_row(r, hh)] = tw[r];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = th[r];
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < C::WS; ++j) RH[j] = scr[qh - j + C::WS - 1] * LOG2E_F;
+        wave_lds_sync();
+        const f32x16_t tw = table_times_qT<PREC, HD>(rel_w, 0, 2 * C::WS - 1, lane, qf);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = tw[r];
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < C::WS; ++j) RW[j] = scr[qw - j + C::WS - 1] * LOG2E_F;
+    }
 
-        const int qc = qin ? q : C::N - 1;
-        const int qh = qc / C::WS, qw = qc % C::WS;
-        const float* trow = tq + ql * C::TSTR;
+    const float c2 = rsqrtf((float)HD) * LOG2E_F;
+    f32x16_t O[C::DT];
+#pragma unroll
+    for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
 
-        f32x16_t S[C::NT];
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t) {
+        f32x16_t S = tile_times_qT<PREC, HD>(Ks + t * 32 * HD, lane, qf);
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < C::NT; ++t) {
-            S[t] = tile_times_qT<PREC, HD>(Ks + t * 32 * HD, lane, qf);
+        for (int r = 0; r < 16; ++r) {
+            // key = k0 + 4*hh; both candidates are compile-time constants after unrolling
+            constexpr int dummy = 0; (void)dummy;
+            const int k0 = 32 * t + acc_row(r, 0), k1 = k0 + 4;
+            const float b0 = (k0 < C::N) ? RH[(k0 < C::N ? k0 : 0) / C::WS] + RW[(k0 < C::N ? k0 : 0) % C::WS] : -INFINITY;
+            const float b1 = (k1 < C::N) ? RH[(k1 < C::N ? k1 : 0) / C::WS] + RW[(k1 < C::N ? k1 : 0) % C::WS] : -INFINITY;
+            const float v = S[r] * c2 + (hh ? b1 : b0);      // -inf for the tile-padding keys (>= 196)
+            S[r] = v;
+            mx = fmaxf(mx, v);
+        }
+        online_softmax_step<C::DT>(&S, 1, mx, 0.f, m_run, l_run, O);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * t + acc_row(r, hh);
-                float v = -INFINITY;
-                if (key < C::N) {
-                    const int kh = key / C::WS, kw = key % C::WS;
-                    v = S[t][r] * scale + trow[qh - kh + C::WS - 1] + trow[32 + qw - kw + C::WS - 1];
-                }
-                S[t][r] = v;
-                mx = fmaxf(mx, v);
+        for (int u = 0; u < 2; ++u) {
+            const uint4 pb = pack_p<PREC>(S, u);
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt) {
+                const uint4 va = load_vt_frag(Vt + (dt * 32 + ql) * C::VSTR + 32 * t, u, hh);
+                O[dt] = ET<PREC>::mfma32(va, pb, O[dt]);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < C::NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __expf(S[t][r] - mx);
-                S[t][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 32, 64);
+    }
 
-        // PV: O^T[d][q]
-        f32x16_t O[C::DT];
+    // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
+    const int y = wy * C::WS + q / C::WS, x = wx * C::WS + q % C::WS;
+    if (qin && y < grid && x < grid) {
+        const float inv = 1.0f / l_run;
+        uint16_t* orow = out + ((size_t)im * grid * grid + (size_t)y * grid + x) * D + head * HD;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < C::NT; ++t)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const uint4 pb = pack_p<PREC>(S[t], u);
-#pragma unroll
-                for (int dt = 0; dt < C::DT; ++dt) {
-                    const uint4 va = load_vt_frag(Vt + (dt * 32 + ql) * C::VSTR + 32 * t, u, hh);
-                    O[dt] = ET<PREC>::mfma32(va, pb, O[dt]);
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * dt + 8 * g + 4 * hh;
+                if (d0 < HD) {
+                    uint2 o;
+                    o.x = pack2_fast<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
+                    o.y = pack2_fast<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
+                    *reinterpret_cast<uint2*>(orow + d0) = o;
                 }
             }
-
-        // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
-        const int y = wy * C::WS + q / C::WS, x = wx * C::WS + q % C::WS;
-        if (qin && y < grid && x < grid) {
-            const float inv = 1.0f / sum;
-            uint16_t* orow = out + ((size_t)im * grid * grid + (size_t)y * grid + x) * D + head * HD;
-#pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d0 = 32 * dt + 8 * g + 4 * hh;
-                    if (d0 < HD) {
-                        uint2 o;
-                        o.x = pack2<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
-                        o.y = pack2<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
-                        *reinterpret_cast<uint2*>(orow + d0) = o;
-                    }
-                }
-        }
-        __builtin_amdgcn_wave_barrier();  // scratch is rewritten by the next strip
     }
 }
 
@@ -388,38 +431,34 @@ __global__ __launch_bounds__(256) void window_attention_kernel(
 // global attention (grid x grid tokens, flash-style online softmax).
 // Block = 128 queries of one (image, head): 4 waves x 32-query strips.  A strip lies inside one
 // image row half, so qh is wave-uniform and qw = qw0 + lane.  Keys are streamed one image row
-// (64 keys) per tile: kh = tile index, kw = position in the tile.
+// (64 keys) per tile: kh = tile index, kw = position in the tile.  80 KB of LDS and <= 256
+// registers -> two blocks (two waves per SIMD) per CU.
 // =========================================================================================
 template <int HD>
 struct GlbCfg {
     static constexpr int G = 64, KT = 64;                 // grid side, keys per tile
     static constexpr int DT = (HD + 31) / 32;
     static constexpr int VSTR = KT + 4;                   // 68: 8-byte aligned, conflict-light
-    static constexpr int TAB_ROWS = 128;                  // 2*G-1 = 127 rows (+1 zero row)
-    static constexpr int TAB_BYTES = 2 * TAB_ROWS * HD * 2;      // rel_h | rel_w as ET
-    static constexpr int TW_STR = 97;                     // per-wave scratch row stride (floats)
-    static constexpr int TW_BYTES = 4 * 32 * TW_STR * 4;
     static constexpr int K_BYTES = KT * HD * 2;
     static constexpr int VT_BYTES = DT * 32 * VSTR * 2;
     static constexpr int KV_BYTES = 2 * (K_BYTES + VT_BYTES);    // double buffered
-    static constexpr int UNION_BYTES = (TAB_BYTES + TW_BYTES) > KV_BYTES ? (TAB_BYTES + TW_BYTES) : KV_BYTES;
+    static constexpr int SSTR = 33;
+    static constexpr int SCR_BYTES = 4 * 32 * SSTR * 4;          // setup scratch, aliases the K/V buffers
+    static constexpr int UNION_BYTES = KV_BYTES > SCR_BYTES ? KV_BYTES : SCR_BYTES;
     static constexpr int RH_STR = 65;
     static constexpr int RH_BYTES = 4 * 32 * RH_STR * 4;
     static constexpr int LDS_BYTES = UNION_BYTES + RH_BYTES;
 };
 
 template <int PREC, int HD>
-__global__ __launch_bounds__(256) void global_attention_kernel(
+__global__ __launch_bounds__(256, 2) void global_attention_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ rel_h, const float* __restrict__ rel_w,
     uint16_t* __restrict__ out, int heads) {
     using C = GlbCfg<HD>;
     constexpr int KS = HD / 16;
     constexpr int G = C::G, NTOK = G * G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // setup view
-    uint16_t* Tab = reinterpret_cast<uint16_t*>(smem);                       // [2][128][HD]
-    float* TW = reinterpret_cast<float*>(smem + C::TAB_BYTES);               // [4][32][TW_STR]
-    // main-loop view (aliases the setup view)
+    float* Scr = reinterpret_cast<float*>(smem);                              // setup only
     // buffer b: K tile at b*(K_BYTES+VT_BYTES), V^T tile right after it (computed, not an array
     // of pointers: runtime-indexed arrays end up in scratch)
     auto Kb = [&](int b) { return reinterpret_cast<uint16_t*>(smem + b * (C::K_BYTES + C::VT_BYTES)); };
@@ -453,42 +492,38 @@ __global__ __launch_bounds__(256) void global_attention_kernel(
     uint4 qf[KS];
     load_q_frags<KS>(base + (size_t)q * (3 * D), hh, qf);
 
-    // ---- setup: rel tables -> LDS (ET), T_h / T_w tiles -> scratch -> RH (LDS) / rw (regs) ----
-    for (int i = tid; i < 2 * C::TAB_ROWS * HD; i += 256) {
-        const int tsel = i / (C::TAB_ROWS * HD);
-        const int r = (i / HD) % C::TAB_ROWS, d = i % HD;
-        float v = 0.f;
-        if (r < 2 * G - 1) v = (tsel ? rel_w : rel_h)[r * HD + d];
-        Tab[i] = ET<PREC>::from_float(v);
-    }
-    __syncthreads();
+    // ---- setup: decomposed rel-pos terms (log2 domain) ---------------------------------------
+    //  RH[q][kh] = q . rel_h[qh - kh + 63]   -> LDS (one value per key tile)
+    //  rw[a][r]  = q . rel_w[qw - kw + 63], kw = 32a + acc_row(r, hh)  -> 32 registers
     float* rh = RH + wave * 32 * C::RH_STR + ql * C::RH_STR;
-    float* tw = TW + wave * 32 * C::TW_STR;
-    {
-        // T_h'[i'][q] = Q[q] . rel_h[qh + i'],  i' = 63 - kh  -> RH[q][kh]
+    float* scr = Scr + wave * 32 * C::SSTR + ql * C::SSTR;
+    float rw[2][16];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const f32x16_t th = tile_times_qT<PREC, HD>(Tab + (qh + 32 * t) * HD, lane, qf);
+    for (int t = 0; t < 2; ++t) {
+        // T_h'[i'][q] = Q[q] . rel_h[qh + i'],  i' = 63 - kh
+        const f32x16_t th = table_times_qT<PREC, HD>(rel_h, qh + 32 * t, 2 * G - 1, lane, qf);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rh[(G - 1) - (32 * t + acc_row(r, hh))] = th[r];
-        }
-        // T_w'[i'][q] = Q[q] . rel_w[qw0 + i'],  i' = ql - kw + 63  in [0, 94]
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const f32x16_t tt = tile_times_qT<PREC, HD>(Tab + (C::TAB_ROWS + qw0 + 32 * t) * HD, lane, qf);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tw[ql * C::TW_STR + 32 * t + acc_row(r, hh)] = tt[r];
-        }
+        for (int r = 0; r < 16; ++r) rh[(G - 1) - (32 * t + acc_row(r, hh))] = th[r] * LOG2E_F;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    float rw[2][16];  // rw[a][r] = RW[q][kw = 32a + acc_row(r, hh)]
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int t = 0; t < 3; ++t) {
+        // T_w'[i'][q] = Q[q] . rel_w[qw0 + i'],  i' = ql - kw + 63  in [0, 94]
+        const f32x16_t tt = table_times_qT<PREC, HD>(rel_w, qw0 + 32 * t, 2 * G - 1, lane, qf);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rw[a][r] = tw[ql * C::TW_STR + ql - (32 * a + acc_row(r, hh)) + (G - 1)];
-    __syncthreads();  // everyone is done with Tab / TW before K/V tiles overwrite them
+        for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = tt[r];
+        wave_lds_sync();
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ip = ql - (32 * a + acc_row(r, hh)) + (G - 1);
+                const float v = scr[ip & 31] * LOG2E_F;
+                if (t == 0) rw[a][r] = 0.f;
+                rw[a][r] = ((ip >> 5) == t) ? v : rw[a][r];
+            }
+        wave_lds_sync();
+    }
+    __syncthreads();  // everyone is done with the scratch before K/V tiles overwrite it
 
     // ---- main loop over key tiles -----------------------------------------------------------
     constexpr int CH = HD / 8;
@@ -525,7 +560,7 @@ __global__ __launch_bounds__(256) void global_attention_kernel(
             const int kp_ = c_ % (C::KT / 2), ch_ = c_ / (C::KT / 2);                           \
             _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_)                                    \
                 *reinterpret_cast<uint32_t*>(Vb(buf_) + (ch_ * 8 + e_) * C::VSTR + 2 * kp_) =   \
-                    (uint32_t)elem16(rv0[i_], e_) | ((uint32_t)elem16(rv1[i_], e_) << 16);      \
+                    pair_elem(rv0[i_], rv1[i_], e_);                                            \
         }                                                                                       \
     }
     // rows d >= HD of V^T must be zero in both buffers (only when HD is not a multiple of 32)
@@ -537,7 +572,7 @@ __global__ __launch_bounds__(256) void global_attention_kernel(
     GLB_LSTORE(0)
     __syncthreads();
 
-    const float scale = rsqrtf((float)HD);
+    const float c2 = rsqrtf((float)HD) * LOG2E_F;
     f32x16_t O[C::DT];
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt)
@@ -549,7 +584,7 @@ __global__ __launch_bounds__(256) void global_attention_kernel(
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         GLB_GLOAD(kt + 1 < nkt ? kt + 1 : kt)
-        const float bh = rh[kt];  // RH[q][kh = kt]
+        const float bh2 = rh[kt];  // RH[q][kh = kt], constant over the tile
 
         f32x16_t S[2];
         float mx = -INFINITY;
@@ -558,30 +593,12 @@ __global__ __launch_bounds__(256) void global_attention_kernel(
             S[a] = tile_times_qT<PREC, HD>(Kb(buf) + a * 32 * HD, lane, qf);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = S[a][r] * scale + bh + rw[a][r];
+                const float v = S[a][r] * c2 + rw[a][r];
                 S[a][r] = v;
                 mx = fmaxf(mx, v);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        float sum = 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __expf(S[a][r] - m_new);
-                S[a][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 32, 64);
-        l_run = l_run * alpha + sum;
-        m_run = m_new;
-#pragma unroll
-        for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
+        online_softmax_step<C::DT>(S, 2, mx, bh2, m_run, l_run, O);
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -606,8 +623,8 @@ __global__ __launch_bounds__(256) void global_attention_kernel(
             const int d0 = 32 * dt + 8 * g + 4 * hh;
             if (d0 < HD) {
                 uint2 o;
-                o.x = pack2<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
-                o.y = pack2<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
+                o.x = pack2_fast<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
+                o.y = pack2_fast<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + d0) = o;
             }
         }
@@ -700,7 +717,7 @@ static hipError_t launch_win(const void* qkv, const float* rh, const float* rw, 
     auto k = window_attention_kernel<PREC, HD>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
     const int nw = (grid + C::WS - 1) / C::WS;
-    dim3 g(n_images * nw * nw, heads), b(256);
+    dim3 g(n_images * nw * nw, heads), b(C::THREADS);
     k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, rh, rw, (uint16_t*)out, grid, heads);
     return hipGetLastError();
 }

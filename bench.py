@@ -186,7 +186,7 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the oracle (a port of the reference's algorithm) on the host cores, one tile + 32 boxes as 20+12 chunks
         from oracle import sam_oracle as so
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))   # more threads oversubscribe the box (256 logical CPUs: 215 s per tile)
         orc = so.OraclePredictor(sd, cfg)
         img = tiles[0].cpu().numpy()
         bx = boxes[0].cpu()

@@ -548,6 +548,193 @@ hipError_t launch_gemm_stag(const void* A, const void* B, void* C, const float* 
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// gemm_et_big_kernel: 256x256x32 block tile, 8 waves as 2 (M) x 4 (N), wave tile 128x64
+// (8 x 4 MFMA 16x16x32 tiles, one full K=32 step per MFMA), FOUR-stage LDS ring (4 x 32 KiB) filled
+// by LDS-DMA three tiles ahead, wave groups staggered by one barrier interval (L | C segments).
+// Versus the 256x128x64 kernel: 4 instead of 6 DMA pieces and 12 instead of 16 ds_read_b128 per 32
+// MFMAs, and 2 instead of 4 barriers -- the per-CU vector-memory / LDS traffic per FLOP is what
+// capped that kernel.
+//
+// LDS rows are 64 B (32 ET): four rows per 256-B bank row, so the ds_read_b128 lane groups
+// (MI355X_MICROARCH.md, LDS table) need the 16-byte chunk index XORed with g(row>>2),
+// g = [0,2,3,1]: checked conflict-free for all four lane groups.
+// ---------------------------------------------------------------------------------------------
+constexpr int QBM = 256, QBN = 256, QBK = 32, QSTAGES = 4, QTHREADS = 512;
+constexpr int QSTAGE_ELEMS = (QBM + QBN) * QBK;                // 16384 ET = 32 KiB
+constexpr int Q_DMA_PER_TILE = (QBM + QBN) * QBK * 2 / (QTHREADS * 16);   // 4 per thread
+
+__device__ __forceinline__ int qswz(int r, int c) { return c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3); }
+
+// ABL (ablation bits, timing experiments only; results are garbage when non-zero):
+//   1 = no DMA, 2 = no fragment reads, 4 = no MFMA, 8 = no barriers
+template <int PREC, bool OUT_F32, bool GELU, int ABL = 0>
+__global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
+    int M, int N, int K, int accumulate) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[QSTAGES * QSTAGE_ELEMS];   // 128 KiB, ONE object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                 // waves w and w+4 share a SIMD -> different groups
+    const int wm = wave >> 2, wn = wave & 3;   // wave tile rows wm*128.., cols wn*64..
+
+    constexpr int GROUP = 8;
+    const int tiles_n = N / QBN, tiles_m = M / QBM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_group = GROUP * tiles_n;
+    const int group = bid / per_group, first_m = group * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = bid - group * per_group;
+    const int tile_m = first_m + in_g % gsz, tile_n = in_g / gsz;
+    const int m0 = tile_m * QBM, n0 = tile_n * QBN;
+
+    // DMA map: one piece (wave instruction) = 1 KiB = 16 rows x 64 B; lane l -> row l>>2, physical
+    // chunk l&3, source chunk (l&3) ^ g(row>>2).  Round i of 8 waves covers rows 128*i + 16*w .. +15.
+    const int g_row = 16 * wave + (lane >> 2);
+    const int g_chunk = qswz(g_row, lane & 3);
+    const uint16_t* gAg = A + (size_t)(m0 + g_row) * K + g_chunk * 8;
+    const uint16_t* gBg = B + (size_t)(n0 + g_row) * K + g_chunk * 8;
+    const uint32_t wave_lds_base = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * (16 * QBK * 2));
+    const size_t rs128 = (size_t)128 * K;
+#define BIG_ISSUE(kt_, stage_)                                                                  \
+    do {                                                                                         \
+        const size_t koff_ = (size_t)(kt_) * QBK;                                                \
+        constexpr int SB_ = (stage_) * QSTAGE_ELEMS * 2;                                         \
+        glds16_asm<SB_ + 0>(gAg + koff_, wave_lds_base);                                         \
+        glds16_asm<SB_ + 128 * QBK * 2>(gAg + rs128 + koff_, wave_lds_base);                     \
+        glds16_asm<SB_ + QBM * QBK * 2>(gBg + koff_, wave_lds_base);                             \
+        glds16_asm<SB_ + QBM * QBK * 2 + 128 * QBK * 2>(gBg + rs128 + koff_, wave_lds_base);     \
+    } while (0)
+
+    f32x4_t acc[4][8];    // [n-tile i][m-tile j]; D[i_local = n][j_local = m]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / QBK;
+    // prologue: tiles 0..2 in flight, tile 0 landed
+    if (!(ABL & 1)) {
+    BIG_ISSUE(0, 0);
+    if (nk > 1) BIG_ISSUE(1, 1);
+    if (nk > 2) BIG_ISSUE(2, 2);
+    }
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Q_DMA_PER_TILE) : "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q_DMA_PER_TILE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1 && !(ABL & 8)) __builtin_amdgcn_s_barrier();          // stagger
+
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment byte-free offsets (elements) inside a stage; rows are fixed per lane, only the stage moves
+    int offA[8], offB[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int r = wm * 128 + j * 16 + fr; offA[j] = r * QBK + qswz(r, fq) * 8; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = wn * 64 + i * 16 + fr; offB[i] = QBM * QBK + r * QBK + qswz(r, fq) * 8; }
+
+    // wait so that tile kt+1 has landed; tiles kt+2 / kt+3 may stay in flight
+#define BIG_WAIT(kt_)                                                                            \
+    if ((kt_) + 3 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Q_DMA_PER_TILE) : "memory"); \
+    else if ((kt_) + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q_DMA_PER_TILE) : "memory"); \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define BIG_STEP(kt_, S_)                                                                        \
+    if ((kt_) < nk) {                                                                            \
+        uint4 fa[8], fb[4];                                                                      \
+        /* L: refill the slot freed last interval, read this step's fragments */                 \
+        if (!(ABL & 1)) { if ((kt_) + 3 < nk) BIG_ISSUE((kt_) + 3, ((S_) + 3) % QSTAGES); }      \
+        if (!(ABL & 2)) {                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            fb[i] = *reinterpret_cast<const uint4*>(lds + (S_) * QSTAGE_ELEMS + offB[i]);        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                            \
+            fa[j] = *reinterpret_cast<const uint4*>(lds + (S_) * QSTAGE_ELEMS + offA[j]);        \
+        } else {                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { fb[i] = make_uint4(lane, i, (kt_), 1); asm volatile("" : "+v"(fb[i].x)); } \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) { fa[j] = make_uint4(lane, j, (kt_), 2); asm volatile("" : "+v"(fa[j].x)); } \
+        }                                                                                        \
+        BIG_WAIT(kt_)                                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();                                            \
+        /* C: 32 MFMAs */                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                           \
+        if (!(ABL & 4)) {                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j)                                        \
+                acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]);                           \
+        } else {                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fb[i].x), "v"(fb[i].w)); \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(fa[j].x), "v"(fa[j].w)); \
+        }                                                                                        \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+        BIG_WAIT(kt_)                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (!(ABL & 8)) __builtin_amdgcn_s_barrier();                                            \
+    }
+    for (int kt = 0; kt < nk; kt += QSTAGES) {
+        BIG_STEP(kt, 0)
+        BIG_STEP(kt + 1, 1)
+        BIG_STEP(kt + 2, 2)
+        BIG_STEP(kt + 3, 3)
+    }
+    if (grp == 0 && !(ABL & 8)) __builtin_amdgcn_s_barrier();          // both groups: 2 + 2*nk barriers
+
+    // epilogue: lane holds C[m][n..n+3], m = m0 + wm*128 + j*16 + fr, n = n0 + wn*64 + i*16 + 4*fq
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * fq;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int m = m0 + wm * 128 + j * 16 + fr;
+            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y;
+            float v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+            if (add2d) {
+                const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
+                v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
+            }
+            if (GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            if (OUT_F32) {
+                float* C = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
+                if (accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(C);
+                    v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
+                }
+                *reinterpret_cast<float4*>(C) = make_float4(v0, v1, v2, v3);
+            } else {
+                uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)m * N + n;
+                uint2 o;
+                o.x = pack2<PREC>(v0, v1);
+                o.y = pack2<PREC>(v2, v3);
+                *reinterpret_cast<uint2*>(C) = o;
+            }
+        }
+    }
+}
+
+template <int PREC>
+hipError_t launch_gemm_big(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
+                           int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
+    dim3 grid((M / QBM) * (N / QBN)), block(QTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (out_f32) {
+        if (gelu) gemm_et_big_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_big_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    } else {
+        if (gelu) gemm_et_big_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_big_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    }
+    return hipGetLastError();
+}
+
 template <int PREC>
 hipError_t launch_gemm_pipe(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                             int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
@@ -673,7 +860,23 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         case 3: return launch_gemm_prec<P, false, 8>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
         default: return launch_gemm_prec<P, true, 8>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
     }
-    if (g_gemm_variant == 5 && M % PBM == 0) {   // staggered-group pipelined kernel
+    if (g_gemm_variant >= 60 && g_gemm_variant < 76 && prec == PREC_F16 && !out_f32 && M % QBM == 0 && N % QBN == 0) {
+        dim3 grid((M / QBM) * (N / QBN)), block(QTHREADS);
+        const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+        const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+#define ABL_CASE(x) case 60 + x: gemm_et_big_kernel<PREC_F16, false, false, x><<<grid, block, 0, s>>>(a, b, C, bias, add2d, add2d_period, M, N, K, 0); break;
+        switch (g_gemm_variant) {
+            ABL_CASE(0) ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(5) ABL_CASE(6) ABL_CASE(8) ABL_CASE(9) ABL_CASE(12) ABL_CASE(7) ABL_CASE(11)
+            default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if (g_gemm_variant == 6 && M % QBM == 0 && N % QBN == 0 && K % QBK == 0) {   // 256x256 staggered kernel
+        if (prec == PREC_BF16) return launch_gemm_big<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_big<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        return hipErrorInvalidValue;
+    }
+    if ((g_gemm_variant == 5 || g_gemm_variant == 6) && M % PBM == 0) {   // staggered-group pipelined kernel
         if (prec == PREC_BF16) return launch_gemm_stag<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_stag<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;

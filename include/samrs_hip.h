@@ -154,9 +154,11 @@ int samrs_k_convert(int prec, const float* in, void* out_et, int64_t n, void* st
 int samrs_k_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                       void* out_et, float* out_f32, int rows_out, int D, int window_mode,
                       int n_images, int grid, int window, void* stream);
-int samrs_k_window_attention(int prec, const void* qkv_et, const float* rel_h, const float* rel_w,
-                             void* out_et, int n_images, int grid, int window, int heads,
-                             int head_dim, void* stream);
+/* qkv_et: [n_images*grid*grid, 3D] in token order; qkv_bias fp32 [3D] supplies k / v of the window
+ * padding positions (zero tokens after norm1 in the reference). */
+int samrs_k_window_attention(int prec, const void* qkv_et, const float* qkv_bias, const float* rel_h,
+                             const float* rel_w, void* out_et, int n_images, int grid, int window,
+                             int heads, int head_dim, void* stream);
 int samrs_k_global_attention(int prec, const void* qkv_et, const float* rel_h, const float* rel_w,
                              void* out_et, int n_images, int grid, int heads, int head_dim,
                              void* stream);

@@ -283,8 +283,12 @@ __device__ __forceinline__ void online_softmax_step(f32x16_t* S, int ntiles, flo
 // =========================================================================================
 // windowed attention: one block (8 waves) per (window, head); wave w < 7 owns the 32-query strip w
 // (7 strips cover the 196 window tokens), keys are visited tile by tile with an online softmax so
-// that a wave needs ~130 registers and two waves fit per SIMD.  qkv rows are in WINDOW order
-// (written by the window-gather LayerNorm + qkv GEMM).
+// that a wave needs ~130 registers and two waves fit per SIMD.
+// qkv rows are in plain TOKEN order [img][y][x]; the kernel does the window partition itself.  A
+// window position that falls in the bottom/right padding is a zero token after norm1 in the
+// reference (image_encoder.py:168-172,256-259), so its k / v are exactly the qkv BIAS: the kernel
+// reads them from `qkv_bias` instead of having the GEMM grind through 17.6 % padding rows.  Padding
+// tokens are valid keys (not masked); padding queries are dropped (image_encoder.py:287-288).
 // =========================================================================================
 template <int HD>
 struct WinCfg {
@@ -301,8 +305,8 @@ struct WinCfg {
 
 template <int PREC, int HD>
 __global__ __launch_bounds__(512) void window_attention_kernel(
-    const uint16_t* __restrict__ qkv, const float* __restrict__ rel_h, const float* __restrict__ rel_w,
-    uint16_t* __restrict__ out, int grid, int heads) {
+    const uint16_t* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ rel_h,
+    const float* __restrict__ rel_w, uint16_t* __restrict__ out, int grid, int heads) {
     using C = WinCfg<HD>;
     constexpr int KS = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -318,8 +322,21 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
     const int nw = (grid + C::WS - 1) / C::WS;
     const int win = wi % (nw * nw), im = wi / (nw * nw);
     const int wy = win / nw, wx = win % nw;
-    const size_t row0 = (size_t)wi * C::N;
-    const uint16_t* base = qkv + row0 * (3 * D) + head * HD;
+    const uint16_t* base = qkv + (size_t)im * grid * grid * (3 * D) + head * HD;   // token row 0 of this image
+    // window position r -> token row offset (elements) or -1 for a padding position
+    auto tok_off = [&](int r) -> long {
+        const int y = wy * C::WS + r / C::WS, x = wx * C::WS + r % C::WS;
+        return (y < grid && x < grid) ? (long)(y * grid + x) * (3 * D) : -1L;
+    };
+    // 8 consecutive channels of the k (part = 1) / v (part = 2) bias of this head, as ET
+    auto bias_chunk = [&](int part, int ch) -> uint4 {
+        const float* b = qkv_bias + part * D + head * HD + ch * 8;
+        const float4 x = *reinterpret_cast<const float4*>(b), y = *reinterpret_cast<const float4*>(b + 4);
+        uint4 o;
+        o.x = pack2<PREC>(x.x, x.y); o.y = pack2<PREC>(x.z, x.w);
+        o.z = pack2<PREC>(y.x, y.y); o.w = pack2<PREC>(y.z, y.w);
+        return o;
+    };
 
     // ---- stage K (row-major) and V^T ---------------------------------------------------------
     constexpr int CH = HD / 8;  // 16-byte chunks per row
@@ -327,7 +344,10 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
     for (int c = tid; c < C::NP * CH; c += C::THREADS) {
         const int r = c / CH, ch = c % CH;
         uint4 kv = make_uint4(0u, 0u, 0u, 0u);
-        if (r < C::N) kv = *reinterpret_cast<const uint4*>(base + (size_t)r * (3 * D) + D + ch * 8);
+        if (r < C::N) {
+            const long off = tok_off(r);
+            kv = off >= 0 ? *reinterpret_cast<const uint4*>(base + off + D + ch * 8) : bias_chunk(1, ch);
+        }
         *reinterpret_cast<uint4*>(Ks + r * HD + ch * 8) = kv;
     }
     // V^T[d][key]: a thread takes one 8-wide d chunk of TWO adjacent keys and writes eight 4-byte
@@ -336,8 +356,14 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         const int kp = c % (C::NP / 2), ch = c / (C::NP / 2);
         const int r0 = 2 * kp;
         uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = v0;
-        if (r0 < C::N) v0 = *reinterpret_cast<const uint4*>(base + (size_t)r0 * (3 * D) + 2 * D + ch * 8);
-        if (r0 + 1 < C::N) v1 = *reinterpret_cast<const uint4*>(base + (size_t)(r0 + 1) * (3 * D) + 2 * D + ch * 8);
+        if (r0 < C::N) {
+            const long off = tok_off(r0);
+            v0 = off >= 0 ? *reinterpret_cast<const uint4*>(base + off + 2 * D + ch * 8) : bias_chunk(2, ch);
+        }
+        if (r0 + 1 < C::N) {
+            const long off = tok_off(r0 + 1);
+            v1 = off >= 0 ? *reinterpret_cast<const uint4*>(base + off + 2 * D + ch * 8) : bias_chunk(2, ch);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + e) * C::VSTR + r0) = pair_elem(v0, v1, e);
@@ -346,13 +372,14 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
     if (wave >= C::NT) return;            // no block-level barrier below this point
 
     const int q = 32 * wave + ql;         // query index inside the window
-    const bool qin = q < C::N;
+    const long qoff = q < C::N ? tok_off(q) : -1L;
+    const bool qin = qoff >= 0;           // a real token (padding / tile-padding queries are dropped)
     uint4 qf[KS];
-    load_q_frags<KS>(qin ? base + (size_t)q * (3 * D) : nullptr, hh, qf);
+    load_q_frags<KS>(qin ? base + qoff : nullptr, hh, qf);
 
     // ---- decomposed rel-pos: RH[j] = q . rel_h[qh - j + 13], RW[j] = q . rel_w[qw - j + 13] -----
     // (log2 domain; image_encoder.py:325-361 uses the UNSCALED q)
-    const int qc = qin ? q : C::N - 1;
+    const int qc = q < C::N ? q : C::N - 1;
     const int qh = qc / C::WS, qw = qc % C::WS;
     float* scr = Scr + wave * 32 * C::SSTR + ql * C::SSTR;
     float RH[C::WS], RW[C::WS];
@@ -408,10 +435,9 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
     }
 
     // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
-    const int y = wy * C::WS + q / C::WS, x = wx * C::WS + q % C::WS;
-    if (qin && y < grid && x < grid) {
+    if (qin) {
         const float inv = 1.0f / l_run;
-        uint16_t* orow = out + ((size_t)im * grid * grid + (size_t)y * grid + x) * D + head * HD;
+        uint16_t* orow = out + (size_t)im * grid * grid * D + (size_t)(qoff / (3 * D)) * D + head * HD;
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
@@ -711,26 +737,26 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
 }
 
 template <int PREC, int HD>
-static hipError_t launch_win(const void* qkv, const float* rh, const float* rw, void* out, int n_images,
+static hipError_t launch_win(const void* qkv, const float* qb, const float* rh, const float* rw, void* out, int n_images,
                              int grid, int heads, hipStream_t s) {
     using C = WinCfg<HD>;
     auto k = window_attention_kernel<PREC, HD>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
     const int nw = (grid + C::WS - 1) / C::WS;
     dim3 g(n_images * nw * nw, heads), b(C::THREADS);
-    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, rh, rw, (uint16_t*)out, grid, heads);
+    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, qb, rh, rw, (uint16_t*)out, grid, heads);
     return hipGetLastError();
 }
 
-hipError_t launch_window_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
+hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
                                    int n_images, int grid, int window, int heads, int head_dim, hipStream_t s) {
     if (window != 14) return hipErrorInvalidValue;
     if (prec == PREC_BF16) {
-        if (head_dim == 64) return launch_win<PREC_BF16, 64>(qkv, rel_h, rel_w, out, n_images, grid, heads, s);
-        if (head_dim == 80) return launch_win<PREC_BF16, 80>(qkv, rel_h, rel_w, out, n_images, grid, heads, s);
+        if (head_dim == 64) return launch_win<PREC_BF16, 64>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s);
+        if (head_dim == 80) return launch_win<PREC_BF16, 80>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s);
     } else if (prec == PREC_F16) {
-        if (head_dim == 64) return launch_win<PREC_F16, 64>(qkv, rel_h, rel_w, out, n_images, grid, heads, s);
-        if (head_dim == 80) return launch_win<PREC_F16, 80>(qkv, rel_h, rel_w, out, n_images, grid, heads, s);
+        if (head_dim == 64) return launch_win<PREC_F16, 64>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s);
+        if (head_dim == 80) return launch_win<PREC_F16, 80>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s);
     }
     return hipErrorInvalidValue;
 }

@@ -65,8 +65,8 @@ struct samrs_engine {
     std::vector<EncBlock> blocks;
     uint16_t *patch_w = nullptr, *neck0_w = nullptr, *neck2_w = nullptr;
     float* X = nullptr;            // residual stream fp32 [Bi*tokens, D]
-    uint16_t* Y = nullptr;         // LN out (ET) [Mw_pad, D]
-    uint16_t* QKV = nullptr;       // [Mw_pad, 3D]
+    uint16_t* Y = nullptr;         // LN out (ET) [Bi*tokens, D]
+    uint16_t* QKV = nullptr;       // [Bi*tokens, 3D], token order
     uint16_t* AO = nullptr;        // attention out [Bi*tokens, D]
     uint16_t* H = nullptr;         // MLP hidden [Bi*tokens, 4D]  (also patch im2col / neck im2col)
     float* N1 = nullptr;           // neck fp32 [Bi*tokens, C]
@@ -414,8 +414,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     // ---- workspaces ----
     const size_t Bi = c.max_images, Bb = c.max_prompts;
     const size_t M = Bi * tokens;
-    const size_t Mw = round_up(Bi * e->nwin * e->nwin * c.window_size * c.window_size, 256);
-    const size_t Mmax = Mw > M ? Mw : M;
+    const size_t Mmax = M;
     CK(e, dalloc(e, &e->X, M * D));
     CK(e, dalloc(e, &e->Y, Mmax * D));
     CK(e, hipMemsetAsync(e->Y, 0, Mmax * D * 2, s));
@@ -460,8 +459,6 @@ static int encode(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int
     CK(e, hipSetDevice(e->device));
     const int D = e->D, C = e->C, g = e->grid, tokens = e->tokens, prec = e->prec;
     const int M = n * tokens;
-    const int Mw = n * e->nwin * e->nwin * c.window_size * c.window_size;
-    const int Mw_pad = (int)round_up(Mw, 256);   // multiple of the 256-row GEMM tile
     for (int i = 0; i < n; ++i) e->slot_set[slot0 + i] = 0;
 
     // patch embed: im2col (normalise + zero pad) -> GEMM (+bias +pos_embed) -> X
@@ -470,15 +467,14 @@ static int encode(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int
                          W(e, "image_encoder.pos_embed"), tokens, M, D, 3 * c.patch_size * c.patch_size, true, false, false, s));
     for (int i = 0; i < c.depth && i < n_blocks; ++i) {
         const EncBlock& b = e->blocks[i];
-        if (!b.global) {
-            CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, Mw, D, 1, g, c.window_size, s));
-            CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, Mw_pad, 3 * D, D, false, false, false, s));
-            CK(e, launch_window_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s));
-        } else {
-            CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
-            CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
+        // norm1 + qkv in plain token order for both block kinds; the windowed kernel partitions
+        // on the fly and takes k / v of padding positions from the qkv bias
+        CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
+        CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
+        if (!b.global)
+            CK(e, launch_window_attention(prec, e->QKV, b.qkv_b, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s));
+        else
             CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, s));
-        }
         CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
         CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
         CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
@@ -700,9 +696,9 @@ int samrs_k_layernorm(int prec, const float* X, const float* gamma, const float*
     (void)n_images;
     KRET(launch_layernorm(prec, X, gamma, beta, eps, out_et, out_f32, rows_out, D, window_mode, grid, window, (hipStream_t)stream));
 }
-int samrs_k_window_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out, int n_images,
-                             int grid, int window, int heads, int head_dim, void* stream) {
-    KRET(launch_window_attention(prec, qkv, rel_h, rel_w, out, n_images, grid, window, heads, head_dim, (hipStream_t)stream));
+int samrs_k_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
+                             int n_images, int grid, int window, int heads, int head_dim, void* stream) {
+    KRET(launch_window_attention(prec, qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, window, heads, head_dim, (hipStream_t)stream));
 }
 int samrs_k_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out, int n_images,
                              int grid, int heads, int head_dim, void* stream) {

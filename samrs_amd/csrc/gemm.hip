@@ -778,22 +778,27 @@ hipError_t launch_gemm_prec(const void* A, const void* B, void* C, const float* 
 
 // ---------------------------------------------------------------------------------------------
 // exact fp32 GEMM: C[M,N] = A[M,K] * W[N,K]^T + bias, optional ReLU / accumulate.
-// 64x64 block tile, 4 waves (2x2), wave tile 32x32 = 2x2 MFMA 16x16x4 (f32 in, f32 acc).
-// M, N arbitrary (bounds-checked), K % 16 == 0.  lda / ldc in elements; W is dense [N][K].
+// Token side of the decoder: M is a few hundred rows, so the launch is latency- and
+// parallelism-bound, not FLOP-bound.  One wave per 32x32 output tile (2x2 MFMA 16x16x4, f32 in /
+// f32 accumulate = an fmaf chain, bitwise), K walked in 32-wide slabs with a register prefetch of
+// the next slab (double-buffered LDS, one barrier per slab), and split-K over blockIdx.z for the
+// long-K projections (partials combined with fp32 atomics into the already-initialised C).
+// M, N arbitrary (bounds-checked), K % 32 == 0.  lda / ldc in elements; W is dense [N][K].
 // ---------------------------------------------------------------------------------------------
-constexpr int FM = 64, FN = 64, FK = 16;
+constexpr int FM = 32, FN = 32, FK = 32;
 
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int lda,
-                                                       const float* __restrict__ W,
-                                                       const float* __restrict__ bias,
-                                                       float* __restrict__ C, int ldc, int M, int N,
-                                                       int K, int relu, int accumulate) {
-    // +1 padding: fragment reads walk rows at fixed k -> stride 17 floats is conflict-free
-    __shared__ float sa[FM][FK + 1];
-    __shared__ float sw[FN][FK + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+__global__ __launch_bounds__(64) void gemm_f32_kernel(const float* __restrict__ A, int lda,
+                                                      const float* __restrict__ W,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ C, int ldc, int M, int N,
+                                                      int K, int relu, int accumulate, int kchunk) {
+    // +1 padding: fragment reads walk rows at fixed k -> stride 33 floats is conflict-free
+    __shared__ float sa[2][FM][FK + 1];
+    __shared__ float sw[2][FN][FK + 1];
+    const int lane = threadIdx.x;
     const int m0 = blockIdx.y * FM, n0 = blockIdx.x * FN;
+    const int kbeg = blockIdx.z * kchunk;
+    const int kend = (kbeg + kchunk) < K ? (kbeg + kchunk) : K;
 
     f32x4_t acc[2][2];
 #pragma unroll
@@ -801,47 +806,72 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // staging: 64 rows x 16 floats = 256 float4; thread t -> row t>>2, float4 index t&3
-    const int sr = tid >> 2, sc = (tid & 3) * 4;
-    for (int k0 = 0; k0 < K; k0 += FK) {
-        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vw = va;
-        if (m0 + sr < M) va = *reinterpret_cast<const float4*>(A + (size_t)(m0 + sr) * lda + k0 + sc);
-        if (n0 + sr < N) vw = *reinterpret_cast<const float4*>(W + (size_t)(n0 + sr) * K + k0 + sc);
-        __syncthreads();  // previous iteration's fragment reads are done
-        sa[sr][sc + 0] = va.x; sa[sr][sc + 1] = va.y; sa[sr][sc + 2] = va.z; sa[sr][sc + 3] = va.w;
-        sw[sr][sc + 0] = vw.x; sw[sr][sc + 1] = vw.y; sw[sr][sc + 2] = vw.z; sw[sr][sc + 3] = vw.w;
-        __syncthreads();
+    // staging: 32 rows x 8 float4 per operand; lane -> rows (lane>>3) + 8*i, float4 column lane&7
+    const int sr = lane >> 3, sc = (lane & 7) * 4;
+    float4 ra[4], rw[4];
+#define F32_GLOAD(k0_)                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                           \
+        const int r_ = sr + 8 * i_;                                                               \
+        ra[i_] = (m0 + r_ < M) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + r_) * lda + (k0_) + sc) \
+                               : make_float4(0.f, 0.f, 0.f, 0.f);                                \
+        rw[i_] = (n0 + r_ < N) ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + r_) * K + (k0_) + sc)   \
+                               : make_float4(0.f, 0.f, 0.f, 0.f);                                \
+    }
+#define F32_LSTORE(buf_)                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                           \
+        const int r_ = sr + 8 * i_;                                                               \
+        sa[buf_][r_][sc + 0] = ra[i_].x; sa[buf_][r_][sc + 1] = ra[i_].y;                         \
+        sa[buf_][r_][sc + 2] = ra[i_].z; sa[buf_][r_][sc + 3] = ra[i_].w;                         \
+        sw[buf_][r_][sc + 0] = rw[i_].x; sw[buf_][r_][sc + 1] = rw[i_].y;                         \
+        sw[buf_][r_][sc + 2] = rw[i_].z; sw[buf_][r_][sc + 3] = rw[i_].w;                         \
+    }
+    F32_GLOAD(kbeg)
+    F32_LSTORE(0)
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += FK) {
+        const int kn = (k0 + FK < kend) ? k0 + FK : k0;     // last slab: harmless re-read
+        F32_GLOAD(kn)
 #pragma unroll
         for (int kk = 0; kk < FK; kk += 4) {
             // 16x16x4: first operand lane l = P[i = l&15][k = l>>4]; second = Q[k = l>>4][j = l&15]
             float fa[2], fw[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fa[j] = sa[wm * 32 + j * 16 + (lane & 15)][kk + (lane >> 4)];
+            for (int j = 0; j < 2; ++j) fa[j] = sa[buf][j * 16 + (lane & 15)][kk + (lane >> 4)];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fw[i] = sw[wn * 32 + i * 16 + (lane & 15)][kk + (lane >> 4)];
+            for (int i = 0; i < 2; ++i) fw[i] = sw[buf][i * 16 + (lane & 15)][kk + (lane >> 4)];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[i], fa[j], acc[i][j], 0, 0, 0);
         }
+        F32_LSTORE(buf ^ 1)
+        __syncthreads();
+        buf ^= 1;
     }
     // D[i_local = n][j_local = m]: lane holds n = base + 4*(lane>>4) + r, m = base + (lane&15)
+    const bool split = gridDim.z > 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int m = m0 + wm * 32 + j * 16 + (lane & 15);
+            const int m = m0 + j * 16 + (lane & 15);
             if (m >= M) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 32 + i * 16 + 4 * (lane >> 4) + r;
+                const int n = n0 + i * 16 + 4 * (lane >> 4) + r;
                 if (n >= N) continue;
-                float v = acc[i][j][r] + (bias ? bias[n] : 0.f);
-                if (relu) v = fmaxf(v, 0.f);
                 float* c = C + (size_t)m * ldc + n;
-                if (accumulate) v += *c;
-                *c = v;
+                if (split) {   // host guarantees accumulate && !relu: C already holds the addend
+                    float v = acc[i][j][r] + ((bias && blockIdx.z == 0) ? bias[n] : 0.f);
+                    unsafeAtomicAdd(c, v);
+                } else {
+                    float v = acc[i][j][r] + (bias ? bias[n] : 0.f);
+                    if (relu) v = fmaxf(v, 0.f);
+                    if (accumulate) v += *c;
+                    *c = v;
+                }
             }
         }
 }
@@ -895,8 +925,12 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s) {
-    if (K % FK || M <= 0 || N <= 0 || (lda % 4) || (K % 4)) return hipErrorInvalidValue;
-    dim3 grid((N + FN - 1) / FN, (M + FM - 1) / FM), block(256);
-    gemm_f32_kernel<<<grid, block, 0, s>>>(A, lda, W, bias, C, ldc, M, N, K, relu ? 1 : 0, accumulate ? 1 : 0);
+    if (K % FK || M <= 0 || N <= 0 || (lda % 4)) return hipErrorInvalidValue;
+    // split-K only where the partial sums can be added into an existing C (accumulate, no ReLU)
+    int splits = 1;
+    if (accumulate && !relu && K >= 1024) splits = K / 512;
+    const int kchunk = K / splits;
+    dim3 grid((N + FN - 1) / FN, (M + FM - 1) / FM, splits), block(64);
+    gemm_f32_kernel<<<grid, block, 0, s>>>(A, lda, W, bias, C, ldc, M, N, K, relu ? 1 : 0, accumulate ? 1 : 0, kchunk);
     return hipGetLastError();
 }

@@ -18,7 +18,7 @@ hipError_t launch_convert(int prec, const float* in, void* out, long n, hipStrea
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
                             int window, hipStream_t s);
-hipError_t launch_window_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
+hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
                                    int n_images, int grid, int window, int heads, int head_dim, hipStream_t s);
 hipError_t launch_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
                                    int n_images, int grid, int heads, int head_dim, hipStream_t s);

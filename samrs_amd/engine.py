@@ -69,7 +69,7 @@ def load_library() -> C.CDLL:
     lib.samrs_k_gemm_f32.argtypes = [vp, ip, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_convert.argtypes = [ip, vp, vp, C.c_int64, vp]
     lib.samrs_k_layernorm.argtypes = [ip, vp, vp, vp, fp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
-    lib.samrs_k_window_attention.argtypes = [ip, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
+    lib.samrs_k_window_attention.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_global_attention.argtypes = [ip, vp, vp, vp, vp, ip, ip, ip, ip, vp]
     lib.samrs_k_postprocess.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, vp, vp]
     for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_get_embedding",

@@ -167,20 +167,25 @@ def _attention_ref(qkv, rel_h, rel_w, heads, S):
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
 @pytest.mark.parametrize("hd,heads", [(64, 2), (80, 2)])
 def test_window_attention(lib, name, prec, dt, ulp, hd, heads):
+    """Token-order qkv in, un-partitioned output; padding positions of the 14x14 windows are zero
+    tokens in the reference (pad AFTER norm1), i.e. their q/k/v equal the qkv bias."""
     g = torch.Generator().manual_seed(hd)
-    n_img, grid, win, nw = 1, 64, 14, 5
+    n_img, grid, win, nw = 2, 64, 14, 5
     D = hd * heads
-    nwin = n_img * nw * nw
-    qkv, qkvb = et_bits(torch.randn(nwin, win * win, 3 * D, generator=g), dt)
-    rel_h, _ = et_bits(0.3 * torch.randn(2 * win - 1, hd, generator=g), dt)   # pre-rounded: the kernel rounds tables to ET
+    qkv, qkvb = et_bits(torch.randn(n_img, grid, grid, 3 * D, generator=g), dt)
+    bias, _ = et_bits(0.5 * torch.randn(3 * D, generator=g), dt)       # pre-rounded: the GEMM epilogue rounds too
+    rel_h, _ = et_bits(0.3 * torch.randn(2 * win - 1, hd, generator=g), dt)
     rel_w, _ = et_bits(0.3 * torch.randn(2 * win - 1, hd, generator=g), dt)
-    ref_w = _attention_ref(qkv, rel_h, rel_w, heads, win)                     # [nwin, 196, D]
-    # un-partition + crop (image_encoder.py:267-289)
+    # reference: pad with the bias rows, partition (image_encoder.py:243-264), attend, un-partition + crop
+    padded = bias.view(1, 1, 1, -1).expand(n_img, nw * win, nw * win, 3 * D).clone()
+    padded[:, :grid, :grid] = qkv
+    xw = padded.view(n_img, nw, win, nw, win, 3 * D).permute(0, 1, 3, 2, 4, 5).reshape(n_img * nw * nw, win * win, 3 * D)
+    ref_w = _attention_ref(xw, rel_h, rel_w, heads, win)
     ref = ref_w.view(n_img, nw, nw, win, win, D).permute(0, 1, 3, 2, 4, 5).reshape(n_img, nw * win, nw * win, D)[:, :grid, :grid]
     out = torch.full((n_img * grid * grid, D), 0x7E00, dtype=torch.int16, device="cuda")  # NaN canary
-    qd, rhd, rwd = dev(qkvb), dev(rel_h), dev(rel_w)
-    assert lib.samrs_k_window_attention(prec, qd.data_ptr(), rhd.data_ptr(), rwd.data_ptr(), out.data_ptr(), n_img, grid, win,
-                                        heads, hd, stream()) == 0
+    qd, bd, rhd, rwd = dev(qkvb), dev(bias), dev(rel_h), dev(rel_w)
+    assert lib.samrs_k_window_attention(prec, qd.data_ptr(), bd.data_ptr(), rhd.data_ptr(), rwd.data_ptr(), out.data_ptr(),
+                                        n_img, grid, win, heads, hd, stream()) == 0
     torch.cuda.synchronize()
     got = out.cpu().view(dt).float().view(n_img, grid, grid, D)
     assert torch.isfinite(got).all(), "some output rows were never written"

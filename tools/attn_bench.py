@@ -9,13 +9,14 @@ n_img, heads, hd, grid = int(os.environ.get("NIMG", "8")), 16, 80, 64
 D = heads * hd
 reps = int(os.environ.get("REPS", "5"))
 g = torch.Generator().manual_seed(0)
-for name, rows, tab in (("window", n_img * 25 * 196, 27), ("global", n_img * 4096, 127)):
+bias = torch.randn(3 * D, generator=g).to(dev)
+for name, rows, tab in (("window", n_img * 4096, 27), ("global", n_img * 4096, 127)):
     qkv = torch.randn(rows, 3 * D, generator=g).to(dev).to(torch.float16)
     rh = (0.02 * torch.randn(tab, hd, generator=g)).to(dev); rw = (0.02 * torch.randn(tab, hd, generator=g)).to(dev)
     out = torch.empty(n_img * 4096, D, dtype=torch.float16, device=dev)
     def run():
         if name == "window":
-            return lib.samrs_k_window_attention(1, qkv.data_ptr(), rh.data_ptr(), rw.data_ptr(), out.data_ptr(), n_img, grid, 14, heads, hd, s)
+            return lib.samrs_k_window_attention(1, qkv.data_ptr(), bias.data_ptr(), rh.data_ptr(), rw.data_ptr(), out.data_ptr(), n_img, grid, 14, heads, hd, s)
         return lib.samrs_k_global_attention(1, qkv.data_ptr(), rh.data_ptr(), rw.data_ptr(), out.data_ptr(), n_img, grid, heads, hd, s)
     assert run() == 0
     torch.cuda.synchronize()

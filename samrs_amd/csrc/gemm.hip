@@ -17,6 +17,8 @@
 // reads are bank-conflict free.  MFMA operands are swapped (first = weight fragment, second =
 // activation fragment) so that each lane ends up with 4 CONSECUTIVE output columns of one row:
 // the epilogue then uses 8-byte (ET) / 16-byte (fp32) vector accesses and float4 bias loads.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -220,6 +222,93 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_et_kernel(
     }
 }
 
+
+__device__ __forceinline__ void wave_lds_sync_g() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Coalesced epilogue.  In the MFMA accumulator layout a lane owns 4 consecutive columns of ONE row,
+// so a direct store instruction scatters 16 rows x 32-byte pieces: measured (ablation)
+// that costs a third of the whole GEMM.  Instead each wave bounces its 64-column sub-tile through
+// its private slice of the (now idle) LDS ring and writes / read-modify-writes FULL 128- or 256-byte
+// row segments with 16 bytes per lane.  bias + GELU are applied before the bounce (per-lane column
+// known), the 2-D addend and the residual accumulate after it (coalesced loads).
+//   acc[i][j]: n-tile i (16 cols), m-tile j (16 rows); NJ m-tiles per wave, JC of them per pass.
+// ---------------------------------------------------------------------------------------------
+template <int PREC, bool OUT_F32, bool GELU, int NJ, int JC>
+__device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[4][NJ], unsigned char* scr /* wave-private */,
+                                                   void* __restrict__ Cv, const float* __restrict__ bias,
+                                                   const float* __restrict__ add2d, int add2d_period, int N,
+                                                   int m_base /* first row of the wave tile */,
+                                                   int n_base /* first column of the wave tile */, int accumulate,
+                                                   int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr int RS = OUT_F32 ? (64 * 4 + 16) : (64 * 2 + 16);    // padded row stride (bytes), 16-B multiple
+    constexpr int TS = 16 * RS;                                     // one m-tile
+    float4 bv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        bv[i] = bias ? *reinterpret_cast<const float4*>(bias + n_base + i * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j0 = 0; j0 < NJ; j0 += JC) {
+        if (j0) wave_lds_sync_g();
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj) {
+            const int j = j0 + jj;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
+                float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+                if (GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                unsigned char* p = scr + jj * TS + fr * RS;
+                if (OUT_F32) {
+                    *reinterpret_cast<float4*>(p + (i * 16 + 4 * fq) * 4) = make_float4(v0, v1, v2, v3);
+                } else {
+                    uint2 o;
+                    o.x = pack2<PREC>(v0, v1);
+                    o.y = pack2<PREC>(v2, v3);
+                    *reinterpret_cast<uint2*>(p + (i * 16 + 4 * fq) * 2) = o;
+                }
+            }
+        }
+        wave_lds_sync_g();
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj) {
+            const int j = j0 + jj;
+            if (OUT_F32) {
+                // 16 rows x 256 B: 4 instructions of 4 rows x (16 lanes x 16 B)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int row = (lane >> 4) + 4 * h, ch = lane & 15;
+                    float4 v = *reinterpret_cast<const float4*>(scr + jj * TS + row * RS + ch * 16);
+                    const int m = m_base + j * 16 + row, n = n_base + ch * 4;
+                    if (add2d) {
+                        const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
+                        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+                    }
+                    float* C = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
+                    if (accumulate) {
+                        const float4 o = *reinterpret_cast<const float4*>(C);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *reinterpret_cast<float4*>(C) = v;
+                }
+            } else {
+                // 16 rows x 128 B: 2 instructions of 8 rows x (8 lanes x 16 B)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = (lane >> 3) + 8 * h, ch = lane & 7;
+                    const uint4 v = *reinterpret_cast<const uint4*>(scr + jj * TS + row * RS + ch * 16);
+                    uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)(m_base + j * 16 + row) * N + n_base + ch * 8;
+                    *reinterpret_cast<uint4*>(C) = v;
+                }
+            }
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // gemm_et_pipe_kernel: 256x128x64 block tile, 512 threads = 8 waves (4 along M x 2 along N, each
@@ -497,37 +586,23 @@ __global__ __launch_bounds__(PTHREADS) void gemm_et_stag_kernel(
         STAG_STEP(kt + 2, 2)
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();          // group 0 finishes one interval early
-
+    // every wave is past its last ring read here -> the ring is free scratch (18 KiB per wave)
+    {
+        unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (PSTAGES * PSTAGE_ELEMS * 2 / 8);
+        // add2d (if any) only comes with fp32 output in the engine; ET output ignores accumulate
+        if (!OUT_F32 && add2d) {
+            // rare combination (ET out + 2-D addend): fold the addend in before the bounce
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + 4 * fq;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + fr;
-            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y;
-            float v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
-            if (add2d) {
-                const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
-                v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
-            }
-            if (GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-            if (OUT_F32) {
-                float* C = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
-                if (accumulate) {
-                    const float4 o = *reinterpret_cast<const float4*>(C);
-                    v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + wm * 64 + j * 16 + fr, n = n0 + wn * 64 + i * 16 + 4 * fq;
+                    const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
+                    acc[i][j][0] += e.x; acc[i][j][1] += e.y; acc[i][j][2] += e.z; acc[i][j][3] += e.w;
                 }
-                *reinterpret_cast<float4*>(C) = make_float4(v0, v1, v2, v3);
-            } else {
-                uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)m * N + n;
-                uint2 o;
-                o.x = pack2<PREC>(v0, v1);
-                o.y = pack2<PREC>(v2, v3);
-                *reinterpret_cast<uint2*>(C) = o;
-            }
         }
+        epilogue_coalesced<PREC, OUT_F32, GELU, 4, 4>(acc, scr, Cv, bias, OUT_F32 ? add2d : nullptr, add2d_period, N,
+                                                      m0 + wm * 64, n0 + wn * 64, accumulate, lane);
     }
 }
 
@@ -685,6 +760,13 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
     if (grp == 0 && !(ABL & 8)) __builtin_amdgcn_s_barrier();          // both groups: 2 + 2*nk barriers
 
     // epilogue: lane holds C[m][n..n+3], m = m0 + wm*128 + j*16 + fr, n = n0 + wn*64 + i*16 + 4*fq
+    if (ABL & 16) {   // timing experiment: keep the accumulators alive, store nothing
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][3]));
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int n = n0 + wn * 64 + i * 16 + 4 * fq;
@@ -735,6 +817,147 @@ hipError_t launch_gemm_big(const void* A, const void* B, void* C, const float* b
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// gemm_et_dual_kernel: the staggered 256x128 kernel with a 32-wide K step: three 24 KiB ring stages
+// = 72 KiB of LDS and <= 128 VGPRs, so TWO blocks (16 waves) are resident per CU and one block's
+// epilogue (HBM-write bound: up to a third of the single-block kernel, ablation in DESIGN.md)
+// overlaps the other block's main loop.  Per K step and wave: 3 DMA pieces, 8 ds_read_b128,
+// 16 MFMAs, two raw barriers (L | C segments, wave groups staggered by one interval).
+// ---------------------------------------------------------------------------------------------
+constexpr int DBM = 256, DBN = 128, DBK = 32, DSTAGES = 3, DTHREADS = 512;
+constexpr int DSTAGE_ELEMS = (DBM + DBN) * DBK;               // 12288 ET = 24 KiB
+constexpr int D_DMA_PER_TILE = (DBM + DBN) * DBK * 2 / (DTHREADS * 16);   // 3 per thread
+
+template <int PREC, bool OUT_F32, bool GELU>
+__global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
+    int M, int N, int K, int accumulate) {
+    __shared__ __attribute__((aligned(16))) uint16_t lds[DSTAGES * DSTAGE_ELEMS];   // 72 KiB, ONE object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    constexpr int GROUP = 8;
+    const int tiles_n = N / DBN, tiles_m = M / DBM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_group = GROUP * tiles_n;
+    const int group = bid / per_group, first_m = group * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = bid - group * per_group;
+    const int tile_m = first_m + in_g % gsz, tile_n = in_g / gsz;
+    const int m0 = tile_m * DBM, n0 = tile_n * DBN;
+
+    // DMA: piece = 16 rows x 64 B; lane l -> row l>>2, physical chunk l&3 (source chunk swizzled).
+    // wave w: A rows 16w.. and 128+16w.., B rows 16w..
+    const int g_row = 16 * wave + (lane >> 2);
+    const int g_chunk = qswz(g_row, lane & 3);
+    const uint16_t* gAg = A + (size_t)(m0 + g_row) * K + g_chunk * 8;
+    const uint16_t* gBg = B + (size_t)(n0 + g_row) * K + g_chunk * 8;
+    const uint32_t wave_lds_base = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * (16 * DBK * 2));
+    const size_t rs128 = (size_t)128 * K;
+#define DUAL_ISSUE(kt_, stage_)                                                                 \
+    do {                                                                                         \
+        const size_t koff_ = (size_t)(kt_) * DBK;                                                \
+        constexpr int SB_ = (stage_) * DSTAGE_ELEMS * 2;                                         \
+        glds16_asm<SB_ + 0>(gAg + koff_, wave_lds_base);                                         \
+        glds16_asm<SB_ + 128 * DBK * 2>(gAg + rs128 + koff_, wave_lds_base);                     \
+        glds16_asm<SB_ + DBM * DBK * 2>(gBg + koff_, wave_lds_base);                             \
+    } while (0)
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / DBK;
+    DUAL_ISSUE(0, 0);
+    if (nk > 1) {
+        DUAL_ISSUE(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D_DMA_PER_TILE) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int r = wm * 64 + j * 16 + fr; offA[j] = r * DBK + qswz(r, fq) * 8; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int r = wn * 64 + i * 16 + fr; offB[i] = DBM * DBK + r * DBK + qswz(r, fq) * 8; }
+
+#define DUAL_WAIT(kt_)                                                                           \
+    if ((kt_) + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D_DMA_PER_TILE) : "memory");     \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define DUAL_STEP(kt_, S_)                                                                       \
+    if ((kt_) < nk) {                                                                            \
+        uint4 fa[4], fb[4];                                                                      \
+        if ((kt_) + 2 < nk) DUAL_ISSUE((kt_) + 2, ((S_) + 2) % DSTAGES);                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            fb[i] = *reinterpret_cast<const uint4*>(lds + (S_) * DSTAGE_ELEMS + offB[i]);        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
+            fa[j] = *reinterpret_cast<const uint4*>(lds + (S_) * DSTAGE_ELEMS + offA[j]);        \
+        DUAL_WAIT(kt_)                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_barrier();                                                            \
+        __builtin_amdgcn_s_setprio(1);                                                           \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                        \
+                acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]);                           \
+        __builtin_amdgcn_s_setprio(0);                                                           \
+        DUAL_WAIT(kt_)                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        __builtin_amdgcn_s_barrier();                                                            \
+    }
+    for (int kt = 0; kt < nk; kt += DSTAGES) {
+        DUAL_STEP(kt, 0)
+        DUAL_STEP(kt + 1, 1)
+        DUAL_STEP(kt + 2, 2)
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // both groups: 2 + 2*nk barriers
+    {
+        unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (DSTAGES * DSTAGE_ELEMS * 2 / 8);   // 9 KiB
+        if (!OUT_F32 && add2d) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + wm * 64 + j * 16 + fr, n = n0 + wn * 64 + i * 16 + 4 * fq;
+                    const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
+                    acc[i][j][0] += e.x; acc[i][j][1] += e.y; acc[i][j][2] += e.z; acc[i][j][3] += e.w;
+                }
+        }
+        epilogue_coalesced<PREC, OUT_F32, GELU, 4, OUT_F32 ? 2 : 4>(acc, scr, Cv, bias, OUT_F32 ? add2d : nullptr, add2d_period,
+                                                                     N, m0 + wm * 64, n0 + wn * 64, accumulate, lane);
+    }
+}
+
+template <int PREC>
+hipError_t launch_gemm_dual(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
+                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
+    dim3 grid((M / DBM) * (N / DBN)), block(DTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (out_f32) {
+        if (gelu) gemm_et_dual_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_dual_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    } else {
+        if (gelu) gemm_et_dual_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_dual_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    }
+    return hipGetLastError();
+}
+
 template <int PREC>
 hipError_t launch_gemm_pipe(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                             int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
@@ -752,7 +975,7 @@ hipError_t launch_gemm_pipe(const void* A, const void* B, void* C, const float* 
     return hipGetLastError();
 }
 
-int g_gemm_variant = 5;   // 0 reg-staged, 1 LDS-DMA, 2 LDS-DMA+grouped, 3 reg+grouped, 4 256x128 3-stage pipe, 5 = 4 + staggered wave groups
+int g_gemm_variant = 8;   // 0 reg-staged 128^2, 1 +LDS-DMA, 2 +grouped order, 3 reg+grouped, 4 256x128 3-stage pipe, 5 +staggered groups, 6 256x256, 7 2 blocks/CU, 8 auto(5|7)
 
 template <int PREC, bool GLDS, int GROUP_M>
 hipError_t launch_gemm_prec(const void* A, const void* B, void* C, const float* bias,
@@ -883,6 +1106,12 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
                           bool gelu, bool accumulate, hipStream_t s) {
     if (M % BM || N % BN || K % BK || M <= 0 || N <= 0 || K <= 0) return hipErrorInvalidValue;
     if (add2d && add2d_period <= 0) return hipErrorInvalidValue;
+    if (add2d && gelu) return hipErrorInvalidValue;   // not needed by the path; the coalesced epilogue orders them differently
+    static const bool env_once = [] {   // tuning knob for A/B runs: SAMRS_GEMM_VARIANT=<n>
+        if (const char* v = getenv("SAMRS_GEMM_VARIANT")) g_gemm_variant = atoi(v);
+        return true;
+    }();
+    (void)env_once;
 #define GEMM_DISPATCH(P)                                                                                         \
     switch (g_gemm_variant) {                                                                                    \
         case 0: return launch_gemm_prec<P, false, 1>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
@@ -890,23 +1119,33 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         case 3: return launch_gemm_prec<P, false, 8>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
         default: return launch_gemm_prec<P, true, 8>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
     }
-    if (g_gemm_variant >= 60 && g_gemm_variant < 76 && prec == PREC_F16 && !out_f32 && M % QBM == 0 && N % QBN == 0) {
+    if (g_gemm_variant >= 60 && g_gemm_variant < 92 && prec == PREC_F16 && !out_f32 && M % QBM == 0 && N % QBN == 0) {
         dim3 grid((M / QBM) * (N / QBN)), block(QTHREADS);
         const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
         const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
 #define ABL_CASE(x) case 60 + x: gemm_et_big_kernel<PREC_F16, false, false, x><<<grid, block, 0, s>>>(a, b, C, bias, add2d, add2d_period, M, N, K, 0); break;
         switch (g_gemm_variant) {
-            ABL_CASE(0) ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(5) ABL_CASE(6) ABL_CASE(8) ABL_CASE(9) ABL_CASE(12) ABL_CASE(7) ABL_CASE(11)
+            ABL_CASE(0) ABL_CASE(1) ABL_CASE(4) ABL_CASE(6) ABL_CASE(8) ABL_CASE(7) ABL_CASE(16) ABL_CASE(22) ABL_CASE(23) ABL_CASE(24)
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
+    }
+    // variant 8 ("auto", default): per-shape pick measured on MI355X (tools/gemm_bench.py) -- the
+    // 2-blocks-per-CU kernel wins where the epilogue dominates (GELU output, or short K with a
+    // narrow N), the 64-wide-K single-block kernel wins on long K / wide N.
+    int variant = g_gemm_variant;
+    if (variant == 8) variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
+    if (variant == 7 && M % DBM == 0 && K % DBK == 0) {   // 2 blocks / CU
+        if (prec == PREC_BF16) return launch_gemm_dual<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_dual<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        return hipErrorInvalidValue;
     }
     if (g_gemm_variant == 6 && M % QBM == 0 && N % QBN == 0 && K % QBK == 0) {   // 256x256 staggered kernel
         if (prec == PREC_BF16) return launch_gemm_big<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_big<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
     }
-    if ((g_gemm_variant == 5 || g_gemm_variant == 6) && M % PBM == 0) {   // staggered-group pipelined kernel
+    if ((variant == 5 || variant == 6 || variant == 7) && M % PBM == 0) {   // staggered-group pipelined kernel
         if (prec == PREC_BF16) return launch_gemm_stag<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_stag<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;

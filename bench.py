@@ -156,9 +156,16 @@ def main() -> None:
     torch.cuda.synchronize()
     gemm_ms = e0.elapsed_time(e1) / reps
     gemm_tflops = 2.0 * M * N * K / (gemm_ms * 1e-3) / 1e12
+    # HBM traffic of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+    # (tools/gpu_round.sh pmc), corrected per MI355X_MICROARCH.md and committed under profiles/.
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_dominant_kernel_pmc.json")
+    if args.model == "vit_h" and args.batch == 8 and os.path.exists(pmc_file):
+        traffic = json.load(open(pmc_file)).get("traffic_bytes_per_launch")
     roofline = {"bound": "mfma", "kernel": f"gemm_et<{args.dtype}> lin1+GELU M={M} N={N} K={K}",
                 "achieved": round(gemm_tflops, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(gemm_tflops / PEAK_MFMA_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(gemm_ms, 4),
+                "frac": round(gemm_tflops / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_bytes": 2 * (M * K + N * K + M * N), "avg_launch_ms": round(gemm_ms, 4),
                 "whole_path_tflops": round(value / world * F / 1e12, 1),
                 "whole_path_frac": round(value / world * F / 1e12 / PEAK_MFMA_TFLOPS, 4)}
 

@@ -64,6 +64,9 @@ def main() -> None:
     ap.add_argument("--boxes", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second (bf16) timing leg")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run encoder and decoder of a batch back to back on one stream instead of overlapping the "
+                         "decoder of batch k with the encoder of batch k+1 on a second HIP stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,29 +91,61 @@ def main() -> None:
         b, _ = synth.make_boxes(rank * 100 + i, args.boxes)
         boxes.append(torch.from_numpy(b).to(dev))            # 1024^2 tiles: input frame == original frame
 
+    pipelined = not args.no_pipeline
+
     def make_step(precision):
-        sam = samrs_amd.sam_model_registry[args.model](state_dict=sd, precision=precision, max_images=args.batch,
+        # two sets of embedding slots: the encoder fills one while the decoder reads the other
+        sam = samrs_amd.sam_model_registry[args.model](state_dict=sd, precision=precision, max_images=2 * args.batch,
                                                        max_prompts=args.boxes, max_points=1).to(dev)
         eng = sam.engine
         masks_sink = [None]
+        s_enc, s_dec = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        ev_enc = [torch.cuda.Event(), torch.cuda.Event()]     # "slot set b holds fresh embeddings"
+        ev_dec = [torch.cuda.Event(), torch.cuda.Event()]     # "slot set b has been consumed"
 
-        def step():
-            eng.set_images(tiles, 0)
+        def encode(b):
+            eng.set_images(tiles, b * args.batch)
+
+        def decode(b):
             for i in range(args.batch):
-                m, q, low = eng.predict(i, boxes[i], None, None, None, False, False, (1024, 1024), (1024, 1024))
+                m, q, low = eng.predict(b * args.batch + i, boxes[i], None, None, None, False, False, (1024, 1024), (1024, 1024))
                 masks_sink[0] = m
-        return sam, eng, step
 
-    def timed(step, steps, warmup):
-        for _ in range(warmup):
-            step()
+        def run(n_steps):
+            """n_steps batches through the whole path (every batch: one encode + one decode)."""
+            if not pipelined:
+                for _ in range(n_steps):
+                    encode(0)
+                    decode(0)
+                return
+            cur = torch.cuda.current_stream()
+            s_enc.wait_stream(cur)
+            s_dec.wait_stream(cur)
+            for k in range(n_steps + 1):
+                b = k & 1
+                if k < n_steps:
+                    with torch.cuda.stream(s_enc):
+                        if k >= 2:
+                            s_enc.wait_event(ev_dec[b])           # decoder of batch k-2 is done with slot set b
+                        encode(b)
+                        ev_enc[b].record(s_enc)
+                if k >= 1:
+                    with torch.cuda.stream(s_dec):
+                        s_dec.wait_event(ev_enc[b ^ 1])           # embeddings of batch k-1 are ready
+                        decode(b ^ 1)
+                        ev_dec[b ^ 1].record(s_dec)
+            cur.wait_stream(s_enc)
+            cur.wait_stream(s_dec)
+        return sam, eng, run
+
+    def timed(run, steps, warmup):
+        run(warmup)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        run(steps)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -215,6 +250,7 @@ def main() -> None:
                                    f"box-only prompt, multimask_output=False, masks u8 in HBM (BASELINE.json configs[1])",
                        "model": args.model, "global_batch": world * args.batch, "boxes_per_image": args.boxes,
                        "parallelism": f"image-parallel x{world}", "weights": "seeded random init (no checkpoint available)",
+                       "pipeline": "decoder of batch k overlaps encoder of batch k+1 (2 HIP streams)" if pipelined else "serial",
                        "accumulate": "f32"},
             "flops_per_image": F, "roofline": roofline, "cpu_baseline": cpu_baseline, "alt_dtype": alt,
             "stats_allreduce": {"total_pixels": int(tot_pix.sum().item()), "total_instances": int(tot_ins.sum().item())},

@@ -29,6 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
 
 PEAK_MFMA_TFLOPS = 2500.0      # dense bf16/f16 MFMA, MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
@@ -73,12 +74,20 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # test hook for 1-GPU boxes: SAMRS_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo, which
+    # exercises the N>1 control flow (barriers, MAX-over-ranks timing, statistics all-reduce)
+    share = os.environ.get("SAMRS_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     import samrs_amd
     from samrs_amd import driver, synth
@@ -138,9 +147,11 @@ def main() -> None:
             cur.wait_stream(s_dec)
         return sam, eng, run
 
-    def timed(run, steps, warmup):
+    def timed(run, steps, warmup, after_warmup=None):
         run(warmup)
         torch.cuda.synchronize()
+        if after_warmup is not None:
+            after_warmup()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -158,38 +169,21 @@ def main() -> None:
         return dt
 
     sam, eng, step = make_step(args.dtype)
-    dt = timed(step, args.steps, args.warmup)
+    # the engine brackets every launch of the dominant kernel (MLP lin1+GELU GEMM) with hipEvents on its
+    # launch stream; warm-up launches are discarded, so the average below is over the timed region
+    eng.time_dominant_kernel(True)
+    dt = timed(step, args.steps, args.warmup, after_warmup=eng.dominant_kernel_time)
+    gemm_ms, gemm_launches, N, K = eng.dominant_kernel_time()
+    eng.time_dominant_kernel(False)
     images = world * args.batch * args.steps
     value = images / dt
     if rank == 0:
         print(f"[bench] {args.dtype}: {value:.2f} images/s over {world} GPU(s), {dt / args.steps * 1e3:.1f} ms/step", file=sys.stderr, flush=True)
     F = flops_per_image(cfg, args.boxes)
 
-    # ---- roofline of the dominant kernel: the MLP lin1 GEMM (57.6 % of encoder FLOPs with lin2) ----
-    from samrs_amd import engine as eng_mod
-    lib = eng_mod.load_library()
-    M, N, K = args.batch * cfg.grid ** 2, 4 * cfg.embed_dim, cfg.embed_dim
-    prec = eng_mod.PRECISIONS[args.dtype]
-    g = torch.Generator().manual_seed(1)
-    A = torch.randn(M, K, generator=g).to(dev)
-    Wt = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
-    bias = torch.randn(N, generator=g).to(dev)
-    Ae = torch.empty(M, K, dtype=torch.int16, device=dev)
-    We = torch.empty(N, K, dtype=torch.int16, device=dev)
-    Ce = torch.empty(M, N, dtype=torch.int16, device=dev)
-    s = torch.cuda.current_stream().cuda_stream
-    lib.samrs_k_convert(prec, A.data_ptr(), Ae.data_ptr(), A.numel(), s)
-    lib.samrs_k_convert(prec, Wt.data_ptr(), We.data_ptr(), Wt.numel(), s)
-    for _ in range(3):
-        lib.samrs_k_gemm(prec, Ae.data_ptr(), We.data_ptr(), Ce.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 0, 1, 0, s)
-    reps = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()                                              # same stream the kernel is launched on
-    for _ in range(reps):
-        lib.samrs_k_gemm(prec, Ae.data_ptr(), We.data_ptr(), Ce.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 0, 1, 0, s)
-    e1.record()
-    torch.cuda.synchronize()
-    gemm_ms = e0.elapsed_time(e1) / reps
+    # ---- roofline of the dominant kernel: the MLP lin1+GELU GEMM (57.6 % of encoder FLOPs with lin2),
+    # timed in situ over the timed region (see above) ----
+    M = args.batch * cfg.grid ** 2
     gemm_tflops = 2.0 * M * N * K / (gemm_ms * 1e-3) / 1e12
     # HBM traffic of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
     # (tools/gpu_round.sh pmc), corrected per MI355X_MICROARCH.md and committed under profiles/.
@@ -201,6 +195,7 @@ def main() -> None:
                 "achieved": round(gemm_tflops, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(gemm_tflops / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
                 "algorithmic_bytes": 2 * (M * K + N * K + M * N), "avg_launch_ms": round(gemm_ms, 4),
+                "launches_timed": gemm_launches, "algorithmic_flops_per_launch": 2.0 * M * N * K,
                 "whole_path_tflops": round(value / world * F / 1e12, 1),
                 "whole_path_frac": round(value / world * F / 1e12 / PEAK_MFMA_TFLOPS, 4)}
 

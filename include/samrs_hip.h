@@ -142,6 +142,13 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
 /* -- test / tuning hook: 0 = register-staged GEMM tiles, 1 = LDS-DMA staging (default). */
 void samrs_debug_set_gemm_variant(int variant);
 
+/* -- measurement hook: when enabled, samrs_set_images brackets every launch of the dominant kernel
+ * (MLP lin1 + GELU GEMM, [n*4096, D] x [4D, D]^T) with hipEvents on the launch stream.
+ * samrs_debug_dominant_kernel_time() synchronises those events, returns the average duration (ms),
+ * the number of launches since the last call, and the GEMM's N / K. */
+int samrs_debug_time_dominant_kernel(samrs_engine_t* e, int enable);
+int samrs_debug_dominant_kernel_time(samrs_engine_t* e, float* avg_ms, int* launches, int* M, int* N, int* K);
+
 /* -- kernel-level entry points (used by the parity tests to check each kernel alone) --------
  * All pointers are device pointers.  `prec` is enum samrs_precision; "et" = MFMA operand type
  * (bf16 or f16 bit patterns in uint16). */

@@ -97,6 +97,11 @@ struct samrs_engine {
     uint16_t* U1 = nullptr;        // [Bb*tokens][256]
     uint16_t* U2 = nullptr;        // [Bb*tokens*4][128]
     float *HY1 = nullptr, *HY2 = nullptr, *HYPER = nullptr, *IOU = nullptr, *LOW = nullptr;
+
+    // optional in-situ timing of the dominant kernel (MLP lin1 + GELU GEMM) with HIP events
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;   // recorded pairs
+    std::vector<hipEvent_t> tpool;                         // recycled events
 };
 
 namespace {
@@ -477,7 +482,20 @@ static int encode(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int
             CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, s));
         CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
         CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
+        hipEvent_t t0 = nullptr, t1 = nullptr;
+        if (e->timing) {
+            auto get = [&](hipEvent_t* ev) -> hipError_t {
+                if (!e->tpool.empty()) { *ev = e->tpool.back(); e->tpool.pop_back(); return hipSuccess; }
+                return hipEventCreate(ev);
+            };
+            CK(e, get(&t0)); CK(e, get(&t1));
+            CK(e, hipEventRecord(t0, s));
+        }
         CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
+        if (e->timing) {
+            CK(e, hipEventRecord(t1, s));
+            e->tev.emplace_back(t0, t1);
+        }
         CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
     }
     if (!do_neck) return SAMRS_OK;
@@ -676,6 +694,34 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
 }
 
 void samrs_debug_set_gemm_variant(int v) { set_gemm_variant(v); }
+
+int samrs_debug_time_dominant_kernel(samrs_engine_t* e, int enable) {
+    if (!e) return SAMRS_ERR_BAD_ARG;
+    e->timing = enable != 0;
+    return SAMRS_OK;
+}
+
+int samrs_debug_dominant_kernel_time(samrs_engine_t* e, float* avg_ms, int* launches, int* M, int* N, int* K) {
+    if (!e || !avg_ms || !launches) return SAMRS_ERR_BAD_ARG;
+    double tot = 0.0;
+    int n = 0;
+    for (auto& pr : e->tev) {
+        CK(e, hipEventSynchronize(pr.second));
+        float ms = 0.f;
+        CK(e, hipEventElapsedTime(&ms, pr.first, pr.second));
+        tot += ms;
+        ++n;
+        e->tpool.push_back(pr.first);
+        e->tpool.push_back(pr.second);
+    }
+    e->tev.clear();
+    *avg_ms = n ? (float)(tot / n) : 0.f;
+    *launches = n;
+    if (M) *M = 0;   // rows vary with the batch of each call; the caller knows its batch
+    if (N) *N = 4 * e->D;
+    if (K) *K = e->D;
+    return SAMRS_OK;
+}
 
 // ---- kernel-level entry points -------------------------------------------------------------------
 #define KRET(expr) do { hipError_t _e = (expr); return _e == hipSuccess ? SAMRS_OK : SAMRS_ERR_HIP; } while (0)

@@ -65,6 +65,10 @@ def load_library() -> C.CDLL:
     lib.samrs_paint.argtypes = [vp, vp, vp, ip, ip, ip, vp, vp, vp, vp, ip, vp]
     lib.samrs_debug_encoder_prefix.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp]
     lib.samrs_debug_encoder_prefix.restype = ip
+    lib.samrs_debug_time_dominant_kernel.argtypes = [vp, ip]
+    lib.samrs_debug_time_dominant_kernel.restype = ip
+    lib.samrs_debug_dominant_kernel_time.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]
+    lib.samrs_debug_dominant_kernel_time.restype = ip
     lib.samrs_k_gemm.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_gemm_f32.argtypes = [vp, ip, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_convert.argtypes = [ip, vp, vp, C.c_int64, vp]
@@ -169,6 +173,15 @@ class Engine:
             self._check(self.lib.samrs_debug_encoder_prefix(self.handle, images_u8.data_ptr(), n, h, w, n_blocks,
                                                             out.data_ptr(), _stream()))
         return out
+
+    def time_dominant_kernel(self, enable: bool) -> None:
+        self._check(self.lib.samrs_debug_time_dominant_kernel(self.handle, int(enable)))
+
+    def dominant_kernel_time(self):
+        """(average ms, launches, N, K) of the MLP lin1+GELU GEMM launches timed since the last call."""
+        ms, n, m, nn, kk = C.c_float(), C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.samrs_debug_dominant_kernel_time(self.handle, C.byref(ms), C.byref(n), C.byref(m), C.byref(nn), C.byref(kk)))
+        return ms.value, n.value, nn.value, kk.value
 
     def get_embedding(self, slot: int = 0) -> torch.Tensor:
         out = torch.empty(1, self.cfg.out_chans, self.cfg.grid, self.cfg.grid, dtype=torch.float32, device=self.device)

@@ -238,7 +238,7 @@ def main() -> None:
 
     if rank == 0:
         out = {
-            "metric": "images/sec (1024^2, ViT-H, 32 boxes/img) SAM box->mask", "value": round(value, 3), "unit": "images/s",
+            "metric": f"images/sec (1024^2, {args.model}, {args.boxes} boxes/img) SAM box->mask", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} SAM, batch={args.batch}x1024^2 synthetic tiles, {args.boxes} hboxes/img, "

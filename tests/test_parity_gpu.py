@@ -268,3 +268,45 @@ def test_encoder_batch_equals_single():
         eng.set_images(imgs[i:i + 1].contiguous(), 3)
         single = eng.get_embedding(3)
         assert torch.equal(single, batch[i]), f"image {i}: batched encode differs from single encode"
+
+
+def test_generation_driver_end_to_end(tmp_path):
+    """N2 row: images + boxes in, gray/color PNG + ins/*.pkl out (main_sam_hbox_semantic.py:195-216),
+    checked against the oracle's painting of the oracle's masks."""
+    import json
+    import pickle
+    from PIL import Image
+    from samrs_amd import generate, rle
+    so = _oracle()
+    img_dir, out_dir = tmp_path / "img", tmp_path / "out"
+    img_dir.mkdir()
+    ann = {}
+    for i in range(2):
+        Image.fromarray(synth.make_image(10 + i)).save(img_dir / f"P{i:04d}.png")
+        b, l = synth.make_boxes(10 + i, 23)          # 23 boxes -> chunks of 20 + 3
+        ann[f"P{i:04d}"] = {"boxes": b.tolist(), "labels": l.tolist()}
+    (tmp_path / "boxes.json").write_text(json.dumps(ann))
+    stats = generate.run(generate.argparse.Namespace(
+        images=str(img_dir), boxes=str(tmp_path / "boxes.json"), out=str(out_dir), model="vit_tiny", checkpoint=None,
+        precision="f16", classes=None, n_classes=18, palette=None, box_batch=20, no_rle=False))
+    orc = get_oracle("vit_tiny")
+    tot_pix = np.zeros(18, np.int64)
+    for i in range(2):
+        stem = f"P{i:04d}"
+        gray = np.array(Image.open(out_dir / "gray" / (stem + ".png")))
+        info = pickle.load(open(out_dir / "ins" / (stem + ".pkl"), "rb"))
+        boxes, labels = np.asarray(ann[stem]["boxes"], np.float32), np.asarray(ann[stem]["labels"])
+        img = synth.make_image(10 + i)
+        orc.set_image(img)
+        m0 = torch.cat([orc.predict_torch(None, None, so.apply_boxes(torch.from_numpy(boxes[s:e]), img.shape[:2]), None,
+                                          multimask_output=False)[0] for s, e in so.box_chunks(len(labels), 20)])[:, 0].numpy()
+        seg0, areas0 = so.paint_semantic(m0, labels, img.shape[:2])
+        assert (gray != seg0).mean() < 2e-3
+        assert len(info) == len(labels)
+        for j, d in enumerate(info):
+            m = rle.decode(d["mask"])
+            assert int(m.sum()) == d["size"] and d["label"] == int(labels[j])
+            assert abs(d["size"] - areas0[j]) <= max(8, 2e-3 * areas0[j])
+            if d["size"] > 0:
+                tot_pix[d["label"]] += d["size"]
+    assert stats["class_pixel_num"] == tot_pix.tolist()

@@ -1,0 +1,67 @@
+"""CPU: COCO RLE restatement (pycocotools is not installed) + the on-disk output contract of the
+generation driver (Generate Dataset/main_sam_hbox_semantic.py:195-216)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from samrs_amd import generate, rle
+
+
+def test_counts_are_column_major_and_start_with_zeros():
+    m = np.array([[0, 1], [1, 1], [0, 0]], dtype=bool)          # columns: [0,1,0], [1,1,0]
+    assert rle.mask_to_counts(m) == [1, 1, 1, 2, 1]
+    assert rle.mask_to_counts(np.ones((2, 2), bool)) == [0, 4]
+    assert rle.mask_to_counts(np.zeros((2, 3), bool)) == [6]
+
+
+def test_known_cocoapi_strings():
+    # hand-computed with the cocoapi rleToString rule (5-bit groups, +48, delta vs counts[i-2] for i > 2)
+    assert rle.counts_to_string([6]) == "6"
+    assert rle.counts_to_string([0, 4]) == "04"
+    assert rle.counts_to_string([1, 1, 1, 2, 1]) == "11110"     # 4th: 2-1 = 1 ; 5th: 1-1 = 0
+    assert rle.counts_to_string([100]) == "T3"                  # 100 = 0b00011_00100 -> (4|0x20)+48='T', 3+48='3'
+    assert rle.counts_to_string([5, 3, 5, 1]) == "535N"         # 4th: 1-3 = -2 -> single group 0b11110 (sign bit set, x == -1 stops)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (7, 5), (64, 64), (250, 333)])
+def test_roundtrip_random_masks(shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    for p in (0.0, 0.03, 0.5, 0.97, 1.0):
+        m = rng.random(shape) < p
+        # blobs, not only salt and pepper: long runs exercise multi-group counts and negative deltas
+        if shape[0] > 8:
+            m[shape[0] // 4: shape[0] // 2] = True
+        r = rle.encode(m)
+        assert r["size"] == list(shape) and isinstance(r["counts"], str) and r["counts"].isascii()
+        assert rle.string_to_counts(r["counts"]) == rle.mask_to_counts(m)
+        assert np.array_equal(rle.decode(r), m)
+
+
+def test_writer_contract(tmp_path):
+    from PIL import Image
+    seg = np.full((16, 20), 255, np.uint8)
+    seg[2:6, 3:9] = 4
+    masks = np.zeros((2, 16, 20), bool)
+    masks[0, 2:6, 3:9] = True
+    boxes = np.array([[3, 2, 8, 5], [0, 0, 1, 1]], np.float32)
+    labels = np.array([4, 7])
+    areas = np.array([24, 0])
+    names = [f"c{i}" for i in range(18)]
+    pal = generate.default_palette(18)
+    generate.write_outputs(str(tmp_path), "P0001", seg, masks, boxes, labels, areas, pal, names)
+    g = np.array(Image.open(tmp_path / "gray" / "P0001.png"))
+    c = np.array(Image.open(tmp_path / "color" / "P0001.png"))
+    assert g.dtype == np.uint8 and np.array_equal(g, seg)
+    assert (c[0, 0] == 255).all() and (c[3, 4] == pal[4]).all()
+    info = pickle.load(open(tmp_path / "ins" / "P0001.pkl", "rb"))
+    assert [sorted(d) for d in info] == [["bbox", "category", "label", "mask", "size"]] * 2
+    assert info[0]["label"] == 4 and info[0]["category"] == "c4" and info[0]["size"] == 24
+    assert np.array_equal(rle.decode(info[0]["mask"]), masks[0]) and info[1]["size"] == 0
+    # what Generate Dataset/statistic.py:15-21 does with these files
+    pix = {i: 0 for i in range(18)}
+    for d in info:
+        if d["size"] > 0:
+            pix[d["label"]] += d["size"]
+    assert pix[4] == 24 and pix[7] == 0

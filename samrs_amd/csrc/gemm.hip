@@ -759,7 +759,6 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
     }
     if (grp == 0 && !(ABL & 8)) __builtin_amdgcn_s_barrier();          // both groups: 2 + 2*nk barriers
 
-    // epilogue: lane holds C[m][n..n+3], m = m0 + wm*128 + j*16 + fr, n = n0 + wn*64 + i*16 + 4*fq
     if (ABL & 16) {   // timing experiment: keep the accumulators alive, store nothing
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -767,36 +766,20 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
             for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][3]));
         return;
     }
+    {   // coalesced epilogue through the idle ring (16 KiB per wave)
+        unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (QSTAGES * QSTAGE_ELEMS * 2 / 8);
+        if (!OUT_F32 && add2d) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + 4 * fq;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int m = m0 + wm * 128 + j * 16 + fr;
-            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y;
-            float v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
-            if (add2d) {
-                const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
-                v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
-            }
-            if (GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-            if (OUT_F32) {
-                float* C = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
-                if (accumulate) {
-                    const float4 o = *reinterpret_cast<const float4*>(C);
-                    v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
+                for (int j = 0; j < 8; ++j) {
+                    const int m = m0 + wm * 128 + j * 16 + fr, n = n0 + wn * 64 + i * 16 + 4 * fq;
+                    const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
+                    acc[i][j][0] += e.x; acc[i][j][1] += e.y; acc[i][j][2] += e.z; acc[i][j][3] += e.w;
                 }
-                *reinterpret_cast<float4*>(C) = make_float4(v0, v1, v2, v3);
-            } else {
-                uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)m * N + n;
-                uint2 o;
-                o.x = pack2<PREC>(v0, v1);
-                o.y = pack2<PREC>(v2, v3);
-                *reinterpret_cast<uint2*>(C) = o;
-            }
         }
+        epilogue_coalesced<PREC, OUT_F32, GELU, 8, OUT_F32 ? 2 : 4>(acc, scr, Cv, bias, OUT_F32 ? add2d : nullptr, add2d_period,
+                                                                     N, m0 + wm * 128, n0 + wn * 64, accumulate, lane);
     }
 }
 
@@ -975,7 +958,7 @@ hipError_t launch_gemm_pipe(const void* A, const void* B, void* C, const float* 
     return hipGetLastError();
 }
 
-int g_gemm_variant = 8;   // 0 reg-staged 128^2, 1 +LDS-DMA, 2 +grouped order, 3 reg+grouped, 4 256x128 3-stage pipe, 5 +staggered groups, 6 256x256, 7 2 blocks/CU, 8 auto(5|7)
+int g_gemm_variant = 8;   // 0 reg-staged 128^2, 1 +LDS-DMA, 2 +grouped order, 3 reg+grouped, 4 256x128 3-stage pipe, 5 +staggered groups, 6 256x256, 7 2 blocks/CU, 8 auto(5|6|7)
 
 template <int PREC, bool GLDS, int GROUP_M>
 hipError_t launch_gemm_prec(const void* A, const void* B, void* C, const float* bias,
@@ -1134,13 +1117,16 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     // 2-blocks-per-CU kernel wins where the epilogue dominates (GELU output, or short K with a
     // narrow N), the 64-wide-K single-block kernel wins on long K / wide N.
     int variant = g_gemm_variant;
-    if (variant == 8) variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
+    if (variant == 8) {
+        if (!gelu && !out_f32 && N >= 2048 && M % QBM == 0 && N % QBN == 0 && K % QBK == 0) variant = 6;   // qkv: 256x256 tile
+        else variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
+    }
     if (variant == 7 && M % DBM == 0 && K % DBK == 0) {   // 2 blocks / CU
         if (prec == PREC_BF16) return launch_gemm_dual<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_dual<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
     }
-    if (g_gemm_variant == 6 && M % QBM == 0 && N % QBN == 0 && K % QBK == 0) {   // 256x256 staggered kernel
+    if (variant == 6 && M % QBM == 0 && N % QBN == 0 && K % QBK == 0) {   // 256x256 staggered kernel
         if (prec == PREC_BF16) return launch_gemm_big<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_big<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;

@@ -812,7 +812,7 @@ constexpr int DBM = 256, DBN = 128, DBK = 32, DSTAGES = 3, DTHREADS = 512;
 constexpr int DSTAGE_ELEMS = (DBM + DBN) * DBK;               // 12288 ET = 24 KiB
 constexpr int D_DMA_PER_TILE = (DBM + DBN) * DBK * 2 / (DTHREADS * 16);   // 3 per thread
 
-template <int PREC, bool OUT_F32, bool GELU>
+template <int PREC, bool OUT_F32, bool GELU, bool STAG = true>
 __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger
+    if (STAG && grp == 1) __builtin_amdgcn_s_barrier();          // stagger
 
     const int fr = lane & 15, fq = lane >> 4;
     int offA[4], offB[4];
@@ -888,16 +888,19 @@ __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
             fb[i] = *reinterpret_cast<const uint4*>(lds + (S_) * DSTAGE_ELEMS + offB[i]);        \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                            \
             fa[j] = *reinterpret_cast<const uint4*>(lds + (S_) * DSTAGE_ELEMS + offA[j]);        \
+        if (STAG) {                                                                              \
         DUAL_WAIT(kt_)                                                                           \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_barrier();                                                            \
+        }                                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                           \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                        \
                 acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]);                           \
         __builtin_amdgcn_s_setprio(0);                                                           \
         DUAL_WAIT(kt_)                                                                           \
+        if (!STAG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                            \
         __builtin_amdgcn_sched_barrier(0);                                                       \
         __builtin_amdgcn_s_barrier();                                                            \
     }
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
         DUAL_STEP(kt + 1, 1)
         DUAL_STEP(kt + 2, 2)
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();          // both groups: 2 + 2*nk barriers
+    if (STAG && grp == 0) __builtin_amdgcn_s_barrier();          // both groups: 2 + 2*nk barriers
     {
         unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (DSTAGES * DSTAGE_ELEMS * 2 / 8);   // 9 KiB
         if (!OUT_F32 && add2d) {
@@ -924,7 +927,7 @@ __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
     }
 }
 
-template <int PREC>
+template <int PREC, bool STAG = true>
 hipError_t launch_gemm_dual(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                             int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
     dim3 grid((M / DBM) * (N / DBN)), block(DTHREADS);
@@ -932,11 +935,11 @@ hipError_t launch_gemm_dual(const void* A, const void* B, void* C, const float* 
     const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
     const int acc = accumulate ? 1 : 0;
     if (out_f32) {
-        if (gelu) gemm_et_dual_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-        else gemm_et_dual_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        if (gelu) gemm_et_dual_kernel<PREC, true, true, STAG><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_dual_kernel<PREC, true, false, STAG><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
     } else {
-        if (gelu) gemm_et_dual_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-        else gemm_et_dual_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        if (gelu) gemm_et_dual_kernel<PREC, false, true, STAG><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_dual_kernel<PREC, false, false, STAG><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
     }
     return hipGetLastError();
 }
@@ -1121,6 +1124,11 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         if (!gelu && !out_f32 && N >= 2048 && M % QBM == 0 && N % QBN == 0 && K % QBK == 0) variant = 6;   // qkv: 256x256 tile
         else variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
     }
+    if (variant == 9 && M % DBM == 0 && K % DBK == 0) {   // 2 blocks / CU, lock-step (one barrier per K step)
+        if (prec == PREC_BF16) return launch_gemm_dual<PREC_BF16, false>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_dual<PREC_F16, false>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        return hipErrorInvalidValue;
+    }
     if (variant == 7 && M % DBM == 0 && K % DBK == 0) {   // 2 blocks / CU
         if (prec == PREC_BF16) return launch_gemm_dual<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_dual<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
@@ -1131,7 +1139,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         if (prec == PREC_F16) return launch_gemm_big<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
     }
-    if ((variant == 5 || variant == 6 || variant == 7) && M % PBM == 0) {   // staggered-group pipelined kernel
+    if ((variant == 5 || variant == 6 || variant == 7 || variant == 9) && M % PBM == 0) {   // staggered-group pipelined kernel
         if (prec == PREC_BF16) return launch_gemm_stag<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_stag<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;

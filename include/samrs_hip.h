@@ -133,6 +133,14 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
                 int orig_h, int orig_w, uint8_t* seg_mask, int64_t* areas_out,
                 int64_t* class_pixels, int64_t* class_instances, int n_classes, void* stream);
 
+/* -- "next row" N3: one separable pass of Pillow's 8-bit resample (ResizeLongestSide.apply_image,
+ * utils/transforms.py:26-31 -> PIL Image.resize BILINEAR).  `bounds` int32 [out_len,2] = (first input
+ * index, tap count), `coef` int32 [out_len,ksize] 22-bit fixed point, both computed on the host exactly
+ * as Pillow does (samrs_amd/transforms.py).  horizontal: in [other,in_len,3] -> out [other,out_len,3];
+ * vertical: in [in_len,other,3] -> out [out_len,other,3].  Bit-exact with PIL. */
+int samrs_resample_pass_u8(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* coef,
+                           int ksize, int in_len, int out_len, int other, int horizontal, void* stream);
+
 /* -- test hook: run preprocess + patch embed + the first n_blocks encoder blocks for n_images
  * tiles and copy the fp32 residual stream [n_images*4096, embed_dim] (channels-last,
  * image_encoder.py:107-112) to x_out.  Invalidates the embedding slots. */

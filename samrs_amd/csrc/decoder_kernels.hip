@@ -504,9 +504,43 @@ __global__ void class_stats_kernel(const unsigned long long* __restrict__ areas,
     }
 }
 
+// ---- PIL-compatible separable resample pass (next-row N3) ------------------------------------
+// Pillow's ImagingResample{Horizontal,Vertical}_8bpc: out = clip8((2^21 + sum_k in[k0 + k] * coef[k]) >> 22)
+// with per-output-index bounds (first input index, tap count) and 22-bit fixed-point coefficients
+// computed on the host exactly like Pillow's precompute_coeffs / normalize_coeffs_8bpc.
+// `horizontal`: in [rows, in_len, 3] -> out [rows, out_len, 3]; else in [in_len, cols, 3] -> out [out_len, cols, 3].
+__global__ void resample_pass_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const int32_t* __restrict__ bounds,
+                                     const int32_t* __restrict__ coef, int ksize, int in_len, int out_len, int other,
+                                     int horizontal) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)out_len * other * 3;
+    if (t >= total) return;
+    const int c = t % 3;
+    long u = t / 3;
+    int o, q;            // o: index along the resampled axis, q: index along the other axis
+    if (horizontal) { o = u % out_len; q = u / out_len; } else { q = u % other; o = u / other; }
+    const int k0 = bounds[2 * o], kn = bounds[2 * o + 1];
+    const int32_t* k = coef + (size_t)o * ksize;
+    int ss = 1 << 21;
+    for (int i = 0; i < kn; ++i) {
+        const size_t idx = horizontal ? ((size_t)q * in_len + (k0 + i)) * 3 + c : ((size_t)(k0 + i) * other + q) * 3 + c;
+        ss += (int)in[idx] * k[i];
+    }
+    ss >>= 22;
+    ss = ss < 0 ? 0 : (ss > 255 ? 255 : ss);
+    out[t] = (uint8_t)ss;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+hipError_t launch_resample_pass(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* coef, int ksize,
+                                int in_len, int out_len, int other, int horizontal, hipStream_t s) {
+    const long total = (long)out_len * other * 3;
+    resample_pass_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(in, out, bounds, coef, ksize, in_len, out_len, other, horizontal);
+    return hipGetLastError();
+}
+
 hipError_t launch_prompt_tokens(const PromptParams& p, float* tokens, int T, hipStream_t s) {
     dim3 g(T, p.n_prompts), b(256);
     prompt_tokens_kernel<<<g, b, 0, s>>>(p, tokens, T, 256);

@@ -750,6 +750,11 @@ int samrs_k_global_attention(int prec, const void* qkv, const float* rel_h, cons
                              int grid, int heads, int head_dim, void* stream) {
     KRET(launch_global_attention(prec, qkv, rel_h, rel_w, out, n_images, grid, heads, head_dim, (hipStream_t)stream));
 }
+int samrs_resample_pass_u8(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* coef, int ksize,
+                           int in_len, int out_len, int other, int horizontal, void* stream) {
+    if (!in || !out || !bounds || !coef || ksize < 1 || in_len < 1 || out_len < 1 || other < 1) return SAMRS_ERR_BAD_ARG;
+    KRET(launch_resample_pass(in, out, bounds, coef, ksize, in_len, out_len, other, horizontal, (hipStream_t)stream));
+}
 int samrs_k_postprocess(const float* low, int n_masks, int in_h, int in_w, int orig_h, int orig_w, int img_size,
                         int return_logits, void* out, void* stream) {
     KRET(launch_postprocess(low, n_masks, in_h, in_w, orig_h, orig_w, img_size, return_logits, out, (hipStream_t)stream));

@@ -72,3 +72,5 @@ hipError_t launch_postprocess(const float* low, int n_masks, int in_h, int in_w,
 hipError_t launch_paint(const uint8_t* masks, const int32_t* labels, int n, int h, int w, uint8_t* seg,
                         unsigned long long* areas, unsigned long long* class_pixels,
                         unsigned long long* class_instances, int n_classes, hipStream_t s);
+hipError_t launch_resample_pass(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* coef, int ksize,
+                                int in_len, int out_len, int other, int horizontal, hipStream_t s);

@@ -69,6 +69,8 @@ def load_library() -> C.CDLL:
     lib.samrs_debug_time_dominant_kernel.restype = ip
     lib.samrs_debug_dominant_kernel_time.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(ip), C.POINTER(ip), C.POINTER(ip), C.POINTER(ip)]
     lib.samrs_debug_dominant_kernel_time.restype = ip
+    lib.samrs_resample_pass_u8.argtypes = [vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
+    lib.samrs_resample_pass_u8.restype = ip
     lib.samrs_k_gemm.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_gemm_f32.argtypes = [vp, ip, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_convert.argtypes = [ip, vp, vp, C.c_int64, vp]

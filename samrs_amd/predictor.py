@@ -29,8 +29,10 @@ class SamPredictor:
         assert image_format in ["RGB", "BGR"], f"image_format must be in ['RGB', 'BGR'], is {image_format}."
         if image_format != self.model.image_format:
             image = image[..., ::-1]
-        input_image = self.transform.apply_image(image)
-        t = torch.as_tensor(np.ascontiguousarray(input_image), device=self.device)      # uint8 HWC
+        # ResizeLongestSide.apply_image (utils/transforms.py:26-31) on the device: bit-exact with the
+        # reference's PIL bilinear resize, identity for tiles whose long side is already 1024
+        t = torch.as_tensor(np.ascontiguousarray(image), device=self.device)            # uint8 HWC
+        t = self.transform.apply_image_device(t)
         self._set_hwc(t[None], tuple(image.shape[:2]))
 
     @torch.no_grad()

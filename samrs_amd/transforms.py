@@ -11,6 +11,60 @@ import numpy as np
 import torch
 
 
+PRECISION_BITS = 32 - 8 - 2      # Pillow Resample.c
+
+
+def pil_bilinear_coeffs(in_size: int, out_size: int):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR (triangle, support 1) filter
+    over the full input range: returns (bounds int32 [out,2], coef int32 [out,ksize], ksize)."""
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 1.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coef = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        x = np.arange(xmax, dtype=np.float64)
+        w = np.abs((x + xmin - center + 0.5) * ss)
+        w = np.where(w < 1.0, 1.0 - w, 0.0)
+        ww = 0.0
+        for v in w:                     # same left-to-right summation order as the C loop
+            ww += v
+        if ww != 0.0:
+            w = w / ww
+        q = w * float(1 << PRECISION_BITS)
+        coef[xx, :xmax] = np.where(q < 0, (q - 0.5).astype(np.int64), (q + 0.5).astype(np.int64)).astype(np.int32)
+        bounds[xx] = (xmin, xmax)
+    return bounds, coef, ksize
+
+
+def resample_reference(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """numpy statement of Pillow's two-pass 8-bit resample (horizontal, then vertical); used by the
+    tests to pin the coefficient tables against PIL itself."""
+    def one_pass(a, out_len, axis):
+        a = np.moveaxis(a, axis, 0).astype(np.int64)
+        b, k, _ = pil_bilinear_coeffs(a.shape[0], out_len)
+        out = np.empty((out_len,) + a.shape[1:], dtype=np.uint8)
+        for o in range(out_len):
+            k0, kn = b[o]
+            ss = (1 << (PRECISION_BITS - 1)) + np.tensordot(k[o, :kn].astype(np.int64), a[k0:k0 + kn], axes=(0, 0))
+            out[o] = np.clip(ss >> PRECISION_BITS, 0, 255)
+        return np.moveaxis(out, 0, axis)
+    h, w = img.shape[:2]
+    tmp = one_pass(img, out_w, 1) if out_w != w else img
+    return one_pass(tmp, out_h, 0) if out_h != h else tmp
+
+
 class ResizeLongestSide:
     def __init__(self, target_length: int) -> None:
         self.target_length = target_length
@@ -22,6 +76,35 @@ class ResizeLongestSide:
             return image
         from PIL import Image
         return np.array(Image.fromarray(image).resize((w, h), Image.BILINEAR))
+
+    def apply_image_device(self, image_u8: torch.Tensor) -> torch.Tensor:
+        """Same result as ``apply_image`` (bit-exact with PIL BILINEAR) for a uint8 HWC tensor that is
+        already on the GPU: two integer resample passes in libsamrs_hip (next-row N3)."""
+        from . import engine
+        assert image_u8.is_cuda and image_u8.dtype == torch.uint8 and image_u8.dim() == 3 and image_u8.shape[2] == 3
+        h, w = int(image_u8.shape[0]), int(image_u8.shape[1])
+        nh, nw = self.get_preprocess_shape(h, w, self.target_length)
+        if (nh, nw) == (h, w):
+            return image_u8
+        lib = engine.load_library()
+        dev = image_u8.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        cur = image_u8.contiguous()
+        if nw != w:                                   # Pillow: horizontal pass first
+            b, k, ks = pil_bilinear_coeffs(w, nw)
+            bd, kd = torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev)
+            out = torch.empty(h, nw, 3, dtype=torch.uint8, device=dev)
+            rc = lib.samrs_resample_pass_u8(cur.data_ptr(), out.data_ptr(), bd.data_ptr(), kd.data_ptr(), ks, w, nw, h, 1, stream)
+            assert rc == 0
+            cur = out
+        if nh != h:
+            b, k, ks = pil_bilinear_coeffs(h, nh)
+            bd, kd = torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev)
+            out = torch.empty(nh, cur.shape[1], 3, dtype=torch.uint8, device=dev)
+            rc = lib.samrs_resample_pass_u8(cur.data_ptr(), out.data_ptr(), bd.data_ptr(), kd.data_ptr(), ks, h, nh, cur.shape[1], 0, stream)
+            assert rc == 0
+            cur = out
+        return cur
 
     def apply_coords(self, coords: np.ndarray, original_size: Tuple[int, ...]) -> np.ndarray:
         old_h, old_w = original_size

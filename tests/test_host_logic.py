@@ -61,3 +61,17 @@ def test_driver_chunking_and_sharding():
     files = [f"P{i:04d}.png" for i in (5, 3, 9, 1, 7, 2, 8, 0, 6, 4)]
     parts = [driver.shard(files, r, 4) for r in range(4)]
     assert sorted(sum(parts, [])) == sorted(files) and parts[0] == ["P0000.png", "P0004.png", "P0008.png"]
+
+
+@pytest.mark.parametrize("hw,out", [((600, 800), (768, 1024)), ((800, 800), (1024, 1024)), ((1500, 1000), (1024, 683)),
+                                    ((333, 1024), (333, 1024)), ((2048, 1365), (1024, 683))])
+def test_pil_resample_restatement_is_bit_exact(hw, out):
+    """The coefficient tables + integer passes used by the GPU resize (N3) reproduce PIL's BILINEAR
+    resize (what ResizeLongestSide.apply_image calls, utils/transforms.py:26-31) bit for bit."""
+    from PIL import Image
+    from samrs_amd.transforms import resample_reference
+    img = synth.make_image(7, *hw)
+    ref = np.array(Image.fromarray(img).resize((out[1], out[0]), Image.BILINEAR))
+    got = resample_reference(img, out[0], out[1])
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref), f"{(got != ref).sum()} differing bytes"

@@ -253,3 +253,17 @@ def test_postprocess_matches_interpolate(lib, in_hw, orig_hw):
     assert lib.samrs_k_postprocess(lowd.data_ptr(), 3, in_hw[0], in_hw[1], orig_hw[0], orig_hw[1], 1024, 0, outm.data_ptr(), stream()) == 0
     mism = (outm.cpu().bool() != (ref > 0)).sum().item()
     assert mism <= 3, mism      # only pixels whose logit is within fp32 noise of zero
+
+
+@pytest.mark.parametrize("hw", [(600, 800), (800, 800), (1500, 1000), (2048, 1365), (1024, 1024)])
+def test_device_resize_is_bit_exact_with_pil(lib, hw):
+    """N3: ResizeLongestSide.apply_image on the GPU == PIL BILINEAR (utils/transforms.py:26-31), integer work."""
+    from PIL import Image
+    from samrs_amd import synth
+    from samrs_amd.transforms import ResizeLongestSide
+    t = ResizeLongestSide(1024)
+    img = synth.make_image(3, *hw)
+    nh, nw = t.get_preprocess_shape(hw[0], hw[1], 1024)
+    ref = np.array(Image.fromarray(img).resize((nw, nh), Image.BILINEAR)) if (nh, nw) != hw else img
+    got = t.apply_image_device(torch.as_tensor(img).cuda()).cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(got, ref)

@@ -9,6 +9,18 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+def _cap_threads():
+    # the GPU boxes expose 256 logical CPUs; torch-CPU (the oracle) oversubscribes badly with that many
+    try:
+        import torch
+        torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
+    except Exception:
+        pass
+
+
+_cap_threads()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: CPU test that takes more than ~30 s")

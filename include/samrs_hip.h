@@ -150,6 +150,10 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
 /* -- test / tuning hook: 0 = register-staged GEMM tiles, 1 = LDS-DMA staging (default). */
 void samrs_debug_set_gemm_variant(int variant);
 
+/* -- test hook: copy a prefix of a named internal decoder buffer (Q, KF, KE, KVQ, OI, U1raw, U1, U2,
+ * HYPER, ...) to a device buffer; used to localise run-to-run differences. */
+int samrs_debug_copy_buffer(samrs_engine_t* e, const char* name, void* dst, size_t bytes, void* stream);
+
 /* -- measurement hook: when enabled, samrs_set_images brackets every launch of the dominant kernel
  * (MLP lin1 + GELU GEMM, [n*4096, D] x [4D, D]^T) with hipEvents on the launch stream.
  * samrs_debug_dominant_kernel_time() synchronises those events, returns the average duration (ms),

@@ -695,6 +695,21 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
 
 void samrs_debug_set_gemm_variant(int v) { set_gemm_variant(v); }
 
+// test hook: copy (a prefix of) a named internal decoder buffer to a caller device buffer
+int samrs_debug_copy_buffer(samrs_engine_t* e, const char* name, void* dst, size_t bytes, void* stream) {
+    if (!e || !name || !dst) return SAMRS_ERR_BAD_ARG;
+    const std::string n(name);
+    const void* src = nullptr;
+    if (n == "Q") src = e->Q; else if (n == "TOK0") src = e->TOK0; else if (n == "KF") src = e->KF; else if (n == "KE") src = e->KE;
+    else if (n == "KVQ") src = e->KVQ; else if (n == "OI") src = e->OI; else if (n == "U1raw") src = e->U1raw;
+    else if (n == "U1") src = e->U1; else if (n == "U2") src = e->U2; else if (n == "HYPER") src = e->HYPER;
+    else if (n == "K0F") src = e->K0F; else if (n == "K0E") src = e->K0E; else if (n == "O128") src = e->O128;
+    else if (n == "MH") src = e->MH; else if (n == "KT") src = e->KT; else if (n == "VT") src = e->VT; else if (n == "QP") src = e->QP;
+    if (!src) return fail(e, SAMRS_ERR_BAD_ARG, "unknown buffer %s", name);
+    CK(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SAMRS_OK;
+}
+
 int samrs_debug_time_dominant_kernel(samrs_engine_t* e, int enable) {
     if (!e) return SAMRS_ERR_BAD_ARG;
     e->timing = enable != 0;

@@ -990,8 +990,8 @@ hipError_t launch_gemm_prec(const void* A, const void* B, void* C, const float* 
 // Token side of the decoder: M is a few hundred rows, so the launch is latency- and
 // parallelism-bound, not FLOP-bound.  One wave per 32x32 output tile (2x2 MFMA 16x16x4, f32 in /
 // f32 accumulate = an fmaf chain, bitwise), K walked in 32-wide slabs with a register prefetch of
-// the next slab (double-buffered LDS, one barrier per slab), and split-K over blockIdx.z for the
-// long-K projections (partials combined with fp32 atomics into the already-initialised C).
+// the next slab (double-buffered LDS, one barrier per slab).  (The kernel can split K over
+// blockIdx.z with fp32 atomics, but the launcher never does: it breaks run-to-run reproducibility.)
 // M, N arbitrary (bounds-checked), K % 32 == 0.  lda / ldc in elements; W is dense [N][K].
 // ---------------------------------------------------------------------------------------------
 constexpr int FM = 32, FN = 32, FK = 32;
@@ -1159,10 +1159,11 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s) {
     if (K % FK || M <= 0 || N <= 0 || (lda % 4)) return hipErrorInvalidValue;
-    // split-K only where the partial sums can be added into an existing C (accumulate, no ReLU)
-    int splits = 1;
-    if (accumulate && !relu && K >= 1024) splits = K / 512;
-    const int kchunk = K / splits;
+    // No split-K: combining partial sums with fp32 atomics made the token side differ by ~1e-7 from run
+    // to run, and the f16 rounding of the image-side activations amplifies that to ~1e-3 of the logit
+    // std (measured) -- reproducible output is worth more than the ~0.5 % of a step it costs.
+    const int splits = 1;
+    const int kchunk = K;
     dim3 grid((N + FN - 1) / FN, (M + FM - 1) / FM, splits), block(64);
     gemm_f32_kernel<<<grid, block, 0, s>>>(A, lda, W, bias, C, ldc, M, N, K, relu ? 1 : 0, accumulate ? 1 : 0, kchunk);
     return hipGetLastError();

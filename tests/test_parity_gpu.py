@@ -310,3 +310,44 @@ def test_generation_driver_end_to_end(tmp_path):
             if d["size"] > 0:
                 tot_pix[d["label"]] += d["size"]
     assert stats["class_pixel_num"] == tot_pix.tolist()
+
+
+def test_vit_h_full_size_properties():
+    """BASELINE.json configs[1] at full size (ViT-H, 8 x 1024^2 tiles, 32 boxes per tile), through
+    size-independent properties (the CPU oracle needs ~10 s per ViT-H tile, the goldens cover one tile):
+      * batched encoder == one tile at a time, bit for bit (rows are independent in every kernel);
+      * 32 boxes in one call == the reference's 20 + 12 chunking (main_sam_hbox_semantic.py:157-181), bit for
+        bit (no atomics anywhere on the path);
+      * on-device painting / areas == recomputation from the returned masks (integer, exact);
+      * predictions are bit-reproducible across repeated calls."""
+    pred = get_predictor("vit_h", "f16", max_prompts=32, max_images=8)
+    eng = pred.model.engine
+    tiles = torch.stack([torch.as_tensor(synth.make_noise_image(40 + i)) for i in range(8)]).cuda()
+    eng.set_images(tiles, 0)
+    emb3 = eng.get_embedding(3).clone()
+    emb7 = eng.get_embedding(7).clone()
+    eng.set_images(tiles[3:4].contiguous(), 0)
+    assert torch.equal(eng.get_embedding(0), emb3), "batched encode differs from single-tile encode"
+    eng.set_images(tiles, 0)
+    assert torch.equal(eng.get_embedding(7), emb7), "encoder is not deterministic"
+    boxes, labels = synth.make_boxes(40, 32)
+    b = torch.from_numpy(boxes).cuda()
+    size = (1024, 1024)
+    m_all, q_all, l_all = eng.predict(3, b, None, None, None, False, False, size, size)
+    parts = [eng.predict(3, b[s:e], None, None, None, False, False, size, size) for s, e in [(0, 20), (20, 32)]]
+    m_ch = torch.cat([p[0] for p in parts]); l_ch = torch.cat([p[2] for p in parts]); q_ch = torch.cat([p[1] for p in parts])
+    scale = l_all.std().item()
+    print(f"vit_h 32 boxes vs 20+12: low-res max diff / std {(l_all - l_ch).abs().max().item() / scale:.2e}, "
+          f"mask pixels differing {(m_all != m_ch).sum().item()} of {m_all.numel()}")
+    assert torch.equal(l_all, l_ch) and torch.equal(q_all, q_ch) and torch.equal(m_all, m_ch)
+    m_rep, q_rep, l_rep = eng.predict(3, b, None, None, None, False, False, size, size)
+    assert torch.equal(l_rep, l_all) and torch.equal(m_rep, m_all), "predict is not reproducible"
+    seg = torch.full(size, 255, dtype=torch.uint8, device="cuda")
+    cp = torch.zeros(18, dtype=torch.int64, device="cuda"); ci = torch.zeros(18, dtype=torch.int64, device="cuda")
+    areas = eng.paint(m_all[:, 0], torch.from_numpy(labels), seg, cp, ci)
+    assert torch.equal(areas, m_all[:, 0].flatten(1).sum(1))
+    seg_ref = torch.full(size, 255, dtype=torch.uint8, device="cuda")
+    for j in range(32):
+        seg_ref[m_all[j, 0]] = int(labels[j])
+    assert torch.equal(seg, seg_ref)
+    assert int(cp.sum()) == int(areas.sum()) and int(ci.sum()) == int((areas > 0).sum())

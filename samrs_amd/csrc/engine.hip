@@ -443,7 +443,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->KVQ, Bb * tokens * 3 * Ci)); CK(e, dalloc(e, &e->OI, Bb * tokens * Ci));
     CK(e, dalloc(e, &e->U1raw, Bb * tokens * C)); CK(e, dalloc(e, &e->U1, Bb * tokens * C));
     CK(e, dalloc(e, &e->U2, Bb * tokens * 4 * (C / 2)));
-    CK(e, dalloc(e, &e->HY1, Bb * C)); CK(e, dalloc(e, &e->HY2, Bb * C));
+    CK(e, dalloc(e, &e->HY1, 5 * Bb * C)); CK(e, dalloc(e, &e->HY2, 5 * Bb * C));
     CK(e, dalloc(e, &e->HYPER, Bb * 4 * (C / 8))); CK(e, dalloc(e, &e->IOU, Bb * 4));
     CK(e, dalloc(e, &e->LOW, Bb * 3 * 256 * 256));
     CK(e, hipStreamSynchronize(s));
@@ -575,6 +575,12 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
     const int Mi = n * tokens;
     auto lin = [&](const float* A, int lda, const float* Wt, const float* b, float* Cout, int ldc, int M, int N, int K,
                    bool relu, bool acc) { return launch_gemm_f32(A, lda, Wt, b, Cout, ldc, M, N, K, relu, acc, s); };
+    auto lin2 = [&](const float* A, const float* A2, int lda, const float* Wt, const float* b, float* Cout, int ldc, int M,
+                    int N, int K) {     // (A + A2) W^T + b
+        F32Batch bt{};
+        bt.A[0] = A; bt.A2[0] = A2; bt.W[0] = Wt; bt.bias[0] = b; bt.C[0] = Cout;
+        return launch_gemm_f32_batch(bt, 1, lda, ldc, M, N, K, false, false, s);
+    };
     auto ln_tok = [&](const float* gw, const float* gb) {
         return launch_layernorm(prec, e->Q, gw, gb, 1e-5f, nullptr, e->Q, BT, C, 0, g, 0, s);
     };
@@ -611,12 +617,15 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
     for (int li = 0; li < 2; ++li) {
         const DecLayer& L = e->layers[li];
         const bool sh = shared0 && li == 0;     // image side still identical for every prompt
-        // (1) token self attention
-        const float* qin = e->Q;
-        if (li > 0) { CK(e, launch_add_f32(e->Q, e->TOK0, e->TA, (long)BT * C, s)); qin = e->TA; }
-        CK(e, lin(qin, C, L.self.qw, L.self.qb, e->TQ, C, BT, C, C, false, false));
-        CK(e, lin(qin, C, L.self.kw, L.self.kb, e->TK, C, BT, C, C, false, false));
-        CK(e, lin(e->Q, C, L.self.vw, L.self.vb, e->TV, C, BT, C, C, false, false));
+        // (1) token self attention: q/k from queries (+ prompt PE after layer 0), v from queries -- one launch
+        {
+            F32Batch bt{};
+            const float* pe = li > 0 ? e->TOK0 : nullptr;
+            bt.A[0] = e->Q; bt.A2[0] = pe; bt.W[0] = L.self.qw; bt.bias[0] = L.self.qb; bt.C[0] = e->TQ;
+            bt.A[1] = e->Q; bt.A2[1] = pe; bt.W[1] = L.self.kw; bt.bias[1] = L.self.kb; bt.C[1] = e->TK;
+            bt.A[2] = e->Q; bt.A2[2] = nullptr; bt.W[2] = L.self.vw; bt.bias[2] = L.self.vb; bt.C[2] = e->TV;
+            CK(e, launch_gemm_f32_batch(bt, 3, C, C, BT, C, C, false, false, s));
+        }
         CK(e, launch_token_self_attn(e->TQ, e->TK, e->TV, e->TO, n, T, C, 8, s));
         CK(e, lin(e->TO, C, L.self.ow, L.self.ob, e->Q, C, BT, C, C, false, li > 0));
         CK(e, ln_tok(L.n1w, L.n1b));
@@ -625,8 +634,7 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
         const long bstride = sh ? 0 : tokens;
         CK(e, launch_gemm_et(prec, keys_et, L.kvq_w, e->KVQ, L.kvq_b, L.kvq_pe, tokens, sh ? tokens : Mi, 3 * Ci, C, false, false, false, s));
         // (2) tokens -> image
-        CK(e, launch_add_f32(e->Q, e->TOK0, e->TA, (long)BT * C, s));
-        CK(e, lin(e->TA, C, L.t2i.qw, L.t2i.qb, e->QP, Ci, BT, Ci, C, false, false));
+        CK(e, lin2(e->Q, e->TOK0, C, L.t2i.qw, L.t2i.qb, e->QP, Ci, BT, Ci, C));
         CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 3 * Ci, bstride, e->O128, n, T, tokens, Ci, 8, s));
         CK(e, lin(e->O128, Ci, L.t2i.ow, L.t2i.ob, e->Q, C, BT, C, Ci, false, true));
         CK(e, ln_tok(L.n2w, L.n2b));
@@ -635,9 +643,12 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
         CK(e, lin(e->MH, 2048, L.m2w, L.m2b, e->Q, C, BT, C, 2048, false, true));
         CK(e, ln_tok(L.n3w, L.n3b));
         // (4) image -> tokens
-        CK(e, launch_add_f32(e->Q, e->TOK0, e->TA, (long)BT * C, s));
-        CK(e, lin(e->TA, C, L.i2t.kw, L.i2t.kb, e->KT, Ci, BT, Ci, C, false, false));
-        CK(e, lin(e->Q, C, L.i2t.vw, L.i2t.vb, e->VT, Ci, BT, Ci, C, false, false));
+        {
+            F32Batch bt{};
+            bt.A[0] = e->Q; bt.A2[0] = e->TOK0; bt.W[0] = L.i2t.kw; bt.bias[0] = L.i2t.kb; bt.C[0] = e->KT;
+            bt.A[1] = e->Q; bt.A2[1] = nullptr; bt.W[1] = L.i2t.vw; bt.bias[1] = L.i2t.vb; bt.C[1] = e->VT;
+            CK(e, launch_gemm_f32_batch(bt, 2, C, Ci, BT, Ci, C, false, false, s));
+        }
         CK(e, launch_i2t_attention(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, e->OI, n, T, tokens, Ci, 8, s));
         if (sh)
             CK(e, launch_gemm_et(prec, e->OI, L.i2t_ow, e->KF, L.i2t.ob, e->K0F, tokens, Mi, C, Ci, true, false, false, s));
@@ -646,25 +657,32 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
         CK(e, launch_layernorm(prec, e->KF, L.n4w, L.n4b, 1e-5f, e->KE, e->KF, Mi, C, 0, g, 0, s));
     }
     // final tokens -> image attention (transformer.py:98-104)
-    CK(e, launch_add_f32(e->Q, e->TOK0, e->TA, (long)BT * C, s));
-    CK(e, lin(e->TA, C, e->fin.qw, e->fin.qb, e->QP, Ci, BT, Ci, C, false, false));
+    CK(e, lin2(e->Q, e->TOK0, C, e->fin.qw, e->fin.qb, e->QP, Ci, BT, Ci, C));
     CK(e, launch_gemm_et(prec, e->KE, e->fin_kv_w, e->KVQ, e->fin_kv_b, e->fin_pe, tokens, Mi, 2 * Ci, C, false, false, false, s));
     CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 2 * Ci, tokens, e->O128, n, T, tokens, Ci, 8, s));
     CK(e, lin(e->O128, Ci, e->fin.ow, e->fin.ob, e->Q, C, BT, C, Ci, false, true));
     CK(e, ln_tok(W(e, "mask_decoder.transformer.norm_final_attn.weight"), W(e, "mask_decoder.transformer.norm_final_attn.bias")));
 
-    // ---- heads (mask_decoder.py:156-172) ----
-    for (int i = 0; i < 4; ++i) {
-        const std::string p = "mask_decoder.output_hypernetworks_mlps." + std::to_string(i) + ".layers";
-        CK(e, lin(e->Q + (size_t)(1 + i) * C, T * C, W(e, p + ".0.weight"), W(e, p + ".0.bias"), e->HY1, C, n, C, C, true, false));
-        CK(e, lin(e->HY1, C, W(e, p + ".1.weight"), W(e, p + ".1.bias"), e->HY2, C, n, C, C, true, false));
-        CK(e, lin(e->HY2, C, W(e, p + ".2.weight"), W(e, p + ".2.bias"), e->HYPER + i * (C / 8), 4 * (C / 8), n, C / 8, C, false, false));
-    }
+    // ---- heads (mask_decoder.py:156-172): 4 hypernetwork MLPs + the IoU MLP, layer by layer in one launch each ----
     {
-        const std::string p = "mask_decoder.iou_prediction_head.layers";
-        CK(e, lin(e->Q, T * C, W(e, p + ".0.weight"), W(e, p + ".0.bias"), e->HY1, C, n, C, C, true, false));
-        CK(e, lin(e->HY1, C, W(e, p + ".1.weight"), W(e, p + ".1.bias"), e->HY2, C, n, C, C, true, false));
-        CK(e, lin(e->HY2, C, W(e, p + ".2.weight"), W(e, p + ".2.bias"), e->IOU, 4, n, 4, C, false, false));
+        const std::string hp = "mask_decoder.output_hypernetworks_mlps.", ip = "mask_decoder.iou_prediction_head.layers";
+        const size_t hs = (size_t)c.max_prompts * C;
+        F32Batch l0{}, l1{}, l2{};
+        for (int i = 0; i < 5; ++i) {
+            const std::string p = i < 4 ? hp + std::to_string(i) + ".layers" : ip;
+            l0.A[i] = i < 4 ? e->Q + (size_t)(1 + i) * C : e->Q;       // mask token i / IoU token of every prompt
+            l0.W[i] = W(e, p + ".0.weight"); l0.bias[i] = W(e, p + ".0.bias"); l0.C[i] = e->HY1 + i * hs;
+            l1.A[i] = e->HY1 + i * hs;
+            l1.W[i] = W(e, p + ".1.weight"); l1.bias[i] = W(e, p + ".1.bias"); l1.C[i] = e->HY2 + i * hs;
+            if (i < 4) {
+                l2.A[i] = e->HY2 + i * hs;
+                l2.W[i] = W(e, p + ".2.weight"); l2.bias[i] = W(e, p + ".2.bias"); l2.C[i] = e->HYPER + i * (C / 8);
+            }
+        }
+        CK(e, launch_gemm_f32_batch(l0, 5, T * C, C, n, C, C, true, false, s));
+        CK(e, launch_gemm_f32_batch(l1, 5, C, C, n, C, C, true, false, s));
+        CK(e, launch_gemm_f32_batch(l2, 4, C, 4 * (C / 8), n, C / 8, C, false, false, s));
+        CK(e, lin(e->HY2 + 4 * hs, C, W(e, ip + ".2.weight"), W(e, ip + ".2.bias"), e->IOU, 4, n, 4, C, false, false));
     }
     // ---- upscaler (mask_decoder.py:53-59,154-155) as two GEMMs + fused tail ----
     CK(e, launch_gemm_et(prec, e->KE, e->up1_w, e->U1raw, e->up1_b, nullptr, 0, Mi, C, C, true, false, false, s));

@@ -986,28 +986,37 @@ hipError_t launch_gemm_prec(const void* A, const void* B, void* C, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// exact fp32 GEMM: C[M,N] = A[M,K] * W[N,K]^T + bias, optional ReLU / accumulate.
-// Token side of the decoder: M is a few hundred rows, so the launch is latency- and
-// parallelism-bound, not FLOP-bound.  One wave per 32x32 output tile (2x2 MFMA 16x16x4, f32 in /
-// f32 accumulate = an fmaf chain, bitwise), K walked in 32-wide slabs with a register prefetch of
-// the next slab (double-buffered LDS, one barrier per slab).  (The kernel can split K over
-// blockIdx.z with fp32 atomics, but the launcher never does: it breaks run-to-run reproducibility.)
-// M, N arbitrary (bounds-checked), K % 32 == 0.  lda / ldc in elements; W is dense [N][K].
+// exact fp32 GEMM: C[M,N] = (A [+ A2])[M,K] * W[N,K]^T + bias, optional ReLU / accumulate, for up
+// to F32_BATCH_MAX independent problems of one shape per launch (blockIdx.z picks the pointer set).
+// Token side of the decoder: M is a few hundred rows, so the launch is latency- and parallelism-
+// bound, not FLOP-bound.  A block of S waves owns one 32x32 output tile and splits K S ways;
+// partial tiles are combined through LDS in a FIXED order, so the result is bit-reproducible
+// (unlike a blockIdx-level split-K with fp32 atomics).
+//
+// No LDS staging of the operands: v_mfma_f32_16x16x4_f32 takes, per lane (i = lane&15, q = lane>>4),
+// ONE element P[i][k_q] of the 16x4 slab, and a sum over k does not care which physical k sits in
+// slot q as long as both operands agree.  So each lane loads a float4 = row i, columns 4q..4q+3 of
+// a 16-wide K slab straight from global memory (16 rows x 64 contiguous bytes per instruction),
+// and MFMA t of the slab consumes component t of both operands: slot q of MFMA t holds k = 4q + t.
+// Up to F32_PF slabs are kept in flight per wave (a register ring).
+// M, N arbitrary (bounds-checked), K % 16 == 0.  lda / ldc in elements; W is dense [N][K].
 // ---------------------------------------------------------------------------------------------
-constexpr int FM = 32, FN = 32, FK = 32;
+constexpr int FM = 32, FN = 32, FKS = 16, F32_PF = 4;
 
-__global__ __launch_bounds__(64) void gemm_f32_kernel(const float* __restrict__ A, int lda,
-                                                      const float* __restrict__ W,
-                                                      const float* __restrict__ bias,
-                                                      float* __restrict__ C, int ldc, int M, int N,
-                                                      int K, int relu, int accumulate, int kchunk) {
-    // +1 padding: fragment reads walk rows at fixed k -> stride 33 floats is conflict-free
-    __shared__ float sa[2][FM][FK + 1];
-    __shared__ float sw[2][FN][FK + 1];
-    const int lane = threadIdx.x;
+template <int S>
+__global__ __launch_bounds__(64 * S) void gemm_f32_kernel(F32Batch bt, int lda, int ldc, int M, int N, int K,
+                                                          int relu, int accumulate) {
+    __shared__ float red[S][FM][FN + 1];
+    const int z = blockIdx.z;
+    const float* __restrict__ A = bt.A[z];
+    const float* __restrict__ A2 = bt.A2[z];
+    const float* __restrict__ W = bt.W[z];
+    const float* __restrict__ bias = bt.bias[z];
+    float* __restrict__ C = bt.C[z];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m0 = blockIdx.y * FM, n0 = blockIdx.x * FN;
-    const int kbeg = blockIdx.z * kchunk;
-    const int kend = (kbeg + kchunk) < K ? (kbeg + kchunk) : K;
+    const int KW = K / S, NS = KW / FKS;
+    const int r = lane & 15, q = lane >> 4;
 
     f32x4_t acc[2][2];
 #pragma unroll
@@ -1015,74 +1024,77 @@ __global__ __launch_bounds__(64) void gemm_f32_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // staging: 32 rows x 8 float4 per operand; lane -> rows (lane>>3) + 8*i, float4 column lane&7
-    const int sr = lane >> 3, sc = (lane & 7) * 4;
-    float4 ra[4], rw[4];
-#define F32_GLOAD(k0_)                                                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                           \
-        const int r_ = sr + 8 * i_;                                                               \
-        ra[i_] = (m0 + r_ < M) ? *reinterpret_cast<const float4*>(A + (size_t)(m0 + r_) * lda + (k0_) + sc) \
-                               : make_float4(0.f, 0.f, 0.f, 0.f);                                \
-        rw[i_] = (n0 + r_ < N) ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + r_) * K + (k0_) + sc)   \
-                               : make_float4(0.f, 0.f, 0.f, 0.f);                                \
+    bool va[2], vw[2];
+    const float *pa[2], *pa2[2], *pw[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        va[h] = m0 + 16 * h + r < M;
+        vw[h] = n0 + 16 * h + r < N;
+        const size_t ao = (size_t)(va[h] ? m0 + 16 * h + r : 0) * lda + wave * KW + 4 * q;
+        pa[h] = A + ao;
+        pa2[h] = A2 ? A2 + ao : nullptr;
+        pw[h] = W + (size_t)(vw[h] ? n0 + 16 * h + r : 0) * K + wave * KW + 4 * q;
     }
-#define F32_LSTORE(buf_)                                                                          \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                           \
-        const int r_ = sr + 8 * i_;                                                               \
-        sa[buf_][r_][sc + 0] = ra[i_].x; sa[buf_][r_][sc + 1] = ra[i_].y;                         \
-        sa[buf_][r_][sc + 2] = ra[i_].z; sa[buf_][r_][sc + 3] = ra[i_].w;                         \
-        sw[buf_][r_][sc + 0] = rw[i_].x; sw[buf_][r_][sc + 1] = rw[i_].y;                         \
-        sw[buf_][r_][sc + 2] = rw[i_].z; sw[buf_][r_][sc + 3] = rw[i_].w;                         \
+    float4 xa[F32_PF][2], xw[F32_PF][2];
+#define F32_LOAD(slot_, s_)                                                                        \
+    if ((s_) < NS) {                                                                               \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                         \
+            float4 a_ = make_float4(0.f, 0.f, 0.f, 0.f), w_ = a_;                                  \
+            if (va[h_]) {                                                                          \
+                a_ = *reinterpret_cast<const float4*>(pa[h_] + (s_) * FKS);                        \
+                if (pa2[h_]) {                                                                     \
+                    const float4 b_ = *reinterpret_cast<const float4*>(pa2[h_] + (s_) * FKS);      \
+                    a_.x += b_.x; a_.y += b_.y; a_.z += b_.z; a_.w += b_.w;                        \
+                }                                                                                  \
+            }                                                                                      \
+            if (vw[h_]) w_ = *reinterpret_cast<const float4*>(pw[h_] + (s_) * FKS);                \
+            xa[slot_][h_] = a_; xw[slot_][h_] = w_;                                                \
+        }                                                                                          \
     }
-    F32_GLOAD(kbeg)
-    F32_LSTORE(0)
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += FK) {
-        const int kn = (k0 + FK < kend) ? k0 + FK : k0;     // last slab: harmless re-read
-        F32_GLOAD(kn)
 #pragma unroll
-        for (int kk = 0; kk < FK; kk += 4) {
-            // 16x16x4: first operand lane l = P[i = l&15][k = l>>4]; second = Q[k = l>>4][j = l&15]
-            float fa[2], fw[2];
+    for (int p = 0; p < F32_PF; ++p) F32_LOAD(p, p)
+    for (int g = 0; g < NS; g += F32_PF) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) fa[j] = sa[buf][j * 16 + (lane & 15)][kk + (lane >> 4)];
+        for (int p = 0; p < F32_PF; ++p) {
+            if (g + p < NS) {
+                const float fa[2][4] = {{xa[p][0].x, xa[p][0].y, xa[p][0].z, xa[p][0].w},
+                                        {xa[p][1].x, xa[p][1].y, xa[p][1].z, xa[p][1].w}};
+                const float fw[2][4] = {{xw[p][0].x, xw[p][0].y, xw[p][0].z, xw[p][0].w},
+                                        {xw[p][1].x, xw[p][1].y, xw[p][1].z, xw[p][1].w}};
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fw[i] = sw[buf][i * 16 + (lane & 15)][kk + (lane >> 4)];
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[i], fa[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[i][t], fa[j][t], acc[i][j], 0, 0, 0);
+                F32_LOAD(p, g + p + F32_PF)
+            }
         }
-        F32_LSTORE(buf ^ 1)
-        __syncthreads();
-        buf ^= 1;
     }
-    // D[i_local = n][j_local = m]: lane holds n = base + 4*(lane>>4) + r, m = base + (lane&15)
-    const bool split = gridDim.z > 1;
+#undef F32_LOAD
+    // D[i_local = n][j_local = m]: lane holds n = base + 4*(lane>>4) + rr, m = base + (lane&15)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = m0 + j * 16 + (lane & 15);
-            if (m >= M) continue;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + i * 16 + 4 * (lane >> 4) + r;
-                if (n >= N) continue;
-                float* c = C + (size_t)m * ldc + n;
-                if (split) {   // host guarantees accumulate && !relu: C already holds the addend
-                    float v = acc[i][j][r] + ((bias && blockIdx.z == 0) ? bias[n] : 0.f);
-                    unsafeAtomicAdd(c, v);
-                } else {
-                    float v = acc[i][j][r] + (bias ? bias[n] : 0.f);
-                    if (relu) v = fmaxf(v, 0.f);
-                    if (accumulate) v += *c;
-                    *c = v;
-                }
-            }
+            for (int rr = 0; rr < 4; ++rr) red[wave][j * 16 + r][i * 16 + 4 * q + rr] = acc[i][j][rr];
+    __syncthreads();
+    for (int o = threadIdx.x; o < FM * FN; o += 64 * S) {
+        const int ml = o >> 5, nl = o & 31;
+        float v = red[0][ml][nl];
+#pragma unroll
+        for (int w = 1; w < S; ++w) v += red[w][ml][nl];     // fixed order: reproducible
+        const int m = m0 + ml, n = n0 + nl;
+        if (m < M && n < N) {
+            float* c = C + (size_t)m * ldc + n;
+            v += bias ? bias[n] : 0.f;
+            if (relu) v = fmaxf(v, 0.f);
+            if (accumulate) v += *c;
+            *c = v;
         }
+    }
 }
 
 }  // namespace
@@ -1156,15 +1168,28 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
 
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 
+hipError_t launch_gemm_f32_batch(const F32Batch& bt, int count, int lda, int ldc, int M, int N, int K, bool relu,
+                                 bool accumulate, hipStream_t s) {
+    if (K % FKS || M <= 0 || N <= 0 || (lda % 4) || count < 1 || count > F32_BATCH_MAX) return hipErrorInvalidValue;
+    // waves per tile: enough to put ~1000 waves on the chip, as long as every wave keeps >= one 16-wide K slab
+    const long tiles = (long)((N + FN - 1) / FN) * ((M + FM - 1) / FM) * count;
+    int S = 1;
+    while (S < 16 && tiles * S < 1024 && K % (2 * FKS * S) == 0) S *= 2;
+    dim3 grid((N + FN - 1) / FN, (M + FM - 1) / FM, count);
+    const int r = relu ? 1 : 0, a = accumulate ? 1 : 0;
+    switch (S) {
+        case 1: gemm_f32_kernel<1><<<grid, 64, 0, s>>>(bt, lda, ldc, M, N, K, r, a); break;
+        case 2: gemm_f32_kernel<2><<<grid, 128, 0, s>>>(bt, lda, ldc, M, N, K, r, a); break;
+        case 4: gemm_f32_kernel<4><<<grid, 256, 0, s>>>(bt, lda, ldc, M, N, K, r, a); break;
+        case 8: gemm_f32_kernel<8><<<grid, 512, 0, s>>>(bt, lda, ldc, M, N, K, r, a); break;
+        default: gemm_f32_kernel<16><<<grid, 1024, 0, s>>>(bt, lda, ldc, M, N, K, r, a); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s) {
-    if (K % FK || M <= 0 || N <= 0 || (lda % 4)) return hipErrorInvalidValue;
-    // No split-K: combining partial sums with fp32 atomics made the token side differ by ~1e-7 from run
-    // to run, and the f16 rounding of the image-side activations amplifies that to ~1e-3 of the logit
-    // std (measured) -- reproducible output is worth more than the ~0.5 % of a step it costs.
-    const int splits = 1;
-    const int kchunk = K;
-    dim3 grid((N + FN - 1) / FN, (M + FM - 1) / FM, splits), block(64);
-    gemm_f32_kernel<<<grid, block, 0, s>>>(A, lda, W, bias, C, ldc, M, N, K, relu ? 1 : 0, accumulate ? 1 : 0, kchunk);
-    return hipGetLastError();
+    F32Batch bt{};
+    bt.A[0] = A; bt.W[0] = W; bt.bias[0] = bias; bt.C[0] = C;
+    return launch_gemm_f32_batch(bt, 1, lda, ldc, M, N, K, relu, accumulate, s);
 }

@@ -10,6 +10,17 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
 void set_gemm_variant(int v);   // 0 = register-staged tiles, 1 = LDS-DMA staging (default)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s);
+// up to F32_BATCH_MAX same-shape fp32 GEMMs in one launch: C[z] = (A[z] (+ A2[z])) * W[z]^T + bias[z]
+constexpr int F32_BATCH_MAX = 5;
+struct F32Batch {
+    const float* A[F32_BATCH_MAX];
+    const float* A2[F32_BATCH_MAX];     // optional elementwise addend of A (same lda), or null
+    const float* W[F32_BATCH_MAX];
+    const float* bias[F32_BATCH_MAX];   // or null
+    float* C[F32_BATCH_MAX];
+};
+hipError_t launch_gemm_f32_batch(const F32Batch& bt, int count, int lda, int ldc, int M, int N, int K, bool relu,
+                                 bool accumulate, hipStream_t s);
 
 // ---- encoder_kernels.hip --------------------------------------------------------------------
 hipError_t launch_patch_im2col(int prec, const uint8_t* img, void* A, int n_images, int in_h, int in_w,

@@ -94,7 +94,8 @@ def test_gemm_et_variants(lib, name, prec, dt, ulp, M, N, K):
 def test_gemm_f32_exact_class(lib):
     g = torch.Generator().manual_seed(5)
     for (M, N, K, lda_pad, relu, acc) in [(7, 32, 256, 0, 0, 0), (224, 2048, 256, 0, 1, 0), (224, 256, 2048, 0, 0, 1),
-                                          (32, 4, 256, 1792 - 256, 0, 0), (4096, 128, 256, 0, 0, 0), (100, 70, 128, 0, 1, 1)]:
+                                          (32, 4, 256, 1792 - 256, 0, 0), (4096, 128, 256, 0, 0, 0), (100, 70, 128, 0, 1, 1),
+                                          (33, 40, 48, 4, 0, 0), (224, 128, 256, 0, 0, 0)]:
         lda = K + lda_pad
         A = torch.randn(M, lda, generator=g)
         Wt = torch.randn(N, K, generator=g) / math.sqrt(K)
@@ -112,6 +113,10 @@ def test_gemm_f32_exact_class(lib):
         print(f"gemm_f32 {M}x{N}x{K} lda={lda} relu={relu} acc={acc}: rel {r:.2e} max {mx:.2e}")
         assert r < 3e-6
         assert torch.equal(out[:, N:], C0[:, N:]), "wrote outside the [M, N] window"
+        # K is split over the waves of a block and combined in a fixed order: bit-reproducible
+        Cd2 = dev(C0.clone())
+        assert lib.samrs_k_gemm_f32(Ad.data_ptr(), lda, Wd.data_ptr(), bd.data_ptr(), Cd2.data_ptr(), N + 8, M, N, K, relu, acc, stream()) == 0
+        assert torch.equal(Cd2.cpu(), out)
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)

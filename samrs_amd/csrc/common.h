@@ -100,12 +100,26 @@ __device__ __forceinline__ float wave_max(float v) {
 //   erfc(z) = t*(a1 + t*(a2 + t*(a3 + t*(a4 + t*a5)))) * exp(-z^2),  t = 1/(1 + p z)
 // and gelu(x) = x - 0.5*x*erfc(z) for x >= 0, 0.5*x*erfc(z) for x < 0, z = |x|/sqrt(2): no
 // cancellation in the negative tail, ~12 VALU ops instead of libm erff's two-branch ~35.
+// Written two elements wide on ext-vector floats so that the polynomial runs on v_pk_fma_f32 /
+// v_pk_mul_f32 (2 fp32 per lane per issue), with the raw v_rcp_f32 / v_exp_f32 (1 ulp, no range
+// fix-ups: 1 + p z is in [1, inf) and the exp2 argument is <= 0, where underflow to 0 is the right
+// answer).  The GEMM epilogues that apply it are VALU-bound on exactly this function.
+//   |h| = 0.5 |x| erfc(z),  gelu(x) = max(x, 0) - |h|      (x >= 0: x - h;  x < 0: h)
+__device__ __forceinline__ float2_t gelu_erf2(float2_t x) {
+    const float2_t ax = {fabsf(x.x), fabsf(x.y)};
+    const float2_t z = ax * 0.70710678118654752440f;
+    const float2_t d = z * 0.3275911f + 1.0f;
+    const float2_t t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const float2_t poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float2_t arg = z * (z * -1.44269504088896340736f);          // -z^2 log2(e)
+    const float2_t ex = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    const float2_t h = (z * 0.70710678118654752440f) * poly * ex;
+    const float2_t r = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
+    return r - h;
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float hxe = 0.5f * x * poly * __expf(-z * z);     // 0.5 * x * erfc(z)
-    return x >= 0.f ? x - hxe : hxe;
+    const float2_t y = gelu_erf2(float2_t{x, x});
+    return y.x;
 }
 
 // XCD-aware, bijective remap of a linear block id (cdna_hip_programming.md T1): the hardware

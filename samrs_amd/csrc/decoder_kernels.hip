@@ -354,8 +354,10 @@ __global__ __launch_bounds__(256) void group_ln_gelu_kernel(const float* __restr
     const float4 g = *reinterpret_cast<const float4*>(gamma + c0);
     const float4 bt = *reinterpret_cast<const float4*>(beta + c0);
     uint2 o;
-    o.x = pack2<PREC>(gelu_erf(a * rstd * g.x + bt.x), gelu_erf(b * rstd * g.y + bt.y));
-    o.y = pack2<PREC>(gelu_erf(c * rstd * g.z + bt.z), gelu_erf(d * rstd * g.w + bt.w));
+    const float2_t g0 = gelu_erf2(float2_t{a * rstd * g.x + bt.x, b * rstd * g.y + bt.y});
+    const float2_t g1 = gelu_erf2(float2_t{c * rstd * g.z + bt.z, d * rstd * g.w + bt.w});
+    o.x = pack2<PREC>(g0.x, g0.y);
+    o.y = pack2<PREC>(g1.x, g1.y);
     reinterpret_cast<uint2*>(out + row * 256)[lane] = o;
 }
 

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_et_kernel(
                     add2d + (size_t)(m % add2d_period) * N + n);
                 v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
             }
-            if (GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
             if (OUT_F32) {
                 float* C = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
                 if (accumulate) {
@@ -262,7 +262,7 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[4][NJ], unsign
             for (int i = 0; i < 4; ++i) {
                 float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
                 float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
-                if (GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
                 unsigned char* p = scr + jj * TS + fr * RS;
                 if (OUT_F32) {
                     *reinterpret_cast<float4*>(p + (i * 16 + 4 * fq) * 4) = make_float4(v0, v1, v2, v3);
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(PTHREADS) void gemm_et_pipe_kernel(
                 const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
                 v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
             }
-            if (GELU) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
             if (OUT_F32) {
                 float* C = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
                 if (accumulate) {
@@ -1133,7 +1133,8 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     // narrow N), the 64-wide-K single-block kernel wins on long K / wide N.
     int variant = g_gemm_variant;
     if (variant == 8) {
-        if (!gelu && !out_f32 && N >= 2048 && M % QBM == 0 && N % QBN == 0 && K % QBK == 0) variant = 6;   // qkv: 256x256 tile
+        // qkv and lin1+GELU at batch size: 256x256 tile, as long as there are >= 4 rounds of tiles over the 256 CUs
+        if (!out_f32 && N >= 2048 && M % QBM == 0 && N % QBN == 0 && K % QBK == 0 && (long)(M / QBM) * (N / QBN) >= 1024) variant = 6;
         else variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
     }
     if (variant == 9 && M % DBM == 0 && K % DBK == 0) {   // 2 blocks / CU, lock-step (one barrier per K step)

@@ -208,70 +208,151 @@ __global__ __launch_bounds__(256) void token_self_attn_kernel(const float* __res
     }
 }
 
-// tokens -> image attention (head dim 16).  grid (heads, n_prompts), 4 waves; wave w owns tokens
-// w, w+4, ...; lanes stride over the image keys with a per-lane online softmax, merged at the end.
-template <int PREC, int TPW>
-__global__ __launch_bounds__(256) void t2i_attention_kernel(const float* __restrict__ qp, const uint16_t* __restrict__ kp,
-                                                            const uint16_t* __restrict__ vp, int ld, long bstride,
-                                                            float* __restrict__ o, int T, int tokens, int Ci) {
-    constexpr int HD = 16;
-    const int h = blockIdx.x, b = blockIdx.y;
+// tokens -> image attention (head dim 16, Ci = 128 = 16 chunks of 8 channels), flash-decoding style.
+// The T (<= a dozen) prompt tokens of one prompt attend to all image keys; the work is reading K and
+// V once, so the layout is chosen for the loads: a wave instruction fetches 4 consecutive key rows x
+// 256 contiguous bytes (lane = key-in-group * 16 + channel chunk), a lane keeps the running softmax
+// of T2I_TG tokens for its (head, half-head) chunk, the two halves of a head meet in a DPP add.
+// Keys are split over gridDim.x blocks x 4 waves; a block merges its waves through LDS and writes
+// one partial (m, l, acc) per (token, chunk); t2i_merge_kernel combines the splits in a fixed order.
+//   grid (splits, n_prompts, ceil(T / T2I_TG)), 256 threads.
+constexpr int T2I_TG = 8;            // tokens per pass
+constexpr int T2I_REC = 10;          // floats per (token, chunk) partial: m, l, acc[8]
+constexpr float T2I_NEG = -1.0e30f;  // finite "-inf": exp2(NEG - NEG) = 1 with l = acc = 0 stays harmless
+
+template <int PREC>
+__global__ __launch_bounds__(256, 2) void t2i_partial_kernel(const float* __restrict__ qp, const uint16_t* __restrict__ kp,
+                                                          const uint16_t* __restrict__ vp, int ld, long bstride,
+                                                          float* __restrict__ part, int T, int tokens, int Ci, int kpw) {
+    __shared__ float sm[4][T2I_TG][16][T2I_REC];
+    const int split = blockIdx.x, b = blockIdx.y, t0 = blockIdx.z * T2I_TG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float qv[TPW][HD], m[TPW], l[TPW], acc[TPW][HD];
+    const int ch = lane & 15, kq = lane >> 4;
+    float q[T2I_TG][8], acc[T2I_TG][8], m[T2I_TG], l[T2I_TG];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int t = wave + 4 * i;
-        m[i] = -INFINITY;
-        l[i] = 0.f;
-#pragma unroll
-        for (int c = 0; c < HD; ++c) {
-            qv[i][c] = (t < T) ? qp[((size_t)b * T + t) * Ci + h * HD + c] * 0.25f : 0.f;  // 1/sqrt(16)
-            acc[i][c] = 0.f;
-        }
-    }
-    const uint16_t* kb = kp + (size_t)b * bstride * ld + h * HD;
-    const uint16_t* vb = vp + (size_t)b * bstride * ld + h * HD;
-    for (int key = lane; key < tokens; key += 64) {
-        const uint4 k0 = *reinterpret_cast<const uint4*>(kb + (size_t)key * ld);
-        const uint4 k1 = *reinterpret_cast<const uint4*>(kb + (size_t)key * ld + 8);
-        const uint4 v0 = *reinterpret_cast<const uint4*>(vb + (size_t)key * ld);
-        const uint4 v1 = *reinterpret_cast<const uint4*>(vb + (size_t)key * ld + 8);
-        float kf[HD], vf[HD];
-        const uint32_t kw[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-        const uint32_t vw[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    for (int t = 0; t < T2I_TG; ++t) {
+        m[t] = T2I_NEG;
+        l[t] = 0.f;
+        const bool tv = t0 + t < T;
+        const float* qr = qp + ((size_t)b * T + (tv ? t0 + t : 0)) * Ci + ch * 8;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            kf[2 * c] = ET<PREC>::to_float((uint16_t)(kw[c] & 0xffffu));
-            kf[2 * c + 1] = ET<PREC>::to_float((uint16_t)(kw[c] >> 16));
-            vf[2 * c] = ET<PREC>::to_float((uint16_t)(vw[c] & 0xffffu));
-            vf[2 * c + 1] = ET<PREC>::to_float((uint16_t)(vw[c] >> 16));
-        }
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < HD; ++c) s += qv[i][c] * kf[c];
-            const float mn = fmaxf(m[i], s);
-            const float corr = __expf(m[i] - mn);
-            const float pj = __expf(s - mn);
-            l[i] = l[i] * corr + pj;
-#pragma unroll
-            for (int c = 0; c < HD; ++c) acc[i][c] = acc[i][c] * corr + pj * vf[c];
-            m[i] = mn;
+            q[t][c] = tv ? qr[c] * (0.25f * 1.44269504088896340736f) : 0.f;   // 1/sqrt(16), exp2 domain
+            acc[t][c] = 0.f;
         }
     }
+    const int kbeg = (split * 4 + wave) * kpw;
+    const int kend = kbeg + kpw < tokens ? kbeg + kpw : tokens;
+    const uint16_t* kb = kp + (size_t)b * bstride * ld + ch * 8;
+    const uint16_t* vb = vp + (size_t)b * bstride * ld + ch * 8;
+    constexpr int U = 2;    // key groups (of 4 keys) in flight per iteration
+    for (int k0 = kbeg; k0 < kend; k0 += 4 * U) {
+        uint4 kk[U], vv[U];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        const int t = wave + 4 * i;
-        const float mall = wave_max(m[i]);
-        const float f = __expf(m[i] - mall);
-        const float lsum = wave_sum(l[i] * f);
+        for (int u = 0; u < U; ++u) {
+            const int key = k0 + 4 * u + kq;
+            kk[u] = vv[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (key < kend) {
+                kk[u] = *reinterpret_cast<const uint4*>(kb + (size_t)key * ld);
+                vv[u] = *reinterpret_cast<const uint4*>(vb + (size_t)key * ld);
+            }
+        }
 #pragma unroll
-        for (int c = 0; c < HD; ++c) {
-            const float a = wave_sum(acc[i][c] * f);
-            if (lane == 0 && t < T) o[((size_t)b * T + t) * Ci + h * HD + c] = a / lsum;
+        for (int u = 0; u < U; ++u) {
+            const bool valid = k0 + 4 * u + kq < kend;      // same for both halves of a head (lane ^ 1)
+            const uint32_t kw[4] = {kk[u].x, kk[u].y, kk[u].z, kk[u].w};
+            const uint32_t vw[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+            float kf[8], vf[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                kf[2 * c] = ET<PREC>::to_float((uint16_t)(kw[c] & 0xffffu));
+                kf[2 * c + 1] = ET<PREC>::to_float((uint16_t)(kw[c] >> 16));
+                vf[2 * c] = ET<PREC>::to_float((uint16_t)(vw[c] & 0xffffu));
+                vf[2 * c + 1] = ET<PREC>::to_float((uint16_t)(vw[c] >> 16));
+            }
+#pragma unroll
+            for (int t = 0; t < T2I_TG; ++t) {
+                float sc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) sc += q[t][c] * kf[c];
+                sc += __shfl_xor(sc, 1, 64);
+                sc = valid ? sc : T2I_NEG;
+                const float mn = fmaxf(m[t], sc);
+                const float corr = __builtin_amdgcn_exp2f(m[t] - mn);
+                const float pj = valid ? __builtin_amdgcn_exp2f(sc - mn) : 0.f;
+                l[t] = l[t] * corr + pj;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[t][c] = acc[t][c] * corr + pj * vf[c];
+                m[t] = mn;
+            }
         }
     }
+    // merge the 4 key phases of the wave (lane bits 4, 5), then the 4 waves through LDS
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+#pragma unroll
+        for (int t = 0; t < T2I_TG; ++t) {
+            const float mo = __shfl_xor(m[t], off, 64), lo = __shfl_xor(l[t], off, 64);
+            const float mn = fmaxf(m[t], mo);
+            const float fs = __builtin_amdgcn_exp2f(m[t] - mn), fo = __builtin_amdgcn_exp2f(mo - mn);
+            l[t] = l[t] * fs + lo * fo;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[t][c] = acc[t][c] * fs + __shfl_xor(acc[t][c], off, 64) * fo;
+            m[t] = mn;
+        }
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int t = 0; t < T2I_TG; ++t) {
+            float* r = sm[wave][t][ch];
+            r[0] = m[t]; r[1] = l[t];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) r[2 + c] = acc[t][c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < T2I_TG * 16) {
+        const int t = threadIdx.x >> 4, c16 = threadIdx.x & 15;
+        float mm = sm[0][t][c16][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) mm = fmaxf(mm, sm[w][t][c16][0]);
+        float ll = 0.f, a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __builtin_amdgcn_exp2f(sm[w][t][c16][0] - mm);
+            ll += sm[w][t][c16][1] * f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[c] += sm[w][t][c16][2 + c] * f;
+        }
+        float* r = part + ((((size_t)b * gridDim.z + blockIdx.z) * gridDim.x + split) * (T2I_TG * 16) + threadIdx.x) * T2I_REC;
+        r[0] = mm; r[1] = ll;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) r[2 + c] = a[c];
+    }
+}
+
+// grid (n_prompts, token groups), T2I_TG * 16 threads = (token, chunk): combine the key splits
+__global__ __launch_bounds__(T2I_TG * 16) void t2i_merge_kernel(const float* __restrict__ part, float* __restrict__ o,
+                                                                int splits, int T, int Ci) {
+    const int b = blockIdx.x, tg = blockIdx.y;
+    const int t = tg * T2I_TG + (threadIdx.x >> 4), ch = threadIdx.x & 15;
+    if (t >= T) return;
+    const float* base = part + (((size_t)b * gridDim.y + tg) * splits * (T2I_TG * 16) + threadIdx.x) * T2I_REC;
+    const size_t sstride = (size_t)(T2I_TG * 16) * T2I_REC;
+    float mm = T2I_NEG;
+    for (int s = 0; s < splits; ++s) mm = fmaxf(mm, base[s * sstride]);
+    float ll = 0.f, a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) {
+        const float* r = base + s * sstride;
+        const float f = __builtin_amdgcn_exp2f(r[0] - mm);
+        ll += r[1] * f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] += r[2 + c] * f;
+    }
+    const float inv = 1.0f / ll;
+    float* orow = o + ((size_t)b * T + t) * Ci + ch * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) orow[c] = a[c] * inv;
 }
 
 // image -> tokens attention (head dim 16).  Thread = (image token, head); keys/values are the T
@@ -578,19 +659,23 @@ hipError_t launch_token_self_attn(const float* q, const float* k, const float* v
     token_self_attn_kernel<32><<<n, 256, 3 * T * C * sizeof(float), s>>>(q, k, v, o, T, C, heads);
     return hipGetLastError();
 }
+size_t t2i_workspace_floats(int n, int T) {
+    return (size_t)n * ((T + T2I_TG - 1) / T2I_TG) * T2I_MAX_SPLITS * (T2I_TG * 16) * T2I_REC;
+}
 hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const void* vp, int ld, long bstride,
-                                float* o, int n, int T, int tokens, int Ci, int heads, hipStream_t s) {
-    if (Ci / heads != 16 || T > TOK_MAX) return hipErrorInvalidValue;
-    dim3 g(heads, n), b(256);
+                                float* o, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s) {
+    if (Ci != 128 || heads != 8 || T > TOK_MAX || !workspace) return hipErrorInvalidValue;
+    // keys per wave: a multiple of 16 (4 groups of 4 keys per iteration), at most T2I_MAX_SPLITS blocks of 4 waves
+    int splits = (tokens + 255) / 256;
+    splits = splits < 1 ? 1 : (splits > T2I_MAX_SPLITS ? T2I_MAX_SPLITS : splits);
+    const int kpw = ((tokens + splits * 4 - 1) / (splits * 4) + 15) / 16 * 16;
+    const int tgs = (T + T2I_TG - 1) / T2I_TG;
+    dim3 g(splits, n, tgs), b(256);
     const uint16_t* k = (const uint16_t*)kp;
     const uint16_t* v = (const uint16_t*)vp;
-    if (T <= 8) {
-        if (prec == PREC_BF16) t2i_attention_kernel<PREC_BF16, 2><<<g, b, 0, s>>>(qp, k, v, ld, bstride, o, T, tokens, Ci);
-        else t2i_attention_kernel<PREC_F16, 2><<<g, b, 0, s>>>(qp, k, v, ld, bstride, o, T, tokens, Ci);
-    } else {
-        if (prec == PREC_BF16) t2i_attention_kernel<PREC_BF16, 4><<<g, b, 0, s>>>(qp, k, v, ld, bstride, o, T, tokens, Ci);
-        else t2i_attention_kernel<PREC_F16, 4><<<g, b, 0, s>>>(qp, k, v, ld, bstride, o, T, tokens, Ci);
-    }
+    if (prec == PREC_BF16) t2i_partial_kernel<PREC_BF16><<<g, b, 0, s>>>(qp, k, v, ld, bstride, workspace, T, tokens, Ci, kpw);
+    else t2i_partial_kernel<PREC_F16><<<g, b, 0, s>>>(qp, k, v, ld, bstride, workspace, T, tokens, Ci, kpw);
+    t2i_merge_kernel<<<dim3(n, tgs), T2I_TG * 16, 0, s>>>(workspace, o, splits, T, Ci);
     return hipGetLastError();
 }
 hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long bstride, const float* kt, const float* vt,

@@ -85,7 +85,7 @@ struct samrs_engine {
 
     // decoder workspaces
     float *TOK0 = nullptr, *Q = nullptr, *TA = nullptr, *TQ = nullptr, *TK = nullptr, *TV = nullptr, *TO = nullptr;
-    float *MH = nullptr, *QP = nullptr, *KT = nullptr, *VT = nullptr, *O128 = nullptr;
+    float *MH = nullptr, *QP = nullptr, *KT = nullptr, *VT = nullptr, *O128 = nullptr, *T2IW = nullptr;
     float *K0F = nullptr;          // shared layer-0 keys fp32 [tokens][C]
     uint16_t* K0E = nullptr;
     float* KF = nullptr;           // per-prompt keys fp32 [Bb*tokens][C]
@@ -438,6 +438,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->TO, BT * C)); CK(e, dalloc(e, &e->MH, BT * 2048));
     CK(e, dalloc(e, &e->QP, BT * Ci)); CK(e, dalloc(e, &e->KT, BT * Ci)); CK(e, dalloc(e, &e->VT, BT * Ci));
     CK(e, dalloc(e, &e->O128, BT * Ci));
+    CK(e, dalloc(e, &e->T2IW, t2i_workspace_floats(c.max_prompts, e->T_max)));
     CK(e, dalloc(e, &e->K0F, (size_t)tokens * C)); CK(e, dalloc(e, &e->K0E, (size_t)tokens * C));
     CK(e, dalloc(e, &e->KF, Bb * tokens * C)); CK(e, dalloc(e, &e->KE, Bb * tokens * C));
     CK(e, dalloc(e, &e->KVQ, Bb * tokens * 3 * Ci)); CK(e, dalloc(e, &e->OI, Bb * tokens * Ci));
@@ -635,7 +636,7 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
         CK(e, launch_gemm_et(prec, keys_et, L.kvq_w, e->KVQ, L.kvq_b, L.kvq_pe, tokens, sh ? tokens : Mi, 3 * Ci, C, false, false, false, s));
         // (2) tokens -> image
         CK(e, lin2(e->Q, e->TOK0, C, L.t2i.qw, L.t2i.qb, e->QP, Ci, BT, Ci, C));
-        CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 3 * Ci, bstride, e->O128, n, T, tokens, Ci, 8, s));
+        CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 3 * Ci, bstride, e->O128, e->T2IW, n, T, tokens, Ci, 8, s));
         CK(e, lin(e->O128, Ci, L.t2i.ow, L.t2i.ob, e->Q, C, BT, C, Ci, false, true));
         CK(e, ln_tok(L.n2w, L.n2b));
         // (3) MLP (ReLU)
@@ -659,7 +660,7 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
     // final tokens -> image attention (transformer.py:98-104)
     CK(e, lin2(e->Q, e->TOK0, C, e->fin.qw, e->fin.qb, e->QP, Ci, BT, Ci, C));
     CK(e, launch_gemm_et(prec, e->KE, e->fin_kv_w, e->KVQ, e->fin_kv_b, e->fin_pe, tokens, Mi, 2 * Ci, C, false, false, false, s));
-    CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 2 * Ci, tokens, e->O128, n, T, tokens, Ci, 8, s));
+    CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 2 * Ci, tokens, e->O128, e->T2IW, n, T, tokens, Ci, 8, s));
     CK(e, lin(e->O128, Ci, e->fin.ow, e->fin.ob, e->Q, C, BT, C, Ci, false, true));
     CK(e, ln_tok(W(e, "mask_decoder.transformer.norm_final_attn.weight"), W(e, "mask_decoder.transformer.norm_final_attn.bias")));
 

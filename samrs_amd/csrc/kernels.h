@@ -66,8 +66,10 @@ hipError_t launch_token_self_attn(const float* q, const float* k, const float* v
                                   int heads, hipStream_t s);
 // tokens -> image attention. qp [n*T, Ci] fp32; kp/vp ET rows of `ld` elements, batch stride in rows
 // (0 = shared by all prompts); o [n*T, Ci] fp32.
+constexpr int T2I_MAX_SPLITS = 16;
+size_t t2i_workspace_floats(int n_prompts, int T);     // scratch for the per-split partial softmax states
 hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const void* vp, int ld, long batch_stride_rows,
-                                float* o, int n, int T, int tokens, int Ci, int heads, hipStream_t s);
+                                float* out, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s);
 // image -> tokens attention. qi ET rows of `ld` elements (batch stride in rows, 0 = shared);
 // kt, vt [n*T, Ci] fp32; out ET [n*tokens, Ci].
 hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long batch_stride_rows, const float* kt,

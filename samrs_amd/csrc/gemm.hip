@@ -238,19 +238,24 @@ __device__ __forceinline__ void wave_lds_sync_g() {
 // known), the 2-D addend and the residual accumulate after it (coalesced loads).
 //   acc[i][j]: n-tile i (16 cols), m-tile j (16 rows); NJ m-tiles per wave, JC of them per pass.
 // ---------------------------------------------------------------------------------------------
-template <int PREC, bool OUT_F32, bool GELU, int NJ, int JC>
-__device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[4][NJ], unsigned char* scr /* wave-private */,
+template <int PREC, bool OUT_F32, bool GELU, int NJ, int JC, int NI = 4>
+__device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsigned char* scr /* wave-private */,
                                                    void* __restrict__ Cv, const float* __restrict__ bias,
                                                    const float* __restrict__ add2d, int add2d_period, int N,
                                                    int m_base /* first row of the wave tile */,
                                                    int n_base /* first column of the wave tile */, int accumulate,
                                                    int lane) {
     const int fr = lane & 15, fq = lane >> 4;
-    constexpr int RS = OUT_F32 ? (64 * 4 + 16) : (64 * 2 + 16);    // padded row stride (bytes), 16-B multiple
+    // padded row stride: the smallest >= the 16*NI-column row with (words % 32) == 4, which spreads the 16
+    // rows of an accumulator column block over all banks (NI = 4: 272 / 144 bytes)
+    constexpr int ROWW = 16 * NI * (OUT_F32 ? 4 : 2) / 4;
+    constexpr int RS = (((ROWW - 4 + 31) / 32) * 32 + 4) * 4;
     constexpr int TS = 16 * RS;                                     // one m-tile
-    float4 bv[4];
+    constexpr int CPR = 16 * NI * (OUT_F32 ? 4 : 2) / 16;           // 16-byte chunks per row segment
+    constexpr int NCH = 16 * CPR, NPASS = (NCH + 63) / 64;
+    float4 bv[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
         bv[i] = bias ? *reinterpret_cast<const float4*>(bias + n_base + i * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j0 = 0; j0 < NJ; j0 += JC) {
@@ -259,7 +264,7 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[4][NJ], unsign
         for (int jj = 0; jj < JC; ++jj) {
             const int j = j0 + jj;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
                 float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
                 if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
@@ -279,10 +284,12 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[4][NJ], unsign
         for (int jj = 0; jj < JC; ++jj) {
             const int j = j0 + jj;
             if (OUT_F32) {
-                // 16 rows x 256 B: 4 instructions of 4 rows x (16 lanes x 16 B)
+                // 16 rows x (64 NI) B in 16-byte chunks, consecutive lanes on consecutive chunks of a row
 #pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int row = (lane >> 4) + 4 * h, ch = lane & 15;
+                for (int h = 0; h < NPASS; ++h) {
+                    const int idx = lane + 64 * h;
+                    if (NCH % 64 != 0 && idx >= NCH) break;
+                    const int row = idx / CPR, ch = idx % CPR;
                     float4 v = *reinterpret_cast<const float4*>(scr + jj * TS + row * RS + ch * 16);
                     const int m = m_base + j * 16 + row, n = n_base + ch * 4;
                     if (add2d) {
@@ -297,10 +304,12 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[4][NJ], unsign
                     *reinterpret_cast<float4*>(C) = v;
                 }
             } else {
-                // 16 rows x 128 B: 2 instructions of 8 rows x (8 lanes x 16 B)
+                // 16 rows x (32 NI) B
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int row = (lane >> 3) + 8 * h, ch = lane & 7;
+                for (int h = 0; h < NPASS; ++h) {
+                    const int idx = lane + 64 * h;
+                    if (NCH % 64 != 0 && idx >= NCH) break;
+                    const int row = idx / CPR, ch = idx % CPR;
                     const uint4 v = *reinterpret_cast<const uint4*>(scr + jj * TS + row * RS + ch * 16);
                     uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)(m_base + j * 16 + row) * N + n_base + ch * 8;
                     *reinterpret_cast<uint4*>(C) = v;
@@ -637,25 +646,31 @@ hipError_t launch_gemm_stag(const void* A, const void* B, void* C, const float* 
 // g = [0,2,3,1]: checked conflict-free for all four lane groups.
 // ---------------------------------------------------------------------------------------------
 constexpr int QBM = 256, QBN = 256, QBK = 32, QSTAGES = 4, QTHREADS = 512;
-constexpr int QSTAGE_ELEMS = (QBM + QBN) * QBK;                // 16384 ET = 32 KiB
-constexpr int Q_DMA_PER_TILE = (QBM + QBN) * QBK * 2 / (QTHREADS * 16);   // 4 per thread
+constexpr int WBN = 320;     // NI = 5 flavour: 256x320 tile (wave tile 128x80), 4 x 36 KiB ring
 
 __device__ __forceinline__ int qswz(int r, int c) { return c ^ ((0x78 >> (2 * ((r >> 2) & 3))) & 3); }
 
 // ABL (ablation bits, timing experiments only; results are garbage when non-zero):
 //   1 = no DMA, 2 = no fragment reads, 4 = no MFMA, 8 = no barriers
-template <int PREC, bool OUT_F32, bool GELU, int ABL = 0>
+// NI = n-tiles (16 columns) per wave: 4 -> 256x256 block tile, 5 -> 256x320.  The wide flavour exists for
+// the wave quantisation: N = 1280 / 3840 / 5120 at M = 32768 give 512 / 1536 / 2048 tiles = exactly
+// 2 / 6 / 8 rounds over 256 CUs (256x256: 2.5 / 7.5 / 10), with 40 MFMAs per 13 fragment reads and
+// 4.5 DMA pieces per wave step.  Its 20 B pieces do not divide by 8 waves: waves 0-3 (= stagger group
+// 0) issue a third B piece, so the counted vmcnt waits are per group.
+template <int PREC, bool OUT_F32, bool GELU, int ABL = 0, int NI = 4>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
     int M, int N, int K, int accumulate) {
-    __shared__ __attribute__((aligned(16))) uint16_t lds[QSTAGES * QSTAGE_ELEMS];   // 128 KiB, ONE object
+    constexpr int QBN = 64 * NI;
+    constexpr int QSTAGE_ELEMS = (QBM + QBN) * QBK;                // NI = 4: 16384 ET = 32 KiB
+    __shared__ __attribute__((aligned(16))) uint16_t lds[QSTAGES * QSTAGE_ELEMS];   // 128 / 144 KiB, ONE object
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;                 // waves w and w+4 share a SIMD -> different groups
-    const int wm = wave >> 2, wn = wave & 3;   // wave tile rows wm*128.., cols wn*64..
+    const int wm = wave >> 2, wn = wave & 3;   // wave tile rows wm*128.., cols wn*(16 NI)..
 
     constexpr int GROUP = 8;
     const int tiles_n = N / QBN, tiles_m = M / QBM;
@@ -684,11 +699,13 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
         glds16_asm<SB_ + 128 * QBK * 2>(gAg + rs128 + koff_, wave_lds_base);                     \
         glds16_asm<SB_ + QBM * QBK * 2>(gBg + koff_, wave_lds_base);                             \
         glds16_asm<SB_ + QBM * QBK * 2 + 128 * QBK * 2>(gBg + rs128 + koff_, wave_lds_base);     \
+        if (NI == 5 && grp == 0)                                                                 \
+            glds16_asm<SB_ + QBM * QBK * 2 + 256 * QBK * 2>(gBg + 2 * rs128 + koff_, wave_lds_base); \
     } while (0)
 
-    f32x4_t acc[4][8];    // [n-tile i][m-tile j]; D[i_local = n][j_local = m]
+    f32x4_t acc[NI][8];    // [n-tile i][m-tile j]; D[i_local = n][j_local = m]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -699,37 +716,43 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
     if (nk > 1) BIG_ISSUE(1, 1);
     if (nk > 2) BIG_ISSUE(2, 2);
     }
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Q_DMA_PER_TILE) : "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q_DMA_PER_TILE) : "memory");
+    // outstanding-DMA budget: this wave's pieces per tile (4, or 5 for group 0 of the wide flavour)
+#define BIG_VMCNT(tiles_)                                                                        \
+    do {                                                                                         \
+        if (NI == 5 && grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((tiles_) * 5) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((tiles_) * 4) : "memory");                 \
+    } while (0)
+    if (nk > 2) BIG_VMCNT(2);
+    else if (nk > 1) BIG_VMCNT(1);
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1 && !(ABL & 8)) __builtin_amdgcn_s_barrier();          // stagger
 
     const int fr = lane & 15, fq = lane >> 4;
     // fragment byte-free offsets (elements) inside a stage; rows are fixed per lane, only the stage moves
-    int offA[8], offB[4];
+    int offA[8], offB[NI];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const int r = wm * 128 + j * 16 + fr; offA[j] = r * QBK + qswz(r, fq) * 8; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int r = wn * 64 + i * 16 + fr; offB[i] = QBM * QBK + r * QBK + qswz(r, fq) * 8; }
+    for (int i = 0; i < NI; ++i) { const int r = wn * (16 * NI) + i * 16 + fr; offB[i] = QBM * QBK + r * QBK + qswz(r, fq) * 8; }
 
     // wait so that tile kt+1 has landed; tiles kt+2 / kt+3 may stay in flight
 #define BIG_WAIT(kt_)                                                                            \
-    if ((kt_) + 3 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Q_DMA_PER_TILE) : "memory"); \
-    else if ((kt_) + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Q_DMA_PER_TILE) : "memory"); \
+    if ((kt_) + 3 < nk) BIG_VMCNT(2);                                                            \
+    else if ((kt_) + 2 < nk) BIG_VMCNT(1);                                                       \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #define BIG_STEP(kt_, S_)                                                                        \
     if ((kt_) < nk) {                                                                            \
-        uint4 fa[8], fb[4];                                                                      \
+        uint4 fa[8], fb[NI];                                                                      \
         /* L: refill the slot freed last interval, read this step's fragments */                 \
         if (!(ABL & 1)) { if ((kt_) + 3 < nk) BIG_ISSUE((kt_) + 3, ((S_) + 3) % QSTAGES); }      \
         if (!(ABL & 2)) {                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i)                                           \
             fb[i] = *reinterpret_cast<const uint4*>(lds + (S_) * QSTAGE_ELEMS + offB[i]);        \
         _Pragma("unroll") for (int j = 0; j < 8; ++j)                                            \
             fa[j] = *reinterpret_cast<const uint4*>(lds + (S_) * QSTAGE_ELEMS + offA[j]);        \
         } else {                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) { fb[i] = make_uint4(lane, i, (kt_), 1); asm volatile("" : "+v"(fb[i].x)); } \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) { fb[i] = make_uint4(lane, i, (kt_), 1); asm volatile("" : "+v"(fb[i].x)); } \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) { fa[j] = make_uint4(lane, j, (kt_), 2); asm volatile("" : "+v"(fa[j].x)); } \
         }                                                                                        \
         BIG_WAIT(kt_)                                                                            \
@@ -739,11 +762,11 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
         /* C: 32 MFMAs */                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                           \
         if (!(ABL & 4)) {                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i)                                           \
             _Pragma("unroll") for (int j = 0; j < 8; ++j)                                        \
                 acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]);                           \
         } else {                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fb[i].x), "v"(fb[i].w)); \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(fb[i].x), "v"(fb[i].w)); \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(fa[j].x), "v"(fa[j].w)); \
         }                                                                                        \
         __builtin_amdgcn_s_setprio(0);                                                           \
@@ -761,7 +784,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
 
     if (ABL & 16) {   // timing experiment: keep the accumulators alive, store nothing
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][3]));
         return;
@@ -770,32 +793,32 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
         unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (QSTAGES * QSTAGE_ELEMS * 2 / 8);
         if (!OUT_F32 && add2d) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int m = m0 + wm * 128 + j * 16 + fr, n = n0 + wn * 64 + i * 16 + 4 * fq;
+                    const int m = m0 + wm * 128 + j * 16 + fr, n = n0 + wn * (16 * NI) + i * 16 + 4 * fq;
                     const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
                     acc[i][j][0] += e.x; acc[i][j][1] += e.y; acc[i][j][2] += e.z; acc[i][j][3] += e.w;
                 }
         }
-        epilogue_coalesced<PREC, OUT_F32, GELU, 8, OUT_F32 ? 2 : 4>(acc, scr, Cv, bias, OUT_F32 ? add2d : nullptr, add2d_period,
-                                                                     N, m0 + wm * 128, n0 + wn * 64, accumulate, lane);
+        epilogue_coalesced<PREC, OUT_F32, GELU, 8, OUT_F32 ? 2 : 4, NI>(acc, scr, Cv, bias, OUT_F32 ? add2d : nullptr, add2d_period,
+                                                                         N, m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane);
     }
 }
 
-template <int PREC>
+template <int PREC, int NI = 4>
 hipError_t launch_gemm_big(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
-    dim3 grid((M / QBM) * (N / QBN)), block(QTHREADS);
+    dim3 grid((M / QBM) * (N / (64 * NI))), block(QTHREADS);
     const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
     const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
     const int acc = accumulate ? 1 : 0;
     if (out_f32) {
-        if (gelu) gemm_et_big_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-        else gemm_et_big_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        if (gelu) gemm_et_big_kernel<PREC, true, true, 0, NI><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_big_kernel<PREC, true, false, 0, NI><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
     } else {
-        if (gelu) gemm_et_big_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-        else gemm_et_big_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        if (gelu) gemm_et_big_kernel<PREC, false, true, 0, NI><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_big_kernel<PREC, false, false, 0, NI><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
     }
     return hipGetLastError();
 }
@@ -1133,8 +1156,15 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     // narrow N), the 64-wide-K single-block kernel wins on long K / wide N.
     int variant = g_gemm_variant;
     if (variant == 8) {
-        // qkv and lin1+GELU at batch size: 256x256 tile, as long as there are >= 4 rounds of tiles over the 256 CUs
-        if (!out_f32 && N >= 2048 && M % QBM == 0 && N % QBN == 0 && K % QBK == 0 && (long)(M / QBM) * (N / QBN) >= 1024) variant = 6;
+        const bool big_ok = M % QBM == 0 && K % QBK == 0;
+        const long t256 = big_ok && N % QBN == 0 ? (long)(M / QBM) * (N / QBN) : 0;
+        const long t320 = big_ok && N % WBN == 0 ? (long)(M / QBM) * (N / WBN) : 0;
+        // fp32 residual outputs (proj, lin2: N = 1280): 256x320 tiles -> an exact number of rounds over the 256 CUs
+        if (out_f32 && t320 >= 256) variant = 10;
+        // qkv and lin1+GELU at batch size: 256x256 tile, as long as there are >= 4 rounds of tiles
+        else if (!out_f32 && N >= 2048 && t256 >= 1024) variant = 6;
+        // small batch: the wide tile when it fills whole rounds (lin1 of one image = exactly 256 tiles)
+        else if (!out_f32 && t320 >= 256 && t320 % 256 == 0) variant = 10;
         else variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
     }
     if (variant == 9 && M % DBM == 0 && K % DBK == 0) {   // 2 blocks / CU, lock-step (one barrier per K step)
@@ -1147,6 +1177,12 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         if (prec == PREC_F16) return launch_gemm_dual<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
     }
+    if (variant == 10 && M % QBM == 0 && N % WBN == 0 && K % QBK == 0) {   // 256x320 staggered kernel
+        if (prec == PREC_BF16) return launch_gemm_big<PREC_BF16, 5>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_big<PREC_F16, 5>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        return hipErrorInvalidValue;
+    }
+    if (variant == 10) variant = 5;
     if (variant == 6 && M % QBM == 0 && N % QBN == 0 && K % QBK == 0) {   // 256x256 staggered kernel
         if (prec == PREC_BF16) return launch_gemm_big<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_big<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
@@ -1172,10 +1208,11 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 hipError_t launch_gemm_f32_batch(const F32Batch& bt, int count, int lda, int ldc, int M, int N, int K, bool relu,
                                  bool accumulate, hipStream_t s) {
     if (K % FKS || M <= 0 || N <= 0 || (lda % 4) || count < 1 || count > F32_BATCH_MAX) return hipErrorInvalidValue;
-    // waves per tile: enough to put ~1000 waves on the chip, as long as every wave keeps >= one 16-wide K slab
-    const long tiles = (long)((N + FN - 1) / FN) * ((M + FM - 1) / FM) * count;
+    // waves per tile = K split: a function of K ALONE, so that the summation order (hence every bit of the
+    // result) does not depend on how many rows -- prompts -- a call carries: predict(32 boxes) must equal
+    // predict(20) + predict(12).  M is a few hundred rows on this path, so the deepest split always pays.
     int S = 1;
-    while (S < 16 && tiles * S < 1024 && K % (2 * FKS * S) == 0) S *= 2;
+    while (S < 16 && K % (2 * FKS * S) == 0) S *= 2;
     dim3 grid((N + FN - 1) / FN, (M + FM - 1) / FM, count);
     const int r = relu ? 1 : 0, a = accumulate ? 1 : 0;
     switch (S) {

@@ -281,14 +281,20 @@ __device__ __forceinline__ void online_softmax_step(f32x16_t* S, int ntiles, flo
 }
 
 // =========================================================================================
-// windowed attention: one block (8 waves) per (window, head); wave w < 7 owns the 32-query strip w
-// (7 strips cover the 196 window tokens), keys are visited tile by tile with an online softmax so
-// that a wave needs ~130 registers and two waves fit per SIMD.
+// windowed attention.  Work item = (window, head); 8 waves, wave w < 7 owns the 32-query strip w
+// (7 strips cover the 196 window tokens), keys are visited tile by tile with an online softmax.
 // qkv rows are in plain TOKEN order [img][y][x]; the kernel does the window partition itself.  A
 // window position that falls in the bottom/right padding is a zero token after norm1 in the
 // reference (image_encoder.py:168-172,256-259), so its k / v are exactly the qkv BIAS: the kernel
 // reads them from `qkv_bias` instead of having the GEMM grind through 17.6 % padding rows.  Padding
 // tokens are valid keys (not masked); padding queries are dropped (image_encoder.py:287-288).
+//
+// PERSISTENT: the launch has one block per CU and a block walks items b, b + gridDim.x, ...  The
+// kernel was latency-bound (59 % of wave cycles waiting at 2 waves / SIMD, PMC): per item a chain
+// global load -> LDS -> barrier -> compute.  Now the Q / K / V loads of item i+1 are issued right
+// after item i's K / V^T have been written to LDS and stay in flight (in registers) during the whole
+// compute of item i.  vmcnt retires loads in order, so nothing else may load from global memory in
+// between: the rel-pos tables are converted into LDS once per block.
 // =========================================================================================
 template <int HD>
 struct WinCfg {
@@ -300,179 +306,203 @@ struct WinCfg {
     static constexpr int K_BYTES = NP * HD * 2;
     static constexpr int VT_BYTES = DT * 32 * VSTR * 2;
     static constexpr int S_BYTES = NW * 32 * SSTR * 4;
-    static constexpr int LDS_BYTES = K_BYTES + VT_BYTES + S_BYTES;
+    static constexpr int TAB_BYTES = 2 * 32 * HD * 2;                  // rel_h | rel_w as ET, 32 rows each (27 used)
+    static constexpr int MAX_D = 1280;                                 // ViT-H width (heads * HD)
+    static constexpr int BIAS_BYTES = 2 * MAX_D * 2;                   // k | v bias of every head as ET
+    static constexpr int LDS_BYTES = K_BYTES + VT_BYTES + S_BYTES + TAB_BYTES + BIAS_BYTES;
 };
 
 template <int PREC, int HD>
 __global__ __launch_bounds__(512) void window_attention_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ rel_h,
-    const float* __restrict__ rel_w, uint16_t* __restrict__ out, int grid, int heads) {
+    const float* __restrict__ rel_w, uint16_t* __restrict__ out, int grid, int heads, int n_items) {
     using C = WinCfg<HD>;
     constexpr int KS = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vt = reinterpret_cast<uint16_t*>(smem + C::K_BYTES);
     float* Scr = reinterpret_cast<float*>(smem + C::K_BYTES + C::VT_BYTES);
+    uint16_t* Tab = reinterpret_cast<uint16_t*>(smem + C::K_BYTES + C::VT_BYTES + C::S_BYTES);
+    uint16_t* Bia = Tab + 2 * 32 * HD;     // [2][D]: k bias | v bias (the k / v of a padding token)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, ql = lane & 31;
-    const int wi = blockIdx.x;            // global window index = img * nw*nw + win
-    const int head = blockIdx.y;
     const int D = heads * HD;
     const int nw = (grid + C::WS - 1) / C::WS;
-    const int win = wi % (nw * nw), im = wi / (nw * nw);
-    const int wy = win / nw, wx = win % nw;
-    const uint16_t* base = qkv + (size_t)im * grid * grid * (3 * D) + head * HD;   // token row 0 of this image
-    // window position r -> token row offset (elements) or -1 for a padding position
-    auto tok_off = [&](int r) -> long {
-        const int y = wy * C::WS + r / C::WS, x = wx * C::WS + r % C::WS;
-        return (y < grid && x < grid) ? (long)(y * grid + x) * (3 * D) : -1L;
-    };
-    // 8 consecutive channels of the k (part = 1) / v (part = 2) bias of this head, as ET
-    auto bias_chunk = [&](int part, int ch) -> uint4 {
-        const float* b = qkv_bias + part * D + head * HD + ch * 8;
-        const float4 x = *reinterpret_cast<const float4*>(b), y = *reinterpret_cast<const float4*>(b + 4);
-        uint4 o;
-        o.x = pack2<PREC>(x.x, x.y); o.y = pack2<PREC>(x.z, x.w);
-        o.z = pack2<PREC>(y.x, y.y); o.w = pack2<PREC>(y.z, y.w);
-        return o;
-    };
+    const size_t img_rows = (size_t)grid * grid;
 
-    // ---- stage K (row-major) and V^T ---------------------------------------------------------
-    // All global loads of the prologue (this wave's Q fragments, this thread's K chunks and V key
-    // pairs) are issued back to back BEFORE anything is stored, so their latencies overlap instead
-    // of paying one L2 / HBM round trip per staging-loop iteration (L2 hit rate here is only ~66 %).
+    // once per block: rel-pos tables and k / v biases -> LDS as ET (table rows >= 27 zero); zero what the
+    // per-item staging never writes: K rows 196..223 (tile padding), all of V^T (its key columns >= 196 and
+    // rows >= HD stay zero)
+    for (int i = tid; i < 2 * 32 * HD; i += C::THREADS) {
+        const int t = i / (32 * HD), r = (i / HD) % 32, d = i % HD;
+        const float v = r < 2 * C::WS - 1 ? (t ? rel_w : rel_h)[r * HD + d] : 0.f;
+        Tab[i] = ET<PREC>::from_float(v);
+    }
+    for (int i = tid; i < 2 * D; i += C::THREADS) Bia[i] = ET<PREC>::from_float(qkv_bias[D + i]);
+    for (int i = tid; i < (C::NP - C::N) * HD; i += C::THREADS) Ks[C::N * HD + i] = 0;
+    for (int i = tid; i < C::DT * 32 * C::VSTR / 2; i += C::THREADS) reinterpret_cast<uint32_t*>(Vt)[i] = 0u;
+
     constexpr int CH = HD / 8;  // 16-byte chunks per row
-    constexpr int NKC = C::NP * CH, NVI = (C::NP / 2) * CH;
+    constexpr int NKC = C::N * CH, NVI = (C::N / 2) * CH;        // real rows / key pairs only
     constexpr int PK = (NKC + C::THREADS - 1) / C::THREADS, PV = (NVI + C::THREADS - 1) / C::THREADS;
     const int q = 32 * (wave < C::NT ? wave : 0) + ql;   // query index inside the window (wave 7 only stages)
-    const long qoff = q < C::N ? tok_off(q) : -1L;
-    const bool qin = qoff >= 0;           // a real token (padding / tile-padding queries are dropped)
-    uint4 qf[KS];
-    load_q_frags<KS>(qin ? base + qoff : nullptr, hh, qf);
-    uint4 kreg[PK], v0reg[PV], v1reg[PV];
-#pragma unroll
-    for (int i = 0; i < PK; ++i) {
-        const int c = tid + i * C::THREADS;
-        const int r = c / CH, ch = c % CH;
-        kreg[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (c < NKC && r < C::N) {
-            const long off = tok_off(r);
-            kreg[i] = off >= 0 ? *reinterpret_cast<const uint4*>(base + off + D + ch * 8) : bias_chunk(1, ch);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < PV; ++i) {
-        const int c = tid + i * C::THREADS;
-        const int kp = c % (C::NP / 2), ch = c / (C::NP / 2);
-        const int r0 = 2 * kp;
-        v0reg[i] = v1reg[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (c < NVI) {
-            if (r0 < C::N) {
-                const long off = tok_off(r0);
-                v0reg[i] = off >= 0 ? *reinterpret_cast<const uint4*>(base + off + 2 * D + ch * 8) : bias_chunk(2, ch);
-            }
-            if (r0 + 1 < C::N) {
-                const long off = tok_off(r0 + 1);
-                v1reg[i] = off >= 0 ? *reinterpret_cast<const uint4*>(base + off + 2 * D + ch * 8) : bias_chunk(2, ch);
-            }
-        }
-    }
-    for (int i = tid; i < (C::DT * 32 - HD) * C::VSTR; i += C::THREADS) Vt[HD * C::VSTR + i] = 0;
-#pragma unroll
-    for (int i = 0; i < PK; ++i) {
-        const int c = tid + i * C::THREADS;
-        if (c < NKC) *reinterpret_cast<uint4*>(Ks + (c / CH) * HD + (c % CH) * 8) = kreg[i];
-    }
-    // V^T[d][key]: a thread takes one 8-wide d chunk of TWO adjacent keys and writes eight 4-byte
-    // words; consecutive lanes take consecutive key pairs -> consecutive banks.
-#pragma unroll
-    for (int i = 0; i < PV; ++i) {
-        const int c = tid + i * C::THREADS;
-        if (c < NVI) {
-            const int kp = c % (C::NP / 2), ch = c / (C::NP / 2);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + e) * C::VSTR + 2 * kp) = pair_elem(v0reg[i], v1reg[i], e);
-        }
-    }
-    __syncthreads();
-    if (wave >= C::NT) return;            // no block-level barrier below this point
-
-    // ---- decomposed rel-pos: RH[j] = q . rel_h[qh - j + 13], RW[j] = q . rel_w[qw - j + 13] -----
-    // (log2 domain; image_encoder.py:325-361 uses the UNSCALED q)
     const int qc = q < C::N ? q : C::N - 1;
     const int qh = qc / C::WS, qw = qc % C::WS;
-    float* scr = Scr + wave * 32 * C::SSTR + ql * C::SSTR;
-    float RH[C::WS], RW[C::WS];
-    {
-        const f32x16_t th = table_times_qT<PREC, HD>(rel_h, 0, 2 * C::WS - 1, lane, qf);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = th[r];
-        wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < C::WS; ++j) RH[j] = scr[qh - j + C::WS - 1] * LOG2E_F;
-        wave_lds_sync();
-        const f32x16_t tw = table_times_qT<PREC, HD>(rel_w, 0, 2 * C::WS - 1, lane, qf);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = tw[r];
-        wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < C::WS; ++j) RW[j] = scr[qw - j + C::WS - 1] * LOG2E_F;
-    }
 
-    const float c2 = rsqrtf((float)HD) * LOG2E_F;
-    f32x16_t O[C::DT];
-#pragma unroll
-    for (int dt = 0; dt < C::DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    // All global loads of an item (this wave's Q fragments, this thread's K chunks and V key pairs) are
+    // issued back to back; n_* describe the item they belong to.
+    uint4 qfn[KS], kreg[PK], v0reg[PV], v1reg[PV];
+    long n_qoff = -1;
+    int n_im = 0, n_head = 0;
+#define WIN_TOK_OFF(r_) ((wy_ * C::WS + (r_) / C::WS < grid && wx_ * C::WS + (r_) % C::WS < grid)                     \
+                             ? (long)((wy_ * C::WS + (r_) / C::WS) * grid + wx_ * C::WS + (r_) % C::WS) * (3 * D) : -1L)
+#define WIN_BIAS_CHUNK(dst_, part_, ch_)                                                                             \
+    (dst_) = *reinterpret_cast<const uint4*>(Bia + ((part_) - 1) * D + n_head * HD + (ch_) * 8)
+#define WIN_ISSUE(it_)                                                                                               \
+    do {                                                                                                             \
+        const int wi_ = (it_) / heads;                                                                               \
+        n_head = (it_) % heads;                                                                                      \
+        const int win_ = wi_ % (nw * nw);                                                                            \
+        n_im = wi_ / (nw * nw);                                                                                      \
+        const int wy_ = win_ / nw, wx_ = win_ % nw;                                                                  \
+        const uint16_t* base_ = qkv + (size_t)n_im * img_rows * (3 * D) + n_head * HD;                               \
+        n_qoff = q < C::N ? WIN_TOK_OFF(q) : -1L;                                                                    \
+        load_q_frags<KS>(n_qoff >= 0 ? base_ + n_qoff : nullptr, hh, qfn);                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < PK; ++i_) {                                                          \
+            const int c_ = tid + i_ * C::THREADS;                                                                    \
+            const int r_ = c_ / CH, ch_ = c_ % CH;                                                                   \
+            kreg[i_] = make_uint4(0u, 0u, 0u, 0u);                                                                   \
+            if (c_ < NKC) {                                                                                          \
+                const long off_ = WIN_TOK_OFF(r_);                                                                   \
+                if (off_ >= 0) kreg[i_] = *reinterpret_cast<const uint4*>(base_ + off_ + D + ch_ * 8);               \
+                else WIN_BIAS_CHUNK(kreg[i_], 1, ch_);                                                               \
+            }                                                                                                        \
+        }                                                                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < PV; ++i_) {                                                          \
+            const int c_ = tid + i_ * C::THREADS;                                                                    \
+            const int kp_ = c_ % (C::N / 2), ch_ = c_ / (C::N / 2);                                                  \
+            const int r0_ = 2 * kp_;                                                                                 \
+            v0reg[i_] = v1reg[i_] = make_uint4(0u, 0u, 0u, 0u);                                                      \
+            if (c_ < NVI) {                                                                                          \
+                const long off0_ = WIN_TOK_OFF(r0_), off1_ = WIN_TOK_OFF(r0_ + 1);                                   \
+                if (off0_ >= 0) v0reg[i_] = *reinterpret_cast<const uint4*>(base_ + off0_ + 2 * D + ch_ * 8);        \
+                else WIN_BIAS_CHUNK(v0reg[i_], 2, ch_);                                                              \
+                if (off1_ >= 0) v1reg[i_] = *reinterpret_cast<const uint4*>(base_ + off1_ + 2 * D + ch_ * 8);        \
+                else WIN_BIAS_CHUNK(v1reg[i_], 2, ch_);                                                              \
+            }                                                                                                        \
+        }                                                                                                            \
+    } while (0)
 
+    __syncthreads();                      // bias table is read by WIN_ISSUE
+    int it = blockIdx.x;
+    if (it < n_items) WIN_ISSUE(it);
+    for (; it < n_items; it += gridDim.x) {
+        // ---- stage this item's K (row-major) and V^T; the previous item's readers are done -------------
+        __syncthreads();
 #pragma unroll
-    for (int t = 0; t < C::NT; ++t) {
-        f32x16_t S = tile_times_qT<PREC, HD>(Ks + t * 32 * HD, lane, qf);
-        float mx = -INFINITY;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // key = k0 + 4*hh; both candidates are compile-time constants after unrolling
-            constexpr int dummy = 0; (void)dummy;
-            const int k0 = 32 * t + acc_row(r, 0), k1 = k0 + 4;
-            const float b0 = (k0 < C::N) ? RH[(k0 < C::N ? k0 : 0) / C::WS] + RW[(k0 < C::N ? k0 : 0) % C::WS] : -INFINITY;
-            const float b1 = (k1 < C::N) ? RH[(k1 < C::N ? k1 : 0) / C::WS] + RW[(k1 < C::N ? k1 : 0) % C::WS] : -INFINITY;
-            const float v = S[r] * c2 + (hh ? b1 : b0);      // -inf for the tile-padding keys (>= 196)
-            S[r] = v;
-            mx = fmaxf(mx, v);
+        for (int i = 0; i < PK; ++i) {
+            const int c = tid + i * C::THREADS;
+            if (c < NKC) *reinterpret_cast<uint4*>(Ks + (c / CH) * HD + (c % CH) * 8) = kreg[i];
         }
-        online_softmax_step<C::DT>(&S, 1, mx, 0.f, m_run, l_run, O);
+        // V^T[d][key]: a thread takes one 8-wide d chunk of TWO adjacent keys and writes eight 4-byte
+        // words; consecutive lanes take consecutive key pairs -> consecutive banks.
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint4 pb = pack_p<PREC>(S, u);
+        for (int i = 0; i < PV; ++i) {
+            const int c = tid + i * C::THREADS;
+            if (c < NVI) {
+                const int kp = c % (C::N / 2), ch = c / (C::N / 2);
 #pragma unroll
-            for (int dt = 0; dt < C::DT; ++dt) {
-                const uint4 va = load_vt_frag(Vt + (dt * 32 + ql) * C::VSTR + 32 * t, u, hh);
-                O[dt] = ET<PREC>::mfma32(va, pb, O[dt]);
+                for (int e = 0; e < 8; ++e)
+                    *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + e) * C::VSTR + 2 * kp) = pair_elem(v0reg[i], v1reg[i], e);
             }
         }
-    }
+        uint4 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = qfn[ks];
+        const long qoff = n_qoff;
+        const bool qin = qoff >= 0;           // a real token (padding / tile-padding queries are dropped)
+        const int im = n_im, head = n_head;
+        __syncthreads();
+        // ---- next item's loads: in flight during the whole compute below --------------------------------
+        if (it + (int)gridDim.x < n_items) WIN_ISSUE(it + (int)gridDim.x);
+        if (wave >= C::NT) continue;          // wave 7 only stages
 
-    // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
-    if (qin) {
-        const float inv = 1.0f / l_run;
-        uint16_t* orow = out + (size_t)im * grid * grid * D + (size_t)(qoff / (3 * D)) * D + head * HD;
+        // ---- decomposed rel-pos: RH[j] = q . rel_h[qh - j + 13], RW[j] = q . rel_w[qw - j + 13] -----
+        // (log2 domain; image_encoder.py:325-361 uses the UNSCALED q)
+        float* scr = Scr + wave * 32 * C::SSTR + ql * C::SSTR;
+        float RH[C::WS], RW[C::WS];
+        {
+            const f32x16_t th = tile_times_qT<PREC, HD>(Tab, lane, qf);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = th[r];
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < C::WS; ++j) RH[j] = scr[qh - j + C::WS - 1] * LOG2E_F;
+            wave_lds_sync();
+            const f32x16_t tw = tile_times_qT<PREC, HD>(Tab + 32 * HD, lane, qf);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = tw[r];
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < C::WS; ++j) RW[j] = scr[qw - j + C::WS - 1] * LOG2E_F;
+        }
+
+        const float c2 = rsqrtf((float)HD) * LOG2E_F;
+        f32x16_t O[C::DT];
 #pragma unroll
         for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 32 * dt + 8 * g + 4 * hh;
-                if (d0 < HD) {
-                    uint2 o;
-                    o.x = pack2_fast<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
-                    o.y = pack2_fast<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
-                    *reinterpret_cast<uint2*>(orow + d0) = o;
+            for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            f32x16_t S = tile_times_qT<PREC, HD>(Ks + t * 32 * HD, lane, qf);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // key = k0 + 4*hh; both candidates are compile-time constants after unrolling
+                const int k0 = 32 * t + acc_row(r, 0), k1 = k0 + 4;
+                const float b0 = (k0 < C::N) ? RH[(k0 < C::N ? k0 : 0) / C::WS] + RW[(k0 < C::N ? k0 : 0) % C::WS] : -INFINITY;
+                const float b1 = (k1 < C::N) ? RH[(k1 < C::N ? k1 : 0) / C::WS] + RW[(k1 < C::N ? k1 : 0) % C::WS] : -INFINITY;
+                const float v = S[r] * c2 + (hh ? b1 : b0);      // -inf for the tile-padding keys (>= 196)
+                S[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            online_softmax_step<C::DT>(&S, 1, mx, 0.f, m_run, l_run, O);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint4 pb = pack_p<PREC>(S, u);
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt) {
+                    const uint4 va = load_vt_frag(Vt + (dt * 32 + ql) * C::VSTR + 32 * t, u, hh);
+                    O[dt] = ET<PREC>::mfma32(va, pb, O[dt]);
                 }
             }
+        }
+
+        // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
+        if (qin) {
+            const float inv = 1.0f / l_run;
+            uint16_t* orow = out + (size_t)im * img_rows * D + (size_t)(qoff / (3 * D)) * D + head * HD;
+#pragma unroll
+            for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 32 * dt + 8 * g + 4 * hh;
+                    if (d0 < HD) {
+                        uint2 o;
+                        o.x = pack2_fast<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
+                        o.y = pack2_fast<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
+                        *reinterpret_cast<uint2*>(orow + d0) = o;
+                    }
+                }
+        }
     }
+#undef WIN_ISSUE
+#undef WIN_BIAS_CHUNK
+#undef WIN_TOK_OFF
 }
 
 // =========================================================================================
@@ -764,9 +794,16 @@ static hipError_t launch_win(const void* qkv, const float* qb, const float* rh, 
     using C = WinCfg<HD>;
     auto k = window_attention_kernel<PREC, HD>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
+    if (heads * HD > C::MAX_D) return hipErrorInvalidValue;
     const int nw = (grid + C::WS - 1) / C::WS;
-    dim3 g(n_images * nw * nw, heads), b(C::THREADS);
-    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, qb, rh, rw, (uint16_t*)out, grid, heads);
+    const int n_items = n_images * nw * nw * heads;
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    dim3 g(n_items < n_cu ? n_items : n_cu), b(C::THREADS);      // persistent: one block per CU (LDS-limited)
+    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, qb, rh, rw, (uint16_t*)out, grid, heads, n_items);
     return hipGetLastError();
 }
 

@@ -245,18 +245,20 @@ __global__ __launch_bounds__(256, 2) void t2i_partial_kernel(const float* __rest
     const int kend = kbeg + kpw < tokens ? kbeg + kpw : tokens;
     const uint16_t* kb = kp + (size_t)b * bstride * ld + ch * 8;
     const uint16_t* vb = vp + (size_t)b * bstride * ld + ch * 8;
-    constexpr int U = 2;    // key groups (of 4 keys) in flight per iteration
+    constexpr int U = 2;    // key groups (of 4 keys) per iteration; the next iteration's loads are already in flight
+    uint4 kk[U], vv[U], kn[U], vn[U];
+#define T2I_LOAD(dk_, dv_, k0_)                                                                  \
+    _Pragma("unroll") for (int u_ = 0; u_ < U; ++u_) {                                           \
+        const int key_ = (k0_) + 4 * u_ + kq;                                                    \
+        dk_[u_] = dv_[u_] = make_uint4(0u, 0u, 0u, 0u);                                          \
+        if (key_ < kend) {                                                                       \
+            dk_[u_] = *reinterpret_cast<const uint4*>(kb + (size_t)key_ * ld);                   \
+            dv_[u_] = *reinterpret_cast<const uint4*>(vb + (size_t)key_ * ld);                   \
+        }                                                                                        \
+    }
+    T2I_LOAD(kk, vv, kbeg)
     for (int k0 = kbeg; k0 < kend; k0 += 4 * U) {
-        uint4 kk[U], vv[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int key = k0 + 4 * u + kq;
-            kk[u] = vv[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (key < kend) {
-                kk[u] = *reinterpret_cast<const uint4*>(kb + (size_t)key * ld);
-                vv[u] = *reinterpret_cast<const uint4*>(vb + (size_t)key * ld);
-            }
-        }
+        T2I_LOAD(kn, vn, k0 + 4 * U)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool valid = k0 + 4 * u + kq < kend;      // same for both halves of a head (lane ^ 1)
@@ -275,7 +277,8 @@ __global__ __launch_bounds__(256, 2) void t2i_partial_kernel(const float* __rest
                 float sc = 0.f;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) sc += q[t][c] * kf[c];
-                sc += __shfl_xor(sc, 1, 64);
+                // other half of the head = lane ^ 1: a DPP quad_perm [1,0,3,2] move, not a ds_bpermute round trip
+                sc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sc), 0xB1, 0xF, 0xF, true));
                 sc = valid ? sc : T2I_NEG;
                 const float mn = fmaxf(m[t], sc);
                 const float corr = __builtin_amdgcn_exp2f(m[t] - mn);
@@ -286,7 +289,10 @@ __global__ __launch_bounds__(256, 2) void t2i_partial_kernel(const float* __rest
                 m[t] = mn;
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { kk[u] = kn[u]; vv[u] = vn[u]; }
     }
+#undef T2I_LOAD
     // merge the 4 key phases of the wave (lane bits 4, 5), then the 4 waves through LDS
 #pragma unroll
     for (int off = 16; off <= 32; off <<= 1) {
@@ -356,22 +362,28 @@ __global__ __launch_bounds__(T2I_TG * 16) void t2i_merge_kernel(const float* __r
 }
 
 // image -> tokens attention (head dim 16).  Thread = (image token, head); keys/values are the T
-// prompt tokens (LDS).  grid (tokens/32, n_prompts).
+// prompt tokens (LDS).  grid (tokens/32, n_prompts).  The 8 heads of a token are 8 adjacent lanes that read
+// DIFFERENT 16-float slices of a k / v row: at the natural stride they fall on 2 banks (PMC: 74 % of the LDS
+// cycles were conflicts), so the LDS copy pads every head slice to I2T_HS = 20 floats -> the eight
+// ds_read_b128 of a wave quarter cover all 32 banks.
+constexpr int I2T_HS = 20;
 template <int PREC>
 __global__ __launch_bounds__(256) void i2t_attention_kernel(const uint16_t* __restrict__ qi, int ld, long bstride,
                                                             const float* __restrict__ kt, const float* __restrict__ vt,
                                                             uint16_t* __restrict__ out, int T, int tokens, int Ci) {
     constexpr int HD = 16;
     extern __shared__ float sm[];  // kt | vt, each [T][Ci]
+    const int heads = Ci / HD;                  // 8
+    const int RS = heads * I2T_HS;              // padded row stride
     float* sk = sm;
-    float* sv = sm + T * Ci;
+    float* sv = sm + T * RS;
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < T * Ci; i += 256) {
-        sk[i] = kt[(size_t)b * T * Ci + i];
-        sv[i] = vt[(size_t)b * T * Ci + i];
+        const int j = i / Ci, c = i % Ci;
+        sk[j * RS + (c / HD) * I2T_HS + c % HD] = kt[(size_t)b * T * Ci + i];
+        sv[j * RS + (c / HD) * I2T_HS + c % HD] = vt[(size_t)b * T * Ci + i];
     }
     __syncthreads();
-    const int heads = Ci / HD;                  // 8
     const int tok = blockIdx.x * (256 / heads) + threadIdx.x / heads;
     const int h = threadIdx.x % heads;
     if (tok >= tokens) return;
@@ -389,8 +401,14 @@ __global__ __launch_bounds__(256) void i2t_attention_kernel(const uint16_t* __re
 #pragma unroll
     for (int c = 0; c < HD; ++c) acc[c] = 0.f;
     for (int j = 0; j < T; ++j) {
-        const float* kr = sk + j * Ci + h * HD;
-        const float* vr = sv + j * Ci + h * HD;
+        float kr[HD], vr[HD];
+#pragma unroll
+        for (int c4 = 0; c4 < HD / 4; ++c4) {
+            const float4 k4 = *reinterpret_cast<const float4*>(sk + j * RS + h * I2T_HS + 4 * c4);
+            const float4 v4 = *reinterpret_cast<const float4*>(sv + j * RS + h * I2T_HS + 4 * c4);
+            kr[4 * c4] = k4.x; kr[4 * c4 + 1] = k4.y; kr[4 * c4 + 2] = k4.z; kr[4 * c4 + 3] = k4.w;
+            vr[4 * c4] = v4.x; vr[4 * c4 + 1] = v4.y; vr[4 * c4 + 2] = v4.z; vr[4 * c4 + 3] = v4.w;
+        }
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < HD; ++c) s += qf[c] * kr[c];
@@ -476,6 +494,92 @@ __global__ __launch_bounds__(256) void mask_product_kernel(const uint16_t* __res
 #pragma unroll
         for (int k = 0; k < 32; ++k) s += hy[c][k] * u[k];
         low[(((size_t)b * n_sel + c) * S + Y) * S + X] = s;
+    }
+}
+
+// ---- fused second transposed conv + GELU + hypernetwork product -------------------------------------
+// mask_decoder.py:57-59,154-167:  up2 = GELU(ConvT2x2(u1)) ; masks = hyper . up2   (32 channels).
+// The ConvT is a per-pixel GEMM with K = 64: rows = (prompt, token, sub-pixel 1) of `u1` [rows][64] ET,
+// columns = sub-pixel 2 x 32 channels (W = [128][64], repacked at load).  K is so short that a GEMM kernel
+// is all epilogue, and the 128-wide result would be written (134 MB for 32 prompts) only to be read back by
+// the 32-channel dot.  Here one wave owns 16 rows at a time: W (64 registers) and the bias stay resident, the
+// A fragments stream straight from global memory (16 rows x 128 contiguous bytes), GELU and the dot run in
+// fp32 on the accumulators, the 4 partial sums of a row meet across the lane quarters, and lane quarter q
+// writes low[b][c][Y][X] of sub-pixel 2 = q.   grid (row blocks per prompt, n_prompts), 256 threads.
+constexpr int U2_GROUPS_PER_WAVE = 16;          // 16-row groups per wave -> 1024 rows per block
+
+template <int PREC, int NSEL>
+__global__ __launch_bounds__(256) void upscale2_mask_kernel(const uint16_t* __restrict__ u1, const uint16_t* __restrict__ w,
+                                                            const float* __restrict__ bias, const float* __restrict__ hyper,
+                                                            float* __restrict__ low, int grid, int n_mask_tokens, int sel0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.y;
+    const int rows_per_prompt = grid * grid * 4;
+    const int S = 4 * grid;
+    uint4 wf[8][2];
+    float bv[8][4], hy[NSEL][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) wf[i][ks] = *reinterpret_cast<const uint4*>(w + (i * 16 + fr) * 64 + ks * 32 + fq * 8);
+        const float4 t = *reinterpret_cast<const float4*>(bias + i * 16 + 4 * fq);
+        bv[i][0] = t.x; bv[i][1] = t.y; bv[i][2] = t.z; bv[i][3] = t.w;
+    }
+    // this lane's channels: c = (i & 1) * 16 + 4 fq + r  (the same for every sub-pixel 2 = i >> 1)
+#pragma unroll
+    for (int c = 0; c < NSEL; ++c) {
+        const float* h = hyper + ((size_t)b * n_mask_tokens + sel0 + c) * 32;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const float4 t = *reinterpret_cast<const float4*>(h + half * 16 + 4 * fq);
+            hy[c][half * 4 + 0] = t.x; hy[c][half * 4 + 1] = t.y; hy[c][half * 4 + 2] = t.z; hy[c][half * 4 + 3] = t.w;
+        }
+    }
+    const int row0 = (blockIdx.x * 4 + wave) * (16 * U2_GROUPS_PER_WAVE);     // first row (within the prompt) of this wave
+    const uint16_t* abase = u1 + ((size_t)b * rows_per_prompt + row0 + fr) * 64 + fq * 8;
+    uint4 a0 = *reinterpret_cast<const uint4*>(abase), a1 = *reinterpret_cast<const uint4*>(abase + 32);
+    for (int g = 0; g < U2_GROUPS_PER_WAVE; ++g) {
+        const uint4 c0 = a0, c1 = a1;
+        if (g + 1 < U2_GROUPS_PER_WAVE) {        // next group's fragments fly during this group's math
+            a0 = *reinterpret_cast<const uint4*>(abase + (size_t)(g + 1) * 16 * 64);
+            a1 = *reinterpret_cast<const uint4*>(abase + (size_t)(g + 1) * 16 * 64 + 32);
+        }
+        float part[NSEL][4];
+#pragma unroll
+        for (int c = 0; c < NSEL; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) part[c][q] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = ET<PREC>::mfma16(wf[i][0], c0, acc);
+            acc = ET<PREC>::mfma16(wf[i][1], c1, acc);
+            const float2_t g01 = gelu_erf2(float2_t{acc[0] + bv[i][0], acc[1] + bv[i][1]});
+            const float2_t g23 = gelu_erf2(float2_t{acc[2] + bv[i][2], acc[3] + bv[i][3]});
+#pragma unroll
+            for (int c = 0; c < NSEL; ++c) {
+                const float* h = hy[c] + (i & 1) * 4;
+                part[c][i >> 1] += h[0] * g01.x + h[1] * g01.y + h[2] * g23.x + h[3] * g23.y;
+            }
+        }
+        // row of this lane: (token t, sub-pixel 1); quarter fq keeps sub-pixel 2 = fq
+        const int row = row0 + g * 16 + fr;
+        const int t = row >> 2, s1 = row & 3;
+        const int y = t / grid, x = t % grid;
+        const int Y = 4 * y + 2 * (s1 >> 1) + (fq >> 1), X = 4 * x + 2 * (s1 & 1) + (fq & 1);
+#pragma unroll
+        for (int c = 0; c < NSEL; ++c) {
+            float mine = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = part[c][q];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                mine = (q == fq) ? v : mine;
+            }
+            low[(((size_t)b * NSEL + c) * S + Y) * S + X] = mine;
+        }
     }
 }
 
@@ -683,7 +787,7 @@ hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long bstride, 
     if (Ci / heads != 16 || 256 % heads) return hipErrorInvalidValue;
     const int per = 256 / heads;
     dim3 g((tokens + per - 1) / per, n), b(256);
-    const size_t sh = 2 * (size_t)T * Ci * sizeof(float);
+    const size_t sh = 2 * (size_t)T * heads * I2T_HS * sizeof(float);
     if (prec == PREC_BF16)
         i2t_attention_kernel<PREC_BF16><<<g, b, sh, s>>>((const uint16_t*)qi, ld, bstride, kt, vt, (uint16_t*)out, T, tokens, Ci);
     else
@@ -705,6 +809,19 @@ hipError_t launch_mask_product(int prec, const void* up2, const float* hyper, fl
     dim3 g(S * S / 256, n), b(256);
     if (prec == PREC_BF16) mask_product_kernel<PREC_BF16><<<g, b, 0, s>>>((const uint16_t*)up2, hyper, low, grid, n_mask_tokens, sel0, n_sel);
     else mask_product_kernel<PREC_F16><<<g, b, 0, s>>>((const uint16_t*)up2, hyper, low, grid, n_mask_tokens, sel0, n_sel);
+    return hipGetLastError();
+}
+hipError_t launch_upscale2_masks(int prec, const void* u1, const void* w, const float* bias, const float* hyper, float* low,
+                                 int n, int grid, int n_mask_tokens, int sel0, int n_sel, hipStream_t s) {
+    const int rows_per_block = 4 * 16 * U2_GROUPS_PER_WAVE;
+    if ((grid * grid * 4) % rows_per_block || (n_sel != 1 && n_sel != 3)) return hipErrorInvalidValue;
+    dim3 g(grid * grid * 4 / rows_per_block, n), b(256);
+    const uint16_t* a = (const uint16_t*)u1;
+    const uint16_t* ww = (const uint16_t*)w;
+#define U2_LAUNCH(P, NS) upscale2_mask_kernel<P, NS><<<g, b, 0, s>>>(a, ww, bias, hyper, low, grid, n_mask_tokens, sel0)
+    if (prec == PREC_BF16) { if (n_sel == 1) U2_LAUNCH(PREC_BF16, 1); else U2_LAUNCH(PREC_BF16, 3); }
+    else { if (n_sel == 1) U2_LAUNCH(PREC_F16, 1); else U2_LAUNCH(PREC_F16, 3); }
+#undef U2_LAUNCH
     return hipGetLastError();
 }
 hipError_t launch_postprocess(const float* low, int n_masks, int in_h, int in_w, int orig_h, int orig_w,

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -80,7 +81,7 @@ struct samrs_engine {
     uint16_t* fin_kv_w = nullptr;  // ET [256][256] = [Wk; Wv]
     float *fin_kv_b = nullptr, *fin_pe = nullptr;
     uint16_t *up1_w = nullptr, *up2_w = nullptr;
-    float *up1_b = nullptr, *up2_b = nullptr;
+    float *up1_b = nullptr, *up2_b = nullptr, *up_ln = nullptr;   // up_ln = LayerNorm2d gamma[64] | beta[64]
     float* PE = nullptr;           // dense PE [tokens][C]
 
     // decoder workspaces
@@ -411,6 +412,9 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     if ((rc = to_et(e, "mask_decoder.output_upscaling.3.weight", &e->up2_w, false, s))) return rc;
     CK(e, dalloc(e, &e->up1_b, (size_t)C));
     CK(e, dalloc(e, &e->up2_b, (size_t)C / 2));
+    CK(e, dalloc(e, &e->up_ln, (size_t)C / 2));
+    CK(e, hipMemcpyAsync(e->up_ln, W(e, "mask_decoder.output_upscaling.1.weight"), sizeof(float) * C / 4, hipMemcpyDeviceToDevice, s));
+    CK(e, hipMemcpyAsync(e->up_ln + C / 4, W(e, "mask_decoder.output_upscaling.1.bias"), sizeof(float) * C / 4, hipMemcpyDeviceToDevice, s));
     for (int k = 0; k < 4; ++k) {
         CK(e, hipMemcpyAsync(e->up1_b + k * (C / 4), W(e, "mask_decoder.output_upscaling.0.bias"), sizeof(float) * C / 4, hipMemcpyDeviceToDevice, s));
         CK(e, hipMemcpyAsync(e->up2_b + k * (C / 8), W(e, "mask_decoder.output_upscaling.3.bias"), sizeof(float) * C / 8, hipMemcpyDeviceToDevice, s));
@@ -686,13 +690,23 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
         CK(e, lin(e->HY2 + 4 * hs, C, W(e, ip + ".2.weight"), W(e, ip + ".2.bias"), e->IOU, 4, n, 4, C, false, false));
     }
     // ---- upscaler (mask_decoder.py:53-59,154-155) as two GEMMs + fused tail ----
-    CK(e, launch_gemm_et(prec, e->KE, e->up1_w, e->U1raw, e->up1_b, nullptr, 0, Mi, C, C, true, false, false, s));
-    CK(e, launch_group_ln_gelu(prec, e->U1raw, W(e, "mask_decoder.output_upscaling.1.weight"),
-                               W(e, "mask_decoder.output_upscaling.1.bias"), 1e-6f, e->U1, (long)Mi, 4, C / 4, s));
-    CK(e, launch_gemm_et(prec, e->U1, e->up2_w, e->U2, e->up2_b, nullptr, 0, Mi * 4, C / 2, C / 4, false, true, false, s));
+    // A/B knob (timing experiments): SAMRS_DECODER_FUSION=0 runs the un-fused upscaler kernels
+    static const bool fuse = [] { const char* v = getenv("SAMRS_DECODER_FUSION"); return !(v && atoi(v) == 0); }();
+    if (fuse && Mi % 256 == 0) {   // ConvT #1 as a GEMM with LayerNorm2d(64) + GELU fused into its epilogue
+        CK(e, launch_gemm_et_gln(prec, e->KE, e->up1_w, e->U1, e->up1_b, e->up_ln, Mi, C, C, s));
+    } else {
+        CK(e, launch_gemm_et(prec, e->KE, e->up1_w, e->U1raw, e->up1_b, nullptr, 0, Mi, C, C, true, false, false, s));
+        CK(e, launch_group_ln_gelu(prec, e->U1raw, W(e, "mask_decoder.output_upscaling.1.weight"),
+                                   W(e, "mask_decoder.output_upscaling.1.bias"), 1e-6f, e->U1, (long)Mi, 4, C / 4, s));
+    }
     const int sel0 = multimask ? 1 : 0, nsel = multimask ? 3 : 1;     // mask_decoder.py:102-107
     float* low = lowres_out ? lowres_out : e->LOW;
-    CK(e, launch_mask_product(prec, e->U2, e->HYPER, low, n, g, 4, sel0, nsel, s));
+    if (fuse && (g * g * 4) % 1024 == 0) {
+        CK(e, launch_upscale2_masks(prec, e->U1, e->up2_w, e->up2_b, e->HYPER, low, n, g, 4, sel0, nsel, s));
+    } else {   // tiny grids (test configurations): GEMM + separate product
+        CK(e, launch_gemm_et(prec, e->U1, e->up2_w, e->U2, e->up2_b, nullptr, 0, Mi * 4, C / 2, C / 4, false, true, false, s));
+        CK(e, launch_mask_product(prec, e->U2, e->HYPER, low, n, g, 4, sel0, nsel, s));
+    }
     if (iou_out)
         CK(e, hipMemcpy2DAsync(iou_out, sizeof(float) * nsel, e->IOU + sel0, sizeof(float) * 4, sizeof(float) * nsel, n,
                                hipMemcpyDeviceToDevice, s));

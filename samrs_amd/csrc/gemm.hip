@@ -238,7 +238,7 @@ __device__ __forceinline__ void wave_lds_sync_g() {
 // known), the 2-D addend and the residual accumulate after it (coalesced loads).
 //   acc[i][j]: n-tile i (16 cols), m-tile j (16 rows); NJ m-tiles per wave, JC of them per pass.
 // ---------------------------------------------------------------------------------------------
-template <int PREC, bool OUT_F32, bool GELU, int NJ, int JC, int NI = 4>
+template <int PREC, bool OUT_F32, bool GELU, int NJ, int JC, int NI = 4, bool GLN = false>
 __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsigned char* scr /* wave-private */,
                                                    void* __restrict__ Cv, const float* __restrict__ bias,
                                                    const float* __restrict__ add2d, int add2d_period, int N,
@@ -263,10 +263,39 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
 #pragma unroll
         for (int jj = 0; jj < JC; ++jj) {
             const int j = j0 + jj;
+            // GLN: LayerNorm2d over the wave's 64 columns (= one channel group of the transposed-conv output,
+            // mask_decoder.py:55-56, eps 1e-6) before the GELU.  A row's 64 values sit in the 4 lane quarters x
+            // 16 registers; two-pass statistics like the stand-alone kernel.  `add2d` carries gamma[64] | beta[64].
+            float gmean = 0.f, grstd = 1.f;
+            if (GLN) {
+                float s1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    s1 += ((acc[i][j][0] + bv[i].x) + (acc[i][j][1] + bv[i].y)) + ((acc[i][j][2] + bv[i].z) + (acc[i][j][3] + bv[i].w));
+                s1 += __shfl_xor(s1, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                gmean = s1 * (1.0f / 64.0f);
+                float s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const float a0 = acc[i][j][0] + bv[i].x - gmean, a1 = acc[i][j][1] + bv[i].y - gmean;
+                    const float a2 = acc[i][j][2] + bv[i].z - gmean, a3 = acc[i][j][3] + bv[i].w - gmean;
+                    s2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+                s2 += __shfl_xor(s2, 16, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                grstd = 1.0f / sqrtf(s2 * (1.0f / 64.0f) + 1e-6f);
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
                 float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+                if (GLN) {
+                    const float4 gm = *reinterpret_cast<const float4*>(add2d + i * 16 + 4 * fq);
+                    const float4 bt = *reinterpret_cast<const float4*>(add2d + 64 + i * 16 + 4 * fq);
+                    v0 = (v0 - gmean) * grstd * gm.x + bt.x; v1 = (v1 - gmean) * grstd * gm.y + bt.y;
+                    v2 = (v2 - gmean) * grstd * gm.z + bt.z; v3 = (v3 - gmean) * grstd * gm.w + bt.w;
+                }
                 if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
                 unsigned char* p = scr + jj * TS + fr * RS;
                 if (OUT_F32) {
@@ -835,7 +864,7 @@ constexpr int DBM = 256, DBN = 128, DBK = 32, DSTAGES = 3, DTHREADS = 512;
 constexpr int DSTAGE_ELEMS = (DBM + DBN) * DBK;               // 12288 ET = 24 KiB
 constexpr int D_DMA_PER_TILE = (DBM + DBN) * DBK * 2 / (DTHREADS * 16);   // 3 per thread
 
-template <int PREC, bool OUT_F32, bool GELU, bool STAG = true>
+template <int PREC, bool OUT_F32, bool GELU, bool STAG = true, bool GLN = false>
 __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
@@ -935,7 +964,7 @@ __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
     if (STAG && grp == 0) __builtin_amdgcn_s_barrier();          // both groups: 2 + 2*nk barriers
     {
         unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (DSTAGES * DSTAGE_ELEMS * 2 / 8);   // 9 KiB
-        if (!OUT_F32 && add2d) {
+        if (!OUT_F32 && !GLN && add2d) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -945,9 +974,19 @@ __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
                     acc[i][j][0] += e.x; acc[i][j][1] += e.y; acc[i][j][2] += e.z; acc[i][j][3] += e.w;
                 }
         }
-        epilogue_coalesced<PREC, OUT_F32, GELU, 4, OUT_F32 ? 2 : 4>(acc, scr, Cv, bias, OUT_F32 ? add2d : nullptr, add2d_period,
-                                                                     N, m0 + wm * 64, n0 + wn * 64, accumulate, lane);
+        epilogue_coalesced<PREC, OUT_F32, GELU, 4, OUT_F32 ? 2 : 4, 4, GLN>(acc, scr, Cv, bias, (OUT_F32 || GLN) ? add2d : nullptr,
+                                                                             add2d_period, N, m0 + wm * 64, n0 + wn * 64, accumulate, lane);
     }
+}
+
+// C (ET) = GELU(LayerNorm2d_64(A B^T + bias)): the 64-column groups of N are normalised independently
+template <int PREC>
+hipError_t launch_gemm_dual_gln(const void* A, const void* B, void* C, const float* bias, const float* gamma_beta,
+                                int M, int N, int K, hipStream_t s) {
+    dim3 grid((M / DBM) * (N / DBN)), block(DTHREADS);
+    gemm_et_dual_kernel<PREC, false, true, true, true><<<grid, block, 0, s>>>(
+        reinterpret_cast<const uint16_t*>(A), reinterpret_cast<const uint16_t*>(B), C, bias, gamma_beta, 1, M, N, K, 0);
+    return hipGetLastError();
 }
 
 template <int PREC, bool STAG = true>
@@ -1230,4 +1269,12 @@ hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float*
     F32Batch bt{};
     bt.A[0] = A; bt.W[0] = W; bt.bias[0] = bias; bt.C[0] = C;
     return launch_gemm_f32_batch(bt, 1, lda, ldc, M, N, K, relu, accumulate, s);
+}
+
+hipError_t launch_gemm_et_gln(int prec, const void* A, const void* B, void* C, const float* bias, const float* gamma_beta,
+                              int M, int N, int K, hipStream_t s) {
+    if (M % DBM || N % DBN || K % DBK || M <= 0 || !gamma_beta) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) return launch_gemm_dual_gln<PREC_BF16>(A, B, C, bias, gamma_beta, M, N, K, s);
+    if (prec == PREC_F16) return launch_gemm_dual_gln<PREC_F16>(A, B, C, bias, gamma_beta, M, N, K, s);
+    return hipErrorInvalidValue;
 }

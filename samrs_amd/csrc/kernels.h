@@ -7,6 +7,9 @@
 hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const float* bias,
                           const float* add2d, int add2d_period, int M, int N, int K, bool out_f32,
                           bool gelu, bool accumulate, hipStream_t s);
+// C (ET) = GELU(LayerNorm2d over every 64-column group of (A B^T + bias)), eps 1e-6; gamma_beta = gamma[64] | beta[64]
+hipError_t launch_gemm_et_gln(int prec, const void* A, const void* B, void* C, const float* bias, const float* gamma_beta,
+                              int M, int N, int K, hipStream_t s);
 void set_gemm_variant(int v);   // 0 = register-staged tiles, 1 = LDS-DMA staging (default)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s);
@@ -78,6 +81,9 @@ hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long batch_str
 hipError_t launch_group_ln_gelu(int prec, const float* in, const float* gamma, const float* beta, float eps,
                                 void* out, long rows, int groups, int gsize, hipStream_t s);
 // low[b, c, Y, X] = sum_ch hyper[b, sel0 + c, ch] * up2[b, y, x, dy, dx, dy2, dx2, ch]
+// fused ConvT #2 (K = 64 GEMM) + GELU + hypernetwork product: u1 [n*grid*grid*4][64] ET -> low [n][n_sel][4 grid][4 grid]
+hipError_t launch_upscale2_masks(int prec, const void* u1, const void* w, const float* bias, const float* hyper, float* low,
+                                 int n, int grid, int n_mask_tokens, int sel0, int n_sel, hipStream_t s);
 hipError_t launch_mask_product(int prec, const void* up2, const float* hyper, float* low, int n, int grid,
                                int n_mask_tokens, int sel0, int n_sel, hipStream_t s);
 hipError_t launch_postprocess(const float* low, int n_masks, int in_h, int in_w, int orig_h, int orig_w,

@@ -35,6 +35,8 @@ for grp in "$@"; do
               run pmc3 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc3 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 2 f16}
               run pmc4 600 rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAIT_INST_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc4 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 2 f16} ;;
     attnb)    run attnb 600 python tools/attn_bench.py ;;
+    decb)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
+              run decb 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/decb -o dec -- python tools/dec_bench.py 20 ;;
     benchq)   run benchq 900 python bench.py --steps ${BENCH_STEPS:-8} --warmup 2 --no-cpu-baseline --no-alt-dtype ${BENCH_EXTRA:-} ;;
     prof)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
               run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;

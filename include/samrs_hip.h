@@ -183,6 +183,19 @@ int samrs_k_global_attention(int prec, const void* qkv_et, const float* rel_h, c
                              void* stream);
 int samrs_k_postprocess(const float* lowres, int n_masks, int in_h, int in_w, int orig_h,
                         int orig_w, int img_size, int return_logits, void* out, void* stream);
+/* First transposed conv of the mask upscaler as a GEMM with LayerNorm2d(64) + GELU in its epilogue
+ * (segment_anything/modeling/mask_decoder.py:53-56): C_et[M,N] = GELU(LN64(A_et[M,K] B_et[N,K]^T + bias)),
+ * every 64-column group of N normalised on its own, eps 1e-6; gamma_beta = gamma[64] | beta[64].
+ * M % 256 == 0, N % 128 == 0, K % 32 == 0. */
+int samrs_k_gemm_gln(int prec, const void* A_et, const void* B_et, void* C_et, const float* bias,
+                     const float* gamma_beta, int M, int N, int K, void* stream);
+/* Second transposed conv + GELU + hypernetwork product (mask_decoder.py:57-59,154-167) in one pass:
+ * u1_et [n*grid*grid*4, 64] (rows = prompt, token, sub-pixel 1), w_et [128, 64] (rows = sub-pixel 2 x 32
+ * channels), bias [128], hyper [n, n_mask_tokens, 32] -> low [n, n_sel, 4*grid, 4*grid] fp32 for mask
+ * tokens sel0 .. sel0+n_sel-1 (n_sel 1 or 3).  grid*grid*4 % 1024 == 0. */
+int samrs_k_upscale2_masks(int prec, const void* u1_et, const void* w_et, const float* bias,
+                           const float* hyper, float* low, int n, int grid, int n_mask_tokens,
+                           int sel0, int n_sel, void* stream);
 
 #ifdef __cplusplus
 }

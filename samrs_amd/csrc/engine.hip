@@ -772,7 +772,12 @@ int samrs_debug_dominant_kernel_time(samrs_engine_t* e, float* avg_ms, int* laun
 }
 
 // ---- kernel-level entry points -------------------------------------------------------------------
-#define KRET(expr) do { hipError_t _e = (expr); return _e == hipSuccess ? SAMRS_OK : SAMRS_ERR_HIP; } while (0)
+#define KRET(expr)                                                                                  \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) fprintf(stderr, "libsamrs_hip: %s: %s\n", __func__, hipGetErrorString(_e)); \
+        return _e == hipSuccess ? SAMRS_OK : SAMRS_ERR_HIP;                                         \
+    } while (0)
 
 int samrs_k_gemm(int prec, const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                  int M, int N, int K, int out_f32, int gelu, int accumulate, void* stream) {
@@ -806,6 +811,14 @@ int samrs_resample_pass_u8(const uint8_t* in, uint8_t* out, const int32_t* bound
 int samrs_k_postprocess(const float* low, int n_masks, int in_h, int in_w, int orig_h, int orig_w, int img_size,
                         int return_logits, void* out, void* stream) {
     KRET(launch_postprocess(low, n_masks, in_h, in_w, orig_h, orig_w, img_size, return_logits, out, (hipStream_t)stream));
+}
+int samrs_k_gemm_gln(int prec, const void* A, const void* B, void* C, const float* bias, const float* gamma_beta, int M, int N,
+                     int K, void* stream) {
+    KRET(launch_gemm_et_gln(prec, A, B, C, bias, gamma_beta, M, N, K, (hipStream_t)stream));
+}
+int samrs_k_upscale2_masks(int prec, const void* u1, const void* w, const float* bias, const float* hyper, float* low, int n,
+                           int grid, int n_mask_tokens, int sel0, int n_sel, void* stream) {
+    KRET(launch_upscale2_masks(prec, u1, w, bias, hyper, low, n, grid, n_mask_tokens, sel0, n_sel, (hipStream_t)stream));
 }
 
 }  // extern "C"

@@ -78,10 +78,12 @@ def load_library() -> C.CDLL:
     lib.samrs_k_window_attention.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_global_attention.argtypes = [ip, vp, vp, vp, vp, ip, ip, ip, ip, vp]
     lib.samrs_k_postprocess.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, vp, vp]
+    lib.samrs_k_gemm_gln.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, vp]
+    lib.samrs_k_upscale2_masks.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_get_embedding",
                  "samrs_set_embedding", "samrs_reset_image", "samrs_predict", "samrs_paint", "samrs_k_gemm",
                  "samrs_k_gemm_f32", "samrs_k_convert", "samrs_k_layernorm", "samrs_k_window_attention",
-                 "samrs_k_global_attention", "samrs_k_postprocess"):
+                 "samrs_k_global_attention", "samrs_k_postprocess", "samrs_k_gemm_gln", "samrs_k_upscale2_masks"):
         getattr(lib, name).restype = ip
     if lib.samrs_abi_version() != 1:
         raise ImportError("libsamrs_hip.so ABI version mismatch; rebuild it")

@@ -91,6 +91,90 @@ def test_gemm_et_variants(lib, name, prec, dt, ulp, M, N, K):
     assert err.max().item() < 1.5 * ulp
 
 
+@pytest.mark.parametrize("variant,M,N,K", [(5, 512, 256, 192), (6, 512, 512, 192), (7, 512, 256, 192), (9, 256, 128, 128),
+                                           (10, 512, 640, 192), (10, 256, 640, 64), (6, 256, 256, 64)])
+def test_gemm_every_tile_variant(lib, variant, M, N, K):
+    """Each tile shape of the pipelined GEMM forced explicitly (the auto rule only picks the 256x256 / 256x320
+    kernels at sizes the unit tests do not reach): fp32 accumulate output, f16 output with 2-D addend, GELU output."""
+    name, prec, dt, ulp = PRECS[0]
+    g = torch.Generator().manual_seed(variant * 1000 + M + N + K)
+    A, Ab = et_bits(torch.randn(M, K, generator=g), dt)
+    B, Bb = et_bits(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
+    bias = torch.randn(N, generator=g)
+    add2d = torch.randn(64, N, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    ref = A.double() @ B.double().t()
+    Ad, Bd, biasd, add2dd = dev(Ab), dev(Bb), dev(bias), dev(add2d)
+    lib.samrs_debug_set_gemm_variant.argtypes = [__import__("ctypes").c_int]
+    lib.samrs_debug_set_gemm_variant(variant)
+    try:
+        out = dev(C0.clone())
+        assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), out.data_ptr(), biasd.data_ptr(), add2dd.data_ptr(), 64,
+                                M, N, K, 1, 0, 1, stream()) == 0
+        r, _ = rel_err(out.cpu(), ref + bias.double() + add2d.double().repeat(M // 64, 1) + C0.double())
+        assert r < 2e-6, f"variant {variant} fp32 out: rel {r:.2e}"
+        out = torch.empty(M, N, dtype=torch.int16, device="cuda")
+        assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), out.data_ptr(), biasd.data_ptr(), add2dd.data_ptr(), 64,
+                                M, N, K, 0, 0, 0, stream()) == 0
+        ref_e = (ref + bias.double() + add2d.double().repeat(M // 64, 1)).float()
+        err = (out.cpu().view(dt).float() - ref_e).abs() / ref_e.abs().clamp(min=1e-2)
+        assert err.max().item() < 1.5 * ulp, f"variant {variant} ET out + add2d"
+        assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), out.data_ptr(), biasd.data_ptr(), None, 0, M, N, K, 0, 1, 0, stream()) == 0
+        ref_c = F.gelu((ref + bias.double()).float())
+        err = (out.cpu().view(dt).float() - ref_c).abs() / ref_c.abs().clamp(min=1e-2)
+        print(f"gemm variant {variant} {M}x{N}x{K}: gelu->ET max rel {err.max().item():.2e}")
+        assert err.max().item() < 1.5 * ulp, f"variant {variant} GELU out"
+    finally:
+        lib.samrs_debug_set_gemm_variant(8)
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_gemm_group_layernorm_gelu_epilogue(lib, name, prec, dt, ulp):
+    """ConvT #1 of the mask upscaler: GEMM + LayerNorm2d over each 64-channel group + GELU (mask_decoder.py:53-56)."""
+    g = torch.Generator().manual_seed(31)
+    M, N, K = 512, 256, 256
+    A, Ab = et_bits(torch.randn(M, K, generator=g), dt)
+    B, Bb = et_bits(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
+    bias = torch.randn(N, generator=g) * 0.5
+    gamma = 1 + 0.2 * torch.randn(64, generator=g)
+    beta = 0.2 * torch.randn(64, generator=g)
+    y = (A.double() @ B.double().t() + bias.double()).view(M, N // 64, 64)
+    mu = y.mean(-1, keepdim=True)
+    var = ((y - mu) ** 2).mean(-1, keepdim=True)
+    ref = F.gelu((((y - mu) / torch.sqrt(var + 1e-6)) * gamma.double() + beta.double()).float()).view(M, N)
+    out = torch.empty(M, N, dtype=torch.int16, device="cuda")
+    gb = dev(torch.cat([gamma, beta]))
+    assert lib.samrs_k_gemm_gln(prec, dev(Ab).data_ptr(), dev(Bb).data_ptr(), out.data_ptr(), dev(bias).data_ptr(), gb.data_ptr(),
+                                M, N, K, stream()) == 0
+    err = (out.cpu().view(dt).float() - ref).abs() / ref.abs().clamp(min=1e-2)
+    print(f"gemm+groupLN+gelu {name}: max rel {err.max().item():.2e}")
+    assert err.max().item() < 1.5 * ulp
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("n_sel,sel0", [(1, 0), (3, 1)])
+def test_upscale2_masks_fused(lib, name, prec, dt, ulp, n_sel, sel0):
+    """ConvT #2 (as a K = 64 GEMM) + GELU + hypernetwork dot, fused (mask_decoder.py:57-59,154-167)."""
+    g = torch.Generator().manual_seed(77 + n_sel)
+    n, grid = 3, 16
+    rows = n * grid * grid * 4
+    U, Ub = et_bits(torch.randn(rows, 64, generator=g), dt)
+    Wt, Wb = et_bits(torch.randn(128, 64, generator=g) / 8, dt)
+    bias = 0.3 * torch.randn(128, generator=g)
+    hyper = torch.randn(n, 4, 32, generator=g)
+    up2 = F.gelu((U.double() @ Wt.double().t() + bias.double()).float()).double()        # [rows][sub2*32 + c]
+    up2 = up2.view(n, grid, grid, 2, 2, 2, 2, 32)                                          # b, y, x, dy, dx, dy2, dx2, c
+    S = 4 * grid
+    ref = torch.einsum("byxijklc,bsc->bsyikxjl", up2, hyper[:, sel0:sel0 + n_sel].double()).reshape(n, n_sel, S, S)
+    low = torch.full((n, n_sel, S, S), float("nan"), device="cuda")
+    assert lib.samrs_k_upscale2_masks(prec, dev(Ub).data_ptr(), dev(Wb).data_ptr(), dev(bias).data_ptr(), dev(hyper).data_ptr(),
+                                      low.data_ptr(), n, grid, 4, sel0, n_sel, stream()) == 0
+    r, mx = rel_err(low.cpu(), ref)
+    print(f"upscale2+mask {name} n_sel={n_sel}: rel {r:.2e} max {mx:.2e}")
+    assert not torch.isnan(low).any(), "some low-res pixels were never written"
+    assert r < 2e-5
+
+
 def test_gemm_f32_exact_class(lib):
     g = torch.Generator().manual_seed(5)
     for (M, N, K, lda_pad, relu, acc) in [(7, 32, 256, 0, 0, 0), (224, 2048, 256, 0, 1, 0), (224, 256, 2048, 0, 0, 1),

@@ -18,7 +18,7 @@ run() { # name timeout cmd...
 PT="python -m pytest -m gpu -q -s -rA -p no:cacheprovider"
 for grp in "$@"; do
   case $grp in
-    k_basic)  run k_basic 600 $PT tests/test_kernels_gpu.py -k "convert or gemm or layernorm or postprocess" ;;
+    k_basic)  run k_basic 600 $PT tests/test_kernels_gpu.py -k "convert or gemm or layernorm or postprocess or upscale2" ;;
     k_win)    run k_win 600 $PT tests/test_kernels_gpu.py -k "window_attention" ;;
     k_glb)    run k_glb 600 $PT tests/test_kernels_gpu.py -k "global_attention" ;;
     p_enc)    run p_enc 900 $PT tests/test_parity_gpu.py -k "encoder_blockwise" ;;

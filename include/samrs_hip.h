@@ -161,6 +161,14 @@ int samrs_debug_copy_buffer(samrs_engine_t* e, const char* name, void* dst, size
 int samrs_debug_time_dominant_kernel(samrs_engine_t* e, int enable);
 int samrs_debug_dominant_kernel_time(samrs_engine_t* e, float* avg_ms, int* launches, int* M, int* N, int* K);
 
+/* Rotated-box MASK prompts, replacing the cv2 pre-step of `Generate Dataset/main_sam_rbox_mask_instance.py:125-141`
+ * (fillPoly -> +-1000 -> resize to the ResizeLongestSide shape -> pad with -1000 -> resize to 256x256).
+ * pts: device int32 [n][n_vertices][2] (x, y) in ORIGINAL image pixels (the reference's `.astype(np.int32)`),
+ * 3 <= n_vertices <= 8; (h, w) original size; (th, tw) = ResizeLongestSide.get_preprocess_shape(h, w, img_size);
+ * out: device fp32 [n][out_size][out_size] = the `mask_input` of samrs_predict (out_size = 256). */
+int samrs_rbox_mask_prompt(const int32_t* pts, int n, int n_vertices, int h, int w, int th, int tw,
+                           int img_size, int out_size, float* out, void* stream);
+
 /* -- kernel-level entry points (used by the parity tests to check each kernel alone) --------
  * All pointers are device pointers.  `prec` is enum samrs_precision; "et" = MFMA operand type
  * (bf16 or f16 bit patterns in uint16). */

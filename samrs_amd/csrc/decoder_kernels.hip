@@ -718,6 +718,120 @@ __global__ void resample_pass_kernel(const uint8_t* __restrict__ in, uint8_t* __
     out[t] = (uint8_t)ss;
 }
 
+// ---- rotated-box mask prompt (N3: replaces cv2.fillPoly / resize / copyMakeBorder) ---------------------
+// `Generate Dataset/main_sam_rbox_mask_instance.py:125-141`: polygon -> +-1000 mask at the image size ->
+// bilinear resize to the ResizeLongestSide shape -> pad to img_size^2 with -1000 -> bilinear resize to 256^2.
+// One thread per OUTPUT pixel composes the two resizes on the fly (2x2 taps of 2x2 taps = 16 polygon tests),
+// so no intermediate image exists.  Arithmetic follows OpenCV's published algorithms (see oracle/rbox_prompt.py
+// for the citations): float32 tap weights from double coordinates, double accumulation, horizontal pass before
+// vertical pass; polygon = FillEdgeCollection spans (16.16 fixed point, ceil(left) .. floor(right)) united with
+// the 8-connected LineIterator walk of every edge, here in closed form:
+//   after i major steps the walk has taken  floor((2 * dminor * i + dmajor - 1) / (2 * dmajor))  minor steps.
+// FP contraction is off: the products of the second stage are not exact, an fma would round differently.
+constexpr int RBOX_MAXV = 8;
+struct RboxPoly {
+    int x[RBOX_MAXV], y[RBOX_MAXV];
+    long long ex[RBOX_MAXV], edx[RBOX_MAXV];      // per edge (v-1 -> v): x at y0 (16.16), dx per scanline
+    int ey0[RBOX_MAXV], ey1[RBOX_MAXV];           // scanline range [y0, y1); y0 == y1 for horizontal edges
+    int nv;
+};
+
+__device__ __forceinline__ bool rbox_on_line(int px, int py, int x1, int y1, int x2, int y2) {
+    if (x2 < x1) { int t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }     // leftToRight
+    const int dx = x2 - x1, sdy = y2 - y1, dy = sdy < 0 ? -sdy : sdy, ys = sdy < 0 ? -1 : 1;
+    if (dy > dx) {                               // y major
+        const int i = (py - y1) * ys;
+        if (i < 0 || i > dy) return false;
+        return px == x1 + (int)((2LL * dx * i + dy - 1) / (2LL * dy));
+    }
+    const int i = px - x1;
+    if (i < 0 || i > dx) return false;
+    if (dx == 0) return py == y1;                // a single point
+    return py == y1 + ys * (int)((2LL * dy * i + dx - 1) / (2LL * dx));
+}
+
+__device__ bool rbox_inside(const RboxPoly& P, int px, int py) {
+    bool in = false;
+    long long xs[RBOX_MAXV];
+    int na = 0;
+    for (int e = 0; e < P.nv; ++e) {
+        const int a = e == 0 ? P.nv - 1 : e - 1;
+        if (rbox_on_line(px, py, P.x[a], P.y[a], P.x[e], P.y[e])) in = true;
+        if (P.ey0[e] <= py && py < P.ey1[e]) {
+            const long long xe = P.ex[e] + (long long)(py - P.ey0[e]) * P.edx[e];
+            int k = na++;
+            while (k > 0 && xs[k - 1] > xe) { xs[k] = xs[k - 1]; --k; }      // insertion sort (<= 8 entries)
+            xs[k] = xe;
+        }
+    }
+    for (int k = 0; k + 1 < na; k += 2) {
+        const long long xa = (xs[k] + 65535) >> 16, xb = xs[k + 1] >> 16;
+        if (xa <= px && px <= xb) in = true;
+    }
+    return in;
+}
+
+struct RTap { int i0, i1; float w0, w1; };
+__device__ __forceinline__ RTap rbox_tap(int d, int n_in, int n_out) {
+#pragma clang fp contract(off)
+    const double inv = (double)n_out / (double)n_in;
+    const double scale = 1.0 / inv;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= n_in - 1) { f = 0.f; s = n_in - 1; }
+    RTap t;
+    t.i0 = s;
+    t.i1 = s + 1 < n_in ? s + 1 : n_in - 1;
+    t.w0 = 1.0f - f;
+    t.w1 = f;
+    return t;
+}
+
+// grid (out*out / 256, n_boxes); pts int32 [n][nv][2] (x, y)
+__global__ __launch_bounds__(256) void rbox_prompt_kernel(const int32_t* __restrict__ pts, int nv, int h, int w, int th, int tw,
+                                                          int img_size, int out_size, float* __restrict__ out) {
+#pragma clang fp contract(off)
+    __shared__ RboxPoly P;
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        P.nv = nv;
+        for (int e = 0; e < nv; ++e) { P.x[e] = pts[((size_t)b * nv + e) * 2]; P.y[e] = pts[((size_t)b * nv + e) * 2 + 1]; }
+        for (int e = 0; e < nv; ++e) {
+            const int a = e == 0 ? nv - 1 : e - 1;
+            const long long x0 = P.x[a], y0 = P.y[a], x1 = P.x[e], y1 = P.y[e];
+            if (y0 == y1) { P.ey0[e] = P.ey1[e] = 0; P.ex[e] = P.edx[e] = 0; continue; }
+            P.edx[e] = ((x1 - x0) << 16) / (y1 - y0);                 // C++ division: truncates toward zero
+            if (y0 < y1) { P.ey0[e] = (int)y0; P.ey1[e] = (int)y1; P.ex[e] = x0 << 16; }
+            else { P.ey0[e] = (int)y1; P.ey1[e] = (int)y0; P.ex[e] = x1 << 16; }
+        }
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= out_size * out_size) return;
+    const int oy = pix / out_size, ox = pix % out_size;
+    const RTap by = rbox_tap(oy, img_size, out_size), bx = rbox_tap(ox, img_size, out_size);
+    const int Ys[2] = {by.i0, by.i1}, Xs[2] = {bx.i0, bx.i1};
+    double pv[2][2];
+    for (int a = 0; a < 2; ++a)
+        for (int c = 0; c < 2; ++c) {
+            const int Y = Ys[a], X = Xs[c];
+            if (Y >= th || X >= tw) { pv[a][c] = -1000.0; continue; }      // copyMakeBorder(value = -1000)
+            const RTap ay = rbox_tap(Y, h, th), ax = rbox_tap(X, w, tw);
+            const double m00 = rbox_inside(P, ax.i0, ay.i0) ? 1000.0 : -1000.0;
+            const double m01 = rbox_inside(P, ax.i1, ay.i0) ? 1000.0 : -1000.0;
+            const double m10 = rbox_inside(P, ax.i0, ay.i1) ? 1000.0 : -1000.0;
+            const double m11 = rbox_inside(P, ax.i1, ay.i1) ? 1000.0 : -1000.0;
+            const double r0 = m00 * (double)ax.w0 + m01 * (double)ax.w1;      // horizontal pass
+            const double r1 = m10 * (double)ax.w0 + m11 * (double)ax.w1;
+            pv[a][c] = r0 * (double)ay.w0 + r1 * (double)ay.w1;              // vertical pass
+        }
+    const double t0 = pv[0][0] * (double)bx.w0 + pv[0][1] * (double)bx.w1;
+    const double t1 = pv[1][0] * (double)bx.w0 + pv[1][1] * (double)bx.w1;
+    out[(size_t)b * out_size * out_size + pix] = (float)(t0 * (double)by.w0 + t1 * (double)by.w1);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -843,5 +957,14 @@ hipError_t launch_paint(const uint8_t* masks, const int32_t* labels, int n, int 
         if (class_pixels || class_instances)
             class_stats_kernel<<<1, 64, 0, s>>>(areas, labels, n, class_pixels, class_instances, n_classes);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_rbox_prompt(const int32_t* pts, int n, int nv, int h, int w, int th, int tw, int img_size, int out_size,
+                              float* out, hipStream_t s) {
+    if (n < 1 || nv < 3 || nv > RBOX_MAXV || h < 1 || w < 1 || th < 1 || tw < 1 || th > img_size || tw > img_size || out_size < 1)
+        return hipErrorInvalidValue;
+    dim3 g((out_size * out_size + 255) / 256, n), b(256);
+    rbox_prompt_kernel<<<g, b, 0, s>>>(pts, nv, h, w, th, tw, img_size, out_size, out);
     return hipGetLastError();
 }

@@ -808,6 +808,11 @@ int samrs_resample_pass_u8(const uint8_t* in, uint8_t* out, const int32_t* bound
     if (!in || !out || !bounds || !coef || ksize < 1 || in_len < 1 || out_len < 1 || other < 1) return SAMRS_ERR_BAD_ARG;
     KRET(launch_resample_pass(in, out, bounds, coef, ksize, in_len, out_len, other, horizontal, (hipStream_t)stream));
 }
+int samrs_rbox_mask_prompt(const int32_t* pts, int n, int n_vertices, int h, int w, int th, int tw, int img_size, int out_size,
+                           float* out, void* stream) {
+    if (!pts || !out) return SAMRS_ERR_BAD_ARG;
+    KRET(launch_rbox_prompt(pts, n, n_vertices, h, w, th, tw, img_size, out_size, out, (hipStream_t)stream));
+}
 int samrs_k_postprocess(const float* low, int n_masks, int in_h, int in_w, int orig_h, int orig_w, int img_size,
                         int return_logits, void* out, void* stream) {
     KRET(launch_postprocess(low, n_masks, in_h, in_w, orig_h, orig_w, img_size, return_logits, out, (hipStream_t)stream));

@@ -93,3 +93,6 @@ hipError_t launch_paint(const uint8_t* masks, const int32_t* labels, int n, int 
                         unsigned long long* class_instances, int n_classes, hipStream_t s);
 hipError_t launch_resample_pass(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* coef, int ksize,
                                 int in_len, int out_len, int other, int horizontal, hipStream_t s);
+// rotated-box polygons (int32 [n][nv][2]) -> mask prompts [n][out][out] fp32 (main_sam_rbox_mask_instance.py:125-141)
+hipError_t launch_rbox_prompt(const int32_t* pts, int n, int nv, int h, int w, int th, int tw, int img_size, int out_size,
+                              float* out, hipStream_t s);

@@ -5,7 +5,7 @@ scaling is the part that sits on the hot path."""
 from __future__ import annotations
 
 from copy import deepcopy
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -133,3 +133,33 @@ class ResizeLongestSide:
         scale = long_side_length * 1.0 / max(oldh, oldw)
         newh, neww = oldh * scale, oldw * scale
         return int(newh + 0.5), int(neww + 0.5)
+
+
+def rbox_mask_prompts(polys, original_size: Tuple[int, int], img_size: int = 1024, out_size: int = 256,
+                      device: Optional["torch.device"] = None) -> torch.Tensor:
+    """Rotated boxes -> SAM mask prompts on the GPU, replacing the cv2 pre-step of
+    `Generate Dataset/main_sam_rbox_mask_instance.py:125-141` (fillPoly -> +-1000 -> resize to the
+    ResizeLongestSide shape -> pad with -1000 -> resize to 256x256).
+
+    polys: [n, V, 2] (x, y) vertices in original-image pixels (float or int; truncated like the reference's
+    `.astype(np.int32)`), 3 <= V <= 8.  Returns fp32 [n, out_size, out_size] on the device; feed
+    `prompts[:, None]` as `mask_input` of `SamPredictor.predict_torch` (main_sam_rbox_mask_instance.py:159-164)."""
+    from . import engine as _engine
+    lib = _engine.load_library()
+    if not torch.cuda.is_available():
+        raise RuntimeError("rbox_mask_prompts needs the HIP device (no CPU fallback)")
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    p = np.asarray(polys)
+    if p.ndim != 3 or p.shape[2] != 2 or not (3 <= p.shape[1] <= 8):
+        raise ValueError(f"polys must be [n, V, 2] with 3 <= V <= 8, got {p.shape}")
+    pts = torch.from_numpy(np.ascontiguousarray(p.astype(np.int32))).to(dev)
+    h, w = int(original_size[0]), int(original_size[1])
+    th, tw = ResizeLongestSide.get_preprocess_shape(h, w, img_size)
+    out = torch.empty(p.shape[0], out_size, out_size, dtype=torch.float32, device=dev)
+    if p.shape[0] == 0:
+        return out
+    rc = lib.samrs_rbox_mask_prompt(pts.data_ptr(), p.shape[0], p.shape[1], h, w, th, tw, img_size, out_size, out.data_ptr(),
+                                    torch.cuda.current_stream(dev).cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"samrs_rbox_mask_prompt failed with code {rc}")
+    return out

@@ -244,7 +244,8 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
                                                    const float* __restrict__ add2d, int add2d_period, int N,
                                                    int m_base /* first row of the wave tile */,
                                                    int n_base /* first column of the wave tile */, int accumulate,
-                                                   int lane) {
+                                                   int lane, const float* __restrict__ pre2d = nullptr /* ET output: 2-D addend
+                                                   applied before the bounce, loaded element by element (keeps registers low) */) {
     const int fr = lane & 15, fq = lane >> 4;
     // padded row stride: the smallest >= the 16*NI-column row with (words % 32) == 4, which spreads the 16
     // rows of an accumulator column block over all banks (NI = 4: 272 / 144 bytes)
@@ -290,6 +291,11 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
             for (int i = 0; i < NI; ++i) {
                 float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
                 float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+                if (pre2d) {
+                    const float4 e = *reinterpret_cast<const float4*>(pre2d + (size_t)((m_base + j * 16 + fr) % add2d_period) * N +
+                                                                      n_base + i * 16 + 4 * fq);
+                    v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
+                }
                 if (GLN) {
                     const float4 gm = *reinterpret_cast<const float4*>(add2d + i * 16 + 4 * fq);
                     const float4 bt = *reinterpret_cast<const float4*>(add2d + 64 + i * 16 + 4 * fq);
@@ -344,6 +350,63 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
                     *reinterpret_cast<uint4*>(C) = v;
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ET-output epilogue of the 256x320 kernel (NI = 5).  A wave's sub-tile is 80 columns = 160 bytes per row:
+// stored per wave, the row segments straddle 64-byte sectors and the generic code spills.  Here the two waves
+// that sit side by side (wn = 2p, 2p+1: 160 columns = 320 bytes, 64-byte aligned) bounce through ONE shared
+// LDS buffer and each stores half of the rows as full 320-byte segments (20 lanes x 16 B per row).
+// Block-wide barriers: all 8 waves are past the main loop here (the stagger has been re-aligned).
+//   acc[i][j]: n-tile i (16 cols), m-tile j (16 rows); 8 m-tiles, 4 per pass.
+// ---------------------------------------------------------------------------------------------
+template <int PREC, bool GELU>
+__device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned char* lds, void* __restrict__ Cv,
+                                                 const float* __restrict__ bias, const float* __restrict__ pre2d, int period, int N,
+                                                 int m_base /* wave tile row 0 */, int n_pair /* first column of the pair */,
+                                                 int wm, int wn, int lane) {
+    constexpr int RS = 400;                 // 320 data bytes + pad: 100 words = 4 (mod 32)
+    constexpr int TS = 16 * RS, JC = 4;
+    const int fr = lane & 15, fq = lane >> 4, half = wn & 1;
+    unsigned char* scr = lds + (wm * 2 + (wn >> 1)) * (JC * TS);
+    float4 bv[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+        bv[i] = bias ? *reinterpret_cast<const float4*>(bias + n_pair + half * 80 + i * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j0 = 0; j0 < 8; j0 += JC) {
+        if (j0) __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj) {
+            const int j = j0 + jj;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
+                float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+                if (pre2d) {
+                    const float4 e = *reinterpret_cast<const float4*>(pre2d + (size_t)((m_base + j * 16 + fr) % period) * N + n_pair +
+                                                                      half * 80 + i * 16 + 4 * fq);
+                    v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
+                }
+                if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
+                uint2 o;
+                o.x = pack2<PREC>(v0, v1);
+                o.y = pack2<PREC>(v2, v3);
+                *reinterpret_cast<uint2*>(scr + jj * TS + fr * RS + half * 160 + (i * 16 + 4 * fq) * 2) = o;
+            }
+        }
+        __syncthreads();
+        // this wave: rows 8*half .. +7 of each of the 4 m-tiles = 4 x 8 rows x 20 chunks = 10 passes of 64 lanes
+#pragma unroll
+        for (int h = 0; h < 10; ++h) {
+            const int idx = lane + 64 * h;
+            const int jj = idx / 160, rem = idx % 160;
+            const int row = 8 * half + rem / 20, ch = rem % 20;
+            const uint4 v = *reinterpret_cast<const uint4*>(scr + jj * TS + row * RS + ch * 16);
+            uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)(m_base + (j0 + jj) * 16 + row) * N + n_pair + ch * 8;
+            *reinterpret_cast<uint4*>(C) = v;
         }
     }
 }
@@ -820,18 +883,14 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
     }
     {   // coalesced epilogue through the idle ring (16 KiB per wave)
         unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (QSTAGES * QSTAGE_ELEMS * 2 / 8);
-        if (!OUT_F32 && add2d) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int m = m0 + wm * 128 + j * 16 + fr, n = n0 + wn * (16 * NI) + i * 16 + 4 * fq;
-                    const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
-                    acc[i][j][0] += e.x; acc[i][j][1] += e.y; acc[i][j][2] += e.z; acc[i][j][3] += e.w;
-                }
+        const float* pre2d = OUT_F32 ? nullptr : add2d;     // ET output: the 2-D addend goes in before the rounding
+        if constexpr (NI == 5 && !OUT_F32) {
+            epilogue_pair_et<PREC, GELU>(acc, reinterpret_cast<unsigned char*>(lds), Cv, bias, pre2d, add2d_period, N, m0 + wm * 128,
+                                         n0 + (wn >> 1) * 160, wm, wn, lane);
+        } else {
+            epilogue_coalesced<PREC, OUT_F32, GELU, 8, OUT_F32 ? 2 : 4, NI>(acc, scr, Cv, bias, OUT_F32 ? add2d : nullptr, add2d_period,
+                                                                             N, m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane, pre2d);
         }
-        epilogue_coalesced<PREC, OUT_F32, GELU, 8, OUT_F32 ? 2 : 4, NI>(acc, scr, Cv, bias, OUT_F32 ? add2d : nullptr, add2d_period,
-                                                                         N, m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane);
     }
 }
 
@@ -1200,10 +1259,10 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         const long t320 = big_ok && N % WBN == 0 ? (long)(M / QBM) * (N / WBN) : 0;
         // fp32 residual outputs (proj, lin2: N = 1280): 256x320 tiles -> an exact number of rounds over the 256 CUs
         if (out_f32 && t320 >= 256) variant = 10;
-        // qkv and lin1+GELU at batch size: 256x256 tile, as long as there are >= 4 rounds of tiles
-        else if (!out_f32 && N >= 2048 && t256 >= 1024) variant = 6;
-        // small batch: the wide tile when it fills whole rounds (lin1 of one image = exactly 256 tiles)
+        // f16 outputs (qkv N = 3840, lin1+GELU N = 5120): the wide tile whenever it fills whole rounds (6 / 8 rounds at
+        // batch 8, exactly one round for lin1 of a single image), else 256x256 as long as there are >= 4 rounds of tiles
         else if (!out_f32 && t320 >= 256 && t320 % 256 == 0) variant = 10;
+        else if (!out_f32 && N >= 2048 && t256 >= 1024) variant = 6;
         else variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
     }
     if (variant == 9 && M % DBM == 0 && K % DBK == 0) {   // 2 blocks / CU, lock-step (one barrier per K step)

@@ -15,7 +15,7 @@ prec_name = sys.argv[2] if len(sys.argv) > 2 else "f16"
 prec = engine.PRECISIONS[prec_name]
 dt = torch.float16 if prec_name == "f16" else torch.bfloat16
 shapes = [("qkv-like", 32768, 3840, 1280, 0, 0, 0)] if os.environ.get("ABL") else [("lin1+gelu", 32768, 5120, 1280, 0, 1, 0), ("lin2+res", 32768, 1280, 5120, 1, 0, 1),
-          ("qkv(win)", 39424, 3840, 1280, 0, 0, 0), ("proj+res", 32768, 1280, 1280, 1, 0, 1),
+          ("qkv     ", 32768, 3840, 1280, 0, 0, 0), ("proj+res", 32768, 1280, 1280, 1, 0, 1),
           ("lin1 b=1", 4096, 5120, 1280, 0, 1, 0)]
 g = torch.Generator().manual_seed(0)
 for name, M, N, K, of32, gelu, acc in shapes:

@@ -260,6 +260,27 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
         bv[i] = bias ? *reinterpret_cast<const float4*>(bias + n_base + i * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j0 = 0; j0 < NJ; j0 += JC) {
+        // fp32 output: the residual (old C) and the 2-D addend of this pass do not depend on the accumulators --
+        // issue their loads FIRST, so that they are in flight during the LDS bounce instead of after it
+        float4 res[OUT_F32 ? JC : 1][OUT_F32 ? NPASS : 1];
+        if (OUT_F32) {
+#pragma unroll
+            for (int jj = 0; jj < JC; ++jj)
+#pragma unroll
+                for (int h = 0; h < NPASS; ++h) {
+                    const int idx = lane + 64 * h;
+                    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (NCH % 64 == 0 || idx < NCH) {
+                        const int m = m_base + (j0 + jj) * 16 + idx / CPR, n = n_base + (idx % CPR) * 4;
+                        if (accumulate) r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cv) + (size_t)m * N + n);
+                        if (add2d) {
+                            const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
+                            r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;
+                        }
+                    }
+                    res[jj][h] = r;
+                }
+        }
         if (j0) wave_lds_sync_g();
 #pragma unroll
         for (int jj = 0; jj < JC; ++jj) {
@@ -327,15 +348,9 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
                     const int row = idx / CPR, ch = idx % CPR;
                     float4 v = *reinterpret_cast<const float4*>(scr + jj * TS + row * RS + ch * 16);
                     const int m = m_base + j * 16 + row, n = n_base + ch * 4;
-                    if (add2d) {
-                        const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
-                        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
-                    }
+                    const float4 o = res[OUT_F32 ? jj : 0][OUT_F32 ? h : 0];
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                     float* C = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
-                    if (accumulate) {
-                        const float4 o = *reinterpret_cast<const float4*>(C);
-                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    }
                     *reinterpret_cast<float4*>(C) = v;
                 }
             } else {

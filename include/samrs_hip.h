@@ -149,6 +149,8 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
 
 /* -- test / tuning hook: 0 = register-staged GEMM tiles, 1 = LDS-DMA staging (default). */
 void samrs_debug_set_gemm_variant(int variant);
+/* test / timing hook: 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm / product launches) */
+void samrs_debug_set_decoder_fusion(int on);
 
 /* -- test hook: copy a prefix of a named internal decoder buffer (Q, KF, KE, KVQ, OI, U1raw, U1, U2,
  * HYPER, ...) to a device buffer; used to localise run-to-run differences. */

@@ -430,6 +430,165 @@ __global__ __launch_bounds__(256) void i2t_attention_kernel(const uint16_t* __re
     *reinterpret_cast<uint4*>(orow + 8) = o1;
 }
 
+// ---- fused image -> tokens attention + output projection + residual + LayerNorm ------------------------
+// transformer.py:176-181 (TwoWayAttentionBlock step 4):  keys = norm4(keys + out_proj(attn(q = keys + pe, k, v)))
+// Everything is local to an image token: a 128-vector of attention output, 256 projected channels, a LayerNorm
+// over those 256.  Done as three kernels the 134 MB fp32 key tensor makes four trips through HBM (GEMM
+// read-modify-write, LN read + write) plus the attention output's round trip; here it makes two.
+// Block = 2 waves, 16 image tokens per group, several groups per block:
+//   * attention: thread = (token, head) exactly as in i2t_attention_kernel; its 16 outputs are rounded to ET and
+//     written to an LDS A tile [16][128] (same rounding point as the unfused path's `OI` buffer);
+//   * projection: wave w owns output columns 128 w .. +127; its W fragments (8 n-tiles x 4 k-steps) stay in 128
+//     registers for the whole block, A fragments come from the LDS tile, `mfma_16x16x32`, same k order as the GEMM;
+//   * + bias + residual (old keys, or the shared image embedding in layer 0), LayerNorm over the row: the 4 lane
+//     quarters of a wave hold 128 of its 256 values, the two waves exchange partial sums through LDS (two-pass
+//     statistics), then write fp32 keys and their ET copy.
+constexpr int I2TF_ROWS = 16;          // image tokens per group
+constexpr int I2TF_AST = 136;          // A-tile row stride (ET): 272 B = 68 words = 4 (mod 32)
+
+template <int PREC>
+__global__ __launch_bounds__(128) void i2t_fused_kernel(const uint16_t* __restrict__ qi, int ld, long q_bstride,
+                                                        const float* __restrict__ kt, const float* __restrict__ vt,
+                                                        const uint16_t* __restrict__ w, const float* __restrict__ bias,
+                                                        const float* __restrict__ resid, long r_bstride,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ outF, uint16_t* __restrict__ outE,
+                                                        int T, int tokens, int groups_per_block) {
+    constexpr int HD = 16, HEADS = 8, CI = 128, CO = 256;
+    constexpr int KRS = HEADS * I2T_HS;                       // padded k / v row stride (floats)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    float* sk = reinterpret_cast<float*>(smraw);              // [T][KRS]
+    float* sv = sk + T * KRS;
+    float* sp = sv + T * KRS;                                 // bias | gamma | beta, [3][256]
+    float* ex = sp + 3 * CO;                                  // [2 stats][2 waves][16 rows]
+    uint16_t* At = reinterpret_cast<uint16_t*>(ex + 2 * 2 * I2TF_ROWS);   // [16][I2TF_AST]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int b = blockIdx.y;
+    for (int i = tid; i < T * CI; i += 128) {
+        const int j = i / CI, c = i % CI;
+        sk[j * KRS + (c / HD) * I2T_HS + c % HD] = kt[(size_t)b * T * CI + i];
+        sv[j * KRS + (c / HD) * I2T_HS + c % HD] = vt[(size_t)b * T * CI + i];
+    }
+    for (int i = tid; i < CO; i += 128) { sp[i] = bias[i]; sp[CO + i] = gamma[i]; sp[2 * CO + i] = beta[i]; }
+    uint4 wf[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            wf[i][ks] = *reinterpret_cast<const uint4*>(w + (size_t)(wave * 128 + i * 16 + fr) * CI + ks * 32 + fq * 8);
+    __syncthreads();
+
+    const int tr = tid >> 3, h = tid & 7;                     // attention role: token-in-group, head
+    const int g0 = blockIdx.x * groups_per_block;
+    // this thread's query slice of the NEXT group is loaded while the current group is projected / normalised
+    const uint16_t* qbase = qi + (size_t)b * q_bstride * ld + (size_t)tr * ld + h * HD;
+    uint4 q0 = make_uint4(0u, 0u, 0u, 0u), q1 = q0;
+    if (g0 * I2TF_ROWS < tokens) {
+        q0 = *reinterpret_cast<const uint4*>(qbase + (size_t)g0 * I2TF_ROWS * ld);
+        q1 = *reinterpret_cast<const uint4*>(qbase + (size_t)g0 * I2TF_ROWS * ld + 8);
+    }
+    for (int g = g0; g < g0 + groups_per_block; ++g) {
+        const int row0 = g * I2TF_ROWS;
+        if (row0 >= tokens) break;
+        // ---- residual loads first: they fly during the attention math -------------------------------------
+        const size_t rrow = (size_t)b * r_bstride + row0 + fr, orow = (size_t)b * tokens + row0 + fr;
+        float4 rs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rs[i] = *reinterpret_cast<const float4*>(resid + rrow * CO + wave * 128 + i * 16 + 4 * fq);
+        // ---- attention of (token tr, head h) over the T prompt tokens ------------------------------------------
+        {
+            const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            float qf[HD];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                qf[2 * c] = ET<PREC>::to_float((uint16_t)(qw[c] & 0xffffu)) * 0.25f;
+                qf[2 * c + 1] = ET<PREC>::to_float((uint16_t)(qw[c] >> 16)) * 0.25f;
+            }
+            float m = -INFINITY, l = 0.f, acc[HD];
+#pragma unroll
+            for (int c = 0; c < HD; ++c) acc[c] = 0.f;
+            for (int j = 0; j < T; ++j) {
+                float kr[HD], vr[HD];
+#pragma unroll
+                for (int c4 = 0; c4 < HD / 4; ++c4) {
+                    const float4 k4 = *reinterpret_cast<const float4*>(sk + j * KRS + h * I2T_HS + 4 * c4);
+                    const float4 v4 = *reinterpret_cast<const float4*>(sv + j * KRS + h * I2T_HS + 4 * c4);
+                    kr[4 * c4] = k4.x; kr[4 * c4 + 1] = k4.y; kr[4 * c4 + 2] = k4.z; kr[4 * c4 + 3] = k4.w;
+                    vr[4 * c4] = v4.x; vr[4 * c4 + 1] = v4.y; vr[4 * c4 + 2] = v4.z; vr[4 * c4 + 3] = v4.w;
+                }
+                float sc = 0.f;
+#pragma unroll
+                for (int c = 0; c < HD; ++c) sc += qf[c] * kr[c];
+                const float mn = fmaxf(m, sc);
+                const float corr = __expf(m - mn), pj = __expf(sc - mn);
+                l = l * corr + pj;
+#pragma unroll
+                for (int c = 0; c < HD; ++c) acc[c] = acc[c] * corr + pj * vr[c];
+                m = mn;
+            }
+            const float inv = 1.0f / l;
+            uint4 o0, o1;
+            o0.x = pack2<PREC>(acc[0] * inv, acc[1] * inv);   o0.y = pack2<PREC>(acc[2] * inv, acc[3] * inv);
+            o0.z = pack2<PREC>(acc[4] * inv, acc[5] * inv);   o0.w = pack2<PREC>(acc[6] * inv, acc[7] * inv);
+            o1.x = pack2<PREC>(acc[8] * inv, acc[9] * inv);   o1.y = pack2<PREC>(acc[10] * inv, acc[11] * inv);
+            o1.z = pack2<PREC>(acc[12] * inv, acc[13] * inv); o1.w = pack2<PREC>(acc[14] * inv, acc[15] * inv);
+            *reinterpret_cast<uint4*>(At + tr * I2TF_AST + h * HD) = o0;
+            *reinterpret_cast<uint4*>(At + tr * I2TF_AST + h * HD + 8) = o1;
+        }
+        __syncthreads();
+        if (g + 1 < g0 + groups_per_block && (g + 1) * I2TF_ROWS < tokens) {
+            q0 = *reinterpret_cast<const uint4*>(qbase + (size_t)(g + 1) * I2TF_ROWS * ld);
+            q1 = *reinterpret_cast<const uint4*>(qbase + (size_t)(g + 1) * I2TF_ROWS * ld + 8);
+        }
+        // ---- projection: 16 rows x 128 columns per wave, K = 128 ----------------------------------------------------
+        uint4 af[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) af[ks] = *reinterpret_cast<const uint4*>(At + fr * I2TF_AST + ks * 32 + fq * 8);
+        float v[8][4];
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) a = ET<PREC>::mfma16(wf[i][ks], af[ks], a);
+            const float4 bb = *reinterpret_cast<const float4*>(sp + wave * 128 + i * 16 + 4 * fq);
+            v[i][0] = (a[0] + bb.x) + rs[i].x; v[i][1] = (a[1] + bb.y) + rs[i].y;
+            v[i][2] = (a[2] + bb.z) + rs[i].z; v[i][3] = (a[3] + bb.w) + rs[i].w;
+            s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        // ---- LayerNorm over the 256 values of row fr: lane quarters, then the two waves ---------------------------
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (fq == 0) ex[wave * I2TF_ROWS + fr] = s1;
+        __syncthreads();
+        const float mean = (ex[fr] + ex[I2TF_ROWS + fr]) * (1.0f / CO);
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[i][r] -= mean; s2 += v[i][r] * v[i][r]; }
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (fq == 0) ex[2 * I2TF_ROWS + wave * I2TF_ROWS + fr] = s2;
+        __syncthreads();
+        const float rstd = 1.0f / sqrtf((ex[2 * I2TF_ROWS + fr] + ex[3 * I2TF_ROWS + fr]) * (1.0f / CO) + eps);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = wave * 128 + i * 16 + 4 * fq;
+            const float4 gm = *reinterpret_cast<const float4*>(sp + CO + n), bt = *reinterpret_cast<const float4*>(sp + 2 * CO + n);
+            const float y0 = v[i][0] * rstd * gm.x + bt.x, y1 = v[i][1] * rstd * gm.y + bt.y;
+            const float y2 = v[i][2] * rstd * gm.z + bt.z, y3 = v[i][3] * rstd * gm.w + bt.w;
+            *reinterpret_cast<float4*>(outF + orow * CO + n) = make_float4(y0, y1, y2, y3);
+            uint2 o;
+            o.x = pack2<PREC>(y0, y1);
+            o.y = pack2<PREC>(y2, y3);
+            *reinterpret_cast<uint2*>(outE + orow * CO + n) = o;
+        }
+        // the next group's A-tile / ex writes come after this group's last barrier and its reads above
+    }
+}
+
 // rows of 256 floats = 4 groups of 64: LayerNorm2d(64) (eps) + GELU per group -> ET.
 // One wave per row; lane holds 4 consecutive values; a group = 16 lanes.
 template <int PREC>
@@ -906,6 +1065,23 @@ hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long bstride, 
         i2t_attention_kernel<PREC_BF16><<<g, b, sh, s>>>((const uint16_t*)qi, ld, bstride, kt, vt, (uint16_t*)out, T, tokens, Ci);
     else
         i2t_attention_kernel<PREC_F16><<<g, b, sh, s>>>((const uint16_t*)qi, ld, bstride, kt, vt, (uint16_t*)out, T, tokens, Ci);
+    return hipGetLastError();
+}
+hipError_t launch_i2t_fused(int prec, const void* qi, int ld, long q_bstride, const float* kt, const float* vt, const void* w,
+                            const float* bias, const float* resid, long r_bstride, const float* gamma, const float* beta, float eps,
+                            float* outF, void* outE, int n, int T, int tokens, int Ci, int C, hipStream_t s) {
+    if (Ci != 128 || C != 256 || T < 1 || T > TOK_MAX || tokens % I2TF_ROWS) return hipErrorInvalidValue;
+    const int groups = tokens / I2TF_ROWS;
+    int gpb = 8;                                   // groups per block: W fragments (64 KB per block) are loaded once
+    while (gpb > 1 && groups % gpb) gpb >>= 1;
+    dim3 g(groups / gpb, n), b(128);
+    const size_t sh = (size_t)(2 * T * 8 * I2T_HS + 3 * 256 + 4 * I2TF_ROWS) * sizeof(float) + (size_t)I2TF_ROWS * I2TF_AST * 2;
+    if (prec == PREC_BF16)
+        i2t_fused_kernel<PREC_BF16><<<g, b, sh, s>>>((const uint16_t*)qi, ld, q_bstride, kt, vt, (const uint16_t*)w, bias, resid,
+                                                     r_bstride, gamma, beta, eps, outF, (uint16_t*)outE, T, tokens, gpb);
+    else
+        i2t_fused_kernel<PREC_F16><<<g, b, sh, s>>>((const uint16_t*)qi, ld, q_bstride, kt, vt, (const uint16_t*)w, bias, resid,
+                                                    r_bstride, gamma, beta, eps, outF, (uint16_t*)outE, T, tokens, gpb);
     return hipGetLastError();
 }
 hipError_t launch_group_ln_gelu(int prec, const float* in, const float* gamma, const float* beta, float eps,

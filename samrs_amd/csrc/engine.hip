@@ -27,6 +27,10 @@ struct DevTensor {
     size_t numel = 0;
 };
 
+// A/B knob for timing experiments and the fused-vs-unfused parity test: the decoder's fused kernels (upscaler, i2t + projection +
+// LayerNorm) can be switched off at run time (samrs_debug_set_decoder_fusion) or at load time (SAMRS_DECODER_FUSION=0).
+static bool g_decoder_fusion = [] { const char* v = getenv("SAMRS_DECODER_FUSION"); return !(v && atoi(v) == 0); }();
+
 struct DecAttn {
     const float *qw, *qb, *kw, *kb, *vw, *vb, *ow, *ob;
 };
@@ -654,12 +658,19 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
             bt.A[1] = e->Q; bt.A2[1] = nullptr; bt.W[1] = L.i2t.vw; bt.bias[1] = L.i2t.vb; bt.C[1] = e->VT;
             CK(e, launch_gemm_f32_batch(bt, 2, C, Ci, BT, Ci, C, false, false, s));
         }
-        CK(e, launch_i2t_attention(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, e->OI, n, T, tokens, Ci, 8, s));
-        if (sh)
-            CK(e, launch_gemm_et(prec, e->OI, L.i2t_ow, e->KF, L.i2t.ob, e->K0F, tokens, Mi, C, Ci, true, false, false, s));
-        else
-            CK(e, launch_gemm_et(prec, e->OI, L.i2t_ow, e->KF, L.i2t.ob, nullptr, 0, Mi, C, Ci, true, false, true, s));
-        CK(e, launch_layernorm(prec, e->KF, L.n4w, L.n4b, 1e-5f, e->KE, e->KF, Mi, C, 0, g, 0, s));
+        if (g_decoder_fusion && tokens % 16 == 0) {
+            // attention + out_proj + residual + norm4 in one pass over the keys (layer 0 without a mask prompt: the residual
+            // is the shared image embedding, batch stride 0)
+            CK(e, launch_i2t_fused(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, L.i2t_ow, L.i2t.ob, sh ? e->K0F : e->KF,
+                                   sh ? 0 : tokens, L.n4w, L.n4b, 1e-5f, e->KF, e->KE, n, T, tokens, Ci, C, s));
+        } else {
+            CK(e, launch_i2t_attention(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, e->OI, n, T, tokens, Ci, 8, s));
+            if (sh)
+                CK(e, launch_gemm_et(prec, e->OI, L.i2t_ow, e->KF, L.i2t.ob, e->K0F, tokens, Mi, C, Ci, true, false, false, s));
+            else
+                CK(e, launch_gemm_et(prec, e->OI, L.i2t_ow, e->KF, L.i2t.ob, nullptr, 0, Mi, C, Ci, true, false, true, s));
+            CK(e, launch_layernorm(prec, e->KF, L.n4w, L.n4b, 1e-5f, e->KE, e->KF, Mi, C, 0, g, 0, s));
+        }
     }
     // final tokens -> image attention (transformer.py:98-104)
     CK(e, lin2(e->Q, e->TOK0, C, e->fin.qw, e->fin.qb, e->QP, Ci, BT, Ci, C));
@@ -691,7 +702,7 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
     }
     // ---- upscaler (mask_decoder.py:53-59,154-155) as two GEMMs + fused tail ----
     // A/B knob (timing experiments): SAMRS_DECODER_FUSION=0 runs the un-fused upscaler kernels
-    static const bool fuse = [] { const char* v = getenv("SAMRS_DECODER_FUSION"); return !(v && atoi(v) == 0); }();
+    const bool fuse = g_decoder_fusion;
     if (fuse && Mi % 256 == 0) {   // ConvT #1 as a GEMM with LayerNorm2d(64) + GELU fused into its epilogue
         CK(e, launch_gemm_et_gln(prec, e->KE, e->up1_w, e->U1, e->up1_b, e->up_ln, Mi, C, C, s));
     } else {
@@ -727,6 +738,7 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
 }
 
 void samrs_debug_set_gemm_variant(int v) { set_gemm_variant(v); }
+void samrs_debug_set_decoder_fusion(int on) { g_decoder_fusion = on != 0; }
 
 // test hook: copy (a prefix of) a named internal decoder buffer to a caller device buffer
 int samrs_debug_copy_buffer(samrs_engine_t* e, const char* name, void* dst, size_t bytes, void* stream) {

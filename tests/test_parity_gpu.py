@@ -351,3 +351,34 @@ def test_vit_h_full_size_properties():
         seg_ref[m_all[j, 0]] = int(labels[j])
     assert torch.equal(seg, seg_ref)
     assert int(cp.sum()) == int(areas.sum()) and int(ci.sum()) == int((areas > 0).sum())
+
+
+def test_decoder_fused_kernels_match_unfused():
+    """The fused decoder kernels (i2t attention + projection + residual + LayerNorm; ConvT1 GEMM + LayerNorm2d + GELU;
+    ConvT2 + GELU + hypernetwork product) against the same computation as separate launches, ViT-H tile, 32 boxes:
+    identical rounding points except the fp32 summation order of the LayerNorm statistics and the un-rounded GELU
+    output in the last product."""
+    pred = get_predictor("vit_h", "f16", max_prompts=32, max_images=8)
+    eng = pred.model.engine
+    from samrs_amd import engine as E
+    lib = E.load_library()
+    tile = torch.as_tensor(synth.make_noise_image(40))[None].cuda()
+    eng.set_images(tile, 0)
+    boxes, _ = synth.make_boxes(40, 32)
+    b = torch.from_numpy(boxes).cuda()
+    size = (1024, 1024)
+    try:
+        lib.samrs_debug_set_decoder_fusion(0)
+        m0, q0, l0 = eng.predict(0, b, None, None, None, False, False, size, size)
+        m0, q0, l0 = m0.clone(), q0.clone(), l0.clone()
+    finally:
+        lib.samrs_debug_set_decoder_fusion(1)
+    m1, q1, l1 = eng.predict(0, b, None, None, None, False, False, size, size)
+    rel = ((l1 - l0).norm() / l0.norm()).item()
+    mx = ((l1 - l0).abs().max() / l0.std()).item()
+    diff = (m1 != m0).sum().item()
+    print(f"fused vs unfused decoder: low-res rel L2 {rel:.2e}, max / std {mx:.2e}, mask pixels differing {diff} of {m0.numel()}")
+    assert rel < 5e-4 and mx < 5e-3
+    # random weights put many logits next to the 0 threshold: a 1e-4-relative logit change flips a few hundred of 33.5 M pixels
+    assert diff < 1e-4 * m0.numel()
+    assert (q1 - q0).abs().max().item() < 1e-3

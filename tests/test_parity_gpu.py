@@ -382,3 +382,18 @@ def test_decoder_fused_kernels_match_unfused():
     # random weights put many logits next to the 0 threshold: a 1e-4-relative logit change flips a few hundred of 33.5 M pixels
     assert diff < 1e-4 * m0.numel()
     assert (q1 - q0).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("batch", [2, 3, 5])
+def test_vit_h_odd_batches_equal_single_tile(batch):
+    """The GEMM tile shape is chosen per (M, N, K): 2, 3 and 5 tiles per encoder pass take other mixes of the
+    256x320 / 256x256 / 256x128 kernels than 1 or 8 tiles do.  Every mix must give the same bits per tile
+    (each output element is accumulated over k in the same order by every tile shape)."""
+    pred = get_predictor("vit_h", "f16", max_prompts=32, max_images=8)
+    eng = pred.model.engine
+    tiles = torch.stack([torch.as_tensor(synth.make_noise_image(60 + i)) for i in range(batch)]).cuda()
+    eng.set_images(tiles, 0)
+    embs = [eng.get_embedding(i).clone() for i in range(batch)]
+    for i in (0, batch - 1):
+        eng.set_images(tiles[i:i + 1].contiguous(), 7)
+        assert torch.equal(eng.get_embedding(7), embs[i]), f"batch {batch}, tile {i}: differs from single-tile encode"

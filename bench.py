@@ -65,6 +65,7 @@ def main() -> None:
     ap.add_argument("--boxes", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second (bf16) timing leg")
+    ap.add_argument("--no-pcie-leg", action="store_true", help="skip the PCIe-inclusive side measurement")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoder and decoder of a batch back to back on one stream instead of overlapping the "
                          "decoder of batch k with the encoder of batch k+1 on a second HIP stream")
@@ -209,6 +210,34 @@ def main() -> None:
     tot_pix, tot_ins = driver.reduce_statistics(gen.class_pixels, gen.class_instances)
     torch.cuda.synchronize()
 
+    # ---- PCIe-inclusive side measurement (never `value`): the same batches, but the tiles start in (pinned) host
+    # memory and what goes back is the painted class map + per-box areas (samrs_paint), i.e. what a host caller of the
+    # generation driver actually moves: 3 MiB in, 1 MiB + 8 B/box out per tile.  Serial on one stream. ----
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_pcie_leg:
+        host_tiles = tiles.cpu().pin_memory()
+        host_seg = torch.empty(args.batch, 1024, 1024, dtype=torch.uint8).pin_memory()
+        host_area = torch.empty(args.batch, args.boxes, dtype=torch.int64).pin_memory()
+        seg_dev = torch.empty(args.batch, 1024, 1024, dtype=torch.uint8, device=dev)
+        area_dev = torch.empty(args.batch, args.boxes, dtype=torch.int64, device=dev)
+        lab_dev = torch.from_numpy(labels).to(dev)
+
+        def step_pcie(n):
+            for _ in range(n):
+                eng.set_images(host_tiles.to(dev, non_blocking=True), 0)
+                seg_dev.fill_(255)
+                for i in range(args.batch):
+                    mk, _, _ = eng.predict(i, boxes[i], None, None, None, False, False, (1024, 1024), (1024, 1024))
+                    area_dev[i] = eng.paint(mk[:, 0], lab_dev, seg_dev[i])
+                host_seg.copy_(seg_dev, non_blocking=True)
+                host_area.copy_(area_dev, non_blocking=True)
+            torch.cuda.synchronize()
+
+        n_p = max(1, args.steps // 2)
+        dtp = timed(step_pcie, n_p, 1)
+        pcie = {"value": round(args.batch * n_p / dtp, 3), "unit": "images/s",
+                "what": "H2D 8 x 3 MiB tiles (pinned) + encoder + decoder + on-device paint + D2H 8 x 1 MiB class maps and areas, serial, one stream"}
+
     alt = None
     if not args.no_alt_dtype:
         other = "bf16" if args.dtype == "f16" else "f16"
@@ -247,7 +276,7 @@ def main() -> None:
                        "parallelism": f"image-parallel x{world}", "weights": "seeded random init (no checkpoint available)",
                        "pipeline": "decoder of batch k overlaps encoder of batch k+1 (2 HIP streams)" if pipelined else "serial",
                        "accumulate": "f32"},
-            "flops_per_image": F, "roofline": roofline, "cpu_baseline": cpu_baseline, "alt_dtype": alt,
+            "flops_per_image": F, "roofline": roofline, "cpu_baseline": cpu_baseline, "alt_dtype": alt, "pcie_inclusive": pcie,
             "stats_allreduce": {"total_pixels": int(tot_pix.sum().item()), "total_instances": int(tot_ins.sum().item())},
         }
         print(json.dumps(out), flush=True)

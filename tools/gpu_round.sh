@@ -37,9 +37,9 @@ for grp in "$@"; do
     attnb)    run attnb 600 python tools/attn_bench.py ;;
     decb)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
               run decb 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/decb -o dec -- python tools/dec_bench.py 20 ;;
-    benchq)   run benchq 900 python bench.py --steps ${BENCH_STEPS:-8} --warmup 2 --no-cpu-baseline --no-alt-dtype ${BENCH_EXTRA:-} ;;
+    benchq)   run benchq 900 python bench.py --steps ${BENCH_STEPS:-8} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg ${BENCH_EXTRA:-} ;;
     prof)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
-              run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype ;;
+              run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-pcie-leg ;;
   esac
 done
 tail -5 gpurun_out/*.log 2>/dev/null | tail -120

@@ -272,7 +272,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} SAM, batch={args.batch}x1024^2 synthetic tiles, {args.boxes} hboxes/img, "
                                    f"box-only prompt, multimask_output=False, masks u8 in HBM (BASELINE.json configs[1])",
-                       "model": args.model, "global_batch": world * args.batch, "boxes_per_image": args.boxes,
+                       "tiles_per_step": world * args.batch, "boxes_per_tile": args.boxes,
                        "parallelism": f"image-parallel x{world}", "weights": "seeded random init (no checkpoint available)",
                        "pipeline": "decoder of batch k overlaps encoder of batch k+1 (2 HIP streams)" if pipelined else "serial",
                        "accumulate": "f32"},

@@ -91,3 +91,75 @@ def reduce_statistics(class_pixels: torch.Tensor, class_instances: torch.Tensor,
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     c = class_pixels.numel()
     return buf[:c].clone(), buf[c:].clone()
+
+
+class InstancePrompter:
+    """The prompt recipes of the HRSC2016 / DOTA instance drivers, one object per rank:
+
+    * ``"point"``     -- ``Generate Dataset/main_sam_hbox_mask_instance.py:160-165``: one foreground point per object,
+      ``point_coords = gt_points[:, None, :]`` passed AS IS (the reference does not run them through
+      ``apply_coords``), labels all 1, no box, no mask;
+    * ``"rbox_mask"`` -- ``main_sam_rbox_mask_instance.py:125-164``: the rotated box rasterised to a +-1000 mask prompt
+      (``transforms.rbox_mask_prompts`` on the GPU instead of cv2), nothing else;
+    * ``"box"``       -- ``main_sam_rhbox_mask_instance.py:160-168``: the enclosing horizontal box through
+      ``apply_boxes_torch``.
+
+    Boxes are processed in chunks of the engine's ``max_prompts`` (results are bit-identical to one call).
+    Returns (masks bool [n, H, W], qualities fp32 [n]) on the device."""
+
+    MODES = ("point", "rbox_mask", "box")
+
+    def __init__(self, predictor):
+        self.predictor = predictor
+
+    @torch.no_grad()
+    def predict(self, image: np.ndarray, mode: str, hboxes=None, rboxes=None, points=None, already_set: bool = False):
+        from . import transforms
+        if mode not in self.MODES:
+            raise ValueError(f"mode must be one of {self.MODES}")
+        p = self.predictor
+        if not already_set:
+            p.set_image(image)
+        h, w = image.shape[:2]
+        dev = p.device
+        src = {"point": points, "rbox_mask": rboxes, "box": hboxes}[mode]
+        if src is None:
+            raise ValueError(f"mode {mode!r} needs its annotation array")
+        n = len(src)
+        cap = p.model.engine.max_prompts
+        masks, quals = [], []
+        for s, e in box_chunks(n, cap):
+            if mode == "point":
+                pc = torch.as_tensor(np.asarray(points[s:e]), dtype=torch.float32, device=dev)[:, None, :]
+                pl = torch.ones(e - s, 1, device=dev)
+                m, q, _ = p.predict_torch(point_coords=pc, point_labels=pl, boxes=None, mask_input=None, multimask_output=False)
+            elif mode == "rbox_mask":
+                prompts = transforms.rbox_mask_prompts(np.asarray(rboxes[s:e]), (h, w), img_size=p.model.image_encoder.img_size,
+                                                       device=dev)
+                m, q, _ = p.predict_torch(point_coords=None, point_labels=None, boxes=None, mask_input=prompts[:, None],
+                                          multimask_output=False)
+            else:
+                tb = p.transform.apply_boxes_torch(torch.as_tensor(np.asarray(hboxes[s:e]), dtype=torch.float32, device=dev), (h, w))
+                m, q, _ = p.predict_torch(point_coords=None, point_labels=None, boxes=tb, mask_input=None, multimask_output=False)
+            masks.append(m[:, 0])
+            quals.append(q[:, 0])
+        return torch.cat(masks), torch.cat(quals)
+
+
+def mean_iou(pred_masks, gt_masks):
+    """``main_sam_rhbox_mask_instance.py:222-241``: per-instance IoU averaged over the instances whose union is not empty
+    ("Average mIOU"), and total intersection / total union ("Area mIOU").  Lists of [n_i, H, W] arrays, one per image."""
+    ious, inter_all, union_all = [], [], []
+    for pm, gm in zip(pred_masks, gt_masks):
+        pm = np.asarray(pm).astype(bool)
+        gm = np.asarray(gm).astype(bool)
+        for j in range(pm.shape[0]):
+            inter = float(np.sum(pm[j] & gm[j]))
+            union = float(np.sum(pm[j] | gm[j]))
+            if union > 0:
+                inter_all.append(inter)
+                union_all.append(union)
+                ious.append(inter / union)
+    if not ious:
+        return float("nan"), float("nan")
+    return float(np.mean(ious)), float(np.sum(inter_all) / np.sum(union_all))

@@ -75,3 +75,23 @@ def test_pil_resample_restatement_is_bit_exact(hw, out):
     got = resample_reference(img, out[0], out[1])
     assert got.shape == ref.shape
     assert np.array_equal(got, ref), f"{(got != ref).sum()} differing bytes"
+
+
+def test_mean_iou_matches_reference_arithmetic():
+    """driver.mean_iou == main_sam_rhbox_mask_instance.py:222-241 (float products / sums of 0-1 arrays)."""
+    from samrs_amd import driver
+    rng = np.random.default_rng(4)
+    preds = [rng.random((3, 20, 30)) > 0.5, rng.random((2, 20, 30)) > 0.7]
+    gts = [rng.random((3, 20, 30)) > 0.5, np.zeros((2, 20, 30), bool)]
+    preds[1][1] = False                                  # empty union -> skipped, like the reference
+    avg, area = driver.mean_iou(preds, gts)
+    ious, inter, union = [], [], []
+    for pm, gm in zip(preds, gts):
+        for j in range(pm.shape[0]):
+            g = gm[j].reshape(-1).astype(float)
+            p = pm[j].reshape(-1).astype(float)
+            i = float(np.sum(g * p))
+            u = float(np.sum(np.array(g + p > 0)))
+            if u > 0:
+                inter.append(i); union.append(u); ious.append(i / u)
+    assert avg == pytest.approx(np.mean(ious)) and area == pytest.approx(np.sum(inter) / np.sum(union))

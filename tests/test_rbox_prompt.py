@@ -162,3 +162,42 @@ def test_rbox_mask_prompt_flow_matches_oracle():
     print(f"rbox mask-prompt flow: low-res rel L2 {l2:.3e}; IoU min {(inter / union).min():.5f}; quality err {(q.cpu() - q0).abs().max():.2e}")
     assert l2 < 1.5e-3                       # same bar as the decoder-alone test (f16 operands)
     assert (inter / union).min() >= 0.999 or union.max() < 16
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["point", "rbox_mask", "box"])
+def test_instance_prompter_modes_match_oracle(mode):
+    """driver.InstancePrompter (the three HRSC instance-driver prompt recipes) against the oracle predictor fed with the
+    same prompts built on the host, on the oracle's embedding; 5 objects through an engine capped at 2 prompts per call
+    (exercises the chunking)."""
+    from oracle import sam_oracle as so
+    from samrs_amd import SamPredictor, driver, sam_model_registry, synth
+    name = "vit_tiny"
+    cfg = synth.CONFIGS[name]
+    sam = sam_model_registry[name](precision="f16", max_images=1, max_prompts=2, max_points=1)
+    sam.to(device="cuda")
+    pred = SamPredictor(sam)
+    orc = so.OraclePredictor(synth.make_state_dict(cfg, 0), cfg)
+    h, w = 600, 800
+    img = synth.make_image(2, h, w)
+    orc.set_image(img)
+    pred.set_image(img)
+    pred.model.engine.set_embedding(orc.features.cuda(), pred.slot)
+    rng = np.random.default_rng(33)
+    rboxes = np.stack([random_rbox(rng, h, w) for _ in range(5)])
+    hboxes = np.concatenate([rboxes.min(1), rboxes.max(1)], axis=1).astype(np.float32)       # enclosing hbox (x0, y0, x1, y1)
+    points = rboxes.mean(1).astype(np.float32)                                               # object centres
+    m, q = driver.InstancePrompter(pred).predict(img, mode, hboxes=hboxes, rboxes=rboxes, points=points, already_set=True)
+    if mode == "point":
+        m0, q0, _ = orc.predict_torch(torch.from_numpy(points)[:, None, :], torch.ones(5, 1), None, None, multimask_output=False)
+    elif mode == "rbox_mask":
+        pr = torch.from_numpy(np.stack([rp.rbox_mask_prompt(p, h, w) for p in rboxes]))
+        m0, q0, _ = orc.predict_torch(None, None, None, pr[:, None], multimask_output=False)
+    else:
+        m0, q0, _ = orc.predict_torch(None, None, so.apply_boxes(torch.from_numpy(hboxes), (h, w)), None, multimask_output=False)
+    assert m.shape == (5, h, w) and q.shape == (5,)
+    inter = (m.cpu() & m0[:, 0]).flatten(1).sum(1).float()
+    union = (m.cpu() | m0[:, 0]).flatten(1).sum(1).float().clamp(min=1)
+    print(f"instance prompter {mode}: IoU min {(inter / union).min():.5f}, quality err {(q.cpu() - q0[:, 0]).abs().max():.2e}")
+    assert (inter / union).min() >= 0.999 or union.max() < 16
+    assert (q.cpu() - q0[:, 0]).abs().max() < 2e-3

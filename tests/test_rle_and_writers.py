@@ -65,3 +65,33 @@ def test_writer_contract(tmp_path):
         if d["size"] > 0:
             pix[d["label"]] += d["size"]
     assert pix[4] == 24 and pix[7] == 0
+
+
+def test_gray_labels_satisfy_the_training_consumer(tmp_path):
+    """N4 (label-format half): what `Pretraining and Finetuning/End_to_End/datasets.py:251-254` does with a generated
+    label -- `np.array(Image.open(lbl_path))` fed as the mask of the augmentation pipeline -- and what
+    `main_finetune.py:263` requires of it (class ids < n_classes, 255 = ignored by CrossEntropyLoss)."""
+    import torch
+    from PIL import Image
+    n_classes = 18
+    rng = np.random.default_rng(0)
+    seg = np.full((64, 80), 255, dtype=np.uint8)                      # main_sam_hbox_semantic.py:162
+    seg[10:30, 5:50] = 3
+    seg[25:60, 40:70] = 17                                            # later box wins (:195-199)
+    masks = np.stack([seg == 3, seg == 17])
+    boxes = np.array([[5, 10, 49, 29], [40, 25, 69, 59]], dtype=np.float32)
+    labels = np.array([3, 17])
+    areas = masks.reshape(2, -1).sum(1)
+    generate.write_outputs(str(tmp_path), "t0", seg, masks, boxes, labels, areas, generate.default_palette(n_classes),
+                           [str(i) for i in range(n_classes)])
+    label = np.array(Image.open(os.path.join(tmp_path, "gray", "t0.png")))          # datasets.py:252
+    assert label.dtype == np.uint8 and label.shape == seg.shape and np.array_equal(label, seg)
+    vals = set(np.unique(label).tolist())
+    assert vals <= set(range(n_classes)) | {255}
+    logits = torch.from_numpy(rng.standard_normal((1, n_classes, *seg.shape)).astype(np.float32))
+    loss = torch.nn.CrossEntropyLoss(ignore_index=255)(logits, torch.from_numpy(label.astype(np.int64))[None])   # main_finetune.py:263
+    assert torch.isfinite(loss)
+    # statistic.py:12-21 reads the pickles back: size == mask area, label is the class id
+    info = pickle.load(open(os.path.join(tmp_path, "ins", "t0.pkl"), "rb"))
+    assert [e["label"] for e in info] == [3, 17] and [e["size"] for e in info] == areas.tolist()
+    assert np.array_equal(rle.decode(info[1]["mask"]), masks[1])

@@ -377,13 +377,13 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
 // Block-wide barriers: all 8 waves are past the main loop here (the stagger has been re-aligned).
 //   acc[i][j]: n-tile i (16 cols), m-tile j (16 rows); 8 m-tiles, 4 per pass.
 // ---------------------------------------------------------------------------------------------
-template <int PREC, bool GELU>
+template <int PREC, bool GELU, int JC = 4>
 __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned char* lds, void* __restrict__ Cv,
                                                  const float* __restrict__ bias, const float* __restrict__ pre2d, int period, int N,
                                                  int m_base /* wave tile row 0 */, int n_pair /* first column of the pair */,
                                                  int wm, int wn, int lane) {
     constexpr int RS = 400;                 // 320 data bytes + pad: 100 words = 4 (mod 32)
-    constexpr int TS = 16 * RS, JC = 4;
+    constexpr int TS = 16 * RS;
     const int fr = lane & 15, fq = lane >> 4, half = wn & 1;
     unsigned char* scr = lds + (wm * 2 + (wn >> 1)) * (JC * TS);
     float4 bv[5];
@@ -413,9 +413,9 @@ __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned 
             }
         }
         __syncthreads();
-        // this wave: rows 8*half .. +7 of each of the 4 m-tiles = 4 x 8 rows x 20 chunks = 10 passes of 64 lanes
+        // this wave: rows 8*half .. +7 of each of the JC m-tiles = JC x 8 rows x 20 chunks = 2.5 JC passes of 64 lanes
 #pragma unroll
-        for (int h = 0; h < 10; ++h) {
+        for (int h = 0; h < JC * 160 / 64; ++h) {
             const int idx = lane + 64 * h;
             const int jj = idx / 160, rem = idx % 160;
             const int row = 8 * half + rem / 20, ch = rem % 20;
@@ -909,6 +909,135 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_et_pers_kernel: the 256x320 kernel above made PERSISTENT -- one block per CU walks tiles
+// L, L + gridDim.x, ...  With one tile per block a CU idles between tiles for the block re-dispatch plus
+// the ~2 us the first ring stage needs to land.  Here the next tile's stages 0 and 1 are issued BEFORE the
+// current tile's epilogue (which confines its bounce scratch to ring slots 2-3), so they land under the
+// epilogue's HBM traffic; after the epilogue: drain (vmcnt 0), one block barrier (scratch free, stages
+// visible), stage 2, and the main loop starts without a fill bubble.  Same main-loop code (macros above).
+// ---------------------------------------------------------------------------------------------
+template <int PREC, bool OUT_F32, bool GELU>
+__global__ __launch_bounds__(QTHREADS) void gemm_et_pers_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
+    int M, int N, int K, int accumulate) {
+    constexpr int NI = 5, ABL = 0;
+    constexpr int QBN = 64 * NI;
+    constexpr int QSTAGE_ELEMS = (QBM + QBN) * QBK;
+    __shared__ __attribute__((aligned(16))) uint16_t lds[QSTAGES * QSTAGE_ELEMS];   // 144 KiB, ONE object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave >> 2, wn = wave & 3;
+    constexpr int GROUP = 8;
+    const int tiles_n = N / QBN, tiles_m = M / QBM, ntiles = tiles_n * tiles_m;
+    const int per_group = GROUP * tiles_n;
+#define PERS_TILE(L_, m_, n_)                                                                    \
+    do {                                                                                         \
+        const int bid_ = xcd_remap((L_), ntiles);                                                \
+        const int group_ = bid_ / per_group, first_m_ = group_ * GROUP;                           \
+        const int gsz_ = (tiles_m - first_m_) < GROUP ? (tiles_m - first_m_) : GROUP;            \
+        const int in_g_ = bid_ - group_ * per_group;                                             \
+        (m_) = (first_m_ + in_g_ % gsz_) * QBM;                                                  \
+        (n_) = (in_g_ / gsz_) * QBN;                                                             \
+    } while (0)
+    const int g_row = 16 * wave + (lane >> 2);
+    const int g_chunk = qswz(g_row, lane & 3);
+    const uint32_t wave_lds_base = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * (16 * QBK * 2));
+    const size_t rs128 = (size_t)128 * K;
+    const int fr = lane & 15, fq = lane >> 4;
+    int offA[8], offB[NI];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int r = wm * 128 + j * 16 + fr; offA[j] = r * QBK + qswz(r, fq) * 8; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int r = wn * (16 * NI) + i * 16 + fr; offB[i] = QBM * QBK + r * QBK + qswz(r, fq) * 8; }
+    const int nk = K / QBK;                     // >= 3 (launcher)
+
+    int L = blockIdx.x, m0, n0;
+    PERS_TILE(L, m0, n0);
+    const uint16_t* gAg = A + (size_t)(m0 + g_row) * K + g_chunk * 8;
+    const uint16_t* gBg = B + (size_t)(n0 + g_row) * K + g_chunk * 8;
+    BIG_ISSUE(0, 0);
+    BIG_ISSUE(1, 1);
+    BIG_ISSUE(2, 2);
+    BIG_VMCNT(2);
+    __builtin_amdgcn_s_barrier();
+    f32x4_t acc[NI][8];
+    for (;;) {
+        if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; kt += QSTAGES) {
+            BIG_STEP(kt, 0)
+            BIG_STEP(kt + 1, 1)
+            BIG_STEP(kt + 2, 2)
+            BIG_STEP(kt + 3, 3)
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();          // re-align the groups: every ring read is done
+
+        // next tile: stages 0 and 1 go out now and land under the epilogue
+        const int Ln = L + (int)gridDim.x;
+        const bool more = Ln < ntiles;
+        int m1 = m0, n1 = n0;
+        if (more) PERS_TILE(Ln, m1, n1);
+        const uint16_t* gAcur = gAg;
+        const uint16_t* gBcur = gBg;
+        (void)gAcur; (void)gBcur;
+        if (more) {
+            gAg = A + (size_t)(m1 + g_row) * K + g_chunk * 8;
+            gBg = B + (size_t)(n1 + g_row) * K + g_chunk * 8;
+            BIG_ISSUE(0, 0);
+            BIG_ISSUE(1, 1);
+        }
+        {   // epilogue of tile (m0, n0); bounce scratch = ring slots 2-3 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
+            unsigned char* upper = reinterpret_cast<unsigned char*>(lds) + 2 * QSTAGE_ELEMS * 2;
+            const float* pre2d = OUT_F32 ? nullptr : add2d;
+            if constexpr (!OUT_F32) {
+                epilogue_pair_et<PREC, GELU, 2>(acc, upper, Cv, bias, pre2d, add2d_period, N, m0 + wm * 128, n0 + (wn >> 1) * 160,
+                                                wm, wn, lane);
+            } else {
+                epilogue_coalesced<PREC, true, GELU, 8, 1, NI>(acc, upper + wave * (2 * QSTAGE_ELEMS * 2 / 8), Cv, bias, add2d,
+                                                               add2d_period, N, m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane);
+            }
+        }
+        if (!more) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores drained, its stage-0/1 pieces landed
+        __builtin_amdgcn_s_barrier();                          // ... for every wave; scratch region free again
+        L = Ln; m0 = m1; n0 = n1;
+        BIG_ISSUE(2, 2);
+    }
+#undef PERS_TILE
+}
+
+template <int PREC>
+hipError_t launch_gemm_pers(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
+                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
+    const int ntiles = (M / QBM) * (N / WBN);
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(QTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (out_f32) {
+        if (gelu) gemm_et_pers_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_pers_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    } else {
+        if (gelu) gemm_et_pers_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_pers_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    }
+    return hipGetLastError();
+}
+
 template <int PREC, int NI = 4>
 hipError_t launch_gemm_big(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
@@ -1290,6 +1419,12 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         if (prec == PREC_F16) return launch_gemm_dual<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
     }
+    if (variant == 11 && M % QBM == 0 && N % WBN == 0 && K % QBK == 0 && K >= 3 * QBK) {   // persistent 256x320 kernel
+        if (prec == PREC_BF16) return launch_gemm_pers<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_pers<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        return hipErrorInvalidValue;
+    }
+    if (variant == 11) variant = 10;
     if (variant == 10 && M % QBM == 0 && N % WBN == 0 && K % QBK == 0) {   // 256x320 staggered kernel
         if (prec == PREC_BF16) return launch_gemm_big<PREC_BF16, 5>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_big<PREC_F16, 5>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);

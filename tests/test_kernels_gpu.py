@@ -92,9 +92,11 @@ def test_gemm_et_variants(lib, name, prec, dt, ulp, M, N, K):
 
 
 @pytest.mark.parametrize("variant,M,N,K", [(5, 512, 256, 192), (6, 512, 512, 192), (7, 512, 256, 192), (9, 256, 128, 128),
-                                           (10, 512, 640, 192), (10, 256, 640, 64), (6, 256, 256, 64)])
+                                           (10, 512, 640, 192), (10, 256, 640, 64), (6, 256, 256, 64),
+                                           (11, 512, 640, 192), (11, 8192, 3200, 192)])
 def test_gemm_every_tile_variant(lib, variant, M, N, K):
-    """Each tile shape of the pipelined GEMM forced explicitly (the auto rule only picks the 256x256 / 256x320
+    """(variant 11 = the persistent 256x320 kernel; 8192 x 3200 gives 320 tiles, so 64 blocks walk two tiles.)
+    Each tile shape of the pipelined GEMM forced explicitly (the auto rule only picks the 256x256 / 256x320
     kernels at sizes the unit tests do not reach): fp32 accumulate output, f16 output with 2-D addend, GELU output."""
     name, prec, dt, ulp = PRECS[0]
     g = torch.Generator().manual_seed(variant * 1000 + M + N + K)

@@ -58,7 +58,7 @@ typedef struct samrs_config {
     int32_t window_size;             /* 14                                                    */
     int32_t out_chans;               /* 256 (== prompt / decoder width)                       */
     int32_t max_images;              /* encoder batch == number of embedding slots            */
-    int32_t max_prompts;             /* max prompts (boxes) per samrs_predict call            */
+    int32_t max_prompts;             /* prompts (boxes) decoded per pass: workspace size      */
     int32_t max_points;              /* max points per prompt                                 */
     int32_t precision;               /* enum samrs_precision                                  */
 } samrs_config;
@@ -93,6 +93,13 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream);
  * slot0 .. slot0+n_images-1. */
 int samrs_set_images(samrs_engine_t* e, const uint8_t* images, int n_images, int in_h, int in_w,
                      int slot0, void* stream);
+/* Ragged batch (the per-image H[] / W[] form): images[i] is the DEVICE pointer of tile i, in_h[i] x in_w[i]
+ * with max(in_h[i], in_w[i]) == img_size; the three arrays themselves are HOST arrays of n_images
+ * entries.  One encoder pass for tiles of different sizes (HRSC2016 / DIOR images after
+ * ResizeLongestSide.apply_image, main_sam_rbox_mask_instance.py:99-101,157); each tile's embedding is
+ * bit-identical to encoding it alone.  Remember each tile's (in_h, in_w) for samrs_predict. */
+int samrs_set_images_ragged(samrs_engine_t* e, const uint8_t* const* images, const int* in_h,
+                            const int* in_w, int n_images, int slot0, void* stream);
 /* SamPredictor.get_image_embedding (predictor.py:247-258): fp32 [out_chans, 64, 64] (NCHW). */
 int samrs_get_embedding(samrs_engine_t* e, int slot, float* out_chw, void* stream);
 /* Install a precomputed embedding (fp32 NCHW) into a slot; marks it set. */
@@ -115,7 +122,10 @@ int samrs_reset_image(samrs_engine_t* e, int slot);
  *  in_h,in_w    size of the image handed to samrs_set_images (predictor.input_size)
  *  orig_h,orig_w size of the original image (predictor.original_size)
  *  masks_out / iou_out [n_prompts,C] / lowres_out [n_prompts,C,256,256]: caller-owned device
- *  buffers; any of them may be NULL to skip that output. */
+ *  buffers; any of them may be NULL to skip that output.
+ *  n_prompts is unbounded like the reference's batch dimension: calls larger than the handle's
+ *  max_prompts run as consecutive chunks on `stream` (results do not depend on the chunking).
+ *  n_points is bounded by max_points (<= 8: the decoder keeps at most 16 tokens per prompt). */
 int samrs_predict(samrs_engine_t* e, int slot, int n_prompts,
                   const float* boxes, const float* point_coords, const int32_t* point_labels,
                   int n_points, const float* mask_input, int multimask, int return_logits,

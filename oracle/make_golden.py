@@ -3,6 +3,7 @@
 Run in the authoring container (needs ``/root/reference``)::
 
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden vit_tiny vit_tiny80 vit_b vit_h
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden vit_b_c2c4 vit_h_c2c4      # C2 / C4 fixtures, margin weights
 
 Weights / images / prompts come from ``samrs_amd.synth`` (seeded, reproducible anywhere), the
 outputs come from the reference's own ``SamPredictor`` (Generate Dataset/segment_anything/
@@ -57,9 +58,94 @@ def run_predictor(pred, apply_boxes, apply_coords, img_shape, kw):
                               multimask_output=kw["multimask_output"])
 
 
+UNSTABLE_TAU = 0.01        # "decision not robust": |full-resolution logit| < UNSTABLE_TAU * std(low-res logits)
+
+
+def _pack(mask_bool: np.ndarray) -> np.ndarray:
+    """[..., H, W] bool -> [..., H*W/8] uint8 (np.packbits, row-major, MSB first)."""
+    m = np.ascontiguousarray(mask_bool).reshape(*mask_bool.shape[:-2], -1)
+    return np.packbits(m, axis=-1)
+
+
+def unstable_class_map(logits: "torch.Tensor", tau: float) -> "torch.Tensor":
+    """Pixels of the painted class map (later box wins, main_sam_hbox_semantic.py:195-199) whose value could change
+    if every logit moved by less than tau: with J = the last box that is ON with margin (logit >= tau), the pixel is
+    decided by J unless some LATER box is within tau of the threshold.  Boxes before J are overpainted anyway."""
+    n = logits.shape[0]
+    idx = torch.arange(1, n + 1).view(n, 1, 1)
+    last_on = (idx * (logits >= tau)).amax(0)                 # 1-based index of J, 0 = none
+    near = logits.abs() < tau
+    return ((idx * near).amax(0) > last_on)                   # an uncertain box after J
+
+
+def extended_inputs():
+    """Inputs of the C2 / C4 fixtures: the same on the authoring machine and on the GPU box."""
+    boxes, labels = synth.make_boxes(7, 32)                 # C2: 32 hboxes on one 1024^2 tile, 18 classes
+    polys, plabels = synth.make_rboxes(0, 4)                # C4: FAIR1M-shaped rotated boxes, 37 classes
+    return dict(boxes=boxes, labels=labels, polys=polys, plabels=plabels, hboxes=synth.enclosing_hboxes(polys))
+
+
+def extended(name: str) -> None:
+    """``tests/golden/<name>_c2c4.npz``: BASELINE.json configs[1] (32 hboxes per tile, 20 + 12 chunks,
+    main_sam_hbox_semantic.py:157-181) and configs[3] (rbox -> enclosing hbox / rbox -> mask prompt with
+    multimask_output=True, main_sam_rhbox_mask_instance.py:125-130, main_sam_rbox_mask_instance.py:125-164) run by the
+    REAL reference on the realistic-margin weights.  Full-resolution masks are stored bit-packed; next to them the
+    set of pixels whose reference decision is not robust (|logit| < UNSTABLE_TAU * std): outside that set the engine
+    must reproduce every bit."""
+    from oracle import rbox_prompt
+    cfg = synth.CONFIGS[name]
+    sd = synth.make_state_dict(cfg, 0, logit_scale=synth.MARGIN_LOGIT_SCALE)
+    sa, sam = ref_import.build_reference_sam(cfg, sd)
+    pred = sa.SamPredictor(sam)
+    inp = extended_inputs()
+    h = w = 1024
+    img = synth.make_image(0, h, w)
+    pred.set_image(img)
+    f = pred.get_image_embedding()
+    blob = {"emb_sample": f[0, ::16, ::4, ::4].numpy().copy(), "emb_norm": np.float64(f.double().norm().item()),
+            "logit_scale": np.float64(synth.MARGIN_LOGIT_SCALE), "tau_frac": np.float64(UNSTABLE_TAU)}
+
+    def run(tag, chunks, multimask, **kw):
+        logits, ious, lows = [], [], []
+        for s0, s1 in chunks:
+            sub = {k: (None if v is None else v[s0:s1]) for k, v in kw.items()}
+            lg, iou, low = pred.predict_torch(sub.get("pc"), sub.get("pl"), sub.get("boxes"), sub.get("mask_input"),
+                                              multimask_output=multimask, return_logits=True)
+            logits.append(lg); ious.append(iou); lows.append(low)
+        lg, iou, low = torch.cat(logits), torch.cat(ious), torch.cat(lows)
+        masks = lg > sam.mask_threshold                                   # predictor.py:242-243
+        tau = UNSTABLE_TAU * low.std().item()
+        blob[tag + "_masks"] = _pack(masks.numpy())
+        blob[tag + "_iou"] = iou.numpy().copy()
+        blob[tag + "_low"] = low[:, :, ::4, ::4].numpy().copy()
+        blob[tag + "_low_std"] = np.float64(low.std().item())
+        blob[tag + "_area"] = masks.flatten(2).sum(-1).numpy().astype(np.int64)
+        blob[tag + "_near"] = (lg.abs() < tau).flatten(2).sum(-1).numpy().astype(np.int64)   # per mask
+        return lg, masks, tau
+
+    tb = pred.transform.apply_boxes_torch(torch.as_tensor(inp["boxes"]), (h, w))
+    lg, masks, tau = run("c2", sam_oracle.box_chunks(32, 20), False, boxes=tb)
+    seg, areas = sam_oracle.paint_semantic(masks[:, 0].numpy(), inp["labels"], (h, w))
+    blob["c2_seg"] = seg
+    blob["c2_unstable"] = _pack(unstable_class_map(lg[:, 0], tau).numpy())
+    tb = pred.transform.apply_boxes_torch(torch.as_tensor(inp["hboxes"]), (h, w))
+    run("c4box", [(0, 4)], True, boxes=tb)
+    prompts = np.stack([rbox_prompt.rbox_mask_prompt(p.astype(np.int32), h, w) for p in inp["polys"]])
+    blob["c4mask_prompt_sum"] = np.float64(prompts.astype(np.float64).sum())
+    run("c4mask", [(0, 4)], True, mask_input=torch.from_numpy(prompts.astype(np.float32))[:, None])
+    path = os.path.join(GOLDEN_DIR, name + "_c2c4.npz")
+    np.savez_compressed(path, **blob)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; unstable class-map pixels:",
+          int(np.unpackbits(blob["c2_unstable"]).sum()), flush=True)
+
+
 def main(names):
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
+    ext = [n[:-5] for n in names if n.endswith("_c2c4")]
+    names = [n for n in names if not n.endswith("_c2c4")]
+    for name in ext:
+        extended(name)
     for name in names:
         cfg = synth.CONFIGS[name]
         sd = synth.make_state_dict(cfg, 0)

@@ -140,6 +140,25 @@ hipError_t dalloc(samrs_engine* e, T** p, size_t count) {
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
+// Every entry point that touches the device runs on the engine's device and then puts the CALLER's current device
+// back (a process that drives several GPUs, or a handle collected at an arbitrary time, must not find its thread's
+// device changed under it).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) status = hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE(e) DeviceGuard _dg((e)->device); CK((e), _dg.status)
+
 bool is_global(const samrs_config& c, int i) {
     for (int k = 0; k < c.n_global; ++k)
         if (c.global_attn_indexes[k] == i) return true;
@@ -262,7 +281,10 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     if (cfg->max_images < 1 || cfg->max_prompts < 1 || cfg->max_points < 0 || cfg->n_global < 0 || cfg->n_global > 8)
         return bad("bad capacity / n_global");
     if (5 + cfg->max_points + 1 + 2 > 16) return bad("max_points too large (token count must stay <= 16)");
-    if (hipSetDevice(device) != hipSuccess) return bad("hipSetDevice failed (no HIP device? this library has no CPU fallback)");
+    {
+        DeviceGuard dg(device);
+        if (dg.status != hipSuccess) return bad("hipSetDevice failed (no HIP device? this library has no CPU fallback)");
+    }
     samrs_engine* e = new samrs_engine();
     e->cfg = *cfg;
     e->device = device;
@@ -280,7 +302,7 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
 
 void samrs_destroy(samrs_engine_t* e) {
     if (!e) return;
-    (void)hipSetDevice(e->device);
+    DeviceGuard dg(e->device);
     for (void* p : e->owned) (void)hipFree(p);
     delete e;
 }
@@ -288,7 +310,7 @@ void samrs_destroy(samrs_engine_t* e) {
 int samrs_load_weight(samrs_engine_t* e, const char* name, const float* host, const int64_t* shape, int ndim) {
     if (!e || !name || !host || !shape || ndim < 1 || ndim > 4) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_load_weight: bad argument");
     if (e->finalized) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "weights already finalized");
-    CK(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     DevTensor t;
     t.shape.assign(shape, shape + ndim);
     t.numel = 1;
@@ -327,7 +349,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     if (!e) return SAMRS_ERR_BAD_ARG;
     if (e->finalized) return SAMRS_OK;
     hipStream_t s = (hipStream_t)stream;
-    CK(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     // ---- strict check (build_sam.py:106 load_state_dict raises on any mismatch) ----
     std::vector<std::pair<std::string, std::vector<int64_t>>> req;
     required_tensors(e, req);
@@ -461,22 +483,36 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
 }
 
 // -------------------------------------------------------------------------------------------------
-static int encode(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int in_w, int slot0, void* stream,
-                  int n_blocks, bool do_neck) {
-    if (!e || !images) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_set_images: null argument");
+// images[i]: device pointer of tile i (uint8 HWC, in_h[i] x in_w[i], long side == img_size).  Tiles of one call may
+// differ in size (HRSC / DIOR images after ResizeLongestSide): only the im2col reads pixels, everything downstream
+// works on the zero-padded 64 x 64 token grid (sam.py:170-173).
+static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in_h, const int* in_w, int n, int slot0,
+                  void* stream, int n_blocks, bool do_neck) {
+    if (!e || !images || !in_h || !in_w) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_set_images: null argument");
     if (!e->finalized) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "weights not finalized");
     const samrs_config& c = e->cfg;
     if (n < 1 || slot0 < 0 || slot0 + n > c.max_images) return fail(e, SAMRS_ERR_CAPACITY, "n_images/slot out of range (max_images=%d)", c.max_images);
-    if (in_h < 1 || in_w < 1 || in_h > c.img_size || in_w > c.img_size || (in_h != c.img_size && in_w != c.img_size))
-        return fail(e, SAMRS_ERR_BAD_SHAPE, "set_torch_image input must be BCHW with long side %d.", c.img_size);
+    for (int i = 0; i < n; ++i) {
+        if (!images[i]) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_set_images: null image pointer (tile %d)", i);
+        if (in_h[i] < 1 || in_w[i] < 1 || in_h[i] > c.img_size || in_w[i] > c.img_size || (in_h[i] != c.img_size && in_w[i] != c.img_size))
+            return fail(e, SAMRS_ERR_BAD_SHAPE, "set_torch_image input must be BCHW with long side %d.", c.img_size);
+    }
     hipStream_t s = (hipStream_t)stream;
-    CK(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     const int D = e->D, C = e->C, g = e->grid, tokens = e->tokens, prec = e->prec;
     const int M = n * tokens;
     for (int i = 0; i < n; ++i) e->slot_set[slot0 + i] = 0;
 
-    // patch embed: im2col (normalise + zero pad) -> GEMM (+bias +pos_embed) -> X
-    CK(e, launch_patch_im2col(prec, images, e->H, n, in_h, in_w, g, c.patch_size, s));
+    // patch embed: im2col (normalise + zero pad) -> GEMM (+bias +pos_embed) -> X.  One im2col launch per run of
+    // same-size tiles that sit back to back in memory (the whole batch for a contiguous tile stack).
+    const size_t KP = (size_t)3 * c.patch_size * c.patch_size;
+    for (int i = 0; i < n;) {
+        int j = i + 1;
+        while (j < n && in_h[j] == in_h[i] && in_w[j] == in_w[i] &&
+               images[j] == images[i] + (size_t)(j - i) * in_h[i] * in_w[i] * 3) ++j;
+        CK(e, launch_patch_im2col(prec, images[i], e->H + (size_t)i * tokens * KP, j - i, in_h[i], in_w[i], g, c.patch_size, s));
+        i = j;
+    }
     CK(e, launch_gemm_et(prec, e->H, e->patch_w, e->X, W(e, "image_encoder.patch_embed.proj.bias"),
                          W(e, "image_encoder.pos_embed"), tokens, M, D, 3 * c.patch_size * c.patch_size, true, false, false, s));
     for (int i = 0; i < c.depth && i < n_blocks; ++i) {
@@ -521,14 +557,29 @@ static int encode(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int
     return SAMRS_OK;
 }
 
+static int encode_stack(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int in_w, int slot0, void* stream,
+                        int n_blocks, bool do_neck) {
+    if (!e || !images) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_set_images: null argument");
+    if (n < 1 || n > e->cfg.max_images) return fail(e, SAMRS_ERR_CAPACITY, "n_images/slot out of range (max_images=%d)", e->cfg.max_images);
+    std::vector<const uint8_t*> ptr(n);
+    std::vector<int> hs(n, in_h), ws(n, in_w);
+    for (int i = 0; i < n; ++i) ptr[i] = images + (size_t)i * (in_h > 0 ? in_h : 0) * (in_w > 0 ? in_w : 0) * 3;
+    return encode(e, ptr.data(), hs.data(), ws.data(), n, slot0, stream, n_blocks, do_neck);
+}
+
 int samrs_set_images(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int in_w, int slot0, void* stream) {
-    return encode(e, images, n, in_h, in_w, slot0, stream, 1 << 30, true);
+    return encode_stack(e, images, n, in_h, in_w, slot0, stream, 1 << 30, true);
+}
+
+int samrs_set_images_ragged(samrs_engine_t* e, const uint8_t* const* images, const int* in_h, const int* in_w, int n,
+                            int slot0, void* stream) {
+    return encode(e, images, in_h, in_w, n, slot0, stream, 1 << 30, true);
 }
 
 int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n, int in_h, int in_w, int n_blocks,
                                float* x_out, void* stream) {
     if (!x_out) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_debug_encoder_prefix: null output");
-    const int rc = encode(e, images, n, in_h, in_w, 0, stream, n_blocks, false);
+    const int rc = encode_stack(e, images, n, in_h, in_w, 0, stream, n_blocks, false);
     if (rc) return rc;
     CK(e, hipMemcpyAsync(x_out, e->X, sizeof(float) * (size_t)n * e->tokens * e->D, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return SAMRS_OK;
@@ -538,7 +589,7 @@ int samrs_get_embedding(samrs_engine_t* e, int slot, float* out_chw, void* strea
     if (!e || !out_chw) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_get_embedding: null argument");
     if (slot < 0 || slot >= e->cfg.max_images) return fail(e, SAMRS_ERR_CAPACITY, "slot out of range");
     if (!e->slot_set[slot]) return fail(e, SAMRS_ERR_NOT_SET, "An image must be set with .set_image(...) to generate an embedding.");
-    CK(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     CK(e, launch_transpose_f32(e->EMB + (size_t)slot * e->tokens * e->C, out_chw, e->tokens, e->C, (hipStream_t)stream));
     return SAMRS_OK;
 }
@@ -547,7 +598,7 @@ int samrs_set_embedding(samrs_engine_t* e, int slot, const float* emb_chw, void*
     if (!e || !emb_chw) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_set_embedding: null argument");
     if (!e->finalized) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "weights not finalized");
     if (slot < 0 || slot >= e->cfg.max_images) return fail(e, SAMRS_ERR_CAPACITY, "slot out of range");
-    CK(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     CK(e, launch_transpose_f32(emb_chw, e->EMB + (size_t)slot * e->tokens * e->C, e->C, e->tokens, (hipStream_t)stream));
     e->slot_set[slot] = 1;
     return SAMRS_OK;
@@ -561,22 +612,54 @@ int samrs_reset_image(samrs_engine_t* e, int slot) {
 }
 
 // -------------------------------------------------------------------------------------------------
+static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes, const float* point_coords,
+                         const int32_t* point_labels, int n_points, const float* mask_input, int multimask,
+                         int return_logits, int in_h, int in_w, int orig_h, int orig_w, void* masks_out, float* iou_out,
+                         float* lowres_out, void* stream);
+
+// The reference takes any number of prompts per call (its instance drivers pass every object of an image at once,
+// main_sam_rbox_mask_instance.py:159-164).  The engine's workspaces hold max_prompts prompts, so a larger call is
+// run as consecutive chunks of max_prompts on the same stream, each writing its slice of the caller's buffers;
+// results do not depend on the chunking (no cross-prompt arithmetic, no atomics anywhere on the path).
 int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const float* point_coords,
                   const int32_t* point_labels, int n_points, const float* mask_input, int multimask,
                   int return_logits, int in_h, int in_w, int orig_h, int orig_w, void* masks_out, float* iou_out,
                   float* lowres_out, void* stream) {
     if (!e) return SAMRS_ERR_BAD_ARG;
+    if (n < 1) return fail(e, SAMRS_ERR_BAD_ARG, "n_prompts must be >= 1");
+    const int cap = e->cfg.max_prompts;
+    const size_t nsel = multimask ? 3 : 1;
+    const size_t mask_stride = nsel * (size_t)(orig_h > 0 ? orig_h : 0) * (size_t)(orig_w > 0 ? orig_w : 0) * (return_logits ? 4 : 1);
+    const int np = point_coords ? n_points : 0;
+    for (int off = 0; off < n; off += cap) {
+        const int m = (n - off) < cap ? (n - off) : cap;
+        const int rc = predict_chunk(
+            e, slot, m, boxes ? boxes + (size_t)off * 4 : nullptr, point_coords ? point_coords + (size_t)off * np * 2 : nullptr,
+            point_labels ? point_labels + (size_t)off * np : nullptr, n_points,
+            mask_input ? mask_input + (size_t)off * 256 * 256 : nullptr, multimask, return_logits, in_h, in_w, orig_h, orig_w,
+            masks_out ? (void*)((unsigned char*)masks_out + (size_t)off * mask_stride) : nullptr,
+            iou_out ? iou_out + (size_t)off * nsel : nullptr, lowres_out ? lowres_out + (size_t)off * nsel * 256 * 256 : nullptr, stream);
+        if (rc) return rc;
+    }
+    return SAMRS_OK;
+}
+
+static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes, const float* point_coords,
+                         const int32_t* point_labels, int n_points, const float* mask_input, int multimask,
+                         int return_logits, int in_h, int in_w, int orig_h, int orig_w, void* masks_out, float* iou_out,
+                         float* lowres_out, void* stream) {
     if (!e->finalized) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "weights not finalized");
     const samrs_config& c = e->cfg;
     if (slot < 0 || slot >= c.max_images) return fail(e, SAMRS_ERR_CAPACITY, "slot out of range");
     if (!e->slot_set[slot]) return fail(e, SAMRS_ERR_NOT_SET, "An image must be set with .set_image(...) before mask prediction.");
     if (n < 1 || n > c.max_prompts) return fail(e, SAMRS_ERR_CAPACITY, "n_prompts=%d exceeds max_prompts=%d", n, c.max_prompts);
+    if (!boxes && !point_coords && !mask_input) return fail(e, SAMRS_ERR_BAD_ARG, "at least one prompt (points, boxes or mask_input) is required");
     if (point_coords && !point_labels) return fail(e, SAMRS_ERR_BAD_ARG, "point_labels must be supplied if point_coords is supplied.");
     if (point_coords && (n_points < 1 || n_points > c.max_points)) return fail(e, SAMRS_ERR_CAPACITY, "n_points=%d exceeds max_points=%d", n_points, c.max_points);
     if (in_h < 1 || in_w < 1 || in_h > c.img_size || in_w > c.img_size || orig_h < 1 || orig_w < 1)
         return fail(e, SAMRS_ERR_BAD_SHAPE, "bad input/original size");
     hipStream_t s = (hipStream_t)stream;
-    CK(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     const int C = e->C, Ci = C / 2, tokens = e->tokens, prec = e->prec, g = e->grid;
     const int npt = point_coords ? n_points + (boxes ? 0 : 1) : 0;
     const int T = 5 + npt + (boxes ? 2 : 0);
@@ -731,7 +814,7 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
                 int64_t* areas, int64_t* cpix, int64_t* cins, int n_classes, void* stream) {
     if (!e || !masks || !labels || n < 1 || h < 1 || w < 1) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_paint: bad argument");
     if ((cpix || cins) && !areas) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_paint: class statistics need areas_out");
-    CK(e, hipSetDevice(e->device));
+    ON_DEVICE(e);
     CK(e, launch_paint(masks, labels, n, h, w, seg, (unsigned long long*)areas, (unsigned long long*)cpix,
                        (unsigned long long*)cins, n_classes, (hipStream_t)stream));
     return SAMRS_OK;

@@ -6,16 +6,24 @@ predictor: per image ``set_image`` once, ``predict_torch`` on box chunks (box-on
 area.  Painting / areas / class statistics run on the device (``samrs_paint``) so that only the
 1 MiB class map and the per-box areas cross PCIe instead of n full-resolution masks.
 
+``TilePipeline`` is the production loop (what ``samrs_amd.generate`` and ``bench.py`` run): batches of
+tiles through ONE encoder pass, H2D of batch k+1 and decode + paint + D2H of batch k-1 overlapped with the
+encoder of batch k on separate HIP streams.  ``SemanticGenerator`` is the same computation one image at a
+time on one stream (the reference's shape); the two give bit-identical outputs (tests/test_pipeline_gpu.py).
+
 Multi-GPU: images are independent, so rank r takes ``sorted(files)[r::world]`` (one process per
-GPU, full weight replica) and there is NO collective on the data path.  The only exchange is the
+GPU, full weight replica) -- or, for long-tailed box counts, pulls batches of image indices from a
+shared counter (``WorkQueue``) -- and there is NO collective on the data path.  The only exchange is the
 dataset statistic of ``Generate Dataset/statistic.py:15-21`` -- per-class pixel and instance
 counts -- which every rank accumulates locally as int64 and all-reduces once (``reduce_statistics``;
 backend ``nccl`` = RCCL over xGMI on the GPU box, ``gloo`` in the CPU tests).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+import queue
+import threading
+from dataclasses import dataclass, field
+from typing import Callable, Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -113,7 +121,10 @@ class InstancePrompter:
         self.predictor = predictor
 
     @torch.no_grad()
-    def predict(self, image: np.ndarray, mode: str, hboxes=None, rboxes=None, points=None, already_set: bool = False):
+    def predict(self, image: np.ndarray, mode: str, hboxes=None, rboxes=None, points=None, already_set: bool = False,
+                multimask_output: bool = False):
+        """multimask_output=True (BASELINE.json configs[3]) decodes the three multimask outputs per object and keeps the
+        one with the highest predicted IoU."""
         from . import transforms
         if mode not in self.MODES:
             raise ValueError(f"mode must be one of {self.MODES}")
@@ -132,17 +143,19 @@ class InstancePrompter:
             if mode == "point":
                 pc = torch.as_tensor(np.asarray(points[s:e]), dtype=torch.float32, device=dev)[:, None, :]
                 pl = torch.ones(e - s, 1, device=dev)
-                m, q, _ = p.predict_torch(point_coords=pc, point_labels=pl, boxes=None, mask_input=None, multimask_output=False)
+                m, q, _ = p.predict_torch(point_coords=pc, point_labels=pl, boxes=None, mask_input=None, multimask_output=multimask_output)
             elif mode == "rbox_mask":
                 prompts = transforms.rbox_mask_prompts(np.asarray(rboxes[s:e]), (h, w), img_size=p.model.image_encoder.img_size,
                                                        device=dev)
                 m, q, _ = p.predict_torch(point_coords=None, point_labels=None, boxes=None, mask_input=prompts[:, None],
-                                          multimask_output=False)
+                                          multimask_output=multimask_output)
             else:
                 tb = p.transform.apply_boxes_torch(torch.as_tensor(np.asarray(hboxes[s:e]), dtype=torch.float32, device=dev), (h, w))
-                m, q, _ = p.predict_torch(point_coords=None, point_labels=None, boxes=tb, mask_input=None, multimask_output=False)
-            masks.append(m[:, 0])
-            quals.append(q[:, 0])
+                m, q, _ = p.predict_torch(point_coords=None, point_labels=None, boxes=tb, mask_input=None, multimask_output=multimask_output)
+            best = q.argmax(1) if multimask_output else torch.zeros(e - s, dtype=torch.long, device=dev)
+            rows = torch.arange(e - s, device=dev)
+            masks.append(m[rows, best])
+            quals.append(q[rows, best])
         return torch.cat(masks), torch.cat(quals)
 
 
@@ -163,3 +176,380 @@ def mean_iou(pred_masks, gt_masks):
     if not ious:
         return float("nan"), float("nan")
     return float(np.mean(ious)), float(np.sum(inter_all) / np.sum(union_all))
+
+
+# ------------------------------------------------------------------------------------------------
+# Work distribution across ranks
+# ------------------------------------------------------------------------------------------------
+class WorkQueue:
+    """Hands out consecutive index ranges [start, end) of a sorted work list to the ranks of one job.
+
+    * ``mode="static"``  -- rank r owns the chunks r, r + world, r + 2 world, ... (no communication; with
+      ``chunk=1`` this is ``sorted(files)[r::world]``);
+    * ``mode="dynamic"`` -- a shared counter: every pull is one atomic fetch-add of ``chunk`` on the job's
+      rendezvous store (``torch.distributed`` TCPStore ``add``: one small round trip to rank 0's store thread,
+      ~0.1 ms, against ~60 ms of GPU work per 8-tile chunk).  A rank that drew images with hundreds of boxes
+      (DOTA-v2: a few per cent of the tiles) simply pulls less often, so the 8 GPUs finish together instead
+      of waiting for the unluckiest static shard.  The data path itself still has no collective.
+    """
+
+    def __init__(self, n_items: int, chunk: int = 1, rank: int = 0, world: int = 1, mode: str = "static",
+                 store=None, name: str = "samrs_wq"):
+        if mode not in ("static", "dynamic"):
+            raise ValueError("mode must be 'static' or 'dynamic'")
+        self.n, self.chunk, self.rank, self.world, self.mode = int(n_items), int(chunk), rank, world, mode
+        self._k = 0
+        self._local = 0
+        self._key = name + "/head"
+        self._store = None
+        if mode == "dynamic" and world > 1:
+            if store is None:
+                import torch.distributed as dist
+                from torch.distributed.distributed_c10d import _get_default_store
+                if not dist.is_initialized():
+                    raise RuntimeError("dynamic WorkQueue over several ranks needs an initialised process group (its store)")
+                store = _get_default_store()
+            self._store = store
+
+    def pull(self) -> Optional[Tuple[int, int]]:
+        """Next range, or None when the list is exhausted."""
+        if self.mode == "static":
+            start = (self._k * self.world + self.rank) * self.chunk
+            self._k += 1
+        elif self._store is None:
+            start = self._local
+            self._local += self.chunk
+        else:
+            start = int(self._store.add(self._key, self.chunk)) - self.chunk
+        if start >= self.n:
+            return None
+        return start, min(self.n, start + self.chunk)
+
+    def __iter__(self) -> Iterator[Tuple[int, int]]:
+        while True:
+            r = self.pull()
+            if r is None:
+                return
+            yield r
+
+
+def gather_mask_sizes(local_sizes: Sequence[int], group=None) -> List[int]:
+    """All ranks' per-instance mask sizes in rank order -- the list `Generate Dataset/statistic.py:34-53` builds from
+    every ``ins/*.pkl`` (``all_mask_size``).  Variable length per rank: all-gather of the counts, then of the
+    sizes padded to the longest rank (RCCL on the GPU box, gloo in the CPU tests)."""
+    import torch.distributed as dist
+    sizes = torch.as_tensor(list(local_sizes), dtype=torch.int64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sizes.tolist()
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    cnt = torch.tensor([sizes.numel()], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt, group=group)
+    m = max(int(c.item()) for c in counts)
+    buf = torch.zeros(max(m, 1), dtype=torch.int64, device=dev)
+    buf[: sizes.numel()] = sizes.to(dev)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    out: List[int] = []
+    for c, b in zip(counts, bufs):
+        out.extend(b[: int(c.item())].cpu().tolist())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# The production loop
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class WorkItem:
+    """One image of the stream: uint8 HWC pixels (host numpy array, host tensor or device tensor), its boxes in
+    ORIGINAL-image pixels (xyxy) and their class labels; `key` travels to the sink untouched."""
+    key: object
+    image: object
+    boxes: np.ndarray
+    labels: np.ndarray
+
+
+@dataclass
+class TileResult:
+    key: object
+    seg_mask: np.ndarray                    # uint8 [H, W] host, 255 = unlabeled (a view of a pinned ring buffer)
+    areas: np.ndarray                       # int64 [n_boxes] host
+    boxes: np.ndarray
+    labels: np.ndarray
+    masks: Optional[np.ndarray] = None      # uint8 [n_boxes, H, W] host when keep_masks
+    quality: Optional[np.ndarray] = None    # fp32 [n_boxes] predicted IoU of the kept mask (instance pipelines)
+
+
+class _OutBuf:
+    def __init__(self, batch: int, side: int, max_boxes: int):
+        self.seg = torch.empty(batch, side, side, dtype=torch.uint8).pin_memory()
+        self.areas = torch.empty(batch, max_boxes, dtype=torch.int64).pin_memory()
+        self.done = torch.cuda.Event()
+        self.masks: List[Optional[torch.Tensor]] = [None] * batch     # keep_masks: host copies of the full masks
+        self.odd: dict = {}                                           # tiles that are not side x side: their class maps
+
+
+class TilePipeline:
+    """hbox -> semantic labels for a stream of tiles (main_sam_hbox_semantic.py:110-216), restructured for the GPU:
+
+        stream h2d : pinned staging -> HBM            tiles + boxes of batch k+1
+        stream enc : samrs_set_images(_ragged)        batch k   (one encoder pass over `batch` tiles)
+        stream dec : predict (box chunks) + paint     batch k-1 (reads the OTHER embedding slot set)
+                     + D2H of class maps / areas
+        host       : hands batch k-2 to `sink`        (PNG / pickle writers run in a thread pool there)
+
+    Two embedding slot sets and two input staging sets, `out_depth` pinned output buffers.  What crosses PCIe per
+    tile: 3 MiB in, 1 MiB class map + 8 B per box out (`samrs_paint` runs on the device; with keep_masks the full
+    masks follow for RLE).  Bit-identical to `SemanticGenerator` (no kernel depends on batch composition or on what
+    runs next to it).  Tiles of one batch may differ in size (non-1024 tiles are resized on the GPU, bit-exact with
+    PIL, and encoded through samrs_set_images_ragged)."""
+
+    BOX_WIDTH = 4          # floats per annotation: xyxy
+
+    def __init__(self, sam, n_classes: int, batch: int = 8, box_batch: int = 20, keep_masks: bool = False,
+                 out_depth: int = 3, max_boxes: int = 512, device_inputs: bool = False):
+        from .transforms import ResizeLongestSide
+        eng = sam.engine
+        if eng is None:
+            raise RuntimeError("move the model to the GPU first: sam.to('cuda')")
+        if eng.max_images < 2 * batch:
+            raise ValueError(f"TilePipeline(batch={batch}) needs an engine with max_images >= {2 * batch} "
+                             f"(two embedding slot sets); got {eng.max_images}")
+        self.sam, self.eng, self.dev = sam, eng, eng.device
+        self.batch, self.box_batch, self.keep_masks, self.max_boxes = batch, box_batch, keep_masks, max_boxes
+        self.side = sam.cfg.img_size
+        self.transform = ResizeLongestSide(sam.image_encoder.img_size)
+        self.class_pixels = torch.zeros(n_classes, dtype=torch.int64, device=self.dev)
+        self.class_instances = torch.zeros(n_classes, dtype=torch.int64, device=self.dev)
+        dev, side = self.dev, self.side
+        self.s_h2d, self.s_enc, self.s_dec = (torch.cuda.Stream(dev) for _ in range(3))
+        self.device_inputs = device_inputs
+        if not device_inputs:
+            self.pin_in = [torch.empty(batch, side, side, 3, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.dev_in = [torch.empty(batch, side, side, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
+        bw = self.BOX_WIDTH
+        self.pin_box = [torch.empty(batch * max_boxes, bw, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.pin_lab = [torch.empty(batch * max_boxes, dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.dev_box = [torch.empty(batch * max_boxes, bw, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.dev_lab = [torch.empty(batch * max_boxes, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.seg_dev = [torch.empty(batch, side, side, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.area_dev = [torch.zeros(batch, max_boxes, dtype=torch.int64, device=dev) for _ in range(2)]
+        self.ev_h2d = [torch.cuda.Event() for _ in range(2)]
+        self.ev_enc = [torch.cuda.Event() for _ in range(2)]
+        self.ev_dec = [torch.cuda.Event() for _ in range(2)]
+        self.ev_in_free = [torch.cuda.Event() for _ in range(2)]     # encoder has consumed input set b
+        self.free_out: "queue.Queue[_OutBuf]" = queue.Queue()
+        for _ in range(out_depth):
+            self.free_out.put(_OutBuf(batch, side, max_boxes))
+
+    # -- stage A: stage tiles + boxes of one batch, H2D on s_h2d ------------------------------------------------
+    def _stage(self, b: int, items: List[WorkItem]):
+        tiles = []         # per image: (device tensor uint8 [h, w, 3] with long side == img_size, original (H, W))
+        same = True
+        n_off = 0
+        offs = []
+        self.ev_in_free[b].synchronize()                  # pinned / device input set b is free again (host wait: the
+        for i, it in enumerate(items):                    # pinned buffer must not be overwritten under an in-flight copy)
+            nb = len(it.labels)
+            if nb > self.max_boxes:
+                raise ValueError(f"{nb} boxes on one image > max_boxes={self.max_boxes}")
+            self.pin_box[b][n_off:n_off + nb] = torch.as_tensor(np.asarray(it.boxes, dtype=np.float32).reshape(-1, self.BOX_WIDTH))
+            self.pin_lab[b][n_off:n_off + nb] = torch.as_tensor(np.asarray(it.labels).astype(np.int32))
+            offs.append((n_off, nb))
+            n_off += nb
+        with torch.cuda.stream(self.s_h2d):
+            self.s_h2d.wait_event(self.ev_dec[b])          # the decoder of batch k-2 read box / label set b
+            self.dev_box[b][:n_off].copy_(self.pin_box[b][:n_off], non_blocking=True)
+            self.dev_lab[b][:n_off].copy_(self.pin_lab[b][:n_off], non_blocking=True)
+            for i, it in enumerate(items):
+                img = it.image
+                H, W = int(img.shape[0]), int(img.shape[1])
+                native = (H == self.side and W == self.side)
+                if isinstance(img, torch.Tensor) and img.is_cuda:
+                    t = img
+                    if native:
+                        self.dev_in[b][i].copy_(t, non_blocking=True)
+                        t = self.dev_in[b][i]
+                elif native:
+                    src = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
+                    if src.is_pinned():                                           # caller-owned pinned memory: straight H2D
+                        self.dev_in[b][i].copy_(src, non_blocking=True)
+                    else:
+                        self.pin_in[b][i].copy_(src)                              # host memcpy into pinned staging
+                        self.dev_in[b][i].copy_(self.pin_in[b][i], non_blocking=True)
+                    t = self.dev_in[b][i]
+                else:
+                    src = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
+                    t = src.to(self.dev)                                          # odd sizes: plain upload, then
+                if not native:
+                    t = self.transform.apply_image_device(t.contiguous())         # PIL-exact resize on the GPU
+                    same = False
+                tiles.append((t, (H, W)))
+            self.ev_h2d[b].record(self.s_h2d)
+        return tiles, same, offs
+
+    def _encode(self, b: int, tiles, same: bool):
+        n = len(tiles)
+        with torch.cuda.stream(self.s_enc):
+            self.s_enc.wait_event(self.ev_h2d[b])
+            self.s_enc.wait_event(self.ev_dec[b])                  # decoder is done with embedding slot set b
+            if same:
+                self.eng.set_images(self.dev_in[b][:n], b * self.batch)
+            else:
+                self.eng.set_images_ragged([t for t, _ in tiles], b * self.batch)
+            self.ev_enc[b].record(self.s_enc)
+            self.ev_in_free[b].record(self.s_enc)
+
+    def _decode_tile(self, b: int, i: int, tile, hw, off: int, nb: int, out: _OutBuf) -> None:
+        """Everything the reference does per image after set_image (main_sam_hbox_semantic.py:157-206), on s_dec."""
+        eng, (H, W) = self.eng, hw
+        in_size = (int(tile.shape[0]), int(tile.shape[1]))
+        native = (H, W) == (self.side, self.side)
+        seg = self.seg_dev[b][i] if native else torch.full((H, W), 255, dtype=torch.uint8, device=self.dev)
+        kept = []
+        for s, e in box_chunks(nb, self.box_batch):                          # :157-181
+            tb = self.transform.apply_boxes_torch(self.dev_box[b][off + s:off + e], (H, W))   # :174
+            masks, _, _ = eng.predict(b * self.batch + i, tb, None, None, None, False, False, in_size, (H, W))
+            a = eng.paint(masks[:, 0], self.dev_lab[b][off + s:off + e], seg, self.class_pixels, self.class_instances)
+            self.area_dev[b][i, s:e] = a
+            if self.keep_masks:
+                kept.append(masks[:, 0].view(torch.uint8))
+        if native:
+            out.seg[i].copy_(seg, non_blocking=True)
+        else:
+            out.odd[i] = seg.cpu()                    # other sizes (DIOR 800^2, HRSC): synchronous copy, rare path
+        # full masks for the per-instance RLE (main_sam_hbox_semantic.py:201-205): n MiB per tile instead of
+        # 1 MiB, copied synchronously -- the full-fidelity mode trades the overlap for the reference's pkl contract
+        out.masks[i] = torch.cat(kept).cpu() if (self.keep_masks and kept) else None
+
+    def _decode(self, b: int, items, tiles, offs, out: _OutBuf):
+        with torch.cuda.stream(self.s_dec):
+            self.s_dec.wait_event(self.ev_enc[b])
+            self.seg_dev[b].fill_(255)                                               # main_sam_hbox_semantic.py:162
+            for i, ((t, hw), (off, nb)) in enumerate(zip(tiles, offs)):
+                self._decode_tile(b, i, t, hw, off, nb, out)
+            out.areas.copy_(self.area_dev[b], non_blocking=True)
+            self._extra_outputs(b, out)
+            self.ev_dec[b].record(self.s_dec)
+            out.done.record(self.s_dec)
+
+    def _extra_outputs(self, b: int, out: _OutBuf) -> None:
+        pass
+
+    def _finish(self, pending, sink):
+        items, offs, out = pending
+        out.done.synchronize()
+        odd = out.odd
+        res = []
+        for i, (it, (_, nb)) in enumerate(zip(items, offs)):
+            seg = odd[i].numpy() if i in odd else out.seg[i].numpy()
+            m = out.masks[i].numpy() if out.masks[i] is not None else None
+            q = out.quality[i, :nb].numpy().copy() if getattr(out, "quality", None) is not None else None
+            res.append(TileResult(it.key, seg, out.areas[i, :nb].numpy().copy(), np.asarray(it.boxes), np.asarray(it.labels), m, q))
+        out.odd = {}
+        release = lambda o=out: self.free_out.put(o)
+        sink(res, release)
+
+    @torch.no_grad()
+    def run(self, batches: Iterable[List[WorkItem]], sink: Callable[[List[TileResult], Callable[[], None]], None]) -> int:
+        """Drives `batches` (lists of <= batch WorkItems) through the pipeline.  `sink(results, release)` is called on the
+        calling thread, in order, once a batch's class maps and areas are on the host; the arrays are views of a pinned
+        ring buffer, so the sink (or whatever it hands them to) must call `release()` when it is done with them.
+        Returns the number of tiles processed."""
+        cur = torch.cuda.current_stream(self.dev)
+        for st in (self.s_h2d, self.s_enc, self.s_dec):
+            st.wait_stream(cur)
+        n_tiles = 0
+        staged = None        # batch k+1: staged, not yet encoded
+        encoded = None       # batch k  : encoder issued
+        decoding = None      # batch k-1: decoder issued, results not yet handed over
+        it = iter(batches)
+        k = 0
+        while True:
+            nxt = next(it, None)
+            if nxt is not None:
+                if len(nxt) < 1 or len(nxt) > self.batch:
+                    raise ValueError(f"a batch must hold 1..{self.batch} work items")
+                b = k & 1
+                tiles, same, offs = self._stage(b, nxt)
+                self._encode(b, tiles, same)
+                staged = (b, nxt, tiles, offs)
+                n_tiles += len(nxt)
+                k += 1
+            if encoded is not None:
+                b, items, tiles, offs = encoded
+                out = self.free_out.get()                              # blocks while the writers hold every buffer
+                self._decode(b, items, tiles, offs, out)
+                if decoding is not None:
+                    self._finish(decoding, sink)
+                decoding = (items, offs, out)
+            encoded, staged = staged, None
+            if nxt is None and encoded is None:
+                break
+        if decoding is not None:
+            self._finish(decoding, sink)
+        for st in (self.s_h2d, self.s_enc, self.s_dec):
+            cur.wait_stream(st)
+        return n_tiles
+
+
+def batched(items: Iterable[WorkItem], batch: int) -> Iterator[List[WorkItem]]:
+    buf: List[WorkItem] = []
+    for it in items:
+        buf.append(it)
+        if len(buf) == batch:
+            yield buf
+            buf = []
+    if buf:
+        yield buf
+
+
+class InstancePipeline(TilePipeline):
+    """The instance drivers' recipe (main_sam_rhbox_mask_instance.py:125-168 / main_sam_rbox_mask_instance.py:125-164)
+    on the same three-stream pipeline, with ``multimask_output=True`` (BASELINE.json configs[3]): annotations are
+    rotated boxes [n, 4, 2]; ``prompt="box"`` feeds the enclosing hbox (min / max of the corners, :125-130) through
+    ``apply_boxes_torch``, ``prompt="rbox_mask"`` rasterises the rbox into a +-1000 mask prompt on the GPU
+    (``transforms.rbox_mask_prompts``).  Of the three masks per object the one with the highest predicted IoU is kept
+    (SAM's own selection rule); per object the host receives its area and quality, the kept masks stay in HBM
+    (``last_masks``) unless keep_masks."""
+
+    BOX_WIDTH = 8          # four (x, y) corners
+
+    def __init__(self, sam, n_classes: int, prompt: str = "box", **kw):
+        if prompt not in ("box", "rbox_mask"):
+            raise ValueError("prompt must be 'box' or 'rbox_mask'")
+        super().__init__(sam, n_classes, **kw)
+        self.prompt = prompt
+        self.qual_dev = [torch.zeros(self.batch, self.max_boxes, dtype=torch.float32, device=self.dev) for _ in range(2)]
+        for _ in range(self.free_out.qsize()):
+            o = self.free_out.get()
+            o.quality = torch.empty(self.batch, self.max_boxes, dtype=torch.float32).pin_memory()
+            self.free_out.put(o)
+        self.last_masks = None
+
+    def _decode_tile(self, b, i, tile, hw, off, nb, out) -> None:
+        from . import transforms
+        eng, (H, W) = self.eng, hw
+        in_size = (int(tile.shape[0]), int(tile.shape[1]))
+        kept = []
+        for s, e in box_chunks(nb, self.box_batch):
+            polys = self.dev_box[b][off + s:off + e].view(-1, 4, 2)
+            if self.prompt == "box":
+                hb = torch.cat([polys.amin(1), polys.amax(1)], dim=1)                                   # :125-130
+                tb = self.transform.apply_boxes_torch(hb, (H, W))
+                m, q, _ = eng.predict(b * self.batch + i, tb, None, None, None, True, False, in_size, (H, W))
+            else:
+                pr = transforms.rbox_mask_prompts_device(polys, (H, W), self.side, device=self.dev)
+                m, q, _ = eng.predict(b * self.batch + i, None, None, None, pr[:, None], True, False, in_size, (H, W))
+            best = q.argmax(1)
+            rows = torch.arange(e - s, device=self.dev)
+            mk = m[rows, best]                                                                          # [n, H, W]
+            self.qual_dev[b][i, s:e] = q[rows, best]
+            self.area_dev[b][i, s:e] = mk.flatten(1).sum(1)
+            kept.append(mk)
+        self.last_masks = kept[-1] if kept else None
+        out.masks[i] = torch.cat(kept).cpu().view(torch.uint8) if (self.keep_masks and kept) else None
+
+    def _extra_outputs(self, b: int, out: _OutBuf) -> None:
+        out.quality.copy_(self.qual_dev[b], non_blocking=True)

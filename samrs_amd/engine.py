@@ -58,6 +58,7 @@ def load_library() -> C.CDLL:
     lib.samrs_load_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), ip]
     lib.samrs_finalize_weights.argtypes = [vp, vp]
     lib.samrs_set_images.argtypes = [vp, vp, ip, ip, ip, ip, vp]
+    lib.samrs_set_images_ragged.argtypes = [vp, C.POINTER(vp), C.POINTER(ip), C.POINTER(ip), ip, ip, vp]
     lib.samrs_get_embedding.argtypes = [vp, ip, vp, vp]
     lib.samrs_set_embedding.argtypes = [vp, ip, vp, vp]
     lib.samrs_reset_image.argtypes = [vp, ip]
@@ -82,7 +83,7 @@ def load_library() -> C.CDLL:
     lib.samrs_k_postprocess.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, vp, vp]
     lib.samrs_k_gemm_gln.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, vp]
     lib.samrs_k_upscale2_masks.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
-    for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_get_embedding",
+    for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_set_images_ragged", "samrs_get_embedding",
                  "samrs_set_embedding", "samrs_reset_image", "samrs_predict", "samrs_paint", "samrs_k_gemm",
                  "samrs_k_gemm_f32", "samrs_k_convert", "samrs_k_layernorm", "samrs_k_window_attention",
                  "samrs_k_global_attention", "samrs_k_postprocess", "samrs_k_gemm_gln", "samrs_k_upscale2_masks"):
@@ -128,7 +129,8 @@ class Engine:
         c.max_images, c.max_prompts, c.max_points = max_images, max_prompts, max_points
         c.precision = PRECISIONS[precision]
         err = C.create_string_buffer(512)
-        self.handle = self.lib.samrs_create(C.byref(c), self.device.index, err, 512)
+        with torch.cuda.device(self.device):
+            self.handle = self.lib.samrs_create(C.byref(c), self.device.index, err, 512)
         if not self.handle:
             raise EngineError("samrs_create failed: " + err.value.decode())
 
@@ -171,6 +173,18 @@ class Engine:
         with torch.cuda.device(self.device):
             self._check(self.lib.samrs_set_images(self.handle, images_u8.data_ptr(), n, h, w, slot0, _stream()))
 
+    def set_images_ragged(self, images_u8, slot0: int = 0) -> None:
+        """One encoder pass over tiles of DIFFERENT sizes: a sequence of uint8 [H_i, W_i, 3] device tensors, each with
+        long side == img_size (samrs_set_images_ragged)."""
+        n = len(images_u8)
+        for t in images_u8:
+            assert t.dtype == torch.uint8 and t.dim() == 3 and t.shape[-1] == 3 and t.is_cuda and t.is_contiguous()
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in images_u8])
+        hs = (C.c_int * n)(*[int(t.shape[0]) for t in images_u8])
+        ws = (C.c_int * n)(*[int(t.shape[1]) for t in images_u8])
+        with torch.cuda.device(self.device):
+            self._check(self.lib.samrs_set_images_ragged(self.handle, ptrs, hs, ws, n, slot0, _stream()))
+
     def debug_encoder_prefix(self, images_u8: torch.Tensor, n_blocks: int) -> torch.Tensor:
         """Test hook: residual stream [n, 64, 64, D] after patch embed + the first n_blocks blocks."""
         n, h, w, _ = images_u8.shape
@@ -212,19 +226,40 @@ class Engine:
         f32 = dict(dtype=torch.float32, device=dev)
         if point_coords is not None and point_labels is None:
             raise AssertionError("point_labels must be supplied if point_coords is supplied.")
+        # shape contract of predictor.py:169-177 / prompt_encoder.py:73-105 -- the library reads raw pointers, so a
+        # mis-shaped prompt must be rejected here (the reference fails with a shape error inside the prompt encoder)
         n = None
         if point_coords is not None:
+            if point_coords.dim() != 3 or point_coords.shape[-1] != 2:
+                raise ValueError(f"point_coords must be BxNx2, got {tuple(point_coords.shape)}")
+            n, npts = int(point_coords.shape[0]), int(point_coords.shape[1])
+            if tuple(point_labels.shape) != (n, npts):
+                raise ValueError(f"point_labels must be BxN = {(n, npts)}, got {tuple(point_labels.shape)}")
+            if npts < 1 or npts > self.max_points:
+                raise ValueError(f"{npts} points per prompt, but this engine was created with max_points={self.max_points} "
+                                 "(hard limit 8: the decoder keeps at most 16 tokens per prompt); pass max_points= to "
+                                 "sam_model_registry[...]")
             point_coords = point_coords.to(**f32).contiguous()
             point_labels = point_labels.to(dtype=torch.int32, device=dev).contiguous()
-            n = point_coords.shape[0]
         if boxes is not None:
+            if boxes.numel() % 4 != 0 or boxes.shape[-1] != 4:
+                raise ValueError(f"boxes must be Bx4, got {tuple(boxes.shape)}")
             boxes = boxes.to(**f32).reshape(-1, 4).contiguous()
-            n = boxes.shape[0] if n is None else n
+            if n is not None and boxes.shape[0] != n:
+                raise ValueError(f"boxes has {boxes.shape[0]} rows but the point prompts have {n}")
+            n = int(boxes.shape[0])
         if mask_input is not None:
+            side = 4 * self.cfg.grid
+            if mask_input.dim() != 4 or tuple(mask_input.shape[1:]) != (1, side, side):
+                raise ValueError(f"mask_input must be Bx1x{side}x{side}, got {tuple(mask_input.shape)}")
+            if n is not None and mask_input.shape[0] != n:
+                raise ValueError(f"mask_input has batch {mask_input.shape[0]} but the other prompts have {n}")
             mask_input = mask_input.to(**f32).contiguous()
-            n = mask_input.shape[0] if n is None else n
+            n = int(mask_input.shape[0])
         if n is None:
             raise AssertionError("at least one prompt (points, boxes or mask_input) is required")
+        if n < 1:
+            raise ValueError("empty prompt batch")
         npts = 0 if point_coords is None else point_coords.shape[1]
         c = 3 if multimask_output else 1
         oh, ow = int(original_size[0]), int(original_size[1])

@@ -10,8 +10,11 @@ training datasets.  Paths are flags instead of the reference's hard-coded module
 ``boxes.json``: ``{"<image stem>": {"boxes": [[x0,y0,x1,y1], ...], "labels": [int, ...]}, ...}`` (how
 the dataset's own annotation format becomes boxes -- loaddata.py -- stays outside the hot path).
 Rotated boxes are reduced to their enclosing hbox by the caller
-(main_sam_rhbox_semantic.py:125-130).  One process per GPU, rank r takes ``sorted(stems)[r::world]``,
-no collective on the data path, one int64 all-reduce for the class statistics at the end.
+(main_sam_rhbox_semantic.py:125-130).  One process per GPU; the stems are sorted and handed out in chunks of
+``--batch`` (statically, or from a shared counter with ``--schedule dynamic``); every rank runs
+``driver.TilePipeline`` (batched encoder, decoder / painting / transfers overlapped on separate HIP streams,
+reader + writer thread pools); no collective on the data path, one int64 all-reduce for the class statistics
+and one all-gather for the mask-size list (statistic.py:34-53) at the end.
 """
 from __future__ import annotations
 
@@ -56,6 +59,7 @@ def write_outputs(out_dir: str, stem: str, seg: np.ndarray, masks: Optional[np.n
 
 def run(args) -> Dict[str, List[int]]:
     import torch.distributed as dist
+    from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
 
     import samrs_amd
@@ -70,27 +74,67 @@ def run(args) -> Dict[str, List[int]]:
     names = [l.strip() for l in open(args.classes)] if args.classes else [str(i) for i in range(args.n_classes)]
     n_classes = len(names)
     palette = np.load(args.palette) if args.palette else default_palette(n_classes)
+    batch = getattr(args, "batch", 8)
     sam = samrs_amd.sam_model_registry[args.model](checkpoint=args.checkpoint, precision=args.precision,
-                                                   max_prompts=args.box_batch).to(f"cuda:{local}")
-    gen = driver.SemanticGenerator(samrs_amd.SamPredictor(sam), n_classes, box_batch=args.box_batch)
+                                                   max_images=2 * batch, max_prompts=args.box_batch).to(f"cuda:{local}")
     exts = (".png", ".jpg", ".jpeg", ".tif", ".bmp")
     files = {os.path.splitext(f)[0]: f for f in os.listdir(args.images) if f.lower().endswith(exts)}
-    stems = driver.shard([s for s in files if s in ann and len(ann[s]["boxes"]) > 0], rank, world)   # :126-129
-    for k, stem in enumerate(stems):
-        img = np.array(Image.open(os.path.join(args.images, files[stem])).convert("RGB"))           # :114
-        boxes = np.asarray(ann[stem]["boxes"], dtype=np.float32)
-        labels = np.asarray(ann[stem]["labels"], dtype=np.int64)
-        res = gen.process_image(img, boxes, labels, keep_masks=not args.no_rle)
-        masks = res.masks.cpu().numpy() if res.masks is not None else None
-        write_outputs(args.out, stem, res.seg_mask.cpu().numpy(), masks, boxes, labels, res.areas.cpu().numpy(), palette, names)
-        if rank == 0 and k % 50 == 0:
-            print(f"[rank 0] {k}/{len(stems)} images", flush=True)
-    pix, ins = driver.reduce_statistics(gen.class_pixels, gen.class_instances)
-    stats = {"class_pixel_num": pix.cpu().tolist(), "class_instance_num": ins.cpu().tolist()}
+    stems = sorted(s for s in files if s in ann and len(ann[s]["boxes"]) > 0)                       # :126-129
+    max_boxes = max([len(ann[s]["labels"]) for s in stems] + [1])
+    pipe = driver.TilePipeline(sam, n_classes, batch=batch, box_batch=args.box_batch, keep_masks=not args.no_rle,
+                               max_boxes=max_boxes)
+    # rank r takes chunks of `batch` consecutive stems: statically (r, r + world, ...) or from the shared counter
+    wq = driver.WorkQueue(len(stems), chunk=batch, rank=rank, world=world, mode=getattr(args, "schedule", "static"))
+
+    def load(stem: str) -> driver.WorkItem:
+        img = np.array(Image.open(os.path.join(args.images, files[stem])).convert("RGB"))            # :114
+        return driver.WorkItem(stem, img, np.asarray(ann[stem]["boxes"], dtype=np.float32),
+                               np.asarray(ann[stem]["labels"], dtype=np.int64))
+
+    def batches():
+        # image decode of the NEXT batch runs on a helper thread while the GPU works on this one
+        with ThreadPoolExecutor(max_workers=getattr(args, "readers", 4)) as readers:
+            nxt = None
+            for s0, s1 in wq:
+                fut = [readers.submit(load, st) for st in stems[s0:s1]]
+                if nxt is not None:
+                    yield [f.result() for f in nxt]
+                nxt = fut
+            if nxt is not None:
+                yield [f.result() for f in nxt]
+
+    done = [0]
+    sizes: List[int] = []
+    writers = ThreadPoolExecutor(max_workers=getattr(args, "writers", 8))
+
+    def sink(results, release):
+        # PNG encode + pickle on the writer pool (zlib releases the GIL); the pinned ring buffer goes back when the
+        # whole batch is on disk
+        def job():
+            try:
+                for r in results:
+                    m = r.masks.astype(bool) if r.masks is not None else None
+                    write_outputs(args.out, r.key, r.seg_mask, m, r.boxes, r.labels, r.areas, palette, names)
+            finally:
+                release()
+        for r in results:
+            sizes.extend(int(a) for a in r.areas if a > 0)                                           # statistic.py:44-49
+        writers.submit(job)
+        done[0] += len(results)
+        if rank == 0 and (done[0] // batch) % 50 == 0:
+            print(f"[rank 0] {done[0]} images", flush=True)
+
+    pipe.run(batches(), sink)
+    writers.shutdown(wait=True)
+    pix, ins = driver.reduce_statistics(pipe.class_pixels, pipe.class_instances)
+    all_sizes = driver.gather_mask_sizes(sizes)
+    stats = {"class_pixel_num": pix.cpu().tolist(), "class_instance_num": ins.cpu().tolist(),
+             "mask_num": len(all_sizes)}                                                             # statistic.py:53
     if rank == 0:
         os.makedirs(os.path.join(args.out, "statistic"), exist_ok=True)
         with open(os.path.join(args.out, "statistic", "class_stats.json"), "w") as f:       # statistic.py:28-31
             json.dump(stats, f)
+        np.save(os.path.join(args.out, "statistic", "all_mask_size.npy"), np.asarray(all_sizes, dtype=np.int64))
     return stats
 
 
@@ -107,6 +151,11 @@ def main(argv=None):
     ap.add_argument("--palette", default=None, help=".npy uint8 [n_classes, 3]")
     ap.add_argument("--box-batch", type=int, default=20)                                    # main_sam_hbox_semantic.py:91
     ap.add_argument("--no-rle", action="store_true", help="skip per-instance RLE (only class maps + areas)")
+    ap.add_argument("--batch", type=int, default=8, help="tiles per encoder pass")
+    ap.add_argument("--schedule", default="static", choices=["static", "dynamic"],
+                    help="static: rank r takes chunks r, r+world, ...; dynamic: shared-counter work queue (long-tailed box counts)")
+    ap.add_argument("--readers", type=int, default=4, help="image decode threads")
+    ap.add_argument("--writers", type=int, default=8, help="PNG / pickle writer threads")
     run(ap.parse_args(argv))
 
 

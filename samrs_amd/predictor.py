@@ -40,9 +40,18 @@ class SamPredictor:
         s = self.model.image_encoder.img_size
         assert (len(transformed_image.shape) == 4 and transformed_image.shape[1] == 3
                 and max(*transformed_image.shape[2:]) == s), f"set_torch_image input must be BCHW with long side {s}."
-        # the reference takes 0..255 pixel values in any dtype here; the engine's input is uint8 HWC
-        hwc = transformed_image.to(self.device).permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8).contiguous()
-        self._set_hwc(hwc[:1], tuple(original_image_size))
+        # One image per predictor, like the reference: its `features` of a B > 1 input could not be used by
+        # predict_torch, whose prompts carry no image index (predictor.py:84-90,168-245).
+        assert transformed_image.shape[0] == 1, "set_torch_image takes ONE image (1x3xHxW); batch through Engine.set_images"
+        # The reference normalises whatever values it is given (sam.py:167); the engine's input is the uint8 HWC tile
+        # every SAMRS driver starts from (set_image, predictor.py:52-58), so 0..255 values are rounded to uint8 here.
+        # Non-integer pixel values would be quantised by that rounding -- refuse them instead of answering differently.
+        t = transformed_image.to(self.device)
+        if t.is_floating_point():
+            assert bool((t == t.round()).all()) and float(t.min()) >= 0 and float(t.max()) <= 255, \
+                "set_torch_image needs integer pixel values in 0..255 (the engine takes uint8 tiles)"
+        hwc = t.permute(0, 2, 3, 1).round().clamp(0, 255).to(torch.uint8).contiguous()
+        self._set_hwc(hwc, tuple(original_image_size))
 
     def _set_hwc(self, hwc_u8: torch.Tensor, original_size: Tuple[int, int]) -> None:
         self.reset_image()

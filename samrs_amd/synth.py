@@ -90,12 +90,21 @@ def _dec_attention(sd, gen, prefix: str, dim: int, internal: int) -> None:
     _linear(sd, gen, prefix + ".out_proj", dim, internal)
 
 
-def make_state_dict(cfg: SamConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+# "Realistic-margin" weights: the last layer of every hypernetwork MLP scaled so that the
+# low-res logits have a checkpoint-like spread (std ~ 4 instead of ~ 0.1).  A power of two, so every logit is
+# EXACTLY 32 x the unscaled one in fp32 and in the engine alike.  NB: a positive scale cannot move a zero
+# crossing -- mask = (logit > 0) -- so this mode changes magnitudes (f16 range, IoU-head inputs, thresholds
+# written in absolute units), not which pixels sit next to the threshold; DESIGN.md 2 has the arithmetic.
+MARGIN_LOGIT_SCALE = 32.0
+
+
+def make_state_dict(cfg: SamConfig, seed: int = 0, logit_scale: float = 1.0) -> "OrderedDict[str, torch.Tensor]":
     """A full SAM ``state_dict`` (fp32, CPU) with the reference's key names and shapes.
 
     Every tensor is random, including the ones the reference zero-initialises
     (``pos_embed``, ``rel_pos_h/w`` -- image_encoder.py:68-70,221-222) so that the rel-pos and
     abs-pos paths are never tested against zeros.
+    ``logit_scale`` multiplies the output layer of the four hypernetwork MLPs (see MARGIN_LOGIT_SCALE).
     """
     gen = torch.Generator().manual_seed(1234567 + seed)
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
@@ -169,6 +178,10 @@ def make_state_dict(cfg: SamConfig, seed: int = 0) -> "OrderedDict[str, torch.Te
     _linear(sd, gen, p + ".0", cfg.iou_hidden, C)
     _linear(sd, gen, p + ".1", cfg.iou_hidden, cfg.iou_hidden)
     _linear(sd, gen, p + ".2", cfg.num_mask_tokens, cfg.iou_hidden)
+    if logit_scale != 1.0:
+        for i in range(cfg.num_mask_tokens):
+            for leaf in ("weight", "bias"):
+                sd[f"mask_decoder.output_hypernetworks_mlps.{i}.layers.2.{leaf}"] *= float(logit_scale)
     return sd
 
 
@@ -203,6 +216,38 @@ def make_boxes(index: int, n: int = 32, h: int = 1024, w: int = 1024, n_classes:
     boxes = np.stack([x0, y0, x1, y1], axis=1).astype(np.float32)
     labels = rng.integers(0, n_classes, n).astype(np.int64)
     return boxes, labels
+
+
+def make_rboxes(index: int, n: int = 12, h: int = 1024, w: int = 1024, n_classes: int = 37):
+    """``n`` rotated boxes as 4-corner polygons [n, 4, 2] (x, y) float32 + labels (FAIR1M has 37 classes,
+    GD/mapping.py:58-63): centres uniform, sides log-uniform in [8, 256] px, angle uniform in [0, pi)
+    (SURVEY.md 8d, config C4).  Corners may leave the image, like real annotations near a tile border."""
+    rng = np.random.default_rng(3000 + index)
+    cx, cy = rng.uniform(0, w, n), rng.uniform(0, h, n)
+    bw = np.exp(rng.uniform(np.log(8), np.log(256), n))
+    bh = np.exp(rng.uniform(np.log(8), np.log(256), n))
+    th = rng.uniform(0, np.pi, n)
+    c, s_ = np.cos(th), np.sin(th)
+    corners = np.array([[-0.5, -0.5], [0.5, -0.5], [0.5, 0.5], [-0.5, 0.5]])
+    polys = np.empty((n, 4, 2), dtype=np.float32)
+    for k, (ux, uy) in enumerate(corners):
+        polys[:, k, 0] = cx + ux * bw * c - uy * bh * s_
+        polys[:, k, 1] = cy + ux * bw * s_ + uy * bh * c
+    labels = rng.integers(0, n_classes, n).astype(np.int64)
+    return polys, labels
+
+
+def enclosing_hboxes(polys: np.ndarray) -> np.ndarray:
+    """rbox -> hbox by min / max of the corners (main_sam_rhbox_mask_instance.py:125-130)."""
+    p = np.asarray(polys)
+    return np.stack([p[:, :, 0].min(1), p[:, :, 1].min(1), p[:, :, 0].max(1), p[:, :, 1].max(1)], axis=1).astype(np.float32)
+
+
+def long_tailed_box_counts(n_images: int, seed: int = 0, mean: float = 32.0, cap: int = 400) -> np.ndarray:
+    """Boxes per image of a DOTA-v2-shaped stream: geometric with the given mean,
+    at least 1, capped."""
+    rng = np.random.default_rng(4000 + seed)
+    return np.clip(rng.geometric(1.0 / mean, size=n_images), 1, cap).astype(np.int64)
 
 
 # BASELINE.json configs[0]: ViT-B, one tile, 4 hboxes (SURVEY.md 8d "C1").

@@ -65,6 +65,23 @@ def resample_reference(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
     return one_pass(tmp, out_h, 0) if out_h != h else tmp
 
 
+_COEF_CACHE = {}
+
+
+def _device_coeffs(in_size: int, out_size: int, dev: torch.device):
+    """Pillow coefficient tables of one (in, out) pair on `dev`: built once (a Python loop over out_size rows) and kept,
+    so that a stream of same-size images (DIOR 800^2, HRSC) pays for the tables and their upload once."""
+    key = (in_size, out_size, dev.type, dev.index)
+    hit = _COEF_CACHE.get(key)
+    if hit is None:
+        b, k, ks = pil_bilinear_coeffs(in_size, out_size)
+        hit = (torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev), ks)
+        if len(_COEF_CACHE) > 64:
+            _COEF_CACHE.clear()
+        _COEF_CACHE[key] = hit
+    return hit
+
+
 class ResizeLongestSide:
     def __init__(self, target_length: int) -> None:
         self.target_length = target_length
@@ -91,15 +108,13 @@ class ResizeLongestSide:
         stream = torch.cuda.current_stream(dev).cuda_stream
         cur = image_u8.contiguous()
         if nw != w:                                   # Pillow: horizontal pass first
-            b, k, ks = pil_bilinear_coeffs(w, nw)
-            bd, kd = torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev)
+            bd, kd, ks = _device_coeffs(w, nw, dev)
             out = torch.empty(h, nw, 3, dtype=torch.uint8, device=dev)
             rc = lib.samrs_resample_pass_u8(cur.data_ptr(), out.data_ptr(), bd.data_ptr(), kd.data_ptr(), ks, w, nw, h, 1, stream)
             assert rc == 0
             cur = out
         if nh != h:
-            b, k, ks = pil_bilinear_coeffs(h, nh)
-            bd, kd = torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev)
+            bd, kd, ks = _device_coeffs(h, nh, dev)
             out = torch.empty(nh, cur.shape[1], 3, dtype=torch.uint8, device=dev)
             rc = lib.samrs_resample_pass_u8(cur.data_ptr(), out.data_ptr(), bd.data_ptr(), kd.data_ptr(), ks, h, nh, cur.shape[1], 0, stream)
             assert rc == 0
@@ -144,8 +159,6 @@ def rbox_mask_prompts(polys, original_size: Tuple[int, int], img_size: int = 102
     polys: [n, V, 2] (x, y) vertices in original-image pixels (float or int; truncated like the reference's
     `.astype(np.int32)`), 3 <= V <= 8.  Returns fp32 [n, out_size, out_size] on the device; feed
     `prompts[:, None]` as `mask_input` of `SamPredictor.predict_torch` (main_sam_rbox_mask_instance.py:159-164)."""
-    from . import engine as _engine
-    lib = _engine.load_library()
     if not torch.cuda.is_available():
         raise RuntimeError("rbox_mask_prompts needs the HIP device (no CPU fallback)")
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -153,13 +166,32 @@ def rbox_mask_prompts(polys, original_size: Tuple[int, int], img_size: int = 102
     if p.ndim != 3 or p.shape[2] != 2 or not (3 <= p.shape[1] <= 8):
         raise ValueError(f"polys must be [n, V, 2] with 3 <= V <= 8, got {p.shape}")
     pts = torch.from_numpy(np.ascontiguousarray(p.astype(np.int32))).to(dev)
+    return _rbox_prompts_from_int_points(pts, original_size, img_size, out_size)
+
+
+def rbox_mask_prompts_device(polys: torch.Tensor, original_size: Tuple[int, int], img_size: int = 1024, out_size: int = 256,
+                             device: Optional["torch.device"] = None) -> torch.Tensor:
+    """Same as ``rbox_mask_prompts`` for vertices that already live on the GPU ([n, V, 2] float or int tensor);
+    float coordinates are truncated toward zero like the reference's ``.astype(np.int32)``."""
+    if polys.dim() != 3 or polys.shape[2] != 2 or not (3 <= polys.shape[1] <= 8):
+        raise ValueError(f"polys must be [n, V, 2] with 3 <= V <= 8, got {tuple(polys.shape)}")
+    assert polys.is_cuda
+    return _rbox_prompts_from_int_points(polys.to(torch.int32).contiguous(), original_size, img_size, out_size)
+
+
+def _rbox_prompts_from_int_points(pts: torch.Tensor, original_size: Tuple[int, int], img_size: int, out_size: int) -> torch.Tensor:
+    from . import engine as _engine
+    lib = _engine.load_library()
+    dev = pts.device
+    n, nv = int(pts.shape[0]), int(pts.shape[1])
     h, w = int(original_size[0]), int(original_size[1])
     th, tw = ResizeLongestSide.get_preprocess_shape(h, w, img_size)
-    out = torch.empty(p.shape[0], out_size, out_size, dtype=torch.float32, device=dev)
-    if p.shape[0] == 0:
+    out = torch.empty(n, out_size, out_size, dtype=torch.float32, device=dev)
+    if n == 0:
         return out
-    rc = lib.samrs_rbox_mask_prompt(pts.data_ptr(), p.shape[0], p.shape[1], h, w, th, tw, img_size, out_size, out.data_ptr(),
-                                    torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        rc = lib.samrs_rbox_mask_prompt(pts.data_ptr(), n, nv, h, w, th, tw, img_size, out_size, out.data_ptr(),
+                                        torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         raise RuntimeError(f"samrs_rbox_mask_prompt failed with code {rc}")
     return out

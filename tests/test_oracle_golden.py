@@ -53,6 +53,42 @@ def test_oracle_matches_reference_vit_b(golden_dir):
     _check("vit_b", golden_dir, [(1024, 1024)])
 
 
+@pytest.mark.slow
+def test_oracle_matches_reference_c2_c4_vit_b(golden_dir):
+    """The C2 (32 hboxes, 20 + 12 chunks) and C4 (enclosing hbox / rbox mask prompt, multimask) fixtures on the
+    realistic-margin weights: full-resolution masks of the REAL reference vs the oracle.  fp32 on both sides, so the
+    only differences allowed are fp32 op-order flips, and those must lie in the fixture's unstable set."""
+    from oracle import rbox_prompt
+    from oracle.make_golden import extended_inputs
+    g = np.load(os.path.join(golden_dir, "vit_b_c2c4.npz"))
+    cfg = synth.CONFIGS["vit_b"]
+    sd = synth.make_state_dict(cfg, 0, logit_scale=float(g["logit_scale"]))
+    assert float(g["logit_scale"]) == synth.MARGIN_LOGIT_SCALE
+    pred = so.OraclePredictor(sd, cfg)
+    inp = extended_inputs()
+    hw = (1024, 1024)
+    pred.set_image(synth.make_image(0))
+    unpack = lambda b: np.unpackbits(b, axis=-1).reshape(*b.shape[:-1], *hw).astype(bool)
+    tb = so.apply_boxes(torch.from_numpy(inp["boxes"]), hw)
+    parts = [pred.predict_torch(None, None, tb[s:e], None, multimask_output=False) for s, e in so.box_chunks(32, 20)]
+    m = torch.cat([p[0] for p in parts]).numpy()
+    low = torch.cat([p[2] for p in parts])
+    assert 2.0 < float(g["c2_low_std"]) < 10.0, "margin weights: checkpoint-like logit spread"
+    np.testing.assert_allclose(low[:, :, ::4, ::4].numpy(), g["c2_low"], atol=LOGIT_ATOL * synth.MARGIN_LOGIT_SCALE, rtol=0)
+    gm = unpack(g["c2_masks"])
+    assert (m != gm).reshape(32, -1).sum(1).max() <= 8
+    seg, _ = so.paint_semantic(m[:, 0], inp["labels"], hw)
+    diff = seg != g["c2_seg"]
+    assert diff.sum() <= 16 and not (diff & ~unpack(g["c2_unstable"])).any()
+    tb = so.apply_boxes(torch.from_numpy(inp["hboxes"]), hw)
+    m, q, low = pred.predict_torch(None, None, tb, None, multimask_output=True)
+    assert (m.numpy() != unpack(g["c4box_masks"])).reshape(12, -1).sum(1).max() <= 8
+    np.testing.assert_allclose(q.numpy(), g["c4box_iou"], atol=LOGIT_ATOL, rtol=0)
+    prompts = np.stack([rbox_prompt.rbox_mask_prompt(p.astype(np.int32), *hw) for p in inp["polys"]]).astype(np.float32)
+    m, q, low = pred.predict_torch(None, None, None, torch.from_numpy(prompts)[:, None], multimask_output=True)
+    assert (m.numpy() != unpack(g["c4mask_masks"])).reshape(12, -1).sum(1).max() <= 8
+
+
 def test_box_chunking_matches_driver():
     # main_sam_hbox_semantic.py:157-181: part_num = n // 20 + 1, empty tail skipped
     assert so.box_chunks(32) == [(0, 20), (20, 32)]

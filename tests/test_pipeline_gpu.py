@@ -1,0 +1,186 @@
+"""GPU: the production loop (driver.TilePipeline -- batched encoder, three HIP streams, two slot sets) against the
+one-image-at-a-time loop that restates the reference driver (driver.SemanticGenerator), plus the boundary features
+that came with it: ragged encoder batches, prompt batches beyond max_prompts, prompt-shape validation.
+Integer / index work and identical kernels on both sides: every comparison is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from samrs_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _sam(name="vit_tiny", **kw):
+    import samrs_amd
+    return samrs_amd.sam_model_registry[name](**kw).to("cuda")
+
+
+def _stream_items(driver, sizes, counts):
+    items = []
+    for i, ((h, w), n) in enumerate(zip(sizes, counts)):
+        img = synth.make_image(20 + i, h, w)
+        boxes, labels = synth.make_boxes(20 + i, n, h, w)
+        items.append(driver.WorkItem(f"img{i}", img, boxes, labels))
+    return items
+
+
+@pytest.mark.parametrize("batch", [2, 3])
+def test_pipeline_equals_serial_loop(batch):
+    import samrs_amd
+    from samrs_amd import driver
+    sam = _sam(max_images=2 * batch, max_prompts=20, precision="f16")
+    sizes = [(1024, 1024), (1024, 1024), (600, 800), (1024, 1024), (1024, 1024), (1024, 1024), (1024, 1024)]
+    counts = [3, 23, 5, 41, 1, 20, 7]
+    items = _stream_items(driver, sizes, counts)
+    # serial: the reference's loop shape, one stream
+    gen = driver.SemanticGenerator(samrs_amd.SamPredictor(sam), 18, box_batch=20)
+    serial = []
+    for it in items:
+        r = gen.process_image(it.image, it.boxes, it.labels, keep_masks=True)
+        serial.append((r.seg_mask.cpu().numpy(), r.areas.cpu().numpy(), r.masks.cpu().numpy()))
+    # pipelined
+    pipe = driver.TilePipeline(sam, 18, batch=batch, box_batch=20, keep_masks=True, max_boxes=64)
+    got = {}
+
+    def sink(results, release):
+        for r in results:
+            got[r.key] = (r.seg_mask.copy(), r.areas.copy(), r.masks.copy())
+        release()
+
+    n = pipe.run(driver.batched(items, batch), sink)
+    assert n == len(items) and len(got) == len(items)
+    for i, it in enumerate(items):
+        seg, areas, masks = got[it.key]
+        assert seg.shape == sizes[i]
+        assert np.array_equal(seg, serial[i][0]), f"{it.key}: class map differs from the serial loop"
+        assert np.array_equal(areas, serial[i][1])
+        assert np.array_equal(masks.astype(bool), serial[i][2].astype(bool))
+    assert torch.equal(pipe.class_pixels, gen.class_pixels) and torch.equal(pipe.class_instances, gen.class_instances)
+    # a second run through the same pipeline object (ring buffers, events and slot sets are reused)
+    got.clear()
+    pipe.run(driver.batched(items[:3], batch), sink)
+    for i in range(3):
+        assert np.array_equal(got[items[i].key][0], serial[i][0])
+
+
+def test_pipeline_device_resident_and_pinned_inputs():
+    from samrs_amd import driver
+    sam = _sam(max_images=4, max_prompts=8)
+    tiles = torch.stack([torch.from_numpy(synth.make_noise_image(70 + i)) for i in range(4)])
+    anns = [synth.make_boxes(70 + i, 6) for i in range(4)]
+    outs = []
+    for kind in ("numpy", "pinned", "device"):
+        src = {"numpy": [t.numpy() for t in tiles], "pinned": list(tiles.pin_memory()), "device": list(tiles.cuda())}[kind]
+        pipe = driver.TilePipeline(sam, 18, batch=2, box_batch=8, max_boxes=8, device_inputs=(kind == "device"))
+        res = {}
+
+        def sink(results, release):
+            for r in results:
+                res[r.key] = (r.seg_mask.copy(), r.areas.copy())
+            release()
+
+        pipe.run(driver.batched([driver.WorkItem(i, src[i], anns[i][0], anns[i][1]) for i in range(4)], 2), sink)
+        outs.append(res)
+    for i in range(4):
+        for o in outs[1:]:
+            assert np.array_equal(o[i][0], outs[0][i][0]) and np.array_equal(o[i][1], outs[0][i][1])
+
+
+def test_ragged_encoder_batch_equals_single_tiles():
+    import samrs_amd
+    sam = _sam(max_images=4)
+    eng = sam.engine
+    tr = samrs_amd.ResizeLongestSide(1024)
+    tiles = []
+    for i, (h, w) in enumerate([(1024, 1024), (600, 800), (1024, 683), (1024, 1024)]):
+        t = torch.as_tensor(synth.make_image(30 + i, h, w)).cuda()
+        tiles.append(tr.apply_image_device(t).contiguous())
+    assert [tuple(t.shape[:2]) for t in tiles] == [(1024, 1024), (768, 1024), (1024, 683), (1024, 1024)]
+    eng.set_images_ragged(tiles, 0)
+    batch = [eng.get_embedding(i).clone() for i in range(4)]
+    for i, t in enumerate(tiles):
+        eng.set_images(t[None].contiguous(), 0)
+        assert torch.equal(eng.get_embedding(0), batch[i]), f"tile {i} ({tuple(t.shape)}): ragged batch differs from single encode"
+    with pytest.raises(AssertionError):
+        eng.set_images_ragged([tiles[0][:512, :512].contiguous()], 0)        # long side != 1024
+
+
+def test_predict_batches_beyond_max_prompts():
+    """The reference takes any B (its instance drivers pass every object of an image at once); the engine decodes
+    max_prompts per pass and chunks inside samrs_predict -- bit-identical to manual chunking."""
+    import samrs_amd
+    sam = _sam(max_prompts=8, max_points=2)
+    pred = samrs_amd.SamPredictor(sam)
+    img = synth.make_image(3)
+    pred.set_image(img)
+    boxes, _ = synth.make_boxes(3, 19)
+    tb = pred.transform.apply_boxes_torch(torch.from_numpy(boxes).cuda(), img.shape[:2])
+    m, q, l = pred.predict_torch(None, None, tb, None, multimask_output=True)
+    assert m.shape == (19, 3, 1024, 1024) and q.shape == (19, 3) and l.shape == (19, 3, 256, 256)
+    parts = [pred.predict_torch(None, None, tb[s:e], None, multimask_output=True) for s, e in [(0, 8), (8, 16), (16, 19)]]
+    assert torch.equal(m, torch.cat([p[0] for p in parts])) and torch.equal(q, torch.cat([p[1] for p in parts]))
+    assert torch.equal(l, torch.cat([p[2] for p in parts]))
+    # every prompt kind at once: points + boxes + mask prompts, logits out
+    g = torch.Generator().manual_seed(5)
+    pc = (torch.rand(19, 2, 2, generator=g) * 1000).cuda()
+    pl = torch.randint(0, 2, (19, 2), generator=g).cuda()
+    mi = torch.where(torch.rand(19, 1, 256, 256, generator=g) > 0.5, 1000.0, -1000.0).cuda()
+    m2, q2, l2 = pred.predict_torch(pc, pl, tb, mi, multimask_output=False, return_logits=True)
+    p2 = [pred.predict_torch(pc[s:e], pl[s:e], tb[s:e], mi[s:e], multimask_output=False, return_logits=True)
+          for s, e in [(0, 8), (8, 16), (16, 19)]]
+    assert m2.dtype == torch.float32 and torch.equal(m2, torch.cat([p[0] for p in p2])) and torch.equal(l2, torch.cat([p[2] for p in p2]))
+
+
+def test_prompt_shape_validation():
+    import samrs_amd
+    sam = _sam(max_prompts=8, max_points=2)
+    pred = samrs_amd.SamPredictor(sam)
+    pred.set_image(synth.make_image(3))
+    b = torch.tensor([[10.0, 10.0, 200.0, 300.0]] * 3).cuda()
+    with pytest.raises(ValueError, match="mask_input must be"):
+        pred.predict_torch(None, None, b, torch.zeros(3, 1, 1024, 1024).cuda())
+    with pytest.raises(ValueError, match="mask_input has batch"):
+        pred.predict_torch(None, None, b, torch.zeros(2, 1, 256, 256).cuda())
+    with pytest.raises(ValueError, match="boxes has 3 rows"):
+        pred.predict_torch(torch.zeros(2, 1, 2).cuda(), torch.ones(2, 1).cuda(), b, None)
+    with pytest.raises(ValueError, match="point_labels must be"):
+        pred.predict_torch(torch.zeros(3, 2, 2).cuda(), torch.ones(3, 1).cuda(), None, None)
+    with pytest.raises(ValueError, match="max_points"):
+        pred.predict_torch(torch.zeros(3, 3, 2).cuda(), torch.ones(3, 3).cuda(), None, None)
+    with pytest.raises(AssertionError):
+        pred.set_torch_image(torch.zeros(2, 3, 1024, 1024), (1024, 1024))        # one image per predictor
+    with pytest.raises(AssertionError):
+        pred.set_torch_image(torch.full((1, 3, 1024, 1024), 0.5), (1024, 1024))  # non-integer pixel values
+
+
+@pytest.mark.parametrize("prompt", ["box", "rbox_mask"])
+def test_instance_pipeline_matches_prompter(prompt):
+    """BASELINE.json configs[3] recipe (rbox -> enclosing hbox / rbox -> mask prompt, multimask_output=True, best of 3)
+    through the three-stream pipeline == the one-image-at-a-time InstancePrompter."""
+    import samrs_amd
+    from samrs_amd import driver
+    sam = _sam(max_images=4, max_prompts=6)
+    prm = driver.InstancePrompter(samrs_amd.SamPredictor(sam))
+    items, ref = [], []
+    for i in range(3):
+        img = synth.make_image(40 + i)
+        polys, labels = synth.make_rboxes(40 + i, 9)
+        items.append(driver.WorkItem(i, img, polys, labels))
+        if prompt == "box":
+            m, q = prm.predict(img, "box", hboxes=synth.enclosing_hboxes(polys), multimask_output=True)
+        else:
+            m, q = prm.predict(img, "rbox_mask", rboxes=polys, multimask_output=True)
+        ref.append((m.cpu().numpy(), q.cpu().numpy()))
+    pipe = driver.InstancePipeline(sam, 37, prompt=prompt, batch=2, box_batch=6, max_boxes=16, keep_masks=True)
+    got = {}
+
+    def sink(results, release):
+        for r in results:
+            got[r.key] = (r.masks.copy(), r.quality.copy(), r.areas.copy())
+        release()
+
+    pipe.run(driver.batched(items, 2), sink)
+    for i in range(3):
+        assert np.array_equal(got[i][0].astype(bool), ref[i][0]) and np.array_equal(got[i][1], ref[i][1])
+        assert np.array_equal(got[i][2], ref[i][0].reshape(9, -1).sum(1))

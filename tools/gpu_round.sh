@@ -27,7 +27,11 @@ for grp in "$@"; do
     p_gold)   run p_gold 1500 $PT tests/test_parity_gpu.py -k "golden or c1_config" ;;
     all)      run all 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider ;;
     smoke)    run smoke 600 python -c "import __graft_entry__ as g; g.smoke()" ;;
-    bench)    run bench 1200 python bench.py --steps 3 --warmup 1 ;;
+    bench)    run bench 1200 python bench.py ${BENCH_ARGS:-} ;;
+    c3)       run c3 600 python bench.py --workload c3 --steps ${BENCH_STEPS:-6} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg ;;
+    c4)       run c4 600 python bench.py --workload c4 --steps ${BENCH_STEPS:-6} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg
+              run c4m 600 python bench.py --workload c4 --c4-prompt rbox_mask --steps ${BENCH_STEPS:-6} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg ;;
+    b2)       SAMRS_BENCH_SHARE_GPU=1 run b2 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --workload c3 --steps 3 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-pcie-leg ;;
     gemmb)    run gemmb 600 python tools/gemm_bench.py ${GEMM_VARIANTS:-0,1} f16 ;;
     pmc)      cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
               run pmc1 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc1 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 2 f16}
@@ -39,7 +43,7 @@ for grp in "$@"; do
               run decb 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/decb -o dec -- python tools/dec_bench.py 20 ;;
     benchq)   run benchq 900 python bench.py --steps ${BENCH_STEPS:-8} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg ${BENCH_EXTRA:-} ;;
     prof)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
-              run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-pcie-leg ;;
+              run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r02 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-pcie-leg ;;
   esac
 done
 tail -5 gpurun_out/*.log 2>/dev/null | tail -120

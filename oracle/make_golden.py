@@ -120,7 +120,9 @@ def extended(name: str) -> None:
         blob[tag + "_low"] = low[:, :, ::4, ::4].numpy().copy()
         blob[tag + "_low_std"] = np.float64(low.std().item())
         blob[tag + "_area"] = masks.flatten(2).sum(-1).numpy().astype(np.int64)
-        blob[tag + "_near"] = (lg.abs() < tau).flatten(2).sum(-1).numpy().astype(np.int64)   # per mask
+        near = lg.abs() < tau
+        blob[tag + "_near"] = near.flatten(2).sum(-1).numpy().astype(np.int64)                # per mask
+        blob[tag + "_nearmask"] = _pack(near.numpy())         # the pixels of each mask whose reference decision has no margin
         return lg, masks, tau
 
     tb = pred.transform.apply_boxes_torch(torch.as_tensor(inp["boxes"]), (h, w))

@@ -910,6 +910,219 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemm_et_x64_kernel: the 256x256 / 256x320 staggered kernel re-staged in PAIR stages of 64 k.
+//
+// Why: the kernel above fetches a k-step of 32 ET = 64 bytes per row, i.e. HALF of a 128-byte cache line per
+// row per LDS-DMA instruction, and asks for the other half one k-step (> 1 us) later, when the 32 KiB vector L1
+// has long dropped the line: every line travels L2 -> L1 twice, and the per-CU L1 fill port (64 B/clk) is the
+// measured ceiling of the fill path (DMA-only ablation: ~21-25 B/clk/CU useful).  Here ONE DMA
+// instruction covers 8 rows x 128 bytes = 8 WHOLE lines (lanes 0-31: k-half 0, lanes 32-63: k-half 1 of the same
+// rows), so each line crosses once.
+//
+// LDS image of a pair stage: 8-row blocks of 1 KiB = [k-half][8 rows][64 B]; inside a k-half the geometry
+// (4 rows per 256-byte bank row, 16-byte chunk index XORed with g(row>>2)) is exactly the one of the kernel above,
+// so its conflict-free ds_read_b128 pattern carries over unchanged.  Two pair stages = 128 / 144 KiB.
+//
+// Schedule (I_n = interval between consecutive block-wide raw barriers; group 1 = waves 4-7 runs one interval
+// behind group 0, so that each SIMD always has one wave in its MFMA segment):
+//     group 0, stage t:  I_4t   L: [issue DMA(t+1)] read fragments of k-half 0     group 1: C(t-1, half 1) [issue DMA(t+1)]
+//                        I_4t+1 C: 8 NI MFMAs                                               L(t, half 0)
+//                        I_4t+2 L: read fragments of k-half 1                               C(t, half 0)
+//                        I_4t+3 C: 8 NI MFMAs, then vmcnt(0)                                L(t, half 1), then vmcnt(0)
+// Stage t+1 goes into the buffer of stage t-1, whose last reads (group 1, I_4t-1) are complete at the barrier
+// that opens I_4t; every wave retires its own pieces (vmcnt(0): one stage in flight per wave) before the barrier
+// that closes I_4t+3, and the first read of stage t+1 comes after that barrier.  Each output element is accumulated
+// over k in ascending 32-wide MFMA steps exactly like every other tile shape (bit-identical results).
+// SPREAD: the DMA pieces are issued between the MFMAs of a C segment instead of as one burst.
+// M % 256 == 0, N % (64 NI) == 0, K % 64 == 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int XBK = 64;
+
+// LDS-DMA, scalar-base form: source = sbase (SGPR pair, wave-uniform) + voff (per-lane byte offset, one VGPR),
+// destination = LDS byte address m0v (wave-uniform) + 16 * lane.  Issued from inline asm for the same reason as
+// glds16_asm (hipcc must not see it in its waitcnt bookkeeping); the caller counts vmcnt by hand.
+__device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint32_t m0v) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(m0v)
+        : "memory");
+}
+
+template <int PREC, bool OUT_F32, bool GELU, int NI = 4, bool SPREAD = false>
+__global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
+    int M, int N, int K, int accumulate) {
+    constexpr int XBN = 64 * NI;
+    constexpr int XROWS = QBM + XBN;                       // 512 / 576 rows per stage
+    constexpr int XSTAGE_ELEMS = XROWS * XBK;              // 64 / 72 KiB
+    constexpr uint32_t XSB = XSTAGE_ELEMS * 2;             // stage bytes
+    constexpr int NPIECE = 4 + NI;                         // DMA pieces per wave and stage (8 rows x 128 B each): 4 A + NI B
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * XSTAGE_ELEMS];   // 128 / 144 KiB, ONE object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                 // waves w and w+4 share a SIMD -> different groups
+    const int wm = wave >> 2, wn = wave & 3;   // wave tile rows wm*128.., cols wn*(16 NI)..
+
+    constexpr int GROUP = 8;
+    const int tiles_n = N / XBN, tiles_m = M / QBM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_group = GROUP * tiles_n;
+    const int group = bid / per_group, first_m = group * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = bid - group * per_group;
+    const int tile_m = first_m + in_g % gsz, tile_n = in_g / gsz;
+    const int m0 = tile_m * QBM, n0 = tile_n * XBN;
+
+    // DMA map: piece q of this wave covers stage rows 64 q + 8 wave .. + 7 (q < 4: A rows, else B rows 64 (q - 4) + ..);
+    // lane l -> k-half l>>5, row (l>>2)&7, physical chunk l&3 which holds source chunk (l&3) ^ g(row>>2) (g depends on
+    // row mod 16 only, and 64 q = 0 mod 16).  The per-lane byte offset is the same for A and B (both have row stride K).
+    const int prow = 8 * wave + ((lane >> 2) & 7);
+    const uint32_t voff = ((uint32_t)prow * (uint32_t)K + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
+    const uint16_t* sA = A + (size_t)m0 * K;               // wave-uniform bases (SGPR pairs)
+    const uint16_t* sB = B + (size_t)n0 * K;
+    const size_t rs64 = (size_t)64 * K;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
+    // piece q_ (literal) of pair stage st_ into the buffer at byte offset wr_
+#define X64_PIECE(st_, wr_, q_)                                                                            \
+    glds16_s(voff, ((q_) < 4 ? sA + (size_t)(q_) * rs64 : sB + (size_t)((q_) - 4) * rs64) + (size_t)(st_) * XBK, \
+             lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u))
+#define X64_ISSUE(st_, wr_)                                                                                \
+    do {                                                                                                   \
+        X64_PIECE(st_, wr_, 0); X64_PIECE(st_, wr_, 1); X64_PIECE(st_, wr_, 2); X64_PIECE(st_, wr_, 3);    \
+        X64_PIECE(st_, wr_, 4); X64_PIECE(st_, wr_, 5); X64_PIECE(st_, wr_, 6); X64_PIECE(st_, wr_, 7);    \
+        if constexpr (NPIECE == 9) X64_PIECE(st_, wr_, 8);                                                 \
+    } while (0)
+
+    f32x4_t acc[NI][8];    // [n-tile i][m-tile j]
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nst = K / XBK;
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment BYTE offsets inside a stage for k-half 0; k-half 1 is +512
+    uint32_t offA[8], offB[NI];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int r = wm * 128 + j * 16 + fr; offA[j] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, fq) * 8) * 2; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = QBM + wn * (16 * NI) + i * 16 + fr;
+        offB[i] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, fq) * 8) * 2;
+    }
+    const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);
+
+    // prologue: stage 0 landed for everybody
+    X64_ISSUE(0, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) {                            // I_0 of group 1: nothing to compute yet; its share of stage 1 goes out
+        if (nst > 1) X64_ISSUE(1, XSB);
+        __builtin_amdgcn_s_barrier();
+    }
+
+#define X64_READ(rd_, kh_)                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i)                                                         \
+        fb[i] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offB[i]);                     \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                          \
+        fa[j] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offA[j]);
+    // 8 NI MFMAs of one k-half; when dma_ (wave-uniform) is set, this wave's pieces of stage st_ go out first (burst)
+    // or one per m-tile row of MFMAs (SPREAD).  The accumulators never sit inside a conditional region.
+#define X64_MFMA(dma_, st_, wr_)                                                                           \
+    if (!SPREAD) { if (dma_) X64_ISSUE(st_, wr_); }                                                        \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                        \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]); \
+        if (SPREAD) {                                                                                      \
+            if (dma_) {                                                                                    \
+                if (j == 0) X64_PIECE(st_, wr_, 0); if (j == 1) X64_PIECE(st_, wr_, 1);                    \
+                if (j == 2) X64_PIECE(st_, wr_, 2); if (j == 3) X64_PIECE(st_, wr_, 3);                    \
+                if (j == 4) X64_PIECE(st_, wr_, 4); if (j == 5) X64_PIECE(st_, wr_, 5);                    \
+                if (j == 6) X64_PIECE(st_, wr_, 6);                                                        \
+                if (j == 7) { X64_PIECE(st_, wr_, 7); if constexpr (NPIECE == 9) X64_PIECE(st_, wr_, 8); } \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+
+    uint32_t rd = 0;                           // byte offset of the buffer that holds stage t
+    for (int t = 0; t < nst; ++t) {
+        uint4 fa[8], fb[NI];
+        const uint32_t wr = XSB - rd;
+        const bool dma0 = (grp == 0) && (t + 1 < nst);     // group 0 feeds stage t+1 from I_4t
+        const bool dma1 = (grp == 1) && (t + 2 < nst);     // group 1 feeds stage t+2 from its C(t, 1) = I_4(t+1)
+        // ---- L(t, 0) ----
+        if (!SPREAD) { if (dma0) X64_ISSUE(t + 1, wr); }
+        X64_READ(rd, 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- C(t, 0) ----
+        __builtin_amdgcn_s_setprio(1);
+        X64_MFMA(SPREAD && dma0, t + 1, wr)
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- L(t, 1); group 1: its pieces of stage t+1 (issued one stage ago) must have landed ----
+        X64_READ(rd, 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- C(t, 1); group 1: buffer `rd` is free from here on (both groups have read k-half 1) ----
+        __builtin_amdgcn_s_setprio(1);
+        X64_MFMA(dma1, t + 2, rd)
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        rd = wr;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // both groups: 2 + 4 nst barriers; every ring read is done
+
+    {   // coalesced epilogue through the idle ring (16 / 18 KiB per wave), identical to the kernel above
+        unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (2 * XSB / 8);
+        const float* pre2d = OUT_F32 ? nullptr : add2d;     // ET output: the 2-D addend goes in before the rounding
+        if constexpr (NI == 5 && !OUT_F32) {
+            epilogue_pair_et<PREC, GELU>(acc, reinterpret_cast<unsigned char*>(lds), Cv, bias, pre2d, add2d_period, N, m0 + wm * 128,
+                                         n0 + (wn >> 1) * 160, wm, wn, lane);
+        } else {
+            epilogue_coalesced<PREC, OUT_F32, GELU, 8, OUT_F32 ? 2 : 4, NI>(acc, scr, Cv, bias, OUT_F32 ? add2d : nullptr, add2d_period,
+                                                                             N, m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane, pre2d);
+        }
+    }
+#undef X64_PIECE
+#undef X64_ISSUE
+#undef X64_READ
+#undef X64_MFMA
+}
+
+template <int PREC, int NI, bool SPREAD>
+hipError_t launch_gemm_x64(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
+                           int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
+    dim3 grid((M / QBM) * (N / (64 * NI))), block(QTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (out_f32) {
+        if (gelu) gemm_et_x64_kernel<PREC, true, true, NI, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_x64_kernel<PREC, true, false, NI, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    } else {
+        if (gelu) gemm_et_x64_kernel<PREC, false, true, NI, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        else gemm_et_x64_kernel<PREC, false, false, NI, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // gemm_et_pers_kernel: the 256x320 kernel above made PERSISTENT -- one block per CU walks tiles
 // L, L + gridDim.x, ...  With one tile per block a CU idles between tiles for the block re-dispatch plus
 // the ~2 us the first ring stage needs to land.  Here the next tile's stages 0 and 1 are issued BEFORE the
@@ -1397,6 +1610,29 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     // 2-blocks-per-CU kernel wins where the epilogue dominates (GELU output, or short K with a
     // narrow N), the 64-wide-K single-block kernel wins on long K / wide N.
     int variant = g_gemm_variant;
+    // 20 / 21: pair-stage (64-deep, whole-cache-line DMA) 256x256 / 256x320 kernel; 22 / 23: the same with the DMA pieces
+    // spread between the MFMAs.  Shapes they do not cover fall through to the automatic choice.
+    if (variant >= 20 && variant <= 23) {
+        const int ni = (variant & 1) ? 5 : 4;
+        if (M % QBM == 0 && N % (64 * ni) == 0 && K % XBK == 0) {
+#define X64_CASE(P, NI_, SP_) return launch_gemm_x64<P, NI_, SP_>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s)
+            if (prec == PREC_F16) {
+                if (variant == 20) X64_CASE(PREC_F16, 4, false);
+                if (variant == 21) X64_CASE(PREC_F16, 5, false);
+                if (variant == 22) X64_CASE(PREC_F16, 4, true);
+                X64_CASE(PREC_F16, 5, true);
+            }
+            if (prec == PREC_BF16) {
+                if (variant == 20) X64_CASE(PREC_BF16, 4, false);
+                if (variant == 21) X64_CASE(PREC_BF16, 5, false);
+                if (variant == 22) X64_CASE(PREC_BF16, 4, true);
+                X64_CASE(PREC_BF16, 5, true);
+            }
+#undef X64_CASE
+            return hipErrorInvalidValue;
+        }
+        variant = 8;
+    }
     if (variant == 8) {
         const bool big_ok = M % QBM == 0 && K % QBK == 0;
         const long t256 = big_ok && N % QBN == 0 ? (long)(M / QBM) * (N / QBN) : 0;

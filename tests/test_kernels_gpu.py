@@ -93,7 +93,11 @@ def test_gemm_et_variants(lib, name, prec, dt, ulp, M, N, K):
 
 @pytest.mark.parametrize("variant,M,N,K", [(5, 512, 256, 192), (6, 512, 512, 192), (7, 512, 256, 192), (9, 256, 128, 128),
                                            (10, 512, 640, 192), (10, 256, 640, 64), (6, 256, 256, 64),
-                                           (11, 512, 640, 192), (11, 8192, 3200, 192)])
+                                           (11, 512, 640, 192), (11, 8192, 3200, 192),
+                                           # pair-stage (64-deep, whole-cache-line DMA) kernels: one stage, odd / even stage counts, many tiles
+                                           (20, 256, 256, 64), (20, 512, 512, 192), (20, 1024, 768, 320), (21, 256, 640, 64),
+                                           (21, 512, 640, 192), (21, 2048, 1280, 256), (22, 512, 512, 192), (22, 256, 256, 128),
+                                           (23, 512, 640, 192), (23, 768, 320, 320)])
 def test_gemm_every_tile_variant(lib, variant, M, N, K):
     """(variant 11 = the persistent 256x320 kernel; 8192 x 3200 gives 320 tiles, so 64 blocks walk two tiles.)
     Each tile shape of the pipelined GEMM forced explicitly (the auto rule only picks the 256x256 / 256x320
@@ -126,6 +130,36 @@ def test_gemm_every_tile_variant(lib, variant, M, N, K):
         err = (out.cpu().view(dt).float() - ref_c).abs() / ref_c.abs().clamp(min=1e-2)
         print(f"gemm variant {variant} {M}x{N}x{K}: gelu->ET max rel {err.max().item():.2e}")
         assert err.max().item() < 1.5 * ulp, f"variant {variant} GELU out"
+    finally:
+        lib.samrs_debug_set_gemm_variant(8)
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_gemm_tile_variants_are_bit_identical(lib, name, prec, dt, ulp):
+    """Every tile shape accumulates each output element over k in the same ascending 32-wide MFMA steps, so the pair-stage
+    kernels (20-23) must reproduce the staggered 256x256 / 256x320 kernels (6 / 10) BIT FOR BIT -- also the strongest
+    race screen for a new LDS pipeline: repeated launches, fp32 and ET outputs, several K depths."""
+    lib.samrs_debug_set_gemm_variant.argtypes = [__import__("ctypes").c_int]
+    try:
+        for (M, N, K) in [(2048, 1280, 1280), (1024, 1280, 320), (512, 1280, 64), (1536, 2560, 704)]:
+            g = torch.Generator().manual_seed(M + N + K)
+            _, Ab = et_bits(torch.randn(M, K, generator=g), dt)
+            _, Bb = et_bits(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
+            bias = dev(torch.randn(N, generator=g))
+            Ad, Bd = dev(Ab), dev(Bb)
+            outs = {}
+            for variant in (10, 6, 20, 21, 22, 23):
+                lib.samrs_debug_set_gemm_variant(variant)
+                for rep in range(3):
+                    of = torch.zeros(M, N, device="cuda")
+                    oe = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+                    assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), of.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 1, 0, 0, stream()) == 0
+                    assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), oe.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 0, 1, 0, stream()) == 0
+                    if not outs:
+                        outs = {"f": of, "e": oe}
+                    else:
+                        assert torch.equal(of, outs["f"]), f"{name} {M}x{N}x{K}: variant {variant} rep {rep} fp32 output differs from variant 10"
+                        assert torch.equal(oe, outs["e"]), f"{name} {M}x{N}x{K}: variant {variant} rep {rep} GELU/ET output differs from variant 10"
     finally:
         lib.samrs_debug_set_gemm_variant(8)
 

@@ -23,6 +23,7 @@ tb = so.apply_boxes(torch.from_numpy(inp["boxes"]), hw)
 
 
 def run(dtype):
+    torch.set_default_dtype(dtype)          # the oracle builds its coordinate grids in the default dtype
     sd = {k: v.to(dtype) for k, v in sd32.items()}
     pred = so.OraclePredictor(sd, cfg)
     x = so.preprocess(img, cfg.img_size).to(dtype)

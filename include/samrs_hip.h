@@ -159,6 +159,8 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
 
 /* -- test / tuning hook: 0 = register-staged GEMM tiles, 1 = LDS-DMA staging (default). */
 void samrs_debug_set_gemm_variant(int variant);
+/* tuning hook: start skew of the first round of GEMM blocks, per XCD / per CU group, in 1024-cycle units (0, 0 = off) */
+void samrs_debug_set_gemm_skew(int xcd_units, int cu_units);
 /* test / timing hook: 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm / product launches) */
 void samrs_debug_set_decoder_fusion(int on);
 

@@ -821,6 +821,7 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
 }
 
 void samrs_debug_set_gemm_variant(int v) { set_gemm_variant(v); }
+void samrs_debug_set_gemm_skew(int xcd_units, int cu_units) { set_gemm_skew(xcd_units, cu_units); }
 void samrs_debug_set_decoder_fusion(int on) { g_decoder_fusion = on != 0; }
 
 // test hook: copy (a prefix of) a named internal decoder buffer to a caller device buffer

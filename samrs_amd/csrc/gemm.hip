@@ -938,6 +938,19 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_big_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int XBK = 64;
 
+// Start skew of the FIRST round of blocks (experiment / tuning knob, SAMRS_GEMM_SKEW=<xcd units>,<cu-group units> in
+// 1024-cycle steps): all 256 CUs start a GEMM together and reach their epilogues together, so the output tile writes
+// arrive as one HBM-bound burst per round while the matrix pipes idle.  Delaying the first block of XCD x by x units (and
+// CU group g by g units) keeps the rounds of different XCDs out of phase for the whole launch: one XCD writes while the
+// others compute.  Blocks of later rounds inherit the skew because each CU takes its next block when it finishes one.
+static int g_x64_skew = [] {
+    const char* v = getenv("SAMRS_GEMM_SKEW");
+    if (!v) return 0;
+    int a = 0, b = 0;
+    sscanf(v, "%d,%d", &a, &b);
+    return (a & 0xffff) | (b << 16);
+}();
+
 // LDS-DMA, scalar-base form: source = sbase (SGPR pair, wave-uniform) + voff (per-lane byte offset, one VGPR),
 // destination = LDS byte address m0v (wave-uniform) + 16 * lane.  Issued from inline asm for the same reason as
 // glds16_asm (hipcc must not see it in its waitcnt bookkeeping); the caller counts vmcnt by hand.
@@ -954,16 +967,24 @@ __device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint3
         : "memory");
 }
 
-template <int PREC, bool OUT_F32, bool GELU, int NI = 4, bool SPREAD = false>
+template <int PREC, bool OUT_F32, bool GELU, int NI = 4, int MODE = 0, int ABL = 0>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
-    int M, int N, int K, int accumulate) {
+    int M, int N, int K, int accumulate, int skew) {
     constexpr int XBN = 64 * NI;
     constexpr int XROWS = QBM + XBN;                       // 512 / 576 rows per stage
     constexpr int XSTAGE_ELEMS = XROWS * XBK;              // 64 / 72 KiB
     constexpr uint32_t XSB = XSTAGE_ELEMS * 2;             // stage bytes
     constexpr int NPIECE = 4 + NI;                         // DMA pieces per wave and stage (8 rows x 128 B each): 4 A + NI B
+    constexpr bool SPREAD = (MODE & 1) != 0;               // DMA pieces issued between the MFMAs instead of as one burst
+    // LIGHT: ONE block-wide barrier per pair stage (the one that hands a landed stage over) instead of four.  The
+    // barriers between the L and C segments of a stage guard no LDS hazard -- they only keep the two waves of a
+    // SIMD in complementary segments, at ~150 cycles of re-convergence per 640-cycle MFMA segment.  Without them
+    // group 1 still runs half a stage behind group 0 (its rendezvous sits between L(t, 1) and C(t, 1)), so its
+    // fragment reads fall into the other wave's MFMA segments by themselves.
+    constexpr bool LIGHT = (MODE & 2) != 0;
+    // ABL (timing experiments only, results are garbage): 1 no DMA, 2 no fragment reads, 4 no MFMA, 16 no epilogue
     __shared__ __attribute__((aligned(16))) uint16_t lds[2 * XSTAGE_ELEMS];   // 128 / 144 KiB, ONE object
 
     const int tid = threadIdx.x;
@@ -994,7 +1015,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
     // piece q_ (literal) of pair stage st_ into the buffer at byte offset wr_
 #define X64_PIECE(st_, wr_, q_)                                                                            \
-    glds16_s(voff, ((q_) < 4 ? sA + (size_t)(q_) * rs64 : sB + (size_t)((q_) - 4) * rs64) + (size_t)(st_) * XBK, \
+    if constexpr (!(ABL & 1)) glds16_s(voff, ((q_) < 4 ? sA + (size_t)(q_) * rs64 : sB + (size_t)((q_) - 4) * rs64) + (size_t)(st_) * XBK, \
              lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u))
 #define X64_ISSUE(st_, wr_)                                                                                \
     do {                                                                                                   \
@@ -1022,6 +1043,10 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     }
     const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);
 
+    if (skew && blockIdx.x < 256) {            // first round only (one block per CU; block b starts on XCD b % 8)
+        const int n = (int)(blockIdx.x & 7) * (skew & 0xffff) + (int)((blockIdx.x >> 3) & 3) * (skew >> 16);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);      // 16 x 64 cycles
+    }
     // prologue: stage 0 landed for everybody
     X64_ISSUE(0, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1032,16 +1057,25 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     }
 
 #define X64_READ(rd_, kh_)                                                                                 \
+    if constexpr (!(ABL & 2)) {                                                                            \
     _Pragma("unroll") for (int i = 0; i < NI; ++i)                                                         \
         fb[i] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offB[i]);                     \
     _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                          \
-        fa[j] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offA[j]);
+        fa[j] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offA[j]);                     \
+    } else {                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i) { fb[i] = make_uint4(lane, i, (rd_), 1); asm volatile("" : "+v"(fb[i].x)); } \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) { fa[j] = make_uint4(lane, j, (rd_), 2); asm volatile("" : "+v"(fa[j].x)); } \
+    }
     // 8 NI MFMAs of one k-half; when dma_ (wave-uniform) is set, this wave's pieces of stage st_ go out first (burst)
     // or one per m-tile row of MFMAs (SPREAD).  The accumulators never sit inside a conditional region.
 #define X64_MFMA(dma_, st_, wr_)                                                                           \
     if (!SPREAD) { if (dma_) X64_ISSUE(st_, wr_); }                                                        \
     _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                        \
+        if constexpr (!(ABL & 4)) {                                                                        \
         _Pragma("unroll") for (int i = 0; i < NI; ++i) acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]); \
+        } else {                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(fb[i].x), "v"(fb[i].w), "v"(fa[j].x), "v"(fa[j].w)); \
+        }                                                                                                  \
         if (SPREAD) {                                                                                      \
             if (dma_) {                                                                                    \
                 if (j == 0) X64_PIECE(st_, wr_, 0); if (j == 1) X64_PIECE(st_, wr_, 1);                    \
@@ -1052,6 +1086,8 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
             }                                                                                              \
         }                                                                                                  \
     }
+    // intra-stage barrier (kept only in the four-barrier schedule)
+#define X64_MIDBAR() if constexpr (!LIGHT) __builtin_amdgcn_s_barrier();
 
     uint32_t rd = 0;                           // byte offset of the buffer that holds stage t
     for (int t = 0; t < nst; ++t) {
@@ -1059,53 +1095,66 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
         const uint32_t wr = XSB - rd;
         const bool dma0 = (grp == 0) && (t + 1 < nst);     // group 0 feeds stage t+1 from I_4t
         const bool dma1 = (grp == 1) && (t + 2 < nst);     // group 1 feeds stage t+2 from its C(t, 1) = I_4(t+1)
+        // LIGHT: rendezvous R_t -- group 0 arrives here (stage t-1 finished, its pieces of stage t landed), group 1
+        // from between L(t-1, 1) and C(t-1, 1) (t = 0: from the prologue)
+        if constexpr (LIGHT) { if (grp == 0) __builtin_amdgcn_s_barrier(); }
         // ---- L(t, 0) ----
         if (!SPREAD) { if (dma0) X64_ISSUE(t + 1, wr); }
         X64_READ(rd, 0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        X64_MIDBAR()
         // ---- C(t, 0) ----
         __builtin_amdgcn_s_setprio(1);
         X64_MFMA(SPREAD && dma0, t + 1, wr)
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        X64_MIDBAR()
         // ---- L(t, 1); group 1: its pieces of stage t+1 (issued one stage ago) must have landed ----
         X64_READ(rd, 1)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (LIGHT) { if (grp == 1) __builtin_amdgcn_s_barrier(); } else __builtin_amdgcn_s_barrier();
         // ---- C(t, 1); group 1: buffer `rd` is free from here on (both groups have read k-half 1) ----
         __builtin_amdgcn_s_setprio(1);
         X64_MFMA(dma1, t + 2, rd)
         __builtin_amdgcn_s_setprio(0);
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!LIGHT) __builtin_amdgcn_s_barrier();
         rd = wr;
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();          // both groups: 2 + 4 nst barriers; every ring read is done
+    if (grp == 0) __builtin_amdgcn_s_barrier();          // both groups: same barrier count; every ring read is done
 
+    if constexpr (ABL & 16) {   // timing experiment: keep the accumulators alive, store nothing
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][3]));
+        return;
+    }
     {   // coalesced epilogue through the idle ring (16 / 18 KiB per wave), identical to the kernel above
         unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (2 * XSB / 8);
         const float* pre2d = OUT_F32 ? nullptr : add2d;     // ET output: the 2-D addend goes in before the rounding
+        // ABL 32 (timing experiment): every block stores to the SAME 256 x 64 NI window -> the stores stay in the L2
+        const int em0 = (ABL & 32) ? 0 : m0, en0 = (ABL & 32) ? 0 : n0;
         if constexpr (NI == 5 && !OUT_F32) {
-            epilogue_pair_et<PREC, GELU>(acc, reinterpret_cast<unsigned char*>(lds), Cv, bias, pre2d, add2d_period, N, m0 + wm * 128,
-                                         n0 + (wn >> 1) * 160, wm, wn, lane);
+            epilogue_pair_et<PREC, GELU>(acc, reinterpret_cast<unsigned char*>(lds), Cv, bias, pre2d, add2d_period, N, em0 + wm * 128,
+                                         en0 + (wn >> 1) * 160, wm, wn, lane);
         } else {
             epilogue_coalesced<PREC, OUT_F32, GELU, 8, OUT_F32 ? 2 : 4, NI>(acc, scr, Cv, bias, OUT_F32 ? add2d : nullptr, add2d_period,
-                                                                             N, m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane, pre2d);
+                                                                             N, em0 + wm * 128, en0 + wn * (16 * NI), accumulate, lane, pre2d);
         }
     }
 #undef X64_PIECE
 #undef X64_ISSUE
 #undef X64_READ
 #undef X64_MFMA
+#undef X64_MIDBAR
 }
 
-template <int PREC, int NI, bool SPREAD>
+template <int PREC, int NI, int MODE>
 hipError_t launch_gemm_x64(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
     dim3 grid((M / QBM) * (N / (64 * NI))), block(QTHREADS);
@@ -1113,11 +1162,11 @@ hipError_t launch_gemm_x64(const void* A, const void* B, void* C, const float* b
     const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
     const int acc = accumulate ? 1 : 0;
     if (out_f32) {
-        if (gelu) gemm_et_x64_kernel<PREC, true, true, NI, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-        else gemm_et_x64_kernel<PREC, true, false, NI, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        if (gelu) gemm_et_x64_kernel<PREC, true, true, NI, MODE><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc, g_x64_skew);
+        else gemm_et_x64_kernel<PREC, true, false, NI, MODE><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc, g_x64_skew);
     } else {
-        if (gelu) gemm_et_x64_kernel<PREC, false, true, NI, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-        else gemm_et_x64_kernel<PREC, false, false, NI, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
+        if (gelu) gemm_et_x64_kernel<PREC, false, true, NI, MODE><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc, g_x64_skew);
+        else gemm_et_x64_kernel<PREC, false, false, NI, MODE><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc, g_x64_skew);
     }
     return hipGetLastError();
 }
@@ -1612,38 +1661,60 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     int variant = g_gemm_variant;
     // 20 / 21: pair-stage (64-deep, whole-cache-line DMA) 256x256 / 256x320 kernel; 22 / 23: the same with the DMA pieces
     // spread between the MFMAs.  Shapes they do not cover fall through to the automatic choice.
-    if (variant >= 20 && variant <= 23) {
-        const int ni = (variant & 1) ? 5 : 4;
+    if (variant >= 20 && variant <= 27) {     // 20 + mode * 2 + (NI == 5): mode bit 0 = spread DMA, bit 1 = one barrier per stage
+        const int ni = (variant & 1) ? 5 : 4, mode = (variant - 20) >> 1;
         if (M % QBM == 0 && N % (64 * ni) == 0 && K % XBK == 0) {
-#define X64_CASE(P, NI_, SP_) return launch_gemm_x64<P, NI_, SP_>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s)
-            if (prec == PREC_F16) {
-                if (variant == 20) X64_CASE(PREC_F16, 4, false);
-                if (variant == 21) X64_CASE(PREC_F16, 5, false);
-                if (variant == 22) X64_CASE(PREC_F16, 4, true);
-                X64_CASE(PREC_F16, 5, true);
+#define X64_CASE(P, NI_, MD_) return launch_gemm_x64<P, NI_, MD_>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s)
+#define X64_MODES(P)                                                             \
+            switch (variant) {                                                   \
+                case 20: X64_CASE(P, 4, 0); case 21: X64_CASE(P, 5, 0);          \
+                case 22: X64_CASE(P, 4, 1); case 23: X64_CASE(P, 5, 1);          \
+                case 24: X64_CASE(P, 4, 2); case 25: X64_CASE(P, 5, 2);          \
+                case 26: X64_CASE(P, 4, 3); default: X64_CASE(P, 5, 3);          \
             }
-            if (prec == PREC_BF16) {
-                if (variant == 20) X64_CASE(PREC_BF16, 4, false);
-                if (variant == 21) X64_CASE(PREC_BF16, 5, false);
-                if (variant == 22) X64_CASE(PREC_BF16, 4, true);
-                X64_CASE(PREC_BF16, 5, true);
-            }
+            (void)mode;
+            if (prec == PREC_F16) { X64_MODES(PREC_F16) }
+            if (prec == PREC_BF16) { X64_MODES(PREC_BF16) }
+#undef X64_MODES
 #undef X64_CASE
             return hipErrorInvalidValue;
         }
         variant = 8;
     }
+    // 100 + abl: ablations of the barrier-light 256x320 kernel (f16, ET output, no GELU): timing experiments only
+    if (variant >= 100 && variant < 164 && prec == PREC_F16 && !out_f32 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0) {
+        dim3 grid((M / QBM) * (N / WBN)), block(QTHREADS);
+        const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+        const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+#define XABL_CASE(x) case 100 + x: gemm_et_x64_kernel<PREC_F16, false, false, 5, 2, x><<<grid, block, 0, s>>>(a, b, C, bias, add2d, add2d_period, M, N, K, 0, g_x64_skew); break;
+        switch (variant) {
+            XABL_CASE(0) XABL_CASE(1) XABL_CASE(2) XABL_CASE(4) XABL_CASE(16) XABL_CASE(6) XABL_CASE(7) XABL_CASE(22) XABL_CASE(23) XABL_CASE(17)
+            XABL_CASE(32) XABL_CASE(33)
+            default: return hipErrorInvalidValue;
+        }
+#undef XABL_CASE
+        return hipGetLastError();
+    }
     if (variant == 8) {
         const bool big_ok = M % QBM == 0 && K % QBK == 0;
         const long t256 = big_ok && N % QBN == 0 ? (long)(M / QBM) * (N / QBN) : 0;
         const long t320 = big_ok && N % WBN == 0 ? (long)(M / QBM) * (N / WBN) : 0;
+        // the 256x320 tile: pair-stage kernel (whole-line DMA, one barrier per 64 k, DMA pieces spread between the MFMAs;
+        // measured +1.5 ... +4 % over the 32-deep ring on all four encoder shapes, bit-identical) when K allows, else
+        // the 32-deep staggered kernel
+        const int wide = (K % XBK == 0) ? 27 : 10;
         // fp32 residual outputs (proj, lin2: N = 1280): 256x320 tiles -> an exact number of rounds over the 256 CUs
-        if (out_f32 && t320 >= 256) variant = 10;
+        if (out_f32 && t320 >= 256) variant = wide;
         // f16 outputs (qkv N = 3840, lin1+GELU N = 5120): the wide tile whenever it fills whole rounds (6 / 8 rounds at
         // batch 8, exactly one round for lin1 of a single image), else 256x256 as long as there are >= 4 rounds of tiles
-        else if (!out_f32 && t320 >= 256 && t320 % 256 == 0) variant = 10;
+        else if (!out_f32 && t320 >= 256 && t320 % 256 == 0) variant = wide;
         else if (!out_f32 && N >= 2048 && t256 >= 1024) variant = 6;
         else variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
+    }
+    if (variant == 27 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0) {   // chosen by the automatic rule above
+        if (prec == PREC_BF16) return launch_gemm_x64<PREC_BF16, 5, 3>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_x64<PREC_F16, 5, 3>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
+        return hipErrorInvalidValue;
     }
     if (variant == 9 && M % DBM == 0 && K % DBK == 0) {   // 2 blocks / CU, lock-step (one barrier per K step)
         if (prec == PREC_BF16) return launch_gemm_dual<PREC_BF16, false>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
@@ -1688,6 +1759,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
 }
 
 void set_gemm_variant(int v) { g_gemm_variant = v; }
+void set_gemm_skew(int xcd_units, int cu_units) { g_x64_skew = (xcd_units & 0xffff) | (cu_units << 16); }
 
 hipError_t launch_gemm_f32_batch(const F32Batch& bt, int count, int lda, int ldc, int M, int N, int K, bool relu,
                                  bool accumulate, hipStream_t s) {

@@ -11,6 +11,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
 hipError_t launch_gemm_et_gln(int prec, const void* A, const void* B, void* C, const float* bias, const float* gamma_beta,
                               int M, int N, int K, hipStream_t s);
 void set_gemm_variant(int v);   // 0 = register-staged tiles, 1 = LDS-DMA staging (default)
+void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s);
 // up to F32_BATCH_MAX same-shape fp32 GEMMs in one launch: C[z] = (A[z] (+ A2[z])) * W[z]^T + bias[z]

@@ -97,7 +97,10 @@ def test_gemm_et_variants(lib, name, prec, dt, ulp, M, N, K):
                                            # pair-stage (64-deep, whole-cache-line DMA) kernels: one stage, odd / even stage counts, many tiles
                                            (20, 256, 256, 64), (20, 512, 512, 192), (20, 1024, 768, 320), (21, 256, 640, 64),
                                            (21, 512, 640, 192), (21, 2048, 1280, 256), (22, 512, 512, 192), (22, 256, 256, 128),
-                                           (23, 512, 640, 192), (23, 768, 320, 320)])
+                                           (23, 512, 640, 192), (23, 768, 640, 320),
+                                           # one block-wide barrier per pair stage
+                                           (24, 512, 512, 192), (24, 256, 256, 64), (25, 512, 640, 192), (25, 2048, 1280, 256),
+                                           (26, 512, 512, 320), (27, 768, 640, 320), (27, 256, 640, 64)])
 def test_gemm_every_tile_variant(lib, variant, M, N, K):
     """(variant 11 = the persistent 256x320 kernel; 8192 x 3200 gives 320 tiles, so 64 blocks walk two tiles.)
     Each tile shape of the pipelined GEMM forced explicitly (the auto rule only picks the 256x256 / 256x320
@@ -148,7 +151,7 @@ def test_gemm_tile_variants_are_bit_identical(lib, name, prec, dt, ulp):
             bias = dev(torch.randn(N, generator=g))
             Ad, Bd = dev(Ab), dev(Bb)
             outs = {}
-            for variant in (10, 6, 20, 21, 22, 23):
+            for variant in (10, 6, 20, 21, 22, 23, 24, 25, 26, 27):
                 lib.samrs_debug_set_gemm_variant(variant)
                 for rep in range(3):
                     of = torch.zeros(M, N, device="cuda")

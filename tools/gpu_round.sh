@@ -19,6 +19,8 @@ PT="python -m pytest -m gpu -q -s -rA -p no:cacheprovider"
 for grp in "$@"; do
   case $grp in
     k_basic)  run k_basic 600 $PT tests/test_kernels_gpu.py -k "convert or gemm or layernorm or postprocess or upscale2" ;;
+    k_gemm)   run k_gemm 900 $PT tests/test_kernels_gpu.py -k "gemm" ;;
+    p_c2c4)   run p_c2c4 900 $PT tests/test_parity_gpu.py -k "c2_c4" ;;
     k_win)    run k_win 600 $PT tests/test_kernels_gpu.py -k "window_attention" ;;
     k_glb)    run k_glb 600 $PT tests/test_kernels_gpu.py -k "global_attention" ;;
     p_enc)    run p_enc 900 $PT tests/test_parity_gpu.py -k "encoder_blockwise" ;;
@@ -38,6 +40,12 @@ for grp in "$@"; do
               run pmc2 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/pmc2 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 2 f16}
               run pmc3 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc3 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 2 f16}
               run pmc4 600 rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAIT_INST_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc4 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 2 f16} ;;
+    clk)      cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
+              run clk 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d gpurun_out/clk -o p -- python ${PMC_CMD:-tools/gemm_bench.py 25 f16} ;;
+    pmcx)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
+              run pmcx1 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d gpurun_out/pmcx1 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 25 f16}
+              run pmcx2 600 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_VMEM_TA_CMD_FIFO_FULL --kernel-trace --output-format csv -d gpurun_out/pmcx2 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 25 f16}
+              run pmcx3 600 rocprofv3 --pmc TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TAGRAM0_REQ_sum GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_ANY --kernel-trace --output-format csv -d gpurun_out/pmcx3 -o p -- python ${PMC_CMD:-tools/gemm_bench.py 25 f16} ;;
     attnb)    run attnb 600 python tools/attn_bench.py ;;
     decb)     cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
               run decb 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/decb -o dec -- python tools/dec_bench.py 20 ;;

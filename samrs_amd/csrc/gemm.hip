@@ -238,7 +238,10 @@ __device__ __forceinline__ void wave_lds_sync_g() {
 // known), the 2-D addend and the residual accumulate after it (coalesced loads).
 //   acc[i][j]: n-tile i (16 cols), m-tile j (16 rows); NJ m-tiles per wave, JC of them per pass.
 // ---------------------------------------------------------------------------------------------
-template <int PREC, bool OUT_F32, bool GELU, int NJ, int JC, int NI = 4, bool GLN = false>
+// DRAIN (persistent kernels): the caller has LDS-DMA pieces of its NEXT tile in flight; they are retired (vmcnt(0)) right
+// before this wave's first global store, i.e. after the bias loads, the VALU work and the first LDS bounce have covered
+// their latency, and before any store joins the queue -- so the stores themselves are never waited for.
+template <int PREC, bool OUT_F32, bool GELU, int NJ, int JC, int NI = 4, bool GLN = false, bool DRAIN = false>
 __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsigned char* scr /* wave-private */,
                                                    void* __restrict__ Cv, const float* __restrict__ bias,
                                                    const float* __restrict__ add2d, int add2d_period, int N,
@@ -336,6 +339,7 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
             }
         }
         wave_lds_sync_g();
+        if (DRAIN && j0 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int jj = 0; jj < JC; ++jj) {
             const int j = j0 + jj;
@@ -377,7 +381,7 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
 // Block-wide barriers: all 8 waves are past the main loop here (the stagger has been re-aligned).
 //   acc[i][j]: n-tile i (16 cols), m-tile j (16 rows); 8 m-tiles, 4 per pass.
 // ---------------------------------------------------------------------------------------------
-template <int PREC, bool GELU, int JC = 4>
+template <int PREC, bool GELU, int JC = 4, bool DRAIN = false>
 __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned char* lds, void* __restrict__ Cv,
                                                  const float* __restrict__ bias, const float* __restrict__ pre2d, int period, int N,
                                                  int m_base /* wave tile row 0 */, int n_pair /* first column of the pair */,
@@ -412,6 +416,7 @@ __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned 
                 *reinterpret_cast<uint2*>(scr + jj * TS + fr * RS + half * 160 + (i * 16 + 4 * fq) * 2) = o;
             }
         }
+        if (DRAIN && j0 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // this wave: rows 8*half .. +7 of each of the JC m-tiles = JC x 8 rows x 20 chunks = 2.5 JC passes of 64 lanes
 #pragma unroll
@@ -1043,6 +1048,17 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     }
     const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);
 
+    // ABL 64 (timing experiment): wave 0 records s_memtime stamps into the buffer passed as add2d: 32 x u64 per block
+    // [0] entry, [1] stage 0 landed, [2 + t] end of stage t (t < 24), [26] loop done, [27] epilogue done, [28] HW_ID | XCC_ID << 32
+    unsigned long long* tl = nullptr;
+    if constexpr (ABL & 64) {
+        tl = reinterpret_cast<unsigned long long*>(const_cast<float*>(add2d)) + (size_t)blockIdx.x * 32;
+        if (tid == 0) {
+            tl[0] = __builtin_amdgcn_s_memtime();
+            tl[28] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                     ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        }
+    }
     if (skew && blockIdx.x < 256) {            // first round only (one block per CU; block b starts on XCD b % 8)
         const int n = (int)(blockIdx.x & 7) * (skew & 0xffff) + (int)((blockIdx.x >> 3) & 3) * (skew >> 16);
         for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);      // 16 x 64 cycles
@@ -1051,6 +1067,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     X64_ISSUE(0, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (ABL & 64) { if (tid == 0) tl[1] = __builtin_amdgcn_s_memtime(); }
     if (grp == 1) {                            // I_0 of group 1: nothing to compute yet; its share of stage 1 goes out
         if (nst > 1) X64_ISSUE(1, XSB);
         __builtin_amdgcn_s_barrier();
@@ -1123,10 +1140,12 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!LIGHT) __builtin_amdgcn_s_barrier();
+        if constexpr (ABL & 64) { if (tid == 0 && t < 24) tl[2 + t] = __builtin_amdgcn_s_memtime(); }
         rd = wr;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();          // both groups: same barrier count; every ring read is done
 
+    if constexpr (ABL & 64) { if (tid == 0) tl[26] = __builtin_amdgcn_s_memtime(); }
     if constexpr (ABL & 16) {   // timing experiment: keep the accumulators alive, store nothing
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -1147,11 +1166,200 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
                                                                              N, em0 + wm * 128, en0 + wn * (16 * NI), accumulate, lane, pre2d);
         }
     }
+    if constexpr (ABL & 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores acknowledged: what s_endpgm would wait for anyway
+        if (tid == 0) tl[27] = __builtin_amdgcn_s_memtime();
+    }
 #undef X64_PIECE
 #undef X64_ISSUE
 #undef X64_READ
 #undef X64_MFMA
 #undef X64_MIDBAR
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_et_x64p_kernel: the pair-stage 256x320 kernel (one barrier per stage, spread DMA) made PERSISTENT: one block per
+// CU walks tiles L, L + gridDim.x, ...  Measured on the one-tile-per-block kernel (s_memtime stamps, tools/gemm_timeline.py,
+// qkv shape): of ~90 k cycles per tile, 3.2 k pass before stage 0 has landed, 2.3 k between a block's end and its successor's
+// first instruction, and the block's last ~2 k wait for store acknowledgements.  Here the next tile's stage 0 goes out
+// (into ring buffer 0, free since the last rendezvous) BEFORE the epilogue, whose bounce scratch is confined to ring buffer
+// 1; every wave retires those pieces just before its first store (epilogue DRAIN), so the stores are never waited for: the
+// next tile's main loop starts right after the epilogue, with its stage 0 already in LDS.  Main loop = the kernel above.
+// add2d is not supported (the encoder's four big GEMMs have none).
+// ---------------------------------------------------------------------------------------------
+template <int PREC, bool OUT_F32, bool GELU>
+__global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, int M, int N, int K, int accumulate) {
+    constexpr int NI = 5;
+    constexpr int XBN = 64 * NI;
+    constexpr int XROWS = QBM + XBN;
+    constexpr int XSTAGE_ELEMS = XROWS * XBK;
+    constexpr uint32_t XSB = XSTAGE_ELEMS * 2;
+    constexpr int NPIECE = 4 + NI;
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * XSTAGE_ELEMS];   // 144 KiB, ONE object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    constexpr int GROUP = 8;
+    const int tiles_n = N / XBN, tiles_m = M / QBM, ntiles = tiles_n * tiles_m;
+    const int per_group = GROUP * tiles_n;
+#define X64P_TILE(L_, m_, n_)                                                                    \
+    do {                                                                                         \
+        const int bid_ = xcd_remap((L_), ntiles);                                                \
+        const int group_ = bid_ / per_group, first_m_ = group_ * GROUP;                           \
+        const int gsz_ = (tiles_m - first_m_) < GROUP ? (tiles_m - first_m_) : GROUP;            \
+        const int in_g_ = bid_ - group_ * per_group;                                             \
+        (m_) = (first_m_ + in_g_ % gsz_) * QBM;                                                  \
+        (n_) = (in_g_ / gsz_) * XBN;                                                             \
+    } while (0)
+
+    const int prow = 8 * wave + ((lane >> 2) & 7);
+    const uint32_t voff = ((uint32_t)prow * (uint32_t)K + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
+    const size_t rs64 = (size_t)64 * K;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
+    const uint16_t* sA;                            // wave-uniform bases of the tile being FED (SGPR pairs)
+    const uint16_t* sB;
+#define X64P_PIECE(st_, wr_, q_)                                                                           \
+    glds16_s(voff, ((q_) < 4 ? sA + (size_t)(q_) * rs64 : sB + (size_t)((q_) - 4) * rs64) + (size_t)(st_) * XBK, \
+             lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u))
+#define X64P_ISSUE(st_, wr_)                                                                               \
+    do {                                                                                                   \
+        X64P_PIECE(st_, wr_, 0); X64P_PIECE(st_, wr_, 1); X64P_PIECE(st_, wr_, 2); X64P_PIECE(st_, wr_, 3); \
+        X64P_PIECE(st_, wr_, 4); X64P_PIECE(st_, wr_, 5); X64P_PIECE(st_, wr_, 6); X64P_PIECE(st_, wr_, 7); \
+        X64P_PIECE(st_, wr_, 8);                                                                           \
+    } while (0)
+
+    const int nst = K / XBK;
+    const int fr = lane & 15, fq = lane >> 4;
+    uint32_t offA[8], offB[NI];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int r = wm * 128 + j * 16 + fr; offA[j] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, fq) * 8) * 2; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = QBM + wn * (16 * NI) + i * 16 + fr;
+        offB[i] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, fq) * 8) * 2;
+    }
+    const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);
+
+#define X64P_READ(rd_, kh_)                                                                                \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i)                                                         \
+        fb[i] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offB[i]);                     \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                          \
+        fa[j] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offA[j]);
+#define X64P_MFMA(dma_, st_, wr_)                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                        \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]); \
+        if (dma_) {                                                                                        \
+            if (j == 0) X64P_PIECE(st_, wr_, 0); if (j == 1) X64P_PIECE(st_, wr_, 1);                      \
+            if (j == 2) X64P_PIECE(st_, wr_, 2); if (j == 3) X64P_PIECE(st_, wr_, 3);                      \
+            if (j == 4) X64P_PIECE(st_, wr_, 4); if (j == 5) X64P_PIECE(st_, wr_, 5);                      \
+            if (j == 6) X64P_PIECE(st_, wr_, 6);                                                           \
+            if (j == 7) { X64P_PIECE(st_, wr_, 7); X64P_PIECE(st_, wr_, 8); }                              \
+        }                                                                                                  \
+    }
+
+    int L = blockIdx.x, m0, n0;
+    X64P_TILE(L, m0, n0);
+    sA = A + (size_t)m0 * K;
+    sB = B + (size_t)n0 * K;
+    X64P_ISSUE(0, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x4_t acc[NI][8];
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (grp == 1) {                        // rendezvous R_0 of group 1; its share of stage 1 goes out first
+            if (nst > 1) X64P_ISSUE(1, XSB);
+            __builtin_amdgcn_s_barrier();
+        }
+        uint32_t rd = 0;
+        for (int t = 0; t < nst; ++t) {
+            uint4 fa[8], fb[NI];
+            const uint32_t wr = XSB - rd;
+            const bool dma0 = (grp == 0) && (t + 1 < nst);
+            const bool dma1 = (grp == 1) && (t + 2 < nst);
+            if (grp == 0) __builtin_amdgcn_s_barrier();                       // R_t
+            X64P_READ(rd, 0)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            X64P_MFMA(dma0, t + 1, wr)
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            X64P_READ(rd, 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 1) __builtin_amdgcn_s_barrier();                       // R_{t+1} of group 1
+            __builtin_amdgcn_s_setprio(1);
+            X64P_MFMA(dma1, t + 2, rd)
+            __builtin_amdgcn_s_setprio(0);
+            if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            rd = wr;
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();      // last rendezvous: every ring read of this tile is done
+
+        // next tile: its stage 0 goes into ring buffer 0 now and lands under the epilogue
+        const int Ln = L + (int)gridDim.x;
+        const bool more = Ln < ntiles;
+        int m1 = m0, n1 = n0;
+        if (more) {
+            X64P_TILE(Ln, m1, n1);
+            sA = A + (size_t)m1 * K;
+            sB = B + (size_t)n1 * K;
+            X64P_ISSUE(0, 0u);
+        }
+        {   // epilogue of tile (m0, n0); bounce scratch = ring buffer 1 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
+            unsigned char* upper = reinterpret_cast<unsigned char*>(lds) + XSB;
+            if constexpr (!OUT_F32) {
+                epilogue_pair_et<PREC, GELU, 2, true>(acc, upper, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + (wn >> 1) * 160, wm, wn, lane);
+            } else {
+                epilogue_coalesced<PREC, true, GELU, 8, 1, NI, false, true>(acc, upper + wave * (XSB / 8), Cv, bias, nullptr, 1, N,
+                                                                           m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane);
+            }
+        }
+        if (!more) break;
+        __builtin_amdgcn_s_barrier();          // scratch free again; stage 0 visible (each wave drained its pieces before its first store)
+        L = Ln; m0 = m1; n0 = n1;
+    }
+#undef X64P_TILE
+#undef X64P_PIECE
+#undef X64P_ISSUE
+#undef X64P_READ
+#undef X64P_MFMA
+}
+
+template <int PREC>
+hipError_t launch_gemm_x64p(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, bool out_f32, bool gelu,
+                            bool accumulate, hipStream_t s) {
+    const int ntiles = (M / QBM) * (N / WBN);
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(QTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (out_f32) {
+        if (gelu) gemm_et_x64p_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        else gemm_et_x64p_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    } else {
+        if (gelu) gemm_et_x64p_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        else gemm_et_x64p_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    }
+    return hipGetLastError();
 }
 
 template <int PREC, int NI, int MODE>
@@ -1661,6 +1869,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     int variant = g_gemm_variant;
     // 20 / 21: pair-stage (64-deep, whole-cache-line DMA) 256x256 / 256x320 kernel; 22 / 23: the same with the DMA pieces
     // spread between the MFMAs.  Shapes they do not cover fall through to the automatic choice.
+    if (variant == 28 && !(M % QBM == 0 && N % WBN == 0 && K % XBK == 0 && !add2d)) variant = 8;
     if (variant >= 20 && variant <= 27) {     // 20 + mode * 2 + (NI == 5): mode bit 0 = spread DMA, bit 1 = one barrier per stage
         const int ni = (variant & 1) ? 5 : 4, mode = (variant - 20) >> 1;
         if (M % QBM == 0 && N % (64 * ni) == 0 && K % XBK == 0) {
@@ -1682,14 +1891,14 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         variant = 8;
     }
     // 100 + abl: ablations of the barrier-light 256x320 kernel (f16, ET output, no GELU): timing experiments only
-    if (variant >= 100 && variant < 164 && prec == PREC_F16 && !out_f32 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0) {
+    if (variant >= 100 && variant < 196 && prec == PREC_F16 && !out_f32 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0) {
         dim3 grid((M / QBM) * (N / WBN)), block(QTHREADS);
         const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
         const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
-#define XABL_CASE(x) case 100 + x: gemm_et_x64_kernel<PREC_F16, false, false, 5, 2, x><<<grid, block, 0, s>>>(a, b, C, bias, add2d, add2d_period, M, N, K, 0, g_x64_skew); break;
+#define XABL_CASE(x) case 100 + x: gemm_et_x64_kernel<PREC_F16, false, false, 5, 3, x><<<grid, block, 0, s>>>(a, b, C, bias, add2d, add2d_period, M, N, K, 0, g_x64_skew); break;
         switch (variant) {
             XABL_CASE(0) XABL_CASE(1) XABL_CASE(2) XABL_CASE(4) XABL_CASE(16) XABL_CASE(6) XABL_CASE(7) XABL_CASE(22) XABL_CASE(23) XABL_CASE(17)
-            XABL_CASE(32) XABL_CASE(33)
+            XABL_CASE(32) XABL_CASE(33) XABL_CASE(64)
             default: return hipErrorInvalidValue;
         }
 #undef XABL_CASE
@@ -1707,10 +1916,17 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         if (out_f32 && t320 >= 256) variant = wide;
         // f16 outputs (qkv N = 3840, lin1+GELU N = 5120): the wide tile whenever it fills whole rounds (6 / 8 rounds at
         // batch 8, exactly one round for lin1 of a single image), else 256x256 as long as there are >= 4 rounds of tiles
-        else if (!out_f32 && t320 >= 256 && t320 % 256 == 0) variant = wide;
+        // (ET outputs without a 2-D addend: the persistent flavour, +3 % on qkv / lin1; its one-m-tile fp32 epilogue loses on proj)
+        else if (!out_f32 && t320 >= 256 && t320 % 256 == 0) variant = (wide == 27 && !add2d) ? 28 : wide;
         else if (!out_f32 && N >= 2048 && t256 >= 1024) variant = 6;
         else variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
     }
+    if (variant == 28 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0 && !add2d) {   // persistent pair-stage kernel
+        if (prec == PREC_BF16) return launch_gemm_x64p<PREC_BF16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_x64p<PREC_F16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, s);
+        return hipErrorInvalidValue;
+    }
+    if (variant == 28) variant = 27;
     if (variant == 27 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0) {   // chosen by the automatic rule above
         if (prec == PREC_BF16) return launch_gemm_x64<PREC_BF16, 5, 3>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_x64<PREC_F16, 5, 3>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);

@@ -100,7 +100,9 @@ def test_gemm_et_variants(lib, name, prec, dt, ulp, M, N, K):
                                            (23, 512, 640, 192), (23, 768, 640, 320),
                                            # one block-wide barrier per pair stage
                                            (24, 512, 512, 192), (24, 256, 256, 64), (25, 512, 640, 192), (25, 2048, 1280, 256),
-                                           (26, 512, 512, 320), (27, 768, 640, 320), (27, 256, 640, 64)])
+                                           (26, 512, 512, 320), (27, 768, 640, 320), (27, 256, 640, 64),
+                                           # persistent pair-stage kernel: 1 tile per block, blocks that walk 2 / 3 tiles, odd stage count
+                                           (28, 512, 640, 192), (28, 8192, 3200, 192), (28, 256, 640, 64), (28, 16384, 3840, 320)])
 def test_gemm_every_tile_variant(lib, variant, M, N, K):
     """(variant 11 = the persistent 256x320 kernel; 8192 x 3200 gives 320 tiles, so 64 blocks walk two tiles.)
     Each tile shape of the pipelined GEMM forced explicitly (the auto rule only picks the 256x256 / 256x320
@@ -144,14 +146,14 @@ def test_gemm_tile_variants_are_bit_identical(lib, name, prec, dt, ulp):
     race screen for a new LDS pipeline: repeated launches, fp32 and ET outputs, several K depths."""
     lib.samrs_debug_set_gemm_variant.argtypes = [__import__("ctypes").c_int]
     try:
-        for (M, N, K) in [(2048, 1280, 1280), (1024, 1280, 320), (512, 1280, 64), (1536, 2560, 704)]:
+        for (M, N, K) in [(2048, 1280, 1280), (1024, 1280, 320), (512, 1280, 64), (1536, 2560, 704), (32768, 1280, 192), (24576, 3840, 128)]:
             g = torch.Generator().manual_seed(M + N + K)
             _, Ab = et_bits(torch.randn(M, K, generator=g), dt)
             _, Bb = et_bits(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
             bias = dev(torch.randn(N, generator=g))
             Ad, Bd = dev(Ab), dev(Bb)
             outs = {}
-            for variant in (10, 6, 20, 21, 22, 23, 24, 25, 26, 27):
+            for variant in (10, 6, 20, 21, 22, 23, 24, 25, 26, 27, 28):
                 lib.samrs_debug_set_gemm_variant(variant)
                 for rep in range(3):
                     of = torch.zeros(M, N, device="cuda")

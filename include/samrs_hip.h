@@ -203,6 +203,9 @@ int samrs_k_window_attention(int prec, const void* qkv_et, const float* qkv_bias
 int samrs_k_global_attention(int prec, const void* qkv_et, const float* rel_h, const float* rel_w,
                              void* out_et, int n_images, int grid, int heads, int head_dim,
                              void* stream);
+/* neck (image_encoder.py:88-104): im2col of the 3x3 / pad 1 convolution on a channels-last ET tensor
+ * in [n_images][grid][grid][C] -> A [n_images*grid*grid][9*C], k = (ky*3 + kx)*C + c, zero outside the image. */
+int samrs_k_neck_im2col(const void* in_et, void* A_et, int n_images, int grid, int C, void* stream);
 int samrs_k_postprocess(const float* lowres, int n_masks, int in_h, int in_w, int orig_h,
                         int orig_w, int img_size, int return_logits, void* out, void* stream);
 /* First transposed conv of the mask upscaler as a GEMM with LayerNorm2d(64) + GELU in its epilogue

@@ -579,7 +579,7 @@ __global__ __launch_bounds__(128) void i2t_fused_kernel(const uint16_t* __restri
             const float4 gm = *reinterpret_cast<const float4*>(sp + CO + n), bt = *reinterpret_cast<const float4*>(sp + 2 * CO + n);
             const float y0 = v[i][0] * rstd * gm.x + bt.x, y1 = v[i][1] * rstd * gm.y + bt.y;
             const float y2 = v[i][2] * rstd * gm.z + bt.z, y3 = v[i][3] * rstd * gm.w + bt.w;
-            *reinterpret_cast<float4*>(outF + orow * CO + n) = make_float4(y0, y1, y2, y3);
+            if (outF) *reinterpret_cast<float4*>(outF + orow * CO + n) = make_float4(y0, y1, y2, y3);
             uint2 o;
             o.x = pack2<PREC>(y0, y1);
             o.y = pack2<PREC>(y2, y3);

@@ -253,10 +253,23 @@ __device__ __forceinline__ void wave_lds_sync() {
 // one online-softmax step on a 32-key S^T tile held in `S` (already = log2-domain logits WITHOUT the
 // per-tile constant `bh2`): updates running max / sum, rescales O only when some lane's max moved,
 // leaves the probabilities in S.
+// Lanes l and l + 32 own the two key halves of one query.  v_permlane32_swap exchanges the halves of two registers
+// inside the VALU (no LDS round trip, unlike ds_bpermute): with both operands = v, every lane ends up with its own and
+// its partner's value.
+__device__ __forceinline__ float xhalf_partner(float v) {
+#ifdef SAMRS_XHALF_SHFL      // A/B build: the LDS-based exchange this replaced
+    return __shfl_xor(v, 32, 64);
+#endif
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+
+// l_run is a PER-LANE partial row sum (this lane's key half): both lanes of a query scale it by the same alpha, so
+// the two halves are only added once, after the last tile (xhalf_partner), instead of once per tile.
 template <int DT>
 __device__ __forceinline__ void online_softmax_step(f32x16_t* S, int ntiles, float mx, float bh2, float& m_run, float& l_run,
                                                     f32x16_t (&O)[DT]) {
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, xhalf_partner(mx));
     const float m_new = fmaxf(m_run, mx + bh2);
     if (__any(m_new != m_run)) {
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -276,7 +289,6 @@ __device__ __forceinline__ void online_softmax_step(f32x16_t* S, int ntiles, flo
             S[a][r] = p;
             sum += p;
         }
-    sum += __shfl_xor(sum, 32, 64);
     l_run += sum;
 }
 
@@ -484,7 +496,7 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
 
         // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
         if (qin) {
-            const float inv = 1.0f / l_run;
+            const float inv = 1.0f / (l_run + xhalf_partner(l_run));
             uint16_t* orow = out + (size_t)im * img_rows * D + (size_t)(qoff / (3 * D)) * D + head * HD;
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt)
@@ -505,6 +517,54 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
 #undef WIN_TOK_OFF
 }
 
+// LDS-DMA with a wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset; destination = LDS byte address
+// m0v (wave-uniform) + 16 * lane.  Inline asm: hipcc must not see the load in its waitcnt bookkeeping (it would drain
+// it before every ds_read); the caller waits with an explicit s_waitcnt vmcnt.  Inactive lanes write nothing.
+__device__ __forceinline__ void glds16_sbase(uint32_t voff, const void* sbase, uint32_t m0v) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(m0v)
+        : "memory");
+}
+
+// V of the global-attention blocks, transposed once per block into vt[img][head][d][token] (ET), so that the attention
+// kernel can DMA its V^T tiles ([d][64 keys], 128 contiguous bytes per row) straight into LDS: a DMA cannot transpose.
+// Block = (image, head, 64-token tile): 64 x HD in, HD x 64 out through LDS.  ~2 x 84 MB per 8-image block, HBM-bound.
+template <int HD>
+__global__ __launch_bounds__(256) void vt_pack_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ vt, int heads,
+                                                      int ntok) {
+    __shared__ uint16_t tile[64][HD + 2];
+    const int tiles = ntok / 64;
+    const int t = blockIdx.x % tiles, P = blockIdx.x / tiles;
+    const int head = P % heads, im = P / heads;
+    const int D = heads * HD;
+    const uint16_t* src = qkv + ((size_t)im * ntok + (size_t)t * 64) * (3 * D) + 2 * D + head * HD;
+    constexpr int CH = HD / 8;
+    for (int c = threadIdx.x; c < 64 * CH; c += 256) {
+        const int r = c / CH, ch = c % CH;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)r * (3 * D) + ch * 8);
+        uint32_t* p = reinterpret_cast<uint32_t*>(&tile[r][ch * 8]);       // rows are 4-byte aligned (HD + 2 even)
+        p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    }
+    __syncthreads();
+    uint16_t* dst = vt + (size_t)P * HD * ntok + (size_t)t * 64;
+    for (int c = threadIdx.x; c < HD * 8; c += 256) {                       // (d, 8-token chunk)
+        const int d = c / 8, k0 = (c % 8) * 8;
+        uint4 o;
+        o.x = tile[k0 + 0][d] | ((uint32_t)tile[k0 + 1][d] << 16);
+        o.y = tile[k0 + 2][d] | ((uint32_t)tile[k0 + 3][d] << 16);
+        o.z = tile[k0 + 4][d] | ((uint32_t)tile[k0 + 5][d] << 16);
+        o.w = tile[k0 + 6][d] | ((uint32_t)tile[k0 + 7][d] << 16);
+        *reinterpret_cast<uint4*>(dst + (size_t)d * ntok + k0) = o;
+    }
+}
+
 // =========================================================================================
 // global attention (grid x grid tokens, flash-style online softmax).
 // Block = 128 queries of one (image, head): 4 waves x 32-query strips.  A strip lies inside one
@@ -512,28 +572,33 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
 // (64 keys) per tile: kh = tile index, kw = position in the tile.  80 KB of LDS and <= 256
 // registers -> two blocks (two waves per SIMD) per CU.
 // =========================================================================================
-template <int HD>
+template <int HD, int NW = 4>
 struct GlbCfg {
     static constexpr int G = 64, KT = 64;                 // grid side, keys per tile
     static constexpr int DT = (HD + 31) / 32;
-    static constexpr int VSTR = KT + 4;                   // 68: 8-byte aligned, conflict-light
+    static constexpr int VSTR = KT + 8;                   // 72 el = 144 B = 9 DMA chunks per d row (8 data + 1 pad): 2-way on the
+                                                          // fragment reads, the best a 16-byte-granular row stride can do
     static constexpr int K_BYTES = KT * HD * 2;
     static constexpr int VT_BYTES = DT * 32 * VSTR * 2;
     static constexpr int KV_BYTES = 2 * (K_BYTES + VT_BYTES);    // double buffered
     static constexpr int SSTR = 33;
-    static constexpr int SCR_BYTES = 4 * 32 * SSTR * 4;          // setup scratch, aliases the K/V buffers
+    static constexpr int SCR_BYTES = NW * 32 * SSTR * 4;         // setup scratch, aliases the K/V buffers
     static constexpr int UNION_BYTES = KV_BYTES > SCR_BYTES ? KV_BYTES : SCR_BYTES;
     static constexpr int RH_STR = 65;
-    static constexpr int RH_BYTES = 4 * 32 * RH_STR * 4;
+    static constexpr int RH_BYTES = NW * 32 * RH_STR * 4;
     static constexpr int LDS_BYTES = UNION_BYTES + RH_BYTES;
 };
 
-template <int PREC, int HD>
-__global__ __launch_bounds__(256, 2) void global_attention_kernel(
-    const uint16_t* __restrict__ qkv, const float* __restrict__ rel_h, const float* __restrict__ rel_w,
-    uint16_t* __restrict__ out, int heads) {
-    using C = GlbCfg<HD>;
+// NW waves = NW x 32 queries per block.  NW = 8 (one block per CU, 113 KiB of LDS): the K / V^T tiles are staged once for
+// 256 queries, which halves the LDS-DMA pieces each wave has to push through the CU's texture-address queue per tile
+// (measured: ~150 cycles of issue time per piece and wave; 22 pieces per tile and block).
+template <int PREC, int HD, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, const float* __restrict__ rel_h,
+    const float* __restrict__ rel_w, uint16_t* __restrict__ out, int heads) {
+    using C = GlbCfg<HD, NW>;
     constexpr int KS = HD / 16;
+    constexpr int QPB = 32 * NW, NTH = 64 * NW;     // queries / threads per block
     constexpr int G = C::G, NTOK = G * G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Scr = reinterpret_cast<float*>(smem);                              // setup only
@@ -541,13 +606,16 @@ __global__ __launch_bounds__(256, 2) void global_attention_kernel(
     // of pointers: runtime-indexed arrays end up in scratch)
     auto Kb = [&](int b) { return reinterpret_cast<uint16_t*>(smem + b * (C::K_BYTES + C::VT_BYTES)); };
     auto Vb = [&](int b) { return reinterpret_cast<uint16_t*>(smem + b * (C::K_BYTES + C::VT_BYTES) + C::K_BYTES); };
-    float* RH = reinterpret_cast<float*>(smem + C::UNION_BYTES);             // [4][32][RH_STR]
+    float* RH = reinterpret_cast<float*>(smem + C::UNION_BYTES);             // [NW][32][RH_STR]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, ql = lane & 31;
+#ifdef GLB_TIMING
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     // 1-D grid.  All 32 query blocks of one (image, head) re-read the same 1.3 MB of K/V, so put
     // them on ONE XCD (hardware: block b -> XCD b % 8) to keep that working set in its 4 MB L2.
-    const int QB = NTOK / 128;
+    const int QB = NTOK / QPB;
     int qb, P;
     {
         const int L = blockIdx.x, npairs = gridDim.x / QB;
@@ -564,9 +632,9 @@ __global__ __launch_bounds__(256, 2) void global_attention_kernel(
     const int D = heads * HD;
     const uint16_t* base = qkv + (size_t)im * NTOK * (3 * D) + head * HD;
 
-    const int q = qb * 128 + wave * 32 + ql;
+    const int q = qb * QPB + wave * 32 + ql;
     const int qh = q / G;                       // wave-uniform
-    const int qw0 = (qb * 128 + wave * 32) % G; // 0 or 32
+    const int qw0 = (qb * QPB + wave * 32) % G; // 0 or 32
     uint4 qf[KS];
     load_q_frags<KS>(base + (size_t)q * (3 * D), hh, qf);
 
@@ -604,50 +672,60 @@ __global__ __launch_bounds__(256, 2) void global_attention_kernel(
     __syncthreads();  // everyone is done with the scratch before K/V tiles overwrite it
 
     // ---- main loop over key tiles -----------------------------------------------------------
+    // K / V staging by LDS-DMA (global_load_lds_dwordx4: global -> LDS without a register hop).  Measured on the
+    // register-staged version (s_memtime stamps): 24 % of a tile went into ISSUING the 7 loads per thread (the CU's
+    // texture-address unit serialises the 56 wave-loads of its 8 waves at ~25 cycles each) and 37 % into waiting for
+    // them + permuting V into V^T + 19 LDS stores per thread, i.e. 61 % staging against 36 % QK^T / softmax / PV.
+    // Now: the K tile comes straight from qkv (per-lane source addresses, rows of 2 HD bytes), the V^T tile from the
+    // pre-transposed copy vt[img][head][d][token] written by vt_pack_kernel; 22 one-KiB pieces per tile and block
+    // instead of 28 loads + 76 LDS stores, no staging registers, nothing to wait for until the end of the tile.
     constexpr int CH = HD / 8;
-    constexpr int NCH = C::KT * CH;                 // 16-byte chunks per K tile
-    constexpr int PER = (NCH + 255) / 256;
-    constexpr int NVP = (C::KT / 2) * CH;           // (key pair, d chunk) items per V tile
-    constexpr int PERV = (NVP + 255) / 256;
-    uint4 rk[PER], rv0[PERV], rv1[PERV];
-    // straight-line, unconditional global loads (out-of-range item ids are clamped and simply
-    // not stored): conditionals / lambdas around these arrays push them into scratch.
-#define GLB_GLOAD(kt_)                                                                         \
-    _Pragma("unroll") for (int i_ = 0; i_ < PER; ++i_) {                                       \
-        int c_ = tid + 256 * i_;                                                                \
-        c_ = c_ < NCH ? c_ : NCH - 1;                                                           \
-        const int r_ = c_ / CH, ch_ = c_ % CH;                                                  \
-        rk[i_] = *reinterpret_cast<const uint4*>(base + (size_t)((kt_) * C::KT + r_) * (3 * D) + D + ch_ * 8); \
-    }                                                                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < PERV; ++i_) {                                      \
-        int c_ = tid + 256 * i_;                                                                \
-        c_ = c_ < NVP ? c_ : NVP - 1;                                                           \
-        const int kp_ = c_ % (C::KT / 2), ch_ = c_ / (C::KT / 2);                               \
-        const uint16_t* p_ = base + (size_t)((kt_) * C::KT + 2 * kp_) * (3 * D) + 2 * D + ch_ * 8; \
-        rv0[i_] = *reinterpret_cast<const uint4*>(p_);                                          \
-        rv1[i_] = *reinterpret_cast<const uint4*>(p_ + 3 * D);                                  \
+    constexpr int NCH = C::KT * CH;                 // 16-byte chunks of a K tile, row-major [key][HD]
+    constexpr int KPC = (NCH + 63) / 64;            // K pieces (640 chunks -> 10)
+    constexpr int VCH = HD * 9;                     // chunks of a V^T tile: HD rows x (8 data + 1 pad)
+    constexpr int VPC = (VCH + 63) / 64;            // V pieces (720 -> 12, the last one partial)
+    constexpr int NPC = KPC + VPC;                  // pieces per tile; wave w takes pieces w, w + NW, ...
+    constexpr int PPW = (NPC + NW - 1) / NW;
+    const uint16_t* vth = vt + (size_t)P * HD * NTOK;                       // this (image, head): [HD][NTOK]
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    // per-lane source byte offsets of this wave's pieces inside a tile (K: relative to the tile's first key row of
+    // qkv's K third; V: relative to vt row 0 at the tile's first token); ~0u = lane idle in that piece
+    uint32_t poff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wave + NW * i;
+        uint32_t o = ~0u;
+        if (pc < KPC) {
+            const int L = pc * 64 + lane;
+            if (L < NCH) o = (uint32_t)((L / CH) * (3 * D) + (L % CH) * 8) * 2u;
+        } else if (pc < NPC) {
+            const int L = (pc - KPC) * 64 + lane;
+            if (L < VCH) { const int d = L / 9, c = (L % 9) < 8 ? (L % 9) : 7; o = (uint32_t)(d * NTOK + c * 8) * 2u; }
+        }
+        poff[i] = o;
     }
-#define GLB_LSTORE(buf_)                                                                       \
-    _Pragma("unroll") for (int i_ = 0; i_ < PER; ++i_) {                                       \
-        const int c_ = tid + 256 * i_;                                                          \
-        if (c_ < NCH) *reinterpret_cast<uint4*>(Kb(buf_) + (c_ / CH) * HD + (c_ % CH) * 8) = rk[i_]; \
-    }                                                                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < PERV; ++i_) {                                      \
-        const int c_ = tid + 256 * i_;                                                          \
-        if (c_ < NVP) {                                                                         \
-            const int kp_ = c_ % (C::KT / 2), ch_ = c_ / (C::KT / 2);                           \
-            _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_)                                    \
-                *reinterpret_cast<uint32_t*>(Vb(buf_) + (ch_ * 8 + e_) * C::VSTR + 2 * kp_) =   \
-                    pair_elem(rv0[i_], rv1[i_], e_);                                            \
-        }                                                                                       \
+#define GLB_DMA(kt_, buf_) GLB_DMA_RANGE(kt_, buf_, 0, PPW)
+    // pieces [i0_, i1_) of this wave: the issue of a piece waits for a slot in the CU's texture-address queue (44 pieces
+    // per tile time from the two resident blocks), so the pieces of the next tile are spread over the tile instead of
+    // being queued in front of its first MFMA
+#define GLB_DMA_RANGE(kt_, buf_, i0_, i1_)                                                                   \
+    _Pragma("unroll") for (int i_ = (i0_); i_ < (i1_) && i_ < PPW; ++i_) {                                   \
+        const int pc_ = __builtin_amdgcn_readfirstlane(wave) + NW * i_;                                       \
+        if (pc_ < NPC && poff[i_] != ~0u) {                                                                  \
+            const bool isk_ = pc_ < KPC;                                                                     \
+            const uint16_t* sb_ = isk_ ? base + (size_t)(kt_) * C::KT * (3 * D) + D : vth + (size_t)(kt_) * C::KT; \
+            const uint32_t dst_ = lds_base + (uint32_t)(buf_) * (C::K_BYTES + C::VT_BYTES) +                 \
+                                  (isk_ ? (uint32_t)pc_ * 1024u : (uint32_t)C::K_BYTES + (uint32_t)(pc_ - KPC) * 1024u); \
+            glds16_sbase(poff[i_], sb_, __builtin_amdgcn_readfirstlane(dst_));                               \
+        }                                                                                                    \
     }
-    // rows d >= HD of V^T must be zero in both buffers (only when HD is not a multiple of 32)
+    // rows d >= HD of V^T must be zero in both buffers (only when HD is not a multiple of 32); the DMA never touches them
     if (C::DT * 32 > HD) {
         for (int b = 0; b < 2; ++b)
-            for (int i = tid; i < (C::DT * 32 - HD) * C::VSTR; i += 256) Vb(b)[HD * C::VSTR + i] = 0;
+            for (int i = tid; i < (C::DT * 32 - HD) * C::VSTR; i += NTH) Vb(b)[HD * C::VSTR + i] = 0;
     }
-    GLB_GLOAD(0)
-    GLB_LSTORE(0)
+    GLB_DMA(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const float c2 = rsqrtf((float)HD) * LOG2E_F;
@@ -659,10 +737,19 @@ __global__ __launch_bounds__(256, 2) void global_attention_kernel(
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nkt = NTOK / C::KT;
+#ifdef GLB_TIMING
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#define GLB_STAMP(i_) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tph[i_] += tn_ - tprev; tprev = tn_; }
+#else
+#define GLB_STAMP(i_)
+#endif
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        GLB_GLOAD(kt + 1 < nkt ? kt + 1 : kt)
+        const bool more = kt + 1 < nkt;
+        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, 0, (PPW + 2) / 3)  // the other buffer was last read before the barrier that ended tile kt-1
         const float bh2 = rh[kt];  // RH[q][kh = kt], constant over the tile
+        GLB_STAMP(0)
 
         f32x16_t S[2];
         float mx = -INFINITY;
@@ -676,7 +763,17 @@ __global__ __launch_bounds__(256, 2) void global_attention_kernel(
                 mx = fmaxf(mx, v);
             }
         }
+#ifdef GLB_TIMING
+        asm volatile("" :: "v"(mx), "v"(S[0][15]), "v"(S[1][15]));
+#endif
+        GLB_STAMP(1)
+        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, (PPW + 2) / 3, 2 * ((PPW + 2) / 3))
         online_softmax_step<C::DT>(S, 2, mx, bh2, m_run, l_run, O);
+#ifdef GLB_TIMING
+        asm volatile("" :: "v"(S[0][0]), "v"(S[1][15]), "v"(l_run));
+#endif
+        GLB_STAMP(2)
+        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, 2 * ((PPW + 2) / 3), PPW)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -688,11 +785,27 @@ __global__ __launch_bounds__(256, 2) void global_attention_kernel(
                     O[dt] = ET<PREC>::mfma32(va, pb, O[dt]);
                 }
             }
-        GLB_LSTORE(buf ^ 1)
-        __syncthreads();
+#ifdef GLB_TIMING
+        asm volatile("" :: "v"(O[0][0]), "v"(O[C::DT - 1][15]));
+#endif
+        GLB_STAMP(3)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 have landed
+        GLB_STAMP(4)
+        __syncthreads();                                        // ... everybody's; and buffer `buf` is free again
+        GLB_STAMP(5)
     }
 
-    const float inv = 1.0f / l_run;
+#ifdef GLB_TIMING
+    if (lane == 0 && wave == 0) {
+        unsigned long long* tp = reinterpret_cast<unsigned long long*>(out) + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 6; ++i) tp[i] = tph[i];
+        tp[6] = __builtin_amdgcn_s_memtime() - tstart;
+        tp[7] = tstart - t_entry;      // setup: Q fragments, rel-pos tables, first tile
+    }
+    asm volatile("" :: "v"(O[0][0]), "v"(O[C::DT - 1][15]), "v"(l_run));
+    return;
+#endif
+    const float inv = 1.0f / (l_run + xhalf_partner(l_run));
     uint16_t* orow = out + ((size_t)im * NTOK + q) * D + head * HD;
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt)
@@ -820,26 +933,40 @@ hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_b
     return hipErrorInvalidValue;
 }
 
-template <int PREC, int HD>
-static hipError_t launch_glb(const void* qkv, const float* rh, const float* rw, void* out, int n_images,
-                             int heads, hipStream_t s) {
-    using C = GlbCfg<HD>;
-    auto k = global_attention_kernel<PREC, HD>;
+// waves per block of the global attention kernel: 8 (256 queries, one block per CU) by default, 4 = the two-blocks-per-CU shape
+static int g_glb_waves = [] { const char* v = getenv("SAMRS_GLB_WAVES"); return (v && atoi(v) == 4) ? 4 : 8; }();
+
+template <int PREC, int HD, int NW>
+static hipError_t launch_glb_nw(const void* qkv, const float* rh, const float* rw, void* out, int n_images,
+                                int heads, void* vt_ws, hipStream_t s) {
+    using C = GlbCfg<HD, NW>;
+    constexpr int NTOK = C::G * C::G;
+    auto k = global_attention_kernel<PREC, HD, NW>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
-    dim3 g((C::G * C::G / 128) * heads * n_images), b(256);
-    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, rh, rw, (uint16_t*)out, heads);
+    dim3 g((NTOK / (32 * NW)) * heads * n_images), b(64 * NW);
+    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, (const uint16_t*)vt_ws, rh, rw, (uint16_t*)out, heads);
     return hipGetLastError();
 }
 
+template <int PREC, int HD>
+static hipError_t launch_glb(const void* qkv, const float* rh, const float* rw, void* out, int n_images,
+                             int heads, void* vt_ws, hipStream_t s) {
+    constexpr int NTOK = GlbCfg<HD>::G * GlbCfg<HD>::G;
+    vt_pack_kernel<HD><<<n_images * heads * (NTOK / 64), 256, 0, s>>>((const uint16_t*)qkv, (uint16_t*)vt_ws, heads, NTOK);
+    HIP_CHECK_RET(hipGetLastError());
+    if (g_glb_waves == 4) return launch_glb_nw<PREC, HD, 4>(qkv, rh, rw, out, n_images, heads, vt_ws, s);
+    return launch_glb_nw<PREC, HD, 8>(qkv, rh, rw, out, n_images, heads, vt_ws, s);
+}
+
 hipError_t launch_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
-                                   int n_images, int grid, int heads, int head_dim, hipStream_t s) {
-    if (grid != 64) return hipErrorInvalidValue;
+                                   int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s) {
+    if (grid != 64 || !vt_ws) return hipErrorInvalidValue;
     if (prec == PREC_BF16) {
-        if (head_dim == 64) return launch_glb<PREC_BF16, 64>(qkv, rel_h, rel_w, out, n_images, heads, s);
-        if (head_dim == 80) return launch_glb<PREC_BF16, 80>(qkv, rel_h, rel_w, out, n_images, heads, s);
+        if (head_dim == 64) return launch_glb<PREC_BF16, 64>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s);
+        if (head_dim == 80) return launch_glb<PREC_BF16, 80>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s);
     } else if (prec == PREC_F16) {
-        if (head_dim == 64) return launch_glb<PREC_F16, 64>(qkv, rel_h, rel_w, out, n_images, heads, s);
-        if (head_dim == 80) return launch_glb<PREC_F16, 80>(qkv, rel_h, rel_w, out, n_images, heads, s);
+        if (head_dim == 64) return launch_glb<PREC_F16, 64>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s);
+        if (head_dim == 80) return launch_glb<PREC_F16, 80>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s);
     }
     return hipErrorInvalidValue;
 }

@@ -73,6 +73,7 @@ struct samrs_engine {
     uint16_t* Y = nullptr;         // LN out (ET) [Bi*tokens, D]
     uint16_t* QKV = nullptr;       // [Bi*tokens, 3D], token order
     uint16_t* AO = nullptr;        // attention out [Bi*tokens, D]
+    uint16_t* VTG = nullptr;       // V of a global-attention block transposed per head: [Bi][heads][hd][tokens]
     uint16_t* H = nullptr;         // MLP hidden [Bi*tokens, 4D]  (also patch im2col / neck im2col)
     float* N1 = nullptr;           // neck fp32 [Bi*tokens, C]
     uint16_t* N1e = nullptr;       // [Bi*tokens, C]
@@ -455,6 +456,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, hipMemsetAsync(e->Y, 0, Mmax * D * 2, s));
     CK(e, dalloc(e, &e->QKV, Mmax * 3 * D));
     CK(e, dalloc(e, &e->AO, M * D));
+    CK(e, dalloc(e, &e->VTG, M * D));
     size_t hsz = M * 4 * D;
     if (M * 9 * C > hsz) hsz = M * 9 * C;
     if (M * 768 > hsz) hsz = M * 768;
@@ -524,7 +526,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         if (!b.global)
             CK(e, launch_window_attention(prec, e->QKV, b.qkv_b, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s));
         else
-            CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, s));
+            CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, e->VTG, s));
         CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
         CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
         hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -744,8 +746,10 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
         if (g_decoder_fusion && tokens % 16 == 0) {
             // attention + out_proj + residual + norm4 in one pass over the keys (layer 0 without a mask prompt: the residual
             // is the shared image embedding, batch stride 0)
+            // the fp32 copy of the keys is the NEXT layer's residual; after the last layer only the ET copy is read
+            // (final t2i projections, upscaler), so its 4 bytes per element are not written
             CK(e, launch_i2t_fused(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, L.i2t_ow, L.i2t.ob, sh ? e->K0F : e->KF,
-                                   sh ? 0 : tokens, L.n4w, L.n4b, 1e-5f, e->KF, e->KE, n, T, tokens, Ci, C, s));
+                                   sh ? 0 : tokens, L.n4w, L.n4b, 1e-5f, li == 1 ? nullptr : e->KF, e->KE, n, T, tokens, Ci, C, s));
         } else {
             CK(e, launch_i2t_attention(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, e->OI, n, T, tokens, Ci, 8, s));
             if (sh)
@@ -897,7 +901,17 @@ int samrs_k_window_attention(int prec, const void* qkv, const float* qkv_bias, c
 }
 int samrs_k_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out, int n_images,
                              int grid, int heads, int head_dim, void* stream) {
-    KRET(launch_global_attention(prec, qkv, rel_h, rel_w, out, n_images, grid, heads, head_dim, (hipStream_t)stream));
+    // test / bench hook: the V^T workspace the engine owns is a grow-only static here
+    static void* ws = nullptr;
+    static size_t ws_bytes = 0;
+    const size_t need = (size_t)n_images * heads * head_dim * grid * grid * 2;
+    if (need > ws_bytes) {
+        if (ws) (void)hipFree(ws);
+        ws = nullptr; ws_bytes = 0;
+        if (hipMalloc(&ws, need) != hipSuccess) return SAMRS_ERR_HIP;
+        ws_bytes = need;
+    }
+    KRET(launch_global_attention(prec, qkv, rel_h, rel_w, out, n_images, grid, heads, head_dim, ws, (hipStream_t)stream));
 }
 int samrs_resample_pass_u8(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* coef, int ksize,
                            int in_len, int out_len, int other, int horizontal, void* stream) {
@@ -908,6 +922,10 @@ int samrs_rbox_mask_prompt(const int32_t* pts, int n, int n_vertices, int h, int
                            float* out, void* stream) {
     if (!pts || !out) return SAMRS_ERR_BAD_ARG;
     KRET(launch_rbox_prompt(pts, n, n_vertices, h, w, th, tw, img_size, out_size, out, (hipStream_t)stream));
+}
+int samrs_k_neck_im2col(const void* in, void* A, int n_images, int grid, int C, void* stream) {
+    if (!in || !A || n_images < 1 || grid < 1 || C < 8 || C % 8) return SAMRS_ERR_BAD_ARG;
+    KRET(launch_neck_im2col(in, A, n_images, grid, C, (hipStream_t)stream));
 }
 int samrs_k_postprocess(const float* low, int n_masks, int in_h, int in_w, int orig_h, int orig_w, int img_size,
                         int return_logits, void* out, void* stream) {

@@ -989,6 +989,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     // group 1 still runs half a stage behind group 0 (its rendezvous sits between L(t, 1) and C(t, 1)), so its
     // fragment reads fall into the other wave's MFMA segments by themselves.
     constexpr bool LIGHT = (MODE & 2) != 0;
+    constexpr bool NOPRIO = (MODE & 4) != 0;               // experiment: no s_setprio around the MFMA segments
     // ABL (timing experiments only, results are garbage): 1 no DMA, 2 no fragment reads, 4 no MFMA, 16 no epilogue
     __shared__ __attribute__((aligned(16))) uint16_t lds[2 * XSTAGE_ELEMS];   // 128 / 144 KiB, ONE object
 
@@ -1122,9 +1123,9 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
         __builtin_amdgcn_sched_barrier(0);
         X64_MIDBAR()
         // ---- C(t, 0) ----
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(1);
         X64_MFMA(SPREAD && dma0, t + 1, wr)
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         X64_MIDBAR()
         // ---- L(t, 1); group 1: its pieces of stage t+1 (issued one stage ago) must have landed ----
@@ -1134,9 +1135,9 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LIGHT) { if (grp == 1) __builtin_amdgcn_s_barrier(); } else __builtin_amdgcn_s_barrier();
         // ---- C(t, 1); group 1: buffer `rd` is free from here on (both groups have read k-half 1) ----
-        __builtin_amdgcn_s_setprio(1);
+        if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(1);
         X64_MFMA(dma1, t + 2, rd)
-        __builtin_amdgcn_s_setprio(0);
+        if constexpr (!NOPRIO) __builtin_amdgcn_s_setprio(0);
         if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!LIGHT) __builtin_amdgcn_s_barrier();
@@ -1870,7 +1871,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     // 20 / 21: pair-stage (64-deep, whole-cache-line DMA) 256x256 / 256x320 kernel; 22 / 23: the same with the DMA pieces
     // spread between the MFMAs.  Shapes they do not cover fall through to the automatic choice.
     if (variant == 28 && !(M % QBM == 0 && N % WBN == 0 && K % XBK == 0 && !add2d)) variant = 8;
-    if (variant >= 20 && variant <= 27) {     // 20 + mode * 2 + (NI == 5): mode bit 0 = spread DMA, bit 1 = one barrier per stage
+    if (variant >= 20 && variant <= 27 || variant == 35) {     // 20 + mode * 2 + (NI == 5): mode bit 0 = spread DMA, bit 1 = one barrier per stage
         const int ni = (variant & 1) ? 5 : 4, mode = (variant - 20) >> 1;
         if (M % QBM == 0 && N % (64 * ni) == 0 && K % XBK == 0) {
 #define X64_CASE(P, NI_, MD_) return launch_gemm_x64<P, NI_, MD_>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s)
@@ -1879,7 +1880,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
                 case 20: X64_CASE(P, 4, 0); case 21: X64_CASE(P, 5, 0);          \
                 case 22: X64_CASE(P, 4, 1); case 23: X64_CASE(P, 5, 1);          \
                 case 24: X64_CASE(P, 4, 2); case 25: X64_CASE(P, 5, 2);          \
-                case 26: X64_CASE(P, 4, 3); default: X64_CASE(P, 5, 3);          \
+                case 26: X64_CASE(P, 4, 3); case 35: X64_CASE(P, 5, 7); default: X64_CASE(P, 5, 3); \
             }
             (void)mode;
             if (prec == PREC_F16) { X64_MODES(PREC_F16) }

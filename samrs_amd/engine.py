@@ -42,11 +42,12 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SAMRS_LIB_PATH", LIB_PATH)          # A/B builds of the same ABI (tools/, never the tests)
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: build it with `make -C samrs_amd/csrc` (or __graft_entry__.build()). "
+            f"{path} not found: build it with `make -C samrs_amd/csrc` (or __graft_entry__.build()). "
             "samrs_amd has no CPU / PyTorch fallback by design.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, ip, fp = C.c_void_p, C.c_int, C.c_float
     lib.samrs_abi_version.restype = ip
     lib.samrs_create.restype = vp
@@ -81,6 +82,8 @@ def load_library() -> C.CDLL:
     lib.samrs_k_window_attention.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_global_attention.argtypes = [ip, vp, vp, vp, vp, ip, ip, ip, ip, vp]
     lib.samrs_k_postprocess.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, vp, vp]
+    lib.samrs_k_neck_im2col.argtypes = [vp, vp, ip, ip, ip, vp]
+    lib.samrs_k_neck_im2col.restype = ip
     lib.samrs_k_gemm_gln.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, vp]
     lib.samrs_k_upscale2_masks.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_set_images_ragged", "samrs_get_embedding",

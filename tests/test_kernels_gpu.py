@@ -216,6 +216,59 @@ def test_upscale2_masks_fused(lib, name, prec, dt, ulp, n_sel, sel0):
     assert r < 2e-5
 
 
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_neck_kernel_level(lib, name, prec, dt, ulp):
+    """The neck alone (image_encoder.py:88-104, LayerNorm2d common.py:31-43): 1x1 conv as a GEMM -> LayerNorm over C (eps 1e-6)
+    -> im2col + GEMM for the bias-free 3x3 / pad 1 conv -> LayerNorm, against torch conv2d in fp64 on the same
+    ET-rounded operands.  The im2col itself is pure data movement: bit-exact against F.unfold."""
+    g = torch.Generator().manual_seed(91)
+    n, grid, D, C = 2, 16, 256, 256
+    X, Xb = et_bits(torch.randn(n * grid * grid, D, generator=g), dt)
+    W0, W0b = et_bits(torch.randn(C, D, generator=g) / math.sqrt(D), dt)
+    W2 = torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    W2r = W2.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()              # [co][(ky*3+kx)*C + ci], the engine's repack
+    W2e, W2b = et_bits(W2r, dt)
+    g1, b1 = 1 + 0.1 * torch.randn(C, generator=g), 0.05 * torch.randn(C, generator=g)
+    g2, b2 = 1 + 0.1 * torch.randn(C, generator=g), 0.05 * torch.randn(C, generator=g)
+    M = n * grid * grid
+    s = stream()
+    n1 = torch.empty(M, C, device="cuda")
+    assert lib.samrs_k_gemm(prec, dev(Xb).data_ptr(), dev(W0b).data_ptr(), n1.data_ptr(), None, None, 0, M, C, D, 1, 0, 0, s) == 0
+    n1e = torch.empty(M, C, dtype=torch.int16, device="cuda")
+    assert lib.samrs_k_layernorm(prec, n1.data_ptr(), dev(g1).data_ptr(), dev(b1).data_ptr(), 1e-6, n1e.data_ptr(), None, M, C, 0, n, grid, 0, s) == 0
+    col = torch.empty(M, 9 * C, dtype=torch.int16, device="cuda")
+    assert lib.samrs_k_neck_im2col(n1e.data_ptr(), col.data_ptr(), n, grid, C, s) == 0
+    # im2col: exact
+    img = n1e.cpu().view(n, grid, grid, C)
+    ref_col = torch.zeros(n, grid, grid, 9, C, dtype=torch.int16)
+    for ky in range(3):
+        for kx in range(3):
+            ys, xs = slice(max(0, 1 - ky), grid - max(0, ky - 1)), slice(max(0, 1 - kx), grid - max(0, kx - 1))
+            yd, xd = slice(max(0, ky - 1), grid - max(0, 1 - ky)), slice(max(0, kx - 1), grid - max(0, 1 - kx))
+            ref_col[:, ys, xs, ky * 3 + kx] = img[:, yd, xd]
+    assert torch.equal(col.cpu().view(n, grid, grid, 9, C), ref_col), "neck im2col is not the 3x3 / pad 1 gather"
+    n2 = torch.empty(M, C, device="cuda")
+    assert lib.samrs_k_gemm(prec, col.data_ptr(), dev(W2b).data_ptr(), n2.data_ptr(), None, None, 0, M, C, 9 * C, 1, 0, 0, s) == 0
+    out = torch.empty(M, C, device="cuda")
+    assert lib.samrs_k_layernorm(prec, n2.data_ptr(), dev(g2).data_ptr(), dev(b2).data_ptr(), 1e-6, None, out.data_ptr(), M, C, 0, n, grid, 0, s) == 0
+    # reference: same rounding points (ET operands into each conv), everything else fp64
+    x = X.double().view(n, grid, grid, D).permute(0, 3, 1, 2)
+    y = F.conv2d(x, W0.double().view(C, D, 1, 1))
+    def ln2d(t, w, b):
+        u = t.mean(1, keepdim=True)
+        v = ((t - u) ** 2).mean(1, keepdim=True)
+        return (t - u) / torch.sqrt(v + 1e-6) * w.double().view(1, -1, 1, 1) + b.double().view(1, -1, 1, 1)
+    y = ln2d(y, g1, b1)
+    y_et = n1e.cpu().view(dt).double().view(n, grid, grid, C).permute(0, 3, 1, 2)        # the engine's rounded LN output
+    r1, _ = rel_err(y_et.float(), y)
+    assert r1 < 1.5 * ulp, f"neck stage 1 (1x1 conv + LayerNorm2d): rel {r1:.2e}"
+    z = F.conv2d(y_et, W2e.double().view(C, 3, 3, C).permute(0, 3, 1, 2), padding=1)
+    z = ln2d(z, g2, b2).permute(0, 2, 3, 1).reshape(M, C)
+    r2, mx = rel_err(out.cpu(), z)
+    print(f"neck {name}: stage 1 rel {r1:.2e}, output rel {r2:.2e} max {mx:.2e}")
+    assert r2 < 5e-6
+
+
 def test_gemm_f32_exact_class(lib):
     g = torch.Generator().manual_seed(5)
     for (M, N, K, lda_pad, relu, acc) in [(7, 32, 256, 0, 0, 0), (224, 2048, 256, 0, 1, 0), (224, 256, 2048, 0, 0, 1),

@@ -13,6 +13,7 @@ import argparse
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import re
@@ -76,6 +77,10 @@ def main() -> None:
             "mfma_busy_frac": v.get("mfma_busy_frac"),
             "l2_hit_rate": v.get("l2_hit_rate"),
             "launches": v["launches"],
+            # bench.py reports `traffic` only while this hash matches the gemm.hip it runs (a stale measurement is dropped)
+            "gemm_hip_sha16": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                               "samrs_amd", "csrc", "gemm.hip"), "rb").read()).hexdigest()[:16],
+            "source": "profiles/dominant_kernel_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, tools/gpu_round.sh pmc)",
         }
         with open(dout, "w") as fh:
             json.dump(dom, fh, indent=1)

@@ -285,10 +285,10 @@ def main() -> None:
             return t1 - t0, time.perf_counter() - t1
 
         one_tile(0)
-        times = [one_tile(1 + i) for i in range(2)]
+        times = [one_tile(1 + i) for i in range(3)]
         enc_s, dec_s = float(np.mean([t[0] for t in times])), float(np.mean([t[1] for t in times]))
         cpu_baseline = {"value": round(1.0 / (enc_s + dec_s), 4), "unit": "images/s", "cores": torch.get_num_threads(),
-                        "kind": "port", "sample": f"1 warm-up + 2 timed tiles, {args.model}: set_image {enc_s:.1f}s + 32 boxes (20+12) "
+                        "kind": "port", "sample": f"1 warm-up + 3 timed tiles, {args.model}: set_image {enc_s:.1f}s + 32 boxes (20+12) "
                                                   f"{dec_s:.1f}s per tile, fp32 torch-CPU oracle"}
 
     if rank == 0:

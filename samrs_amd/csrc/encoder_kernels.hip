@@ -408,10 +408,19 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
 
     __syncthreads();                      // bias table is read by WIN_ISSUE
     int it = blockIdx.x;
+#ifdef WIN_TIMING
+    unsigned long long wph[6] = {0, 0, 0, 0, 0, 0}, wprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long wstart = wprev;
+    int n_done = 0;
+#define WIN_STAMP(i_) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); wph[i_] += tn_ - wprev; wprev = tn_; }
+#else
+#define WIN_STAMP(i_)
+#endif
     if (it < n_items) WIN_ISSUE(it);
     for (; it < n_items; it += gridDim.x) {
         // ---- stage this item's K (row-major) and V^T; the previous item's readers are done -------------
         __syncthreads();
+        WIN_STAMP(0)
 #pragma unroll
         for (int i = 0; i < PK; ++i) {
             const int c = tid + i * C::THREADS;
@@ -435,9 +444,15 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         const long qoff = n_qoff;
         const bool qin = qoff >= 0;           // a real token (padding / tile-padding queries are dropped)
         const int im = n_im, head = n_head;
+        WIN_STAMP(1)
         __syncthreads();
+        WIN_STAMP(2)
         // ---- next item's loads: in flight during the whole compute below --------------------------------
         if (it + (int)gridDim.x < n_items) WIN_ISSUE(it + (int)gridDim.x);
+        WIN_STAMP(3)
+#ifdef WIN_TIMING
+        ++n_done;
+#endif
         if (wave >= C::NT) continue;          // wave 7 only stages
 
         // ---- decomposed rel-pos: RH[j] = q . rel_h[qh - j + 13], RW[j] = q . rel_w[qw - j + 13] -----
@@ -467,6 +482,10 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
+#ifdef WIN_TIMING
+        asm volatile("" :: "v"(RH[0]), "v"(RW[13]));
+#endif
+        WIN_STAMP(4)
 
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
@@ -494,6 +513,11 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
             }
         }
 
+#ifdef WIN_TIMING
+        asm volatile("" :: "v"(O[0][0]), "v"(O[C::DT - 1][15]), "v"(l_run), "v"(qin), "v"(im), "v"(head));
+        WIN_STAMP(5)
+        continue;
+#endif
         // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
         if (qin) {
             const float inv = 1.0f / (l_run + xhalf_partner(l_run));
@@ -512,6 +536,14 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
                 }
         }
     }
+#ifdef WIN_TIMING
+    if (lane == 0 && wave == 0) {
+        unsigned long long* tp = reinterpret_cast<unsigned long long*>(out) + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 6; ++i) tp[i] = wph[i];
+        tp[6] = __builtin_amdgcn_s_memtime() - wstart;
+        tp[7] = n_done;
+    }
+#endif
 #undef WIN_ISSUE
 #undef WIN_BIAS_CHUNK
 #undef WIN_TOK_OFF

@@ -85,7 +85,19 @@ __global__ void convert_kernel(const float* __restrict__ in, uint16_t* __restric
 // order [(img, wy, wx), (iy, ix)] and rows that fall in the bottom/right padding are ZERO (the
 // reference pads after norm1, image_encoder.py:168-172,256-259).
 // -----------------------------------------------------------------------------------------
+// Measured alternatives (tools/ln_bench.py, 32768 x 1280, input cold): this kernel 51.6 us = 4.9 TB/s; non-temporal
+// loads 45.5 us; two / four rows per wave 50 / 57 us.  In the tile loop the non-temporal variant LOSES 4 % of the whole
+// step (59.3 vs 57.0 ms, three alternations on one box): the row it reads was written by the GEMM just before and is
+// still partly in L2 / MALL, which a streaming load does not use.  Plain loads stay.
 constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
+
+// A/B build switches (tools/ab_env.sh with SAMRS_LIB_PATH): all on in the product build
+#ifndef SAMRS_WIN_ONES
+#define SAMRS_WIN_ONES 1
+#endif
+#ifndef SAMRS_GLB_ONES
+#define SAMRS_GLB_ONES 1
+#endif
 
 template <int PREC>
 __global__ __launch_bounds__(256) void layernorm_kernel(
@@ -244,6 +256,10 @@ __device__ __forceinline__ uint32_t pair_elem(const uint4& v0, const uint4& v1, 
     return __builtin_amdgcn_perm(word_of(v1, e >> 1), word_of(v0, e >> 1), (e & 1) ? 0x07060302u : 0x05040100u);
 }
 
+__device__ __forceinline__ uint4 sel4(bool c, const uint4& a, const uint4& b) {
+    return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -266,7 +282,8 @@ __device__ __forceinline__ float xhalf_partner(float v) {
 
 // l_run is a PER-LANE partial row sum (this lane's key half): both lanes of a query scale it by the same alpha, so
 // the two halves are only added once, after the last tile (xhalf_partner), instead of once per tile.
-template <int DT>
+// SUM = false: the caller gets the row sum out of the PV product instead (a V^T row of ones, see ones_row_sum).
+template <int DT, bool SUM = true>
 __device__ __forceinline__ void online_softmax_step(f32x16_t* S, int ntiles, float mx, float bh2, float& m_run, float& l_run,
                                                     f32x16_t (&O)[DT]) {
     mx = fmaxf(mx, xhalf_partner(mx));
@@ -287,9 +304,21 @@ __device__ __forceinline__ void online_softmax_step(f32x16_t* S, int ntiles, flo
         for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(S[a][r] - off);
             S[a][r] = p;
-            sum += p;
+            if (SUM) sum += p;
         }
     l_run += sum;
+}
+
+// When HD is not a multiple of 32 the last d tile of the PV product has spare rows.  With V^T row HD set to ONE, row HD
+// of O^T accumulates sum_k P[q][k] of the ROUNDED probabilities -- the weights PV really applies -- through the same
+// alpha rescaling as O, and the 16 (32) adds per key tile of an explicit row sum disappear.  Row HD sits in register
+// `orr` of the lanes of half `oh`; the other half fetches it from its partner lane.
+template <int HD, int DT>
+__device__ __forceinline__ float ones_row_sum(const f32x16_t (&O)[DT], int hh) {
+    constexpr int dl = HD % 32, oh = (dl >> 2) & 1, orr = (dl & 3) + 4 * (dl >> 3);
+    static_assert(dl != 0 && acc_row(orr, oh) == dl, "a spare row is needed");
+    const float mine = O[DT - 1][orr], other = xhalf_partner(mine);
+    return hh == oh ? mine : other;
 }
 
 // =========================================================================================
@@ -307,11 +336,27 @@ __device__ __forceinline__ void online_softmax_step(f32x16_t* S, int ntiles, flo
 // after item i's K / V^T have been written to LDS and stay in flight (in registers) during the whole
 // compute of item i.  vmcnt retires loads in order, so nothing else may load from global memory in
 // between: the rel-pos tables are converted into LDS once per block.
+//
+// Round 2 (s_memtime phase timing, tools/win_timeline.py, profiles/r02_window_attention_phase_timing.txt):
+//   * the issue of the next item's 13 loads per lane was 19 % of an item: a branch + an LDS read of the bias + a wait
+//     per load (padding positions).  Now every load is issued, from clamped coordinates, and padding slots are
+//     replaced when the registers go to LDS (12 %); the loads are further spread over the first five key tiles of the
+//     computing waves instead of one burst from all 8 waves into the TA queue (3 %);
+//   * a key tile is two window rows (28 keys + 4 zero keys) so the rel-pos bias of accumulator register r does not
+//     depend on the tile: S*c2 + BW[r] is one fma, the row term RH[2t + row] merges with the softmax offset into the
+//     one add in front of exp2;
+//   * HD = 80: the spare V^T row 80 holds ones, the PV product delivers the row sum (ones_row_sum).
+// 166 -> 145 us per launch (8 tiles, ViT-H) on its own; in the tile loop the step time did not move (the loop runs at
+// the socket power limit).
 // =========================================================================================
 template <int HD>
 struct WinCfg {
-    static constexpr int WS = 14, N = WS * WS, NT = 7, NP = NT * 32;  // 196 tokens -> 7 tiles of 32
+    // A key tile = TWO window rows (28 keys) + 4 zero keys: 7 tiles as with a dense packing, but the rel-pos bias of
+    // accumulator register r is then the same function of (r, lane half) in every tile (see the tile loop).
+    static constexpr int WS = 14, N = WS * WS, TK = 2 * WS, NT = N / TK, NP = NT * 32;
     static constexpr int DT = (HD + 31) / 32;                          // d tiles for PV
+    static constexpr bool ONES = SAMRS_WIN_ONES && DT * 32 > HD;       // a spare V^T row carries the row sum
+    __device__ static constexpr int lds_key(int key) { return key + (32 - TK) * (key / TK); }   // key -> K row / V^T column
     static constexpr int VSTR = 228;                                   // V^T row stride (elements)
     static constexpr int NW = 8, THREADS = NW * 64;
     static constexpr int SSTR = 33;                                    // scratch row stride (floats)
@@ -352,8 +397,13 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         Tab[i] = ET<PREC>::from_float(v);
     }
     for (int i = tid; i < 2 * D; i += C::THREADS) Bia[i] = ET<PREC>::from_float(qkv_bias[D + i]);
-    for (int i = tid; i < (C::NP - C::N) * HD; i += C::THREADS) Ks[C::N * HD + i] = 0;
+    for (int i = tid; i < C::NT * (32 - C::TK) * HD; i += C::THREADS)      // rows 28..31 of every key tile
+        Ks[((i / HD) / (32 - C::TK) * 32 + C::TK + (i / HD) % (32 - C::TK)) * HD + i % HD] = 0;
     for (int i = tid; i < C::DT * 32 * C::VSTR / 2; i += C::THREADS) reinterpret_cast<uint32_t*>(Vt)[i] = 0u;
+    if (C::ONES) {                        // V^T row HD = 1: the PV product's spare row accumulates the softmax row sum
+        __syncthreads();
+        for (int i = tid; i < C::NP; i += C::THREADS) Vt[HD * C::VSTR + i] = ET<PREC>::from_float(1.0f);
+    }
 
     constexpr int CH = HD / 8;  // 16-byte chunks per row
     constexpr int NKC = C::N * CH, NVI = (C::N / 2) * CH;        // real rows / key pairs only
@@ -365,45 +415,82 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
     // All global loads of an item (this wave's Q fragments, this thread's K chunks and V key pairs) are
     // issued back to back; n_* describe the item they belong to.
     uint4 qfn[KS], kreg[PK], v0reg[PV], v1reg[PV];
-    long n_qoff = -1;
+    int n_qoff = -1;                      // element offset of this lane's query row inside its image, -1 = dropped
+    uint32_t n_pad = 0;                   // bit i: K slot i; bit PK + 2i (+1): V slot i key 0 (1) is a padding token
     int n_im = 0, n_head = 0;
-#define WIN_TOK_OFF(r_) ((wy_ * C::WS + (r_) / C::WS < grid && wx_ * C::WS + (r_) % C::WS < grid)                     \
-                             ? (long)((wy_ * C::WS + (r_) / C::WS) * grid + wx_ * C::WS + (r_) % C::WS) * (3 * D) : -1L)
-#define WIN_BIAS_CHUNK(dst_, part_, ch_)                                                                             \
-    (dst_) = *reinterpret_cast<const uint4*>(Bia + ((part_) - 1) * D + n_head * HD + (ch_) * 8)
-#define WIN_ISSUE(it_)                                                                                               \
+    // A padding position still issues its load, from the nearest real token (clamped coordinates), and is replaced by
+    // the bias chunk when the registers are written to LDS: the issue sequence is straight-line, 13 loads back to back
+    // (the earlier form branched per load and waited on an LDS read of the bias before each one: 19 % of the item,
+    // profiles/r02_window_attention_phase_timing.txt).
+#define WIN_TOK(r_, off_, pad_)                                                                                      \
+    const int ty_##off_ = y0_ + (r_) / C::WS, tx_##off_ = x0_ + (r_) % C::WS;                                        \
+    const bool pad_ = ty_##off_ >= grid || tx_##off_ >= grid;                                                        \
+    const int off_ = (min(ty_##off_, grid - 1) * grid + min(tx_##off_, grid - 1)) * (3 * D)
+    // The issue is split into a head (item decode) and 5 groups of loads: a computing wave spreads the groups over its
+    // first key tiles (a burst of 13 loads per lane from all 8 waves at once fills the TA queue and every wave then
+    // blocks in issue: 12 % of the item); wave 7, which only stages, issues everything at once.
+    const uint16_t* n_base = qkv;
+    int n_y0 = 0, n_x0 = 0;
+#define WIN_HEAD(it_)                                                                                                \
     do {                                                                                                             \
         const int wi_ = (it_) / heads;                                                                               \
         n_head = (it_) % heads;                                                                                      \
         const int win_ = wi_ % (nw * nw);                                                                            \
         n_im = wi_ / (nw * nw);                                                                                      \
-        const int wy_ = win_ / nw, wx_ = win_ % nw;                                                                  \
-        const uint16_t* base_ = qkv + (size_t)n_im * img_rows * (3 * D) + n_head * HD;                               \
-        n_qoff = q < C::N ? WIN_TOK_OFF(q) : -1L;                                                                    \
-        load_q_frags<KS>(n_qoff >= 0 ? base_ + n_qoff : nullptr, hh, qfn);                                           \
-        _Pragma("unroll") for (int i_ = 0; i_ < PK; ++i_) {                                                          \
-            const int c_ = tid + i_ * C::THREADS;                                                                    \
-            const int r_ = c_ / CH, ch_ = c_ % CH;                                                                   \
-            kreg[i_] = make_uint4(0u, 0u, 0u, 0u);                                                                   \
-            if (c_ < NKC) {                                                                                          \
-                const long off_ = WIN_TOK_OFF(r_);                                                                   \
-                if (off_ >= 0) kreg[i_] = *reinterpret_cast<const uint4*>(base_ + off_ + D + ch_ * 8);               \
-                else WIN_BIAS_CHUNK(kreg[i_], 1, ch_);                                                               \
-            }                                                                                                        \
+        n_y0 = (win_ / nw) * C::WS;                                                                                  \
+        n_x0 = (win_ % nw) * C::WS;                                                                                  \
+        n_base = qkv + (size_t)n_im * img_rows * (3 * D) + n_head * HD;                                              \
+        n_pad = 0u;                                                                                                  \
+    } while (0)
+#define WIN_LOAD_Q()                                                                                                 \
+    do {                                                                                                             \
+        const int y0_ = n_y0, x0_ = n_x0;                                                                            \
+        WIN_TOK(qc, qo_, qp_);                                                                                       \
+        n_qoff = (q < C::N && !qp_) ? qo_ : -1;                                                                      \
+        _Pragma("unroll") for (int ks_ = 0; ks_ < KS; ++ks_)                                                         \
+            qfn[ks_] = *reinterpret_cast<const uint4*>(n_base + qo_ + 16 * ks_ + 8 * hh);                            \
+    } while (0)
+#define WIN_LOAD_K(i_)                                                                                               \
+    do {                                                                                                             \
+        const int y0_ = n_y0, x0_ = n_x0;                                                                            \
+        const int c_ = tid + (i_) * C::THREADS;                                                                      \
+        const int r_ = c_ / CH, ch_ = c_ % CH;                                                                       \
+        if (c_ < NKC) {                                                                                              \
+            WIN_TOK(r_, ko_, kp_);                                                                                   \
+            n_pad |= (uint32_t)kp_ << (i_);                                                                          \
+            kreg[i_] = *reinterpret_cast<const uint4*>(n_base + ko_ + D + ch_ * 8);                                  \
         }                                                                                                            \
-        _Pragma("unroll") for (int i_ = 0; i_ < PV; ++i_) {                                                          \
-            const int c_ = tid + i_ * C::THREADS;                                                                    \
-            const int kp_ = c_ % (C::N / 2), ch_ = c_ / (C::N / 2);                                                  \
-            const int r0_ = 2 * kp_;                                                                                 \
-            v0reg[i_] = v1reg[i_] = make_uint4(0u, 0u, 0u, 0u);                                                      \
-            if (c_ < NVI) {                                                                                          \
-                const long off0_ = WIN_TOK_OFF(r0_), off1_ = WIN_TOK_OFF(r0_ + 1);                                   \
-                if (off0_ >= 0) v0reg[i_] = *reinterpret_cast<const uint4*>(base_ + off0_ + 2 * D + ch_ * 8);        \
-                else WIN_BIAS_CHUNK(v0reg[i_], 2, ch_);                                                              \
-                if (off1_ >= 0) v1reg[i_] = *reinterpret_cast<const uint4*>(base_ + off1_ + 2 * D + ch_ * 8);        \
-                else WIN_BIAS_CHUNK(v1reg[i_], 2, ch_);                                                              \
-            }                                                                                                        \
+    } while (0)
+#define WIN_LOAD_V(i_)                                                                                               \
+    do {                                                                                                             \
+        const int y0_ = n_y0, x0_ = n_x0;                                                                            \
+        int tid_ = tid;                                                                                              \
+        asm volatile("" : "+v"(tid_));   /* recompute the slot's token per item: hoisted, these spill (HD = 80) */   \
+        const int c_ = tid_ + (i_) * C::THREADS;                                                                     \
+        const int kp_ = c_ % (C::N / 2), ch_ = c_ / (C::N / 2);                                                      \
+        if (c_ < NVI) {                                                                                              \
+            WIN_TOK(2 * kp_, vo0_, vp0_);                                                                            \
+            WIN_TOK(2 * kp_ + 1, vo1_, vp1_);                                                                        \
+            n_pad |= ((uint32_t)vp0_ | ((uint32_t)vp1_ << 1)) << (PK + 2 * (i_));                                   \
+            v0reg[i_] = *reinterpret_cast<const uint4*>(n_base + vo0_ + 2 * D + ch_ * 8);                            \
+            v1reg[i_] = *reinterpret_cast<const uint4*>(n_base + vo1_ + 2 * D + ch_ * 8);                            \
         }                                                                                                            \
+    } while (0)
+    // group g of the issue: 0 = Q, 1 .. = K slots two at a time, then V slots one at a time
+    constexpr int NGK = (PK + 1) / 2, NGRP = 1 + NGK + PV;
+    static_assert(NGRP <= C::NT, "issue groups are spread over the key tiles");
+#define WIN_GROUP(g_)                                                                                                \
+    do {                                                                                                             \
+        if ((g_) == 0) WIN_LOAD_Q();                                                                                 \
+        else if ((g_) <= NGK) {                                                                                      \
+            WIN_LOAD_K(2 * ((g_) - 1));                                                                              \
+            if (2 * ((g_) - 1) + 1 < PK) WIN_LOAD_K(2 * ((g_) - 1) + 1 < PK ? 2 * ((g_) - 1) + 1 : 0);               \
+        } else WIN_LOAD_V((g_) - 1 - NGK < PV ? (g_) - 1 - NGK : 0);                                                 \
+    } while (0)
+#define WIN_ISSUE(it_)                                                                                               \
+    do {                                                                                                             \
+        WIN_HEAD(it_);                                                                                               \
+        _Pragma("unroll") for (int g_ = 0; g_ < NGRP; ++g_) WIN_GROUP(g_);                                           \
     } while (0)
 
     __syncthreads();                      // bias table is read by WIN_ISSUE
@@ -421,10 +508,23 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         // ---- stage this item's K (row-major) and V^T; the previous item's readers are done -------------
         __syncthreads();
         WIN_STAMP(0)
+        if (__any(n_pad != 0u)) {             // only the bottom / right windows: k / v of a padding token = the bias
+#pragma unroll
+            for (int i = 0; i < PK; ++i) {
+                const uint4 kb = *reinterpret_cast<const uint4*>(Bia + n_head * HD + ((tid + i * C::THREADS) % CH) * 8);
+                kreg[i] = sel4((n_pad >> i) & 1u, kb, kreg[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < PV; ++i) {
+                const uint4 vb = *reinterpret_cast<const uint4*>(Bia + D + n_head * HD + ((tid + i * C::THREADS) / (C::N / 2)) % CH * 8);
+                v0reg[i] = sel4((n_pad >> (PK + 2 * i)) & 1u, vb, v0reg[i]);
+                v1reg[i] = sel4((n_pad >> (PK + 2 * i + 1)) & 1u, vb, v1reg[i]);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PK; ++i) {
             const int c = tid + i * C::THREADS;
-            if (c < NKC) *reinterpret_cast<uint4*>(Ks + (c / CH) * HD + (c % CH) * 8) = kreg[i];
+            if (c < NKC) *reinterpret_cast<uint4*>(Ks + C::lds_key(c / CH) * HD + (c % CH) * 8) = kreg[i];
         }
         // V^T[d][key]: a thread takes one 8-wide d chunk of TWO adjacent keys and writes eight 4-byte
         // words; consecutive lanes take consecutive key pairs -> consecutive banks.
@@ -435,20 +535,24 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
                 const int kp = c % (C::N / 2), ch = c / (C::N / 2);
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + e) * C::VSTR + 2 * kp) = pair_elem(v0reg[i], v1reg[i], e);
+                    *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + e) * C::VSTR + C::lds_key(2 * kp)) = pair_elem(v0reg[i], v1reg[i], e);
             }
         }
         uint4 qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = qfn[ks];
-        const long qoff = n_qoff;
+        const int qoff = n_qoff;
         const bool qin = qoff >= 0;           // a real token (padding / tile-padding queries are dropped)
         const int im = n_im, head = n_head;
         WIN_STAMP(1)
         __syncthreads();
         WIN_STAMP(2)
         // ---- next item's loads: in flight during the whole compute below --------------------------------
-        if (it + (int)gridDim.x < n_items) WIN_ISSUE(it + (int)gridDim.x);
+        const bool has_next = it + (int)gridDim.x < n_items;
+        if (has_next) {
+            if (wave >= C::NT) WIN_ISSUE(it + (int)gridDim.x);
+            else WIN_HEAD(it + (int)gridDim.x);
+        }
         WIN_STAMP(3)
 #ifdef WIN_TIMING
         ++n_done;
@@ -458,7 +562,9 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         // ---- decomposed rel-pos: RH[j] = q . rel_h[qh - j + 13], RW[j] = q . rel_w[qw - j + 13] -----
         // (log2 domain; image_encoder.py:325-361 uses the UNSCALED q)
         float* scr = Scr + wave * 32 * C::SSTR + ql * C::SSTR;
-        float RH[C::WS], RW[C::WS];
+        // bias of accumulator register r (tile-local key c = acc_row(r, hh): window row 2t + c / 14, column c % 14):
+        //   RH[2t + c / 14] + BW[r],  BW[r] = RW[c % 14]  (-inf for the 4 zero keys c >= 28)
+        float RH[C::WS], BW[16];
         {
             const f32x16_t th = tile_times_qT<PREC, HD>(Tab, lane, qf);
 #pragma unroll
@@ -472,7 +578,10 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
             for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = tw[r];
             wave_lds_sync();
 #pragma unroll
-            for (int j = 0; j < C::WS; ++j) RW[j] = scr[qw - j + C::WS - 1] * LOG2E_F;
+            for (int r = 0; r < 16; ++r) {
+                const int c = acc_row(r, hh);
+                BW[r] = c < C::TK ? scr[qw - c % C::WS + C::WS - 1] * LOG2E_F : -INFINITY;
+            }
         }
 
         const float c2 = rsqrtf((float)HD) * LOG2E_F;
@@ -483,25 +592,44 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
             for (int r = 0; r < 16; ++r) O[dt][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
 #ifdef WIN_TIMING
-        asm volatile("" :: "v"(RH[0]), "v"(RW[13]));
+        asm volatile("" :: "v"(RH[0]), "v"(BW[15]));
 #endif
         WIN_STAMP(4)
 
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
+            if (t < NGRP && has_next) WIN_GROUP(t);
             f32x16_t S = tile_times_qT<PREC, HD>(Ks + t * 32 * HD, lane, qf);
-            float mx = -INFINITY;
+            // registers 0..5 hold keys of window row 2t, 8..15 of row 2t + 1, 6 and 7 of row 2t + hh (c = 10, 11 | 14, 15)
+            const float rh0 = RH[2 * t], rh1 = RH[2 * t + 1], rhx = hh ? rh1 : rh0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                // key = k0 + 4*hh; both candidates are compile-time constants after unrolling
-                const int k0 = 32 * t + acc_row(r, 0), k1 = k0 + 4;
-                const float b0 = (k0 < C::N) ? RH[(k0 < C::N ? k0 : 0) / C::WS] + RW[(k0 < C::N ? k0 : 0) % C::WS] : -INFINITY;
-                const float b1 = (k1 < C::N) ? RH[(k1 < C::N ? k1 : 0) / C::WS] + RW[(k1 < C::N ? k1 : 0) % C::WS] : -INFINITY;
-                const float v = S[r] * c2 + (hh ? b1 : b0);      // -inf for the tile-padding keys (>= 196)
-                S[r] = v;
-                mx = fmaxf(mx, v);
+            for (int r = 0; r < 16; ++r) S[r] = S[r] * c2 + BW[r];
+            float m0 = fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3]));
+            m0 = fmaxf(m0, fmaxf(S[4], S[5]));
+            const float mxx = fmaxf(S[6], S[7]);
+            float m1 = fmaxf(fmaxf(S[8], S[9]), fmaxf(S[10], S[11]));
+            m1 = fmaxf(m1, fmaxf(fmaxf(S[12], S[13]), fmaxf(S[14], S[15])));
+            float mx = fmaxf(fmaxf(m0 + rh0, mxx + rhx), m1 + rh1);
+            mx = fmaxf(mx, xhalf_partner(mx));
+            const float m_new = fmaxf(m_run, mx);
+            if (__any(m_new != m_run)) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < C::DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[dt][r] *= alpha;
             }
-            online_softmax_step<C::DT>(&S, 1, mx, 0.f, m_run, l_run, O);
+            m_run = m_new;
+            const float o0 = rh0 - m_new, o1 = rh1 - m_new, ox = rhx - m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) S[r] = __builtin_amdgcn_exp2f(S[r] + (r < 6 ? o0 : r < 8 ? ox : o1));
+            if (!C::ONES) {
+                float sum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += S[r];
+                l_run += sum;
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const uint4 pb = pack_p<PREC>(S, u);
@@ -512,6 +640,8 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
                 }
             }
         }
+        if constexpr (C::ONES) l_run = ones_row_sum<HD, C::DT>(O, hh);
+        else l_run += xhalf_partner(l_run);
 
 #ifdef WIN_TIMING
         asm volatile("" :: "v"(O[0][0]), "v"(O[C::DT - 1][15]), "v"(l_run), "v"(qin), "v"(im), "v"(head));
@@ -520,7 +650,7 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
 #endif
         // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
         if (qin) {
-            const float inv = 1.0f / (l_run + xhalf_partner(l_run));
+            const float inv = 1.0f / l_run;
             uint16_t* orow = out + (size_t)im * img_rows * D + (size_t)(qoff / (3 * D)) * D + head * HD;
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt)
@@ -545,8 +675,12 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
     }
 #endif
 #undef WIN_ISSUE
-#undef WIN_BIAS_CHUNK
-#undef WIN_TOK_OFF
+#undef WIN_GROUP
+#undef WIN_LOAD_V
+#undef WIN_LOAD_K
+#undef WIN_LOAD_Q
+#undef WIN_HEAD
+#undef WIN_TOK
 }
 
 // LDS-DMA with a wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset; destination = LDS byte address
@@ -752,9 +886,11 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
         }                                                                                                    \
     }
     // rows d >= HD of V^T must be zero in both buffers (only when HD is not a multiple of 32); the DMA never touches them
+    constexpr bool ONES = SAMRS_GLB_ONES && C::DT * 32 > HD;   // ... except row HD = 1: the softmax row sum rides on the PV product
     if (C::DT * 32 > HD) {
         for (int b = 0; b < 2; ++b)
-            for (int i = tid; i < (C::DT * 32 - HD) * C::VSTR; i += NTH) Vb(b)[HD * C::VSTR + i] = 0;
+            for (int i = tid; i < (C::DT * 32 - HD) * C::VSTR; i += NTH)
+                Vb(b)[HD * C::VSTR + i] = (ONES && i < C::VSTR) ? ET<PREC>::from_float(1.0f) : (uint16_t)0;
     }
     GLB_DMA(0, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -800,7 +936,7 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
 #endif
         GLB_STAMP(1)
         if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, (PPW + 2) / 3, 2 * ((PPW + 2) / 3))
-        online_softmax_step<C::DT>(S, 2, mx, bh2, m_run, l_run, O);
+        online_softmax_step<C::DT, !ONES>(S, 2, mx, bh2, m_run, l_run, O);
 #ifdef GLB_TIMING
         asm volatile("" :: "v"(S[0][0]), "v"(S[1][15]), "v"(l_run));
 #endif
@@ -837,7 +973,9 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
     asm volatile("" :: "v"(O[0][0]), "v"(O[C::DT - 1][15]), "v"(l_run));
     return;
 #endif
-    const float inv = 1.0f / (l_run + xhalf_partner(l_run));
+    if constexpr (ONES) l_run = ones_row_sum<HD, C::DT>(O, hh);
+    else l_run += xhalf_partner(l_run);
+    const float inv = 1.0f / l_run;
     uint16_t* orow = out + ((size_t)im * NTOK + q) * D + head * HD;
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt)

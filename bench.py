@@ -290,6 +290,32 @@ def main() -> None:
         cpu_baseline = {"value": round(1.0 / (enc_s + dec_s), 4), "unit": "images/s", "cores": torch.get_num_threads(),
                         "kind": "port", "sample": f"1 warm-up + 3 timed tiles, {args.model}: set_image {enc_s:.1f}s + 32 boxes (20+12) "
                                                   f"{dec_s:.1f}s per tile, fp32 torch-CPU oracle"}
+        # "the reference as users run it" -- the same oracle code in torch eager fp32 on this GPU
+        # (rocBLAS / MIOpen behind torch), same tiles, same 20 + 12 box chunks, one tile at a time as the reference driver does
+        try:
+            sd_gpu = {k: v.to(dev) for k, v in sd.items()}
+            orc = so.OraclePredictor(sd_gpu, cfg)
+
+            def one_tile_gpu(i):
+                img = host_tiles[i].numpy()
+                bx = torch.from_numpy(synth.make_boxes(i, 32)[0]).to(dev)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                orc.set_image(img)
+                for s0, s1 in so.box_chunks(32, 20):
+                    m, _, _ = orc.predict_torch(None, None, so.apply_boxes(bx[s0:s1], (1024, 1024)), None, multimask_output=False)
+                    m.cpu()                                         # main_sam_hbox_semantic.py:189
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+
+            one_tile_gpu(0)
+            tg = float(np.mean([one_tile_gpu(1 + i) for i in range(3)]))
+            cpu_baseline["eager_gpu"] = {"value": round(1.0 / tg, 3), "unit": "images/s",
+                                         "note": "same oracle, torch eager fp32 on cuda:0, 1 warm-up + 3 timed tiles; not the "
+                                                 "product path (no library of this repo is involved)"}
+            del sd_gpu, orc
+        except Exception as ex:                                      # a baseline leg must not take the bench line down
+            cpu_baseline["eager_gpu"] = {"value": None, "note": f"failed: {type(ex).__name__}: {ex}"}
 
     if rank == 0:
         wl = {"c2": f"{args.model} SAM, batch={B}x1024^2 synthetic tiles, {args.boxes} hboxes/img in one box-only predict, "

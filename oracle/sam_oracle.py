@@ -87,7 +87,7 @@ def _rel_tables(q_size: int, rel_pos: Tensor) -> Tensor:
     """R[q, k, :] = rel_pos[(q - k) + (S - 1)]  (image_encoder.py:292-322 with q_size == k_size;
     the table already has 2S-1 rows so no interpolation happens, :304-306)."""
     idx = torch.arange(q_size)[:, None] - torch.arange(q_size)[None, :] + (q_size - 1)
-    return rel_pos[idx]
+    return rel_pos[idx.to(rel_pos.device)]
 
 
 def _attention(x: Tensor, sd: SD, p: str, heads: int, rd: Rounding) -> Tensor:
@@ -180,7 +180,8 @@ def _pe_encoding(sd: SD, coords01: Tensor) -> Tensor:
 def dense_pe(sd: SD, cfg) -> Tensor:
     """[1,256,64,64] grid PE at pixel centres (i+0.5)/64 (prompt_encoder.py:62-71,199-209)."""
     g = cfg.grid
-    t = (torch.arange(g, dtype=torch.float32) + 0.5) / g
+    dev = sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].device
+    t = (torch.arange(g, dtype=torch.float32, device=dev) + 0.5) / g
     yy, xx = torch.meshgrid(t, t, indexing="ij")
     pe = _pe_encoding(sd, torch.stack([xx, yy], dim=-1))
     return pe.permute(2, 0, 1)[None]
@@ -198,13 +199,14 @@ def prompt_encoder(sd: SD, cfg, points: Optional[Tuple[Tensor, Tensor]], boxes: 
         bs = masks.shape[0]
     else:
         bs = 1
-    sparse = torch.empty(bs, 0, C)
+    dev = sd["prompt_encoder.no_mask_embed.weight"].device
+    sparse = torch.empty(bs, 0, C, device=dev)
     if points is not None:                                                    # :73-91
         coords, labels = points
         coords = coords.to(torch.float32) + 0.5
         if boxes is None:
-            coords = torch.cat([coords, torch.zeros(bs, 1, 2)], dim=1)
-            labels = torch.cat([labels, -torch.ones(bs, 1, dtype=labels.dtype)], dim=1)
+            coords = torch.cat([coords, torch.zeros(bs, 1, 2, device=coords.device)], dim=1)
+            labels = torch.cat([labels, -torch.ones(bs, 1, dtype=labels.dtype, device=labels.device)], dim=1)
         emb = _pe_encoding(sd, coords / S)
         emb[labels == -1] = 0.0
         emb[labels == -1] += sd["prompt_encoder.not_a_point_embed.weight"]
@@ -368,7 +370,8 @@ def apply_boxes(boxes: Tensor, original_size: Tuple[int, int], long_side: int = 
 
 
 class OraclePredictor:
-    """Same surface as the reference ``SamPredictor`` (predictor.py), CPU fp32."""
+    """Same surface as the reference ``SamPredictor`` (predictor.py), fp32 on the device of the state dict: CPU in every
+    test, ``cuda`` only in bench.py's eager-on-GPU baseline leg (the reference as its users run it: torch eager)."""
 
     mask_threshold = 0.0
 
@@ -386,7 +389,8 @@ class OraclePredictor:
         inp = apply_image(image, self.cfg.img_size)
         self.original_size = tuple(image.shape[:2])
         self.input_size = tuple(inp.shape[:2])
-        self.features = image_encoder(self.sd, self.cfg, preprocess(inp, self.cfg.img_size), self.rd)
+        x = preprocess(inp, self.cfg.img_size).to(self.pe.device)     # cpu unless the state dict lives elsewhere
+        self.features = image_encoder(self.sd, self.cfg, x, self.rd)
         self.is_image_set = True
 
     @torch.no_grad()

@@ -838,6 +838,55 @@ __global__ void area_kernel(const uint8_t* __restrict__ masks, long hw, unsigned
     c = wave_sum(c);
     if ((threadIdx.x & 63) == 0 && c > 0.f) atomicAdd(&areas[j], (unsigned long long)c);
 }
+// Both of the above in ONE pass over the masks with 16-byte loads (the two kernels read every mask byte by byte, twice:
+// 26 + 58 us for 32 masks of 1024^2 against ~10 us for the 32 MiB at HBM speed).  A thread owns 16 adjacent pixels:
+// for j = n-1 .. 0 it counts the non-zero bytes of mask j (area) and paints the pixels no later mask has claimed.
+// Integer arithmetic only: seg and areas are bit-identical to paint_kernel + area_kernel.
+constexpr int PA_CHUNK = 64;          // masks per LDS counter chunk
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) {      // 0x80 in every byte of w that is not 0
+    return (((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u;
+}
+__global__ __launch_bounds__(256) void paint_area_kernel(const uint8_t* __restrict__ masks, const int32_t* __restrict__ labels,
+                                                         int n, long hw, uint8_t* __restrict__ seg,
+                                                         unsigned long long* __restrict__ areas) {
+    __shared__ unsigned int cnt_s[PA_CHUNK];
+    const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * 16;
+    const bool in = p0 < hw;                              // hw % 16 == 0 (launcher)
+    uint32_t done[4] = {0u, 0u, 0u, 0u}, res[4] = {0u, 0u, 0u, 0u};
+    for (int jhi = n; jhi > 0; jhi -= PA_CHUNK) {
+        const int jlo = jhi > PA_CHUNK ? jhi - PA_CHUNK : 0;
+        if (threadIdx.x < PA_CHUNK) cnt_s[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int j = jhi - 1; j >= jlo; --j) {
+            unsigned int cnt = 0;
+            if (in) {
+                const uint4 m = *reinterpret_cast<const uint4*>(masks + (size_t)j * hw + p0);
+                const uint32_t w[4] = {m.x, m.y, m.z, m.w};
+                const uint32_t lab = (uint32_t)(uint8_t)labels[j] * 0x01010101u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t t = nonzero_bytes(w[k]);
+                    cnt += __popc(t);
+                    const uint32_t mm = (t >> 7) * 0xFFu, fresh = mm & ~done[k];
+                    res[k] = (res[k] & ~fresh) | (fresh & lab);
+                    done[k] |= mm;
+                }
+            }
+            float c = wave_sum((float)cnt);               // <= 1024, exact
+            if ((threadIdx.x & 63) == 0 && c > 0.f) atomicAdd(&cnt_s[j - jlo], (unsigned int)c);
+        }
+        __syncthreads();
+        if (threadIdx.x < jhi - jlo && cnt_s[threadIdx.x]) atomicAdd(&areas[jlo + threadIdx.x], (unsigned long long)cnt_s[threadIdx.x]);
+        __syncthreads();
+    }
+    if (in && (done[0] | done[1] | done[2] | done[3])) {
+        uint4* sp = reinterpret_cast<uint4*>(seg + p0);
+        uint4 o = *sp;
+        o.x = (o.x & ~done[0]) | res[0]; o.y = (o.y & ~done[1]) | res[1];
+        o.z = (o.z & ~done[2]) | res[2]; o.w = (o.w & ~done[3]) | res[3];
+        *sp = o;
+    }
+}
 __global__ void class_stats_kernel(const unsigned long long* __restrict__ areas, const int32_t* __restrict__ labels, int n,
                                    unsigned long long* __restrict__ cpix, unsigned long long* __restrict__ cins, int n_classes) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1125,11 +1174,16 @@ hipError_t launch_paint(const uint8_t* masks, const int32_t* labels, int n, int 
                         unsigned long long* areas, unsigned long long* class_pixels,
                         unsigned long long* class_instances, int n_classes, hipStream_t s) {
     const long hw = (long)h * w;
-    if (seg) paint_kernel<<<(int)((hw + 255) / 256), 256, 0, s>>>(masks, labels, n, hw, seg);
+    const bool fused = seg && areas && hw % 16 == 0 && (((uintptr_t)masks | (uintptr_t)seg) & 15) == 0;
+    if (seg && !fused) paint_kernel<<<(int)((hw + 255) / 256), 256, 0, s>>>(masks, labels, n, hw, seg);
     if (areas) {
         HIP_CHECK_RET(hipMemsetAsync(areas, 0, sizeof(unsigned long long) * n, s));
-        dim3 g(64, n);
-        area_kernel<<<g, 256, 0, s>>>(masks, hw, areas);
+        if (fused) {
+            paint_area_kernel<<<(int)((hw / 16 + 255) / 256), 256, 0, s>>>(masks, labels, n, hw, seg, areas);
+        } else {
+            dim3 g(64, n);
+            area_kernel<<<g, 256, 0, s>>>(masks, hw, areas);
+        }
         if (class_pixels || class_instances)
             class_stats_kernel<<<1, 64, 0, s>>>(areas, labels, n, class_pixels, class_instances, n_classes);
     }

@@ -319,6 +319,34 @@ def test_paint_and_statistics_on_device():
     assert np.array_equal(cpix.cpu().numpy(), pix0) and np.array_equal(cins.cpu().numpy(), ins0)
 
 
+@pytest.mark.parametrize("h,w,n", [(64, 48, 70), (33, 21, 5), (1024, 1024, 3)])
+def test_paint_kernel_paths_are_bit_exact(h, w, n):
+    """samrs_paint on arbitrary u8 masks (any non-zero byte = set), more masks than one LDS counter chunk (64), sizes
+    that take the 16-byte fused kernel (h*w % 16 == 0) and the byte-wise fallback: seg, areas and class counters equal
+    the driver loop of main_sam_hbox_semantic.py:183-206 / statistic.py:15-21 (numpy restatement below)."""
+    eng = get_predictor("vit_tiny", "f16").model.engine
+    rng = np.random.default_rng(h * 1000 + n)
+    masks = (rng.random((n, h, w)) < 0.15).astype(np.uint8) * rng.choice(np.array([1, 2, 128, 255], np.uint8), (n, h, w))
+    masks[n // 2] = 0                                       # an empty mask: no instance, no pixels (statistic.py:18)
+    labels = rng.integers(0, 18, n).astype(np.int32)
+    seg0 = np.full((h, w), 255, np.uint8)
+    for j in range(n):
+        seg0[masks[j] != 0] = labels[j]
+    areas0 = (masks != 0).reshape(n, -1).sum(1).astype(np.int64)
+    pix0, ins0 = np.zeros(18, np.int64), np.zeros(18, np.int64)
+    for j in range(n):
+        if areas0[j] > 0:
+            pix0[labels[j]] += areas0[j]
+            ins0[labels[j]] += 1
+    seg = torch.full((h, w), 255, dtype=torch.uint8, device="cuda")
+    cpix = torch.zeros(18, dtype=torch.int64, device="cuda")
+    cins = torch.zeros(18, dtype=torch.int64, device="cuda")
+    areas = eng.paint(torch.from_numpy(masks).cuda(), torch.from_numpy(labels), seg, cpix, cins)
+    assert np.array_equal(seg.cpu().numpy(), seg0)
+    assert np.array_equal(areas.cpu().numpy(), areas0)
+    assert np.array_equal(cpix.cpu().numpy(), pix0) and np.array_equal(cins.cpu().numpy(), ins0)
+
+
 def test_error_behaviour_matches_reference():
     import samrs_amd
     pred = get_predictor("vit_tiny", "f16")

@@ -31,6 +31,9 @@ dt = torch.float16 if prec_name == "f16" else torch.bfloat16
 shapes = [("qkv-like", 32768, 3840, 1280, 0, 0, 0), ("lin2-like ET", 32768, 1280, 5120, 0, 0, 0)] if os.environ.get("ABL") else [("lin1+gelu", 32768, 5120, 1280, 0, 1, 0), ("lin2+res", 32768, 1280, 5120, 1, 0, 1),
           ("qkv     ", 32768, 3840, 1280, 0, 0, 0), ("proj+res", 32768, 1280, 1280, 1, 0, 1),
           ("lin1 b=1", 4096, 5120, 1280, 0, 1, 0)]
+if os.environ.get("DEC_SHAPES"):
+    # the decoder's image-side projections for 32 prompts (rows = 32 x 4096 keys, K = 256, 2-D addend = folded PE with period 4096)
+    shapes = [("dec kvq  ", 131072, 384, 256, 0, 0, 0), ("dec finkv", 131072, 256, 256, 0, 0, 0)]
 if os.environ.get("STRIDE_PROBE"):
     # L2-channel probe: the same GEMM with a row stride of 10 x 256 B (K = 1280), 11 x 256 B (K = 1408), 40 x 256 B (K = 5120), 41 x 256 B
     shapes = [("K=1280   ", 32768, 5120, 1280, 0, 1, 0), ("K=1408   ", 32768, 5120, 1408, 0, 1, 0), ("K=1344   ", 32768, 5120, 1344, 0, 1, 0),
@@ -42,6 +45,12 @@ for name, M, N, K, of32, gelu, acc in shapes:
     bias = torch.randn(N, generator=g).to(dev)
     C = torch.zeros(M, N, dtype=torch.float32 if of32 else torch.int16, device=dev)
     ref = A.float() @ W.float().t() + bias
+    add2d, period = None, 0
+    if os.environ.get("DEC_SHAPES"):
+        period = 4096
+        add2d = torch.randn(period, N, generator=g).to(dev)
+        ref = (ref.view(-1, period, N) + add2d).view(M, N)
+    add_ptr = add2d.data_ptr() if add2d is not None else None
     if gelu:
         ref = torch.nn.functional.gelu(ref)
     res = {}
@@ -49,7 +58,7 @@ for name, M, N, K, of32, gelu, acc in shapes:
     for v in variants:
         set_variant(v)
         C.zero_()
-        lib.samrs_k_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), None, 0, M, N, K, of32, gelu, acc, s)
+        lib.samrs_k_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), add_ptr, period, M, N, K, of32, gelu, acc, s)
         got = C.float() if of32 else C.view(dt).float()
         err = ((got - ref).norm() / ref.norm()).item()
         if first is None:
@@ -63,7 +72,7 @@ for name, M, N, K, of32, gelu, acc in shapes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                lib.samrs_k_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), None, 0, M, N, K, of32, gelu, acc, s)
+                lib.samrs_k_gemm(prec, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), add_ptr, period, M, N, K, of32, gelu, acc, s)
             e1.record(); torch.cuda.synchronize()
             res[v]["ms"].append(e0.elapsed_time(e1) / 10)
     lib.samrs_debug_set_gemm_skew(0, 0)

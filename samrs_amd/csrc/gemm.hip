@@ -24,36 +24,6 @@
 
 namespace {
 
-// Tile walk of the two encoder kernels (x64 / x64p).  Logical ids (contiguous per XCD after xcd_remap) run over GN = 4
-// tile COLUMNS fastest, then over all tile rows, then to the next column group.  The 32 tiles an XCD works on at a time are
-// still 8 rows x 4 columns (A 5.2 MB + B 3.3 MB at K = 1280), but from one round to the next only the A panels change:
-// the 4 B panels stay in the XCD's 4 MiB L2 for the whole walk down M, where the row-grouped walk (8 rows fastest, then
-// every column) re-streamed its 8 A panels once per 4 columns.  Bijective, so results do not change.  SAMRS_TILE_WALK=0
-// builds the old walk (A/B: tools/ab_libs.sh).
-#ifndef SAMRS_TILE_WALK
-#define SAMRS_TILE_WALK 1
-#endif
-__device__ __forceinline__ void tile_of_id(int bid, int tiles_m, int tiles_n, int& tm, int& tn) {
-#if SAMRS_TILE_WALK
-    constexpr int GN = 4;
-    const int per = tiles_m * GN;
-    const int g = bid / per, first_n = g * GN;
-    const int gsz = (tiles_n - first_n) < GN ? (tiles_n - first_n) : GN;
-    const int in_g = bid - g * per;
-    tm = in_g / gsz;
-    tn = first_n + in_g % gsz;
-#else
-    constexpr int GROUP = 8;
-    const int per_group = GROUP * tiles_n;
-    const int group = bid / per_group, first_m = group * GROUP;
-    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-    const int in_g = bid - group * per_group;
-    tm = first_m + in_g % gsz;
-    tn = in_g / gsz;
-#endif
-}
-
-
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GEMM_THREADS = 256;
 
@@ -1029,9 +999,14 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     const int grp = wave >> 2;                 // waves w and w+4 share a SIMD -> different groups
     const int wm = wave >> 2, wn = wave & 3;   // wave tile rows wm*128.., cols wn*(16 NI)..
 
+    constexpr int GROUP = 8;
     const int tiles_n = N / XBN, tiles_m = M / QBM;
-    int tile_m, tile_n;
-    tile_of_id(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tile_m, tile_n);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_group = GROUP * tiles_n;
+    const int group = bid / per_group, first_m = group * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = bid - group * per_group;
+    const int tile_m = first_m + in_g % gsz, tile_n = in_g / gsz;
     const int m0 = tile_m * QBM, n0 = tile_n * XBN;
 
     // DMA map: piece q of this wave covers stage rows 64 q + 8 wave .. + 7 (q < 4: A rows, else B rows 64 (q - 4) + ..);
@@ -1231,13 +1206,17 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const int grp = wave >> 2;
     const int wm = wave >> 2, wn = wave & 3;
 
+    constexpr int GROUP = 8;
     const int tiles_n = N / XBN, tiles_m = M / QBM, ntiles = tiles_n * tiles_m;
+    const int per_group = GROUP * tiles_n;
 #define X64P_TILE(L_, m_, n_)                                                                    \
     do {                                                                                         \
-        int tm_, tn_;                                                                            \
-        tile_of_id(xcd_remap((L_), ntiles), tiles_m, tiles_n, tm_, tn_);                         \
-        (m_) = tm_ * QBM;                                                                        \
-        (n_) = tn_ * XBN;                                                                        \
+        const int bid_ = xcd_remap((L_), ntiles);                                                \
+        const int group_ = bid_ / per_group, first_m_ = group_ * GROUP;                           \
+        const int gsz_ = (tiles_m - first_m_) < GROUP ? (tiles_m - first_m_) : GROUP;            \
+        const int in_g_ = bid_ - group_ * per_group;                                             \
+        (m_) = (first_m_ + in_g_ % gsz_) * QBM;                                                  \
+        (n_) = (in_g_ / gsz_) * XBN;                                                             \
     } while (0)
 
     const int prow = 8 * wave + ((lane >> 2) & 7);

@@ -1,7 +1,7 @@
 """How well-posed is "bit-identical class map" on this data?  Runs the fp32 oracle (pinned to the reference) and the SAME
 arithmetic in float64 on the C2 fixture inputs and counts the pixels whose thresholded decision differs: the
 reference's own fp32 rounding noise, a floor no implementation can go below.
-    python tools/ref_noise_floor.py [vit_b|vit_h]"""
+    python -m oracle.ref_noise_floor [vit_b|vit_h]"""
 import os
 import sys
 

@@ -172,7 +172,7 @@ def image_encoder(sd: SD, cfg, x: Tensor, rd: Rounding = _EXACT, taps: Optional[
 def _pe_encoding(sd: SD, coords01: Tensor) -> Tensor:
     """prompt_encoder.py:190-197: 2c-1, @G, *2pi, cat(sin, cos)."""
     g = sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"]
-    c = (2.0 * coords01.to(g.dtype) - 1.0) @ g      # (a no-op cast in fp32; lets tools/ref_noise_floor.py run the same code in fp64)
+    c = (2.0 * coords01.to(g.dtype) - 1.0) @ g      # (a no-op cast in fp32; lets oracle/ref_noise_floor.py run the same code in fp64)
     c = 2.0 * np.pi * c
     return torch.cat([torch.sin(c), torch.cos(c)], dim=-1)
 

@@ -1697,6 +1697,178 @@ hipError_t launch_gemm_pipe(const void* A, const void* B, void* C, const float* 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// K = 256 streaming GEMM (the decoder's image-side projections: rows = prompts x 4096 keys, N = 256 / 384).
+// With K this short a tiled GEMM is all prologue and epilogue (82 / 52 us for 167 / 134 MB, hipBLASLt 66 / 32): the
+// operand that matters is A, read once, and C, written once.  So: a PERSISTENT block keeps its whole weight slice in
+// registers (wave w: columns 64 w .. +63 x 256 k = 32 uint4 fragments), walks 128-row tiles of A that arrive by LDS-DMA
+// into a double buffer (tile t+1 is in flight while tile t is multiplied and stored), and stores straight from the
+// accumulators (a wave's 4 column blocks complete whole 128-byte lines of a row).  No B traffic after the first tile, one
+// barrier per tile.  Same k order as every other kernel (ascending 32-wide steps from a zero accumulator), same
+// epilogue arithmetic as the tiled path ((acc + add2d) + bias) -> bit-identical results.
+// LDS image of a tile: row r = 32 16-byte chunks, chunk c of the row at position c ^ (r & 15): the fragment reads of a
+// 16-row group (lane (fr, fq) reads chunk 4 ks + fq of row fr) are conflict-free, and a DMA piece is two whole rows.
+// ---------------------------------------------------------------------------------------------
+constexpr int K2_ROWS = 128, K2_K = 256, K2_TILE_BYTES = K2_ROWS * K2_K * 2;
+
+// RS = row split: RS waves share a column slice (each keeps its own copy of the weight fragments) and take every RS-th
+// 16-row group -- N = 256: 8 waves instead of 4, twice the loads in flight per CU for the L2-latency-bound 2-D addend.
+template <int PREC, int NW, int RS>
+__global__ __launch_bounds__(64 * NW * RS) void gemm_et_k256_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, uint16_t* __restrict__ C,
+    const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period, int M) {
+    constexpr int N = 64 * NW, K = K2_K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char k2_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0 .. NW RS - 1: DMA piece owner
+    const int wave = wid % NW, part = wid / NW;                    // column slice, row-group phase
+    const int fr = lane & 15, fq = lane >> 4;
+    const int ntiles = M / K2_ROWS;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)k2_lds);
+    constexpr int NWT = NW * RS;
+
+    // DMA piece p (two rows 2p, 2p + 1): lane l fetches row 2p + (l >> 5), source chunk (l & 31) ^ (row & 15)
+#define K2_ISSUE(tile_, buf_)                                                                                      \
+    do {                                                                                                           \
+        const uint16_t* sb_ = A + (size_t)(tile_) * K2_ROWS * K;                                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < (64 + NWT - 1) / NWT; ++i_) {                                      \
+            const int p_ = wid + NWT * i_;                                                                         \
+            if (p_ < 64) {                                                                                         \
+                const int row_ = 2 * p_ + (lane >> 5);                                                             \
+                const uint32_t voff_ = (uint32_t)(row_ * K + (((lane & 31) ^ (row_ & 15)) << 3)) * 2u;             \
+                glds16_s(voff_, sb_, lds0 + (uint32_t)(buf_) * K2_TILE_BYTES + (uint32_t)p_ * 1024u);              \
+            }                                                                                                      \
+        }                                                                                                          \
+    } while (0)
+
+    int t = blockIdx.x, buf = 0;
+    if (t < ntiles) K2_ISSUE(t, 0);
+    // weight slice and bias of this wave: resident for the whole launch
+    uint4 wf[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            wf[i][ks] = *reinterpret_cast<const uint4*>(B + (size_t)(wave * 64 + i * 16 + fr) * K + ks * 32 + fq * 8);
+    // the bias lives in LDS behind the two tile buffers (16 registers the pipelined loop needs elsewhere)
+    constexpr int K2_PS = 144;                 // patch row stride (bytes): 128 + 16
+    unsigned char* patch = k2_lds + 2 * K2_TILE_BYTES + 2048 + wid * (16 * K2_PS);
+    float* bias_s = reinterpret_cast<float*>(k2_lds + 2 * K2_TILE_BYTES);
+    for (int i = tid; i < N; i += 64 * NWT) bias_s[i] = bias ? bias[i] : 0.f;
+#ifdef K2_TIMING
+    unsigned long long kph[4] = {0, 0, 0, 0}, kprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long kstart = kprev;
+    int kn = 0;
+#define K2_STAMP(i_) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); kph[i_] += tn_ - kprev; kprev = tn_; }
+#else
+#define K2_STAMP(i_)
+#endif
+    constexpr int NG = (K2_ROWS / 16) / RS;                   // row groups per wave and tile
+#define K2_AF(tile_, g_, ks_) (*reinterpret_cast<const uint4*>((tile_) + ((((g_) * 16 + fr) * 32 + (((ks_) * 4 + fq) ^ fr)) << 4)))
+#define K2_ADDEND(dst_, row_)                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                               \
+        dst_[i_] = add2d ? *reinterpret_cast<const float4*>(add2d + (size_t)((row_) % add2d_period) * N + wave * 64 + i_ * 16 + 4 * fq) \
+                         : make_float4(0.f, 0.f, 0.f, 0.f)
+    for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile t have landed
+        K2_STAMP(0)
+        __syncthreads();                                        // everybody's; and nobody reads the other buffer any more
+        K2_STAMP(1)
+        if (t + (int)gridDim.x < ntiles) K2_ISSUE(t + (int)gridDim.x, buf ^ 1);
+        K2_STAMP(2)
+        const unsigned char* tile = k2_lds + buf * K2_TILE_BYTES;
+        // Software pipeline over this wave's NG row groups: a group's addend is loaded before its MFMAs, the next group's A
+        // fragments replace the current ones k-step by k-step as the MFMAs consume them; the four column blocks advance
+        // together (4 independent accumulator chains).
+        uint4 af[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) af[ks] = K2_AF(tile, part, ks);
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int g = part + gi * RS;
+            const bool more = gi + 1 < NG;
+            float4 e[4];                          // in flight during this group's MFMAs (no room for a second set)
+            K2_ADDEND(e, t * K2_ROWS + g * 16 + fr);
+            f32x4_t acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = ET<PREC>::mfma16(wf[i][ks], af[ks], acc[i]);
+                if (more) af[ks] = K2_AF(tile, g + RS, ks);
+            }
+            // Bounce through a wave-private LDS patch: straight from the accumulators a store instruction would touch 16
+            // cache lines with 32 bytes each (measured: ~320 cycles of issue time per store, 5 k of 9 k cycles per tile);
+            // after the bounce a lane stores 16 bytes and an instruction covers 8 whole 128-byte lines.
+            if (gi) wave_lds_sync_g();            // the previous group's reads of the patch are done
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 bb = *reinterpret_cast<const float4*>(bias_s + wave * 64 + i * 16 + 4 * fq);
+                uint2 o;
+                o.x = pack2<PREC>((acc[i][0] + e[i].x) + bb.x, (acc[i][1] + e[i].y) + bb.y);
+                o.y = pack2<PREC>((acc[i][2] + e[i].z) + bb.z, (acc[i][3] + e[i].w) + bb.w);
+                *reinterpret_cast<uint2*>(patch + fr * K2_PS + (i * 16 + 4 * fq) * 2) = o;
+            }
+            wave_lds_sync_g();
+            uint16_t* cbase = C + (size_t)(t * K2_ROWS + g * 16) * N + wave * 64;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = h * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(patch + r * K2_PS + ch * 16);
+                *reinterpret_cast<uint4*>(cbase + (size_t)r * N + ch * 8) = v;
+            }
+        }
+        K2_STAMP(3)
+#ifdef K2_TIMING
+        ++kn;
+#endif
+    }
+#ifdef K2_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && wid == 0) {   // timing build: the first rows of C hold the stamps instead of results
+        unsigned long long* tp = reinterpret_cast<unsigned long long*>(C) + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 4; ++i) tp[i] = kph[i];
+        tp[4] = __builtin_amdgcn_s_memtime() - kstart;
+        tp[5] = kn;
+    }
+#endif
+#undef K2_ISSUE
+#undef K2_STAMP
+#undef K2_AF
+#undef K2_ADDEND
+}
+
+template <int PREC>
+hipError_t launch_gemm_k256(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
+                            int M, int N, hipStream_t s) {
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const int ntiles = M / K2_ROWS;
+    dim3 grid(ntiles < n_cu ? ntiles : n_cu);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    constexpr int LDS = 2 * K2_TILE_BYTES + 2048 + 8 * 16 * 144;   // two tile buffers + the bias + 8 store patches
+#define K2_LAUNCH(NW_, RS_)                                                                                          \
+    do {                                                                                                             \
+        auto k = gemm_et_k256_kernel<PREC, NW_, RS_>;                                                                \
+        HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+        k<<<grid, 64 * NW_ * RS_, LDS, s>>>(a, b, (uint16_t*)C, bias, add2d, period, M);                             \
+    } while (0)
+    if (N == 256) K2_LAUNCH(4, 2);
+    else if (N == 384) K2_LAUNCH(6, 1);
+    else return hipErrorInvalidValue;
+#undef K2_LAUNCH
+    return hipGetLastError();
+}
+// shapes the streaming kernel takes: ET output without GELU / accumulate, K = 256, N = 256 or 384, whole 128-row tiles
+static bool k256_ok(int M, int N, int K, bool out_f32, bool gelu, bool accumulate) {
+    return !out_f32 && !gelu && !accumulate && K == K2_K && (N == 256 || N == 384) && M % K2_ROWS == 0;
+}
+
 int g_gemm_variant = 8;   // 0 reg-staged 128^2, 1 +LDS-DMA, 2 +grouped order, 3 reg+grouped, 4 256x128 3-stage pipe, 5 +staggered groups, 6 256x256, 7 2 blocks/CU, 8 auto(5|6|7)
 
 template <int PREC, bool GLDS, int GROUP_M>
@@ -1863,6 +2035,12 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
+    }
+    // 40: K = 256 streaming kernel (decoder image side); automatic for its shapes once there are >= 2 tiles per CU
+    if ((g_gemm_variant == 40 || (g_gemm_variant == 8 && M / K2_ROWS >= 512)) && k256_ok(M, N, K, out_f32, gelu, accumulate)) {
+        if (prec == PREC_BF16) return launch_gemm_k256<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, s);
+        if (prec == PREC_F16) return launch_gemm_k256<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, s);
+        return hipErrorInvalidValue;
     }
     // variant 8 ("auto", default): per-shape pick measured on MI355X (tools/gemm_bench.py) -- the
     // 2-blocks-per-CU kernel wins where the epilogue dominates (GELU output, or short K with a

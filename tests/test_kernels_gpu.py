@@ -170,6 +170,44 @@ def test_gemm_tile_variants_are_bit_identical(lib, name, prec, dt, ulp):
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("N", [256, 384])
+def test_gemm_k256_streaming_kernel_is_bit_identical(lib, name, prec, dt, ulp, N):
+    """The decoder's image-side projections (rows = prompts x 4096 keys, K = 256, 2-D addend with period 4096): the persistent
+    weights-in-registers kernel (variant 40; automatic from 512 tiles of 128 rows) must reproduce the tiled 2-blocks-per-CU
+    kernel (7) bit for bit -- more tiles than blocks (each block walks 3 tiles: both LDS buffers are reused), a ragged last
+    round, repeated launches, with and without the addend -- and agree with fp64."""
+    lib.samrs_debug_set_gemm_variant.argtypes = [__import__("ctypes").c_int]
+    M, K, period = 128 * 700, 256, 4096
+    g = torch.Generator().manual_seed(N)
+    A, Ab = et_bits(torch.randn(M, K, generator=g), dt)
+    B, Bb = et_bits(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
+    bias = torch.randn(N, generator=g)
+    add = torch.randn(period, N, generator=g)
+    Ad, Bd, biasd, addd = dev(Ab), dev(Bb), dev(bias), dev(add)
+    try:
+        for with_add in (True, False):
+            outs = {}
+            for variant in (7, 40, 40, 8):
+                lib.samrs_debug_set_gemm_variant(variant)
+                o = torch.full((M, N), 0x7E00, dtype=torch.int16, device="cuda")      # NaN canary
+                assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), o.data_ptr(), biasd.data_ptr(),
+                                        addd.data_ptr() if with_add else None, period if with_add else 0, M, N, K, 0, 0, 0, stream()) == 0
+                torch.cuda.synchronize()
+                if not outs:
+                    outs["ref"] = o
+                else:
+                    assert torch.equal(o, outs["ref"]), f"{name} N={N} add2d={with_add}: variant {variant} differs from the tiled kernel"
+            ref = A.double() @ B.double().t() + bias.double()
+            if with_add:
+                ref = ref + add.double()[torch.arange(M) % period]
+            got = outs["ref"].cpu().view(dt).double()
+            r, _ = rel_err(got, ref)
+            assert r < (1e-3 if name == "f16" else 8e-3), r
+    finally:
+        lib.samrs_debug_set_gemm_variant(8)
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
 def test_gemm_group_layernorm_gelu_epilogue(lib, name, prec, dt, ulp):
     """ConvT #1 of the mask upscaler: GEMM + LayerNorm2d over each 64-channel group + GELU (mask_decoder.py:53-56)."""
     g = torch.Generator().manual_seed(31)

@@ -1363,6 +1363,321 @@ hipError_t launch_gemm_x64p(const void* A, const void* B, void* C, const float* 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_et_m32_kernel: the pair-stage 256x320 kernel (same LDS image, same whole-line LDS-DMA map) on
+// v_mfma_f32_32x32x16 with a SYMMETRIC, register-double-buffered schedule.
+//
+// Why another main loop.  Measured on the 16x16x32 kernels above: a 64-k stage takes ~3.5 k cycles
+// against 2.56 k of matrix-pipe time; one 16x16x32 MFMA occupies the pipe for ~17 cycles (MI355X_MICROARCH.md: 4.2
+// quad-cycles, i.e. 6 % above its nominal 16), leaves ~4 issue slots before the next one is due, and an LDS-DMA piece
+// (m0 write + s_nop + the load + address SALU) does not fit into such a gap -- every piece opens a bubble in the issuing
+// wave's MFMA stream that only the partner wave can fill, which is why that schedule needs the two wave groups half a
+// stage apart and L / C segments.  A 32x32x16 MFMA runs 32 cycles at the full rate, reads HALF the operand registers
+// per FLOP (2 x 512 elements for 32 K FLOP instead of 16 K) and leaves ~8 issue slots: one ds_read_b128 plus one DMA
+// piece fit behind every MFMA.  So here every wave runs ONE uninterrupted MFMA stream; the fragments of k-step s+1 are
+// read while the MFMAs of step s run (two register sets), the DMA pieces ride in the same gaps, and there is no load
+// segment and no group asymmetry.  The two waves of a SIMD share its matrix pipe by the hardware's age arbitration.
+//
+// Wave layout 4 (M) x 2 (N): wave tile 64 x 160 = 2 x 5 MFMA tiles, 160 accumulator registers; a wave owns whole
+// 320-byte (f16) / 640-byte (fp32) row segments of the output, so the epilogue bounces through a wave-private scratch
+// without block barriers.  Per 16-k step and wave: 10 MFMAs, 7 ds_read_b128 (14.3 KiB per 32 k against 13.3 KiB for
+// the 128 x 80 wave tile).
+//
+// Stage hand-over (one block barrier per 64-k stage, placed between steps 2 and 3 of the stage):
+//     steps 0, 1, 2 of stage t : MFMAs | reads of the next step's fragments (buffer t & 1)
+//     lgkmcnt(0) (every fragment of stage t is in registers), vmcnt(0) (this wave's pieces of stage t+1 have landed), barrier B_t
+//     step 3 of stage t        : MFMAs | reads of step 0 of stage t+1 (other buffer) | DMA pieces of stage t+2 -> buffer t & 1
+// so a stage is in flight for three steps (~2 k cycles).  Persistent: the stream of stages simply continues into the next
+// tile -- at t = nst-2 the pieces issued are the next tile's stage 0 (they land under the last stage and the epilogue);
+// the epilogue bounces through buffer 1 (free after B_nst-1; nst must be even), and the next tile's stage 1 goes out
+// right after it.  K % 128 == 0, M % 256 == 0, N % 320 == 0, no 2-D addend.
+// k is accumulated in 16-wide MFMA steps, so results are NOT bit-identical with the 16x16x32 kernels (same fp32
+// accumulation error class; tests/test_kernels_gpu.py::test_gemm_m32_*).
+// ---------------------------------------------------------------------------------------------
+constexpr int M32_RS = 144;                   // scratch row stride (bytes): 128 data bytes + 16; 36 words = 4 (mod 32)
+
+// Epilogue of one wave tile: acc[i][j] = 32 (n) x 32 (m) block, lane (m = l & 31, h = l >> 5) holds n = 8 g + 4 h + 0..3
+// for g = 0..3 in registers 4 g .. 4 g + 3.  Bounce through `scr` (wave-private, 32 rows x M32_RS bytes) so that the global
+// accesses are whole 128-byte row segments, 8 rows per instruction.
+template <int PREC, bool OUT_F32, bool GELU>
+__device__ __forceinline__ void epilogue_m32(f32x16_t (&acc)[5][2], unsigned char* scr, void* __restrict__ Cv,
+                                             const float* __restrict__ bias, int N, int m_base, int n_base, int wn,
+                                             int accumulate, int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+    if constexpr (OUT_F32) {
+        float* C = reinterpret_cast<float*>(Cv);
+        bool first = true;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                // the residual (old C) does not depend on the accumulators: its loads go out first
+                float4 res[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int idx = lane + 64 * p, row = idx >> 3, ch = idx & 7;
+                    res[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (accumulate) res[p] = *reinterpret_cast<const float4*>(C + (size_t)(m_base + j * 32 + row) * N + n_base + i * 32 + ch * 4);
+                }
+                if (!first) wave_lds_sync_g();
+                first = false;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n_base + i * 32 + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float v0 = acc[i][j][4 * g] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+                    float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+                    if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
+                    *reinterpret_cast<float4*>(scr + l31 * M32_RS + (8 * g + 4 * h) * 4) = make_float4(v0, v1, v2, v3);
+                }
+                wave_lds_sync_g();
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int idx = lane + 64 * p, row = idx >> 3, ch = idx & 7;
+                    float4 v = *reinterpret_cast<const float4*>(scr + row * M32_RS + ch * 16);
+                    v.x += res[p].x; v.y += res[p].y; v.z += res[p].z; v.w += res[p].w;
+                    *reinterpret_cast<float4*>(C + (size_t)(m_base + j * 32 + row) * N + n_base + i * 32 + ch * 4) = v;
+                }
+            }
+    } else {
+        uint16_t* C = reinterpret_cast<uint16_t*>(Cv);
+        // one pass = n-tiles [I0, I0 + CNT): CNT * 64 bytes per row.  The wave's 320-byte row segment starts on a 128-byte
+        // line for wn = 0 and in the middle of one for wn = 1, so the passes are grouped {0,1}{2,3}{4} / {0}{1,2}{3,4}: every
+        // two-tile pass writes whole lines.
+#define M32_ET_PASS(j_, I0, CNT)                                                                                     \
+        do {                                                                                                         \
+            wave_lds_sync_g();                                                                                       \
+            _Pragma("unroll") for (int ii = 0; ii < (CNT); ++ii)                                                     \
+            _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                          \
+                const int i = (I0) + ii;                                                                             \
+                const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + n_base + i * 32 + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f); \
+                float v0 = acc[i][j_][4 * g] + bv.x, v1 = acc[i][j_][4 * g + 1] + bv.y;                              \
+                float v2 = acc[i][j_][4 * g + 2] + bv.z, v3 = acc[i][j_][4 * g + 3] + bv.w;                          \
+                if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; } \
+                uint2 o;                                                                                             \
+                o.x = pack2<PREC>(v0, v1);                                                                           \
+                o.y = pack2<PREC>(v2, v3);                                                                           \
+                *reinterpret_cast<uint2*>(scr + l31 * M32_RS + (ii * 32 + 8 * g + 4 * h) * 2) = o;                   \
+            }                                                                                                        \
+            wave_lds_sync_g();                                                                                       \
+            _Pragma("unroll") for (int p = 0; p < 2 * (CNT); ++p) {                                                  \
+                const int idx = lane + 64 * p, row = idx / (4 * (CNT)), ch = idx % (4 * (CNT));                      \
+                const uint4 v = *reinterpret_cast<const uint4*>(scr + row * M32_RS + ch * 16);                       \
+                *reinterpret_cast<uint4*>(C + (size_t)(m_base + (j_) * 32 + row) * N + n_base + (I0) * 32 + ch * 8) = v; \
+            }                                                                                                        \
+        } while (0)
+        if (wn == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { M32_ET_PASS(j, 0, 2); M32_ET_PASS(j, 2, 2); M32_ET_PASS(j, 4, 1); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { M32_ET_PASS(j, 0, 1); M32_ET_PASS(j, 1, 2); M32_ET_PASS(j, 3, 2); }
+        }
+#undef M32_ET_PASS
+    }
+}
+
+// LDS-DMA piece with M0 declared as clobbered instead of saved / restored (two SALU instructions less per piece)
+__device__ __forceinline__ void glds16_m(uint32_t voff, const void* sbase, uint32_t m0v) {
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1"
+        :
+        : "v"(voff), "s"(sbase), "s"(m0v)
+        : "memory", "m0");
+}
+
+// SPREAD: 0 = the 9 DMA pieces of a stage all go out in step 3 (one behind each of the first 9 MFMAs); 1 = pieces 0-4 in
+// step 3 and pieces 5-8 in step 0 of the following stage (fewer fillers per gap, one step less in flight)
+template <int PREC, bool OUT_F32, bool GELU, int SPREAD>
+__global__ __launch_bounds__(QTHREADS) void gemm_et_m32_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, int M, int N, int K, int accumulate) {
+    constexpr int NI = 5, NJ = 2;
+    constexpr int XBN = 32 * NI * 2;                       // 320
+    constexpr int XROWS = QBM + XBN;
+    constexpr int XSTAGE_ELEMS = XROWS * XBK;
+    constexpr uint32_t XSB = XSTAGE_ELEMS * 2;             // 72 KiB per stage
+    constexpr int NP3 = SPREAD ? 5 : 9;                    // pieces [0, NP3) ride in step 3, [NP3, 9) in the next step 0
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * XSTAGE_ELEMS];   // 144 KiB, ONE object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;   // wave tile rows wm*64.., cols wn*160..
+
+    constexpr int GROUP = 8;
+    const int tiles_n = N / XBN, tiles_m = M / QBM, ntiles = tiles_n * tiles_m;
+    const int per_group = GROUP * tiles_n;
+#define M32_TILE(L_, m_, n_)                                                                     \
+    do {                                                                                         \
+        const int bid_ = xcd_remap((L_), ntiles);                                                \
+        const int group_ = bid_ / per_group, first_m_ = group_ * GROUP;                           \
+        const int gsz_ = (tiles_m - first_m_) < GROUP ? (tiles_m - first_m_) : GROUP;            \
+        const int in_g_ = bid_ - group_ * per_group;                                             \
+        (m_) = (first_m_ + in_g_ % gsz_) * QBM;                                                  \
+        (n_) = (in_g_ / gsz_) * XBN;                                                             \
+    } while (0)
+
+    // DMA map: identical to the 16x16x32 pair-stage kernels (piece q of a wave = stage rows 64 q + 8 wave .. + 7)
+    const int prow = 8 * wave + ((lane >> 2) & 7);
+    const uint32_t voff = ((uint32_t)prow * (uint32_t)K + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
+    const size_t rs64 = (size_t)64 * K;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
+    // piece q_ (literal) of the stage whose A / B rows start at pa_ / pb_ (wave-uniform) into the buffer at byte offset wr_
+#define M32_PIECE(pa_, pb_, wr_, q_)                                                                       \
+    glds16_m(voff, ((q_) < 4 ? (pa_) + (size_t)(q_) * rs64 : (pb_) + (size_t)((q_) - 4) * rs64),          \
+             lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u))
+
+    // fragment BYTE offsets inside a stage for k-step 0 of k-half 0 (16-byte chunk h of the row); step parity 1 = chunk
+    // h + 2 = the physical chunk XOR 2 (byte offset XOR 32), k-half 1 = +512
+    const int nst = K / XBK;
+    const int l31 = lane & 31, hh = lane >> 5;
+    uint32_t offA[NJ], offB[NI];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int r = wm * 64 + j * 32 + l31; offA[j] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, hh) * 8) * 2; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = QBM + wn * 160 + i * 32 + l31;
+        offB[i] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, hh) * 8) * 2;
+    }
+    const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);
+
+    // fragments of k-step s_ (0..3) of the stage in the buffer at byte offset rd_ -> register set fa / fb
+#define M32_RDB(fb_, rd_, s_, i_) fb_[i_] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + ((s_) >> 1) * 512 + (offB[i_] ^ (((s_) & 1) * 32u)))
+#define M32_RDA(fa_, rd_, s_, j_) fa_[j_] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + ((s_) >> 1) * 512 + (offA[j_] ^ (((s_) & 1) * 32u)))
+    // one k-step: 10 MFMAs on the set (ca_, cb_); behind MFMA k one read of the NEXT step's set (na_, nb_) from (nrd_, ns_)
+    // and DMA piece Q0_ + k (while < Q1_) of the stage (pa_, pb_) -> buffer wr_: D_ = 0 none, 1 always, 2 when dma_ (wave-
+    // uniform) is set.  The accumulators never sit inside a conditional region.
+#define M32_SLOT(k_, i_, j_, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)             \
+        acc[i_][j_] = ET<PREC>::mfma32(cb_[i_], ca_[j_], acc[i_][j_]);                                     \
+        if constexpr ((k_) < 5) { M32_RDB(nb_, nrd_, ns_, ((k_) < 5 ? (k_) : 0)); }                        \
+        else if constexpr ((k_) < 7) { M32_RDA(na_, nrd_, ns_, ((k_) >= 5 && (k_) < 7 ? (k_) - 5 : 0)); }  \
+        if constexpr ((D_) != 0 && (Q0_) + (k_) < (Q1_)) {                                                 \
+            if ((D_) == 1 || (dma_)) M32_PIECE(pa_, pb_, wr_, ((Q0_) + (k_) < 9 ? (Q0_) + (k_) : 0));      \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);
+#define M32_STEP(ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                         \
+        M32_SLOT(0, 0, 0, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                \
+        M32_SLOT(1, 1, 0, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                \
+        M32_SLOT(2, 2, 0, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                \
+        M32_SLOT(3, 3, 0, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                \
+        M32_SLOT(4, 4, 0, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                \
+        M32_SLOT(5, 0, 1, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                \
+        M32_SLOT(6, 1, 1, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                \
+        M32_SLOT(7, 2, 1, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                \
+        M32_SLOT(8, 3, 1, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                \
+        M32_SLOT(9, 4, 1, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)
+    // one 64-k stage held in buffer rd.  Step 0 carries the late pieces [NP3, 9) of the stage that goes into the OTHER buffer
+    // (D0_, d0_, a0_, b0_); step 3, after the hand-over barrier, the early pieces [0, NP3) of the stage that goes into THIS
+    // buffer (D3_, d3_, a3_, b3_).
+#define M32_STAGE(D0_, d0_, a0_, b0_, D3_, d3_, a3_, b3_)                                                  \
+        {                                                                                                  \
+            const uint32_t ot = XSB - rd;                                                                  \
+            M32_STEP(fa0, fb0, fa1, fb1, rd, 1, D0_, d0_, NP3, 9, a0_, b0_, ot)                            \
+            M32_STEP(fa1, fb1, fa0, fb0, rd, 2, 0, false, 0, 0, a0_, b0_, ot)                              \
+            M32_STEP(fa0, fb0, fa1, fb1, rd, 3, 0, false, 0, 0, a0_, b0_, ot)                              \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            M32_STEP(fa1, fb1, fa0, fb0, ot, 0, D3_, d3_, 0, NP3, a3_, b3_, rd)                            \
+            rd = ot;                                                                                       \
+        }
+
+    int L = blockIdx.x, m0, n0;
+    M32_TILE(L, m0, n0);
+    const uint16_t* sA = A + (size_t)m0 * K;       // rows of the tile being computed (wave-uniform: SGPR pairs)
+    const uint16_t* sB = B + (size_t)n0 * K;
+    M32_PIECE(sA, sB, 0u, 0); M32_PIECE(sA, sB, 0u, 1); M32_PIECE(sA, sB, 0u, 2); M32_PIECE(sA, sB, 0u, 3); M32_PIECE(sA, sB, 0u, 4);
+    M32_PIECE(sA, sB, 0u, 5); M32_PIECE(sA, sB, 0u, 6); M32_PIECE(sA, sB, 0u, 7); M32_PIECE(sA, sB, 0u, 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x16_t acc[NI][NJ];
+    for (;;) {
+        // the tile after this one (its stage 0 is fed from inside this tile's main loop)
+        const int Ln = L + (int)gridDim.x;
+        const bool more = Ln < ntiles;
+        int m1 = m0, n1 = n0;
+        if (more) M32_TILE(Ln, m1, n1);
+        const uint16_t* nA = A + (size_t)m1 * K;
+        const uint16_t* nB = B + (size_t)n1 * K;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        {   // early pieces of stage 1 -> buffer 1 (the late ones ride in step 0 of stage 0)
+            const uint16_t* a1 = sA + XBK;
+            const uint16_t* b1 = sB + XBK;
+            M32_PIECE(a1, b1, XSB, 0); M32_PIECE(a1, b1, XSB, 1); M32_PIECE(a1, b1, XSB, 2); M32_PIECE(a1, b1, XSB, 3); M32_PIECE(a1, b1, XSB, 4);
+            if constexpr (!SPREAD) { M32_PIECE(a1, b1, XSB, 5); M32_PIECE(a1, b1, XSB, 6); M32_PIECE(a1, b1, XSB, 7); M32_PIECE(a1, b1, XSB, 8); }
+        }
+        uint4 fa0[NJ], fb0[NI], fa1[NJ], fb1[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) M32_RDB(fb0, 0u, 0, i);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) M32_RDA(fa0, 0u, 0, j);
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t rd = 0;
+        // stage t: step 0 completes stage t+1, step 3 starts stage t+2
+        const uint16_t* pa = sA + XBK;
+        const uint16_t* pb = sB + XBK;
+        for (int t = 0; t + 2 < nst; ++t) {
+            M32_STAGE(1, true, pa, pb, 1, true, pa + XBK, pb + XBK)
+            pa += XBK;
+            pb += XBK;
+        }
+        // t = nst-2 (buffer 0): completes the last stage; starts the NEXT tile's stage 0 in buffer 0 when there is one
+        M32_STAGE(1, true, pa, pb, 2, more, nA, nB)
+        // t = nst-1 (buffer 1): completes the next tile's stage 0
+        M32_STAGE(2, more, nA, nB, 0, false, nA, nB)
+        // all fragment reads of this tile are complete (B_nst-1); buffer 1 held its last stage -> scratch
+        {
+            unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + XSB + wave * (XSB / 8);
+            epilogue_m32<PREC, OUT_F32, GELU>(acc, scr, Cv, bias, N, m0 + wm * 64, n0 + wn * 160, wn, accumulate, lane);
+        }
+        if (!more) break;
+        __builtin_amdgcn_s_barrier();              // every wave is done with its scratch before stage 1 of the next tile lands there
+        L = Ln; m0 = m1; n0 = n1; sA = nA; sB = nB;
+    }
+#undef M32_TILE
+#undef M32_PIECE
+#undef M32_RDA
+#undef M32_RDB
+#undef M32_SLOT
+#undef M32_STEP
+#undef M32_STAGE
+}
+
+// persistent = one block per CU walks the tiles; otherwise one tile per block (same kernel: `more` is never true)
+template <int PREC, int SPREAD>
+hipError_t launch_gemm_m32(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, bool out_f32, bool gelu,
+                           bool accumulate, bool persistent, hipStream_t s) {
+    const int ntiles = (M / QBM) * (N / WBN);
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    dim3 grid(persistent && ntiles > n_cu ? n_cu : ntiles), block(QTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (out_f32) {
+        if (gelu) gemm_et_m32_kernel<PREC, true, true, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        else gemm_et_m32_kernel<PREC, true, false, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    } else {
+        if (gelu) gemm_et_m32_kernel<PREC, false, true, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        else gemm_et_m32_kernel<PREC, false, false, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    }
+    return hipGetLastError();
+}
+static bool m32_ok(int M, int N, int K, const float* add2d) {
+    return M % QBM == 0 && N % WBN == 0 && K % (2 * XBK) == 0 && K >= 2 * XBK && !add2d;
+}
+
 template <int PREC, int NI, int MODE>
 hipError_t launch_gemm_x64(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
@@ -2099,6 +2414,24 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         else if (!out_f32 && t320 >= 256 && t320 % 256 == 0) variant = (wide == 27 && !add2d) ? 28 : wide;
         else if (!out_f32 && N >= 2048 && t256 >= 1024) variant = 6;
         else variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
+    }
+    // 30 / 31: 32x32x16 symmetric-schedule kernel, persistent / one tile per block.  SAMRS_GEMM_M32=<mask> lets the automatic
+    // rule pick it for A/B runs of the whole loop: bit 0 = ET outputs (qkv, lin1), bit 1 = fp32 outputs (proj, lin2),
+    // bit 2 = one tile per block instead of persistent, bit 3 = spread pieces
+    static const int m32_mask = [] { const char* v = getenv("SAMRS_GEMM_M32"); return v ? atoi(v) : 0; }();
+    if ((variant == 27 || variant == 28) && m32_ok(M, N, K, add2d) && (m32_mask & (out_f32 ? 2 : 1)))
+        variant = 30 + ((m32_mask & 4) ? 1 : 0) + ((m32_mask & 8) ? 2 : 0);
+    if (variant >= 30 && variant <= 33 && !m32_ok(M, N, K, add2d)) variant = add2d ? 27 : 28;
+    if (variant >= 30 && variant <= 33) {     // 30 / 31: all pieces in step 3; 32 / 33: pieces spread over two steps
+        const bool pers = !(variant & 1);
+        if (variant < 32) {
+            if (prec == PREC_BF16) return launch_gemm_m32<PREC_BF16, 0>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, pers, s);
+            if (prec == PREC_F16) return launch_gemm_m32<PREC_F16, 0>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, pers, s);
+        } else {
+            if (prec == PREC_BF16) return launch_gemm_m32<PREC_BF16, 1>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, pers, s);
+            if (prec == PREC_F16) return launch_gemm_m32<PREC_F16, 1>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, pers, s);
+        }
+        return hipErrorInvalidValue;
     }
     if (variant == 28 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0 && !add2d) {   // persistent pair-stage kernel
         if (prec == PREC_BF16) return launch_gemm_x64p<PREC_BF16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, s);

@@ -170,6 +170,69 @@ def test_gemm_tile_variants_are_bit_identical(lib, name, prec, dt, ulp):
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("variant", [30, 31, 32, 33])
+def test_gemm_m32_kernel(lib, name, prec, dt, ulp, variant):
+    """The 32x32x16 symmetric-schedule kernel (30 persistent / 31 one tile per block; 32 / 33 with the DMA pieces spread over
+    two steps).  It sums k in 16-wide MFMA steps, so it is not bit-identical with the 16x16x32 tile family; it must agree with
+    it to fp32-summation-order accuracy (fp32 output: rel. L2 < 2e-6; ET output: <= 1 ulp apart, and only where the fp32 value
+    sits on a rounding boundary), with fp64 on the small shapes, and with ITSELF bit for bit across repeated launches (the race
+    screen: 2, 4, 6 and 80 stages, one to three tiles per block, the real proj / lin2 / qkv shapes of an 8-tile batch)."""
+    lib.samrs_debug_set_gemm_variant.argtypes = [__import__("ctypes").c_int]
+    shapes = [(256, 320, 128), (512, 640, 256), (8192, 3200, 256), (16384, 3840, 384), (32768, 1280, 1280)]
+    if variant == 30:
+        shapes += [(32768, 1280, 5120), (32768, 3840, 1280)]
+    try:
+        for (M, N, K) in shapes:
+            g = torch.Generator().manual_seed(M + N + K + variant)
+            A, Ab = et_bits(torch.randn(M, K, generator=g), dt)
+            B, Bb = et_bits(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
+            bias = dev(torch.randn(N, generator=g))
+            C0 = dev(torch.randn(M, N, generator=g))
+            Ad, Bd = dev(Ab), dev(Bb)
+
+            def run(v):
+                lib.samrs_debug_set_gemm_variant(v)
+                of = C0.clone()                                                       # fp32 out: bias + residual (proj / lin2)
+                oe = torch.full((M, N), 0x7E00, dtype=torch.int16, device="cuda")     # NaN canaries
+                og = torch.full((M, N), 0x7E00, dtype=torch.int16, device="cuda")
+                assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), of.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 1, 0, 1, stream()) == 0
+                assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), oe.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 0, 0, 0, stream()) == 0
+                assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), og.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 0, 1, 0, stream()) == 0
+                torch.cuda.synchronize()
+                return of, oe, og
+
+            rf, re_, rg = run(27)                     # the 16x16x32 pair-stage kernel
+            first = None
+            for rep in range(3):
+                of, oe, og = run(variant)
+                if first is None:
+                    first = (of, oe, og)
+                else:
+                    assert torch.equal(of, first[0]) and torch.equal(oe, first[1]) and torch.equal(og, first[2]), \
+                        f"{name} variant {variant} {M}x{N}x{K}: rep {rep} differs from rep 0 (race)"
+            of, oe, og = first
+            r = ((of - rf).double().norm() / rf.double().norm()).item()
+            mx = (of - rf).abs().max().item()
+            assert r < 2e-6 and mx < 1e-4 * math.sqrt(K / 128), f"{name} variant {variant} {M}x{N}x{K} fp32 out: rel {r:.2e} max {mx:.2e}"
+            for tag, o, ref in (("ET", oe, re_), ("GELU", og, rg)):
+                a, b = o.view(dt).float(), ref.view(dt).float()
+                assert torch.isfinite(a).all(), f"{name} variant {variant} {M}x{N}x{K} {tag}: untouched / non-finite outputs"
+                err = ((a - b).abs() / b.abs().clamp(min=1e-2)).max().item()
+                frac = (o != ref).float().mean().item()
+                assert err < 1.1 * ulp and frac < 2e-2, f"{name} variant {variant} {M}x{N}x{K} {tag}: max rel {err:.2e}, {frac:.2e} of the outputs differ"
+            if M * N * K <= 512 * 640 * 256:
+                ref = A.double() @ B.double().t() + bias.cpu().double()
+                r, _ = rel_err(of.cpu(), ref + C0.cpu().double())
+                assert r < 2e-6, f"{name} variant {variant} {M}x{N}x{K} vs fp64: {r:.2e}"
+                got = oe.cpu().view(dt).float()
+                err = ((got - ref.float()).abs() / ref.float().abs().clamp(min=1e-2)).max().item()
+                assert err < 1.5 * ulp, f"{name} variant {variant} {M}x{N}x{K} ET vs fp64: {err:.2e}"
+            print(f"m32 variant {variant} {name} {M}x{N}x{K}: fp32 rel {r:.2e}")
+    finally:
+        lib.samrs_debug_set_gemm_variant(8)
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
 @pytest.mark.parametrize("N", [256, 384])
 def test_gemm_k256_streaming_kernel_is_bit_identical(lib, name, prec, dt, ulp, N):
     """The decoder's image-side projections (rows = prompts x 4096 keys, K = 256, 2-D addend with period 4096): the persistent

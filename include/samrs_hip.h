@@ -164,6 +164,10 @@ void samrs_debug_set_gemm_skew(int xcd_units, int cu_units);
 /* test / timing hook: 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm / product launches) */
 void samrs_debug_set_decoder_fusion(int on);
 
+/* test / timing hook: 0 = run the ViT-H encoder blocks with stand-alone LayerNorm launches instead of the LayerNorm folded
+ * into the qkv / lin1 GEMMs (default on for embed_dim 1280; SAMRS_LN_FOLD=0 at load time does the same) */
+void samrs_debug_set_ln_fold(int on);
+
 /* -- test hook: copy a prefix of a named internal decoder buffer (Q, KF, KE, KVQ, OI, U1raw, U1, U2,
  * HYPER, ...) to a device buffer; used to localise run-to-run differences. */
 int samrs_debug_copy_buffer(samrs_engine_t* e, const char* name, void* dst, size_t bytes, void* stream);
@@ -191,6 +195,20 @@ int samrs_k_gemm(int prec, const void* A_et, const void* B_et, void* C, const fl
                  int out_f32, int gelu, int accumulate, void* stream);
 int samrs_k_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C, int ldc,
                      int M, int N, int K, int relu, int accumulate, void* stream);
+/* LayerNorm folded into the neighbouring GEMMs of an encoder block (image_encoder.py:168,177; residual stream of 1280 columns):
+ *   samrs_k_gemm_stats       C (fp32) += A_et B_et^T + bias;  xh_et = ET(C);  stats[m][8] = (mean, sum of squared deviations)
+ *                            of eight 160-element groups of row m.  M % 256 == 0, N == 1280, K % 128 == 0.
+ *   samrs_k_gemm_fold        C_et = [GELU](rstd_m (xh_et Wf_et^T - mean_m cvec) + bias_f), (mean_m, rstd_m) merged from stats[m][.]
+ *                            with eps.  M % 256 == 0, N % 320 == 0, K == 1280.
+ *   samrs_k_ln_fold_weight   Wf_et = ET(W diag(gamma)), cvec[n] = sum_k Wf_et[n][k], bias_f = bias + W beta  (W fp32 [N][K])
+ *   samrs_k_rowstats_convert xh_et = ET(X), stats as above, for X fp32 [rows][1280] */
+int samrs_k_gemm_stats(int prec, const void* A_et, const void* B_et, float* C, const float* bias, void* xh_et, float* stats,
+                       int M, int N, int K, void* stream);
+int samrs_k_gemm_fold(int prec, const void* xh_et, const void* Wf_et, void* C_et, const float* bias_f, const float* cvec,
+                      const float* stats, float eps, int M, int N, int K, int gelu, void* stream);
+int samrs_k_ln_fold_weight(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_et,
+                           float* cvec, float* bias_f, int N, int K, void* stream);
+int samrs_k_rowstats_convert(int prec, const float* X, void* xh_et, float* stats, int rows, int D, void* stream);
 int samrs_k_convert(int prec, const float* in, void* out_et, int64_t n, void* stream);
 int samrs_k_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                       void* out_et, float* out_f32, int rows_out, int D, int window_mode,

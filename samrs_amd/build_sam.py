@@ -98,6 +98,10 @@ def build_sam_vit_tiny80(checkpoint=None, **kw):
     return _build_sam("vit_tiny80", checkpoint, **kw)
 
 
+def build_sam_vit_tiny1280(checkpoint=None, **kw):
+    return _build_sam("vit_tiny1280", checkpoint, **kw)
+
+
 build_sam = build_sam_vit_h
 
 sam_model_registry = {
@@ -107,4 +111,5 @@ sam_model_registry = {
     "vit_b": build_sam_vit_b,
     "vit_tiny": build_sam_vit_tiny,
     "vit_tiny80": build_sam_vit_tiny80,
+    "vit_tiny1280": build_sam_vit_tiny1280,
 }

@@ -1059,6 +1059,90 @@ hipError_t launch_convert(int prec, const float* in, void* out, long n, hipStrea
     return hipGetLastError();
 }
 
+// -----------------------------------------------------------------------------------------
+// LayerNorm folded into the GEMM behind it (ViT-H encoder blocks; image_encoder.py:168,177 + 227 / common.py:25):
+//     LN(x) W^T + b = rstd (x (W diag(gamma))^T - mean c) + (b + W beta),   c_n = sum_k (W diag(gamma))_nk
+// ln_fold_weight_kernel prepares one output row n per block, once at load: Wf = ET(W diag(gamma)), c_n summed over the
+// ROUNDED Wf (so that the mean term cancels exactly what the MFMA adds up), bias_f in double.
+// -----------------------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(256) void ln_fold_weight_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ bias,
+                                                             uint16_t* __restrict__ Wf, float* __restrict__ cvec,
+                                                             float* __restrict__ bias_f, int K) {
+    __shared__ double red[2][256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    double cs = 0.0, bs = 0.0;
+    for (int k = tid; k < K; k += 256) {
+        const float w = W[(size_t)n * K + k];
+        const uint16_t u = ET<PREC>::from_float(w * gamma[k]);
+        Wf[(size_t)n * K + k] = u;
+        cs += (double)ET<PREC>::to_float(u);
+        bs += (double)w * (double)beta[k];
+    }
+    red[0][tid] = cs;
+    red[1][tid] = bs;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) { red[0][tid] += red[0][tid + st]; red[1][tid] += red[1][tid + st]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        cvec[n] = (float)red[0][0];
+        bias_f[n] = (float)((double)(bias ? bias[n] : 0.f) + red[1][0]);
+    }
+}
+
+hipError_t launch_ln_fold_weight(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf,
+                                 float* cvec, float* bias_f, int N, int K, hipStream_t s) {
+    if (N < 1 || K < 1) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) ln_fold_weight_kernel<PREC_BF16><<<N, 256, 0, s>>>(W, gamma, beta, bias, (uint16_t*)Wf, cvec, bias_f, K);
+    else ln_fold_weight_kernel<PREC_F16><<<N, 256, 0, s>>>(W, gamma, beta, bias, (uint16_t*)Wf, cvec, bias_f, K);
+    return hipGetLastError();
+}
+
+// Entry of the folded path (the residual stream as the patch-embed GEMM left it): Xh = ET(X) and, per row, the (mean, M2) pairs
+// of eight 160-element groups -- the same partials the residual GEMMs emit (gemm.hip, epilogue_m32<STATS>; the merge does not
+// care WHICH 160 elements form a group).  One wave per row of 1280: lane l holds float4 l, l + 64, ... (20 values), a group =
+// 8 consecutive lanes, two-pass inside the group.
+template <int PREC>
+__global__ __launch_bounds__(256) void rowstats_convert_kernel(const float* __restrict__ X, uint16_t* __restrict__ Xh,
+                                                               float2* __restrict__ stats, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(X + (size_t)row * 1280);
+    float4 v[5];
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        v[i] = xr[lane + 64 * i];
+        sm += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        uint2 o;
+        o.x = pack2<PREC>(v[i].x, v[i].y);
+        o.y = pack2<PREC>(v[i].z, v[i].w);
+        reinterpret_cast<uint2*>(Xh + (size_t)row * 1280)[lane + 64 * i] = o;
+    }
+    sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+    const float gm = sm * (1.0f / 160.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float a = v[i].x - gm, b = v[i].y - gm, c = v[i].z - gm, d = v[i].w - gm;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+    if ((lane & 7) == 0) stats[(size_t)row * 8 + (lane >> 3)] = make_float2(gm, q);
+}
+
+hipError_t launch_rowstats_convert(int prec, const float* X, void* Xh, float* stats, int rows, int D, hipStream_t s) {
+    if (D != 1280 || rows < 1) return hipErrorInvalidValue;
+    const int blocks = (rows + 3) / 4;
+    if (prec == PREC_BF16) rowstats_convert_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(X, (uint16_t*)Xh, reinterpret_cast<float2*>(stats), rows);
+    else rowstats_convert_kernel<PREC_F16><<<blocks, 256, 0, s>>>(X, (uint16_t*)Xh, reinterpret_cast<float2*>(stats), rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
                             int window, hipStream_t s) {

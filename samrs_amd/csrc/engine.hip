@@ -49,7 +49,14 @@ struct EncBlock {
     bool global = false;
     const float *ln1w, *ln1b, *ln2w, *ln2b, *qkv_b, *proj_b, *lin1_b, *lin2_b, *rel_h, *rel_w;
     uint16_t *qkv_w = nullptr, *proj_w = nullptr, *lin1_w = nullptr, *lin2_w = nullptr;
+    // LayerNorm folded into qkv / lin1 (ViT-H): W diag(gamma) in ET, its row sums, b + W beta
+    uint16_t *qkv_wf = nullptr, *lin1_wf = nullptr;
+    float *qkv_c = nullptr, *qkv_bf = nullptr, *lin1_c = nullptr, *lin1_bf = nullptr;
 };
+
+// LayerNorm folding (encoder blocks, embed_dim 1280 only): run-time switch for A/B runs and the folded-vs-unfolded parity
+// test (samrs_debug_set_ln_fold), load-time default SAMRS_LN_FOLD (on).
+static bool g_ln_fold = [] { const char* v = getenv("SAMRS_LN_FOLD"); return !(v && atoi(v) == 0); }();
 
 }  // namespace
 
@@ -70,7 +77,9 @@ struct samrs_engine {
     std::vector<EncBlock> blocks;
     uint16_t *patch_w = nullptr, *neck0_w = nullptr, *neck2_w = nullptr;
     float* X = nullptr;            // residual stream fp32 [Bi*tokens, D]
-    uint16_t* Y = nullptr;         // LN out (ET) [Bi*tokens, D]
+    uint16_t* Y = nullptr;         // LN out (ET) [Bi*tokens, D]; folded path: the residual stream itself rounded to ET
+    float* STATS = nullptr;        // folded path: per-row (mean, M2) of eight 160-column groups [Bi*tokens][8][2]
+    bool can_fold = false;         // embed_dim == 1280 and the folded weights exist
     uint16_t* QKV = nullptr;       // [Bi*tokens, 3D], token order
     uint16_t* AO = nullptr;        // attention out [Bi*tokens, D]
     uint16_t* VTG = nullptr;       // V of a global-attention block transposed per head: [Bi][heads][hd][tokens]
@@ -378,6 +387,17 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
         const std::string p = "image_encoder.blocks." + std::to_string(i);
         EncBlock& b = e->blocks[i];
         b.global = is_global(c, i);
+        b.ln1w = W(e, p + ".norm1.weight"); b.ln1b = W(e, p + ".norm1.bias");
+        b.ln2w = W(e, p + ".norm2.weight"); b.ln2b = W(e, p + ".norm2.bias");
+        if (D == 1280) {       // folded LayerNorm needs the fp32 weights: before to_et() frees them
+            CK(e, dalloc(e, &b.qkv_wf, (size_t)3 * D * D)); CK(e, dalloc(e, &b.qkv_c, (size_t)3 * D)); CK(e, dalloc(e, &b.qkv_bf, (size_t)3 * D));
+            CK(e, dalloc(e, &b.lin1_wf, (size_t)4 * D * D)); CK(e, dalloc(e, &b.lin1_c, (size_t)4 * D)); CK(e, dalloc(e, &b.lin1_bf, (size_t)4 * D));
+            CK(e, launch_ln_fold_weight(e->prec, W(e, p + ".attn.qkv.weight"), b.ln1w, b.ln1b, W(e, p + ".attn.qkv.bias"), b.qkv_wf,
+                                        b.qkv_c, b.qkv_bf, 3 * D, D, s));
+            CK(e, launch_ln_fold_weight(e->prec, W(e, p + ".mlp.lin1.weight"), b.ln2w, b.ln2b, W(e, p + ".mlp.lin1.bias"), b.lin1_wf,
+                                        b.lin1_c, b.lin1_bf, 4 * D, D, s));
+            e->can_fold = true;
+        }
         if ((rc = to_et(e, p + ".attn.qkv.weight", &b.qkv_w, true, s))) return rc;
         if ((rc = to_et(e, p + ".attn.proj.weight", &b.proj_w, true, s))) return rc;
         if ((rc = to_et(e, p + ".mlp.lin1.weight", &b.lin1_w, true, s))) return rc;
@@ -454,6 +474,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->X, M * D));
     CK(e, dalloc(e, &e->Y, Mmax * D));
     CK(e, hipMemsetAsync(e->Y, 0, Mmax * D * 2, s));
+    if (e->can_fold) CK(e, dalloc(e, &e->STATS, Mmax * 16));
     CK(e, dalloc(e, &e->QKV, Mmax * 3 * D));
     CK(e, dalloc(e, &e->AO, M * D));
     CK(e, dalloc(e, &e->VTG, M * D));
@@ -517,18 +538,31 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     }
     CK(e, launch_gemm_et(prec, e->H, e->patch_w, e->X, W(e, "image_encoder.patch_embed.proj.bias"),
                          W(e, "image_encoder.pos_embed"), tokens, M, D, 3 * c.patch_size * c.patch_size, true, false, false, s));
+    // Folded LayerNorm (embed_dim 1280): no LayerNorm launches inside the blocks.  Y holds the residual stream rounded to ET and
+    // STATS its per-row partial statistics, both written by the epilogue of the GEMM that produced X (proj, lin2; here, once,
+    // by rowstats_convert); qkv / lin1 run on the gamma-folded weights and normalise in their epilogue (gemm.hip).
+    const bool fold = e->can_fold && g_ln_fold;
+    if (fold && n_blocks > 0) CK(e, launch_rowstats_convert(prec, e->X, e->Y, e->STATS, M, D, s));
     for (int i = 0; i < c.depth && i < n_blocks; ++i) {
         const EncBlock& b = e->blocks[i];
         // norm1 + qkv in plain token order for both block kinds; the windowed kernel partitions
         // on the fly and takes k / v of padding positions from the qkv bias
-        CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
-        CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
+        if (fold) {
+            CK(e, launch_gemm_et_fold(prec, e->Y, b.qkv_wf, e->QKV, b.qkv_bf, b.qkv_c, e->STATS, 1e-6f, M, 3 * D, D, false, s));
+        } else {
+            CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
+            CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
+        }
         if (!b.global)
             CK(e, launch_window_attention(prec, e->QKV, b.qkv_b, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s));
         else
             CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, e->VTG, s));
-        CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
-        CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
+        if (fold) {
+            CK(e, launch_gemm_et_stats(prec, e->AO, b.proj_w, e->X, b.proj_b, e->Y, e->STATS, M, D, D, s));
+        } else {
+            CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
+            CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
+        }
         hipEvent_t t0 = nullptr, t1 = nullptr;
         if (e->timing) {
             auto get = [&](hipEvent_t* ev) -> hipError_t {
@@ -538,16 +572,18 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, get(&t0)); CK(e, get(&t1));
             CK(e, hipEventRecord(t0, s));
         }
-        CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
+        if (fold) CK(e, launch_gemm_et_fold(prec, e->Y, b.lin1_wf, e->H, b.lin1_bf, b.lin1_c, e->STATS, 1e-6f, M, 4 * D, D, true, s));
+        else CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
         if (e->timing) {
             CK(e, hipEventRecord(t1, s));
             e->tev.emplace_back(t0, t1);
         }
-        CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
+        if (fold) CK(e, launch_gemm_et_stats(prec, e->H, b.lin2_w, e->X, b.lin2_b, e->Y, e->STATS, M, D, 4 * D, s));
+        else CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
     }
     if (!do_neck) return SAMRS_OK;
-    // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d   (all channels-last)
-    CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s));
+    // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d   (all channels-last).  Folded path: Y already is ET(X).
+    if (!(fold && c.depth > 0 && n_blocks >= c.depth)) CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s));
     CK(e, launch_gemm_et(prec, e->Y, e->neck0_w, e->N1, nullptr, nullptr, 0, M, C, D, true, false, false, s));
     CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.1.weight"), W(e, "image_encoder.neck.1.bias"), 1e-6f,
                            e->N1e, nullptr, M, C, 0, g, 0, s));
@@ -827,6 +863,7 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
 void samrs_debug_set_gemm_variant(int v) { set_gemm_variant(v); }
 void samrs_debug_set_gemm_skew(int xcd_units, int cu_units) { set_gemm_skew(xcd_units, cu_units); }
 void samrs_debug_set_decoder_fusion(int on) { g_decoder_fusion = on != 0; }
+void samrs_debug_set_ln_fold(int on) { g_ln_fold = on != 0; }
 
 // test hook: copy (a prefix of) a named internal decoder buffer to a caller device buffer
 int samrs_debug_copy_buffer(samrs_engine_t* e, const char* name, void* dst, size_t bytes, void* stream) {
@@ -882,6 +919,21 @@ int samrs_debug_dominant_kernel_time(samrs_engine_t* e, float* avg_ms, int* laun
 int samrs_k_gemm(int prec, const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                  int M, int N, int K, int out_f32, int gelu, int accumulate, void* stream) {
     KRET(launch_gemm_et(prec, A, B, C, bias, add2d, period, M, N, K, out_f32 != 0, gelu != 0, accumulate != 0, (hipStream_t)stream));
+}
+int samrs_k_gemm_stats(int prec, const void* A, const void* B, float* C, const float* bias, void* xh, float* stats, int M, int N,
+                       int K, void* stream) {
+    KRET(launch_gemm_et_stats(prec, A, B, C, bias, xh, stats, M, N, K, (hipStream_t)stream));
+}
+int samrs_k_gemm_fold(int prec, const void* xh, const void* Wf, void* C, const float* bias_f, const float* cvec, const float* stats,
+                      float eps, int M, int N, int K, int gelu, void* stream) {
+    KRET(launch_gemm_et_fold(prec, xh, Wf, C, bias_f, cvec, stats, eps, M, N, K, gelu != 0, (hipStream_t)stream));
+}
+int samrs_k_ln_fold_weight(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, float* cvec,
+                           float* bias_f, int N, int K, void* stream) {
+    KRET(launch_ln_fold_weight(prec, W, gamma, beta, bias, Wf, cvec, bias_f, N, K, (hipStream_t)stream));
+}
+int samrs_k_rowstats_convert(int prec, const float* X, void* xh, float* stats, int rows, int D, void* stream) {
+    KRET(launch_rowstats_convert(prec, X, xh, stats, rows, D, (hipStream_t)stream));
 }
 int samrs_k_gemm_f32(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M, int N, int K,
                      int relu, int accumulate, void* stream) {

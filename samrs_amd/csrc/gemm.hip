@@ -381,11 +381,14 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
 // Block-wide barriers: all 8 waves are past the main loop here (the stagger has been re-aligned).
 //   acc[i][j]: n-tile i (16 cols), m-tile j (16 rows); 8 m-tiles, 4 per pass.
 // ---------------------------------------------------------------------------------------------
-template <int PREC, bool GELU, int JC = 4, bool DRAIN = false>
+// FOLD (LayerNorm folded into this GEMM, see gemm_et_x64p_kernel): the value is rstd_m * acc + (-rstd_m mean_m) * cvec_n +
+// bias_n with (rstd_m, -rstd_m mean_m) = rowstat[tile row] (LDS) instead of acc + bias_n.
+template <int PREC, bool GELU, int JC = 4, bool DRAIN = false, bool FOLD = false>
 __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned char* lds, void* __restrict__ Cv,
                                                  const float* __restrict__ bias, const float* __restrict__ pre2d, int period, int N,
                                                  int m_base /* wave tile row 0 */, int n_pair /* first column of the pair */,
-                                                 int wm, int wn, int lane) {
+                                                 int wm, int wn, int lane, const float2* rowstat = nullptr /* LDS, FOLD */,
+                                                 const float* __restrict__ cvec = nullptr /* FOLD */) {
     constexpr int RS = 400;                 // 320 data bytes + pad: 100 words = 4 (mod 32)
     constexpr int TS = 16 * RS;
     const int fr = lane & 15, fq = lane >> 4, half = wn & 1;
@@ -400,10 +403,17 @@ __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned 
 #pragma unroll
         for (int jj = 0; jj < JC; ++jj) {
             const int j = j0 + jj;
+            float2 rs = make_float2(1.f, 0.f);
+            if constexpr (FOLD) rs = rowstat[wm * 128 + j * 16 + fr];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
                 float v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+                if constexpr (FOLD) {
+                    const float4 cv = *reinterpret_cast<const float4*>(cvec + n_pair + half * 80 + i * 16 + 4 * fq);
+                    v0 = fmaf(rs.x, acc[i][j][0], fmaf(rs.y, cv.x, bv[i].x)); v1 = fmaf(rs.x, acc[i][j][1], fmaf(rs.y, cv.y, bv[i].y));
+                    v2 = fmaf(rs.x, acc[i][j][2], fmaf(rs.y, cv.z, bv[i].z)); v3 = fmaf(rs.x, acc[i][j][3], fmaf(rs.y, cv.w, bv[i].w));
+                }
                 if (pre2d) {
                     const float4 e = *reinterpret_cast<const float4*>(pre2d + (size_t)((m_base + j * 16 + fr) % period) * N + n_pair +
                                                                       half * 80 + i * 16 + 4 * fq);
@@ -1188,10 +1198,22 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
 // next tile's main loop starts right after the epilogue, with its stage 0 already in LDS.  Main loop = the kernel above.
 // add2d is not supported (the encoder's four big GEMMs have none).
 // ---------------------------------------------------------------------------------------------
-template <int PREC, bool OUT_F32, bool GELU>
+//
+// FOLD: the LayerNorm in front of this GEMM (image_encoder.py:168,177) folded into it.  A = the raw residual stream rounded to
+// ET (written by the GEMM that produced it, gemm_et_m32_kernel<STATS>), B = W diag(gamma) rounded to ET, cvec_n = sum_k of
+// that B row, bias_n = b_n + sum_k W_nk beta_k:
+//     LN(x) W^T + b  =  rstd (x W'^T - mean cvec) + bias'
+// The per-row (mean, M2) partials of the LN_NS 160-column groups of a row are merged (Chan) in a fixed order by the first 256
+// threads at the start of every tile into (rstd, -rstd mean) in LDS; only the ET epilogue reads them.
+constexpr int LN_NS = 8;                       // 1280 / 160: ViT-H only
+
+template <int PREC, bool OUT_F32, bool GELU, bool FOLD = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
-    const float* __restrict__ bias, int M, int N, int K, int accumulate) {
+    const float* __restrict__ bias, int M, int N, int K, int accumulate,
+    const float2* __restrict__ stats = nullptr, const float* __restrict__ cvec = nullptr, float eps = 0.f) {
+    static_assert(!(FOLD && OUT_F32), "the folded LayerNorm feeds ET outputs only (qkv, lin1)");
+    __shared__ float2 rowstat[FOLD ? QBM : 1];
     constexpr int NI = 5;
     constexpr int XBN = 64 * NI;
     constexpr int XROWS = QBM + XBN;
@@ -1320,10 +1342,32 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
             sB = B + (size_t)n1 * K;
             X64P_ISSUE(0, 0u);
         }
+        if constexpr (FOLD) {
+            // row statistics of this tile's 256 rows -> LDS.  The loads sit where the epilogue's bias loads sit: behind the DMA
+            // pieces just issued (in-order vmcnt), whose landing the first bounce waits for anyway.
+            if (tid < QBM) {
+                const float4* sp = reinterpret_cast<const float4*>(stats + (size_t)(m0 + tid) * LN_NS);
+                float4 q[LN_NS / 2];
+#pragma unroll
+                for (int h = 0; h < LN_NS / 2; ++h) q[h] = sp[h];
+                float mean = q[0].x, m2 = q[0].y;
+#pragma unroll
+                for (int g = 1; g < LN_NS; ++g) {                    // Chan merge of equal-size groups, fixed order
+                    const float gm = (g & 1) ? q[g >> 1].z : q[g >> 1].x, gq = (g & 1) ? q[g >> 1].w : q[g >> 1].y;
+                    const float d = gm - mean;
+                    mean += d * (1.0f / (g + 1));
+                    m2 += gq + d * d * (160.0f * g / (g + 1));
+                }
+                const float rstd = 1.0f / sqrtf(m2 * (1.0f / (160.0f * LN_NS)) + eps);
+                rowstat[tid] = make_float2(rstd, -rstd * mean);
+            }
+            __syncthreads();
+        }
         {   // epilogue of tile (m0, n0); bounce scratch = ring buffer 1 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
             unsigned char* upper = reinterpret_cast<unsigned char*>(lds) + XSB;
             if constexpr (!OUT_F32) {
-                epilogue_pair_et<PREC, GELU, 2, true>(acc, upper, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + (wn >> 1) * 160, wm, wn, lane);
+                epilogue_pair_et<PREC, GELU, 2, true, FOLD>(acc, upper, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + (wn >> 1) * 160, wm, wn, lane,
+                                                            rowstat, cvec);
             } else {
                 epilogue_coalesced<PREC, true, GELU, 8, 1, NI, false, true>(acc, upper + wave * (XSB / 8), Cv, bias, nullptr, 1, N,
                                                                            m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane);
@@ -1399,16 +1443,23 @@ constexpr int M32_RS = 144;                   // scratch row stride (bytes): 128
 // Epilogue of one wave tile: acc[i][j] = 32 (n) x 32 (m) block, lane (m = l & 31, h = l >> 5) holds n = 8 g + 4 h + 0..3
 // for g = 0..3 in registers 4 g .. 4 g + 3.  Bounce through `scr` (wave-private, 32 rows x M32_RS bytes) so that the global
 // accesses are whole 128-byte row segments, 8 rows per instruction.
-template <int PREC, bool OUT_F32, bool GELU>
+// STATS (fp32 output = the residual stream; the LayerNorm that follows is folded into the next GEMM, gemm_et_x64p_kernel<FOLD>):
+// besides C the final values are written rounded to ET into Xh (same [M][N] shape), and stats[m][n_base / 160] receives
+// (mean, M2 = sum of squared deviations) of the wave's 160 columns of row m.  In the read-out a row's 32 columns of a pass sit
+// in 8 consecutive lanes: group mean / M2 by three xor-shuffles each (two-pass inside the group), merged into the running
+// pair over the five passes by Chan's update -- no E[x^2] - mean^2 cancellation, fixed order, bit-reproducible.
+template <int PREC, bool OUT_F32, bool GELU, bool STATS = false>
 __device__ __forceinline__ void epilogue_m32(f32x16_t (&acc)[5][2], unsigned char* scr, void* __restrict__ Cv,
                                              const float* __restrict__ bias, int N, int m_base, int n_base, int wn,
-                                             int accumulate, int lane) {
+                                             int accumulate, int lane, uint16_t* __restrict__ Xh = nullptr,
+                                             float2* __restrict__ stats = nullptr) {
     const int l31 = lane & 31, h = lane >> 5;
     if constexpr (OUT_F32) {
         float* C = reinterpret_cast<float*>(Cv);
         bool first = true;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            float rmean[4], rm2[4];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 // the residual (old C) does not depend on the accumulators: its loads go out first
@@ -1435,9 +1486,36 @@ __device__ __forceinline__ void epilogue_m32(f32x16_t (&acc)[5][2], unsigned cha
                     const int idx = lane + 64 * p, row = idx >> 3, ch = idx & 7;
                     float4 v = *reinterpret_cast<const float4*>(scr + row * M32_RS + ch * 16);
                     v.x += res[p].x; v.y += res[p].y; v.z += res[p].z; v.w += res[p].w;
-                    *reinterpret_cast<float4*>(C + (size_t)(m_base + j * 32 + row) * N + n_base + i * 32 + ch * 4) = v;
+                    const size_t o = (size_t)(m_base + j * 32 + row) * N + n_base + i * 32 + ch * 4;
+                    *reinterpret_cast<float4*>(C + o) = v;
+                    if constexpr (STATS) {
+                        uint2 e;
+                        e.x = pack2<PREC>(v.x, v.y);
+                        e.y = pack2<PREC>(v.z, v.w);
+                        *reinterpret_cast<uint2*>(Xh + o) = e;
+                        float sm = (v.x + v.y) + (v.z + v.w);
+                        sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                        const float gm = sm * (1.0f / 32.0f);
+                        const float d0 = v.x - gm, d1 = v.y - gm, d2 = v.z - gm, d3 = v.w - gm;
+                        float gq = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                        gq += __shfl_xor(gq, 1, 64); gq += __shfl_xor(gq, 2, 64); gq += __shfl_xor(gq, 4, 64);
+                        if (i == 0) { rmean[p] = gm; rm2[p] = gq; }
+                        else {
+                            const float d = gm - rmean[p];
+                            rmean[p] += d * (1.0f / (i + 1));
+                            rm2[p] += gq + d * d * (32.0f * i / (i + 1));
+                        }
+                    }
                 }
             }
+            if constexpr (STATS) {
+                if ((lane & 7) == 0) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        stats[(size_t)(m_base + j * 32 + (lane >> 3) + 8 * p) * (N / 160) + n_base / 160] = make_float2(rmean[p], rm2[p]);
+                }
+            }
+        }
     } else {
         uint16_t* C = reinterpret_cast<uint16_t*>(Cv);
         // one pass = n-tiles [I0, I0 + CNT): CNT * 64 bytes per row.  The wave's 320-byte row segment starts on a 128-byte
@@ -1489,10 +1567,12 @@ __device__ __forceinline__ void glds16_m(uint32_t voff, const void* sbase, uint3
 
 // SPREAD: 0 = the 9 DMA pieces of a stage all go out in step 3 (one behind each of the first 9 MFMAs); 1 = pieces 0-4 in
 // step 3 and pieces 5-8 in step 0 of the following stage (fewer fillers per gap, one step less in flight)
-template <int PREC, bool OUT_F32, bool GELU, int SPREAD>
+template <int PREC, bool OUT_F32, bool GELU, int SPREAD, bool STATS = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_m32_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
-    const float* __restrict__ bias, int M, int N, int K, int accumulate) {
+    const float* __restrict__ bias, int M, int N, int K, int accumulate,
+    uint16_t* __restrict__ Xh = nullptr, float2* __restrict__ stats = nullptr) {
+    static_assert(!STATS || (OUT_F32 && !GELU), "row statistics accompany the fp32 residual output only");
     constexpr int NI = 5, NJ = 2;
     constexpr int XBN = 32 * NI * 2;                       // 320
     constexpr int XROWS = QBM + XBN;
@@ -1636,7 +1716,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_m32_kernel(
         // all fragment reads of this tile are complete (B_nst-1); buffer 1 held its last stage -> scratch
         {
             unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + XSB + wave * (XSB / 8);
-            epilogue_m32<PREC, OUT_F32, GELU>(acc, scr, Cv, bias, N, m0 + wm * 64, n0 + wn * 160, wn, accumulate, lane);
+            epilogue_m32<PREC, OUT_F32, GELU, STATS>(acc, scr, Cv, bias, N, m0 + wm * 64, n0 + wn * 160, wn, accumulate, lane, Xh, stats);
         }
         if (!more) break;
         __builtin_amdgcn_s_barrier();              // every wave is done with its scratch before stage 1 of the next tile lands there
@@ -1672,6 +1752,37 @@ hipError_t launch_gemm_m32(const void* A, const void* B, void* C, const float* b
         if (gelu) gemm_et_m32_kernel<PREC, false, true, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
         else gemm_et_m32_kernel<PREC, false, false, SPREAD><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     }
+    return hipGetLastError();
+}
+// producer of the folded LayerNorm: C = A B^T + bias + C (fp32), Xh = ET(C), stats[m][N / 160] = (mean, M2) per 160 columns
+template <int PREC>
+hipError_t launch_gemm_m32_stats(const void* A, const void* B, float* C, const float* bias, void* Xh, float* stats,
+                                 int M, int N, int K, int spread, hipStream_t s) {
+    const int ntiles = (M / QBM) * (N / WBN);
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    dim3 grid(ntiles > n_cu ? n_cu : ntiles), block(QTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    if (spread) gemm_et_m32_kernel<PREC, true, false, 1, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 1, reinterpret_cast<uint16_t*>(Xh), reinterpret_cast<float2*>(stats));
+    else gemm_et_m32_kernel<PREC, true, false, 0, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 1, reinterpret_cast<uint16_t*>(Xh), reinterpret_cast<float2*>(stats));
+    return hipGetLastError();
+}
+// consumer: C (ET) = [GELU](rstd (Xh Wf^T - mean cvec) + bias_f) on the persistent pair-stage kernel
+template <int PREC>
+hipError_t launch_gemm_x64p_fold(const void* A, const void* B, void* C, const float* bias, const float* cvec, const float* stats,
+                                 float eps, int M, int N, int K, bool gelu, hipStream_t s) {
+    const int ntiles = (M / QBM) * (N / WBN);
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_cu <= 0) n_cu = 256;
+    dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(QTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const float2* st = reinterpret_cast<const float2*>(stats);
+    if (gelu) gemm_et_x64p_kernel<PREC, false, true, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, st, cvec, eps);
+    else gemm_et_x64p_kernel<PREC, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, st, cvec, eps);
     return hipGetLastError();
 }
 static bool m32_ok(int M, int N, int K, const float* add2d) {
@@ -2483,6 +2594,23 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     }
     if (prec == PREC_BF16) { GEMM_DISPATCH(PREC_BF16) }
     if (prec == PREC_F16) { GEMM_DISPATCH(PREC_F16) }
+    return hipErrorInvalidValue;
+}
+
+// LayerNorm folded into the neighbouring GEMMs (ViT-H: the residual stream has N = 1280 = LN_NS x 160 columns).
+hipError_t launch_gemm_et_stats(int prec, const void* A, const void* B, float* C, const float* bias, void* Xh, float* stats,
+                                int M, int N, int K, hipStream_t s) {
+    if (!m32_ok(M, N, K, nullptr) || N != 160 * LN_NS || !Xh || !stats) return hipErrorInvalidValue;
+    static const int spread = [] { const char* v = getenv("SAMRS_GEMM_M32"); return v ? ((atoi(v) & 8) ? 1 : 0) : 1; }();
+    if (prec == PREC_BF16) return launch_gemm_m32_stats<PREC_BF16>(A, B, C, bias, Xh, stats, M, N, K, spread, s);
+    if (prec == PREC_F16) return launch_gemm_m32_stats<PREC_F16>(A, B, C, bias, Xh, stats, M, N, K, spread, s);
+    return hipErrorInvalidValue;
+}
+hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C, const float* bias_f, const float* cvec,
+                               const float* stats, float eps, int M, int N, int K, bool gelu, hipStream_t s) {
+    if (M % QBM || N % WBN || K != 160 * LN_NS || !bias_f || !cvec || !stats) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) return launch_gemm_x64p_fold<PREC_BF16>(Xh, Wf, C, bias_f, cvec, stats, eps, M, N, K, gelu, s);
+    if (prec == PREC_F16) return launch_gemm_x64p_fold<PREC_F16>(Xh, Wf, C, bias_f, cvec, stats, eps, M, N, K, gelu, s);
     return hipErrorInvalidValue;
 }
 

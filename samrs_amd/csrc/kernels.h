@@ -10,6 +10,13 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
 // C (ET) = GELU(LayerNorm2d over every 64-column group of (A B^T + bias)), eps 1e-6; gamma_beta = gamma[64] | beta[64]
 hipError_t launch_gemm_et_gln(int prec, const void* A, const void* B, void* C, const float* bias, const float* gamma_beta,
                               int M, int N, int K, hipStream_t s);
+// LayerNorm folded into the neighbouring GEMMs (residual stream of N = 1280 columns):
+//   producer  C (fp32) += A B^T + bias;  Xh = ET(C);  stats[m][N / 160] = (mean, sum of squared deviations) per 160 columns
+//   consumer  C (ET) = [GELU](rstd_m (Xh Wf^T - mean_m cvec) + bias_f), (mean_m, rstd_m) merged from stats[m][.] with eps
+hipError_t launch_gemm_et_stats(int prec, const void* A, const void* B, float* C, const float* bias, void* Xh, float* stats,
+                                int M, int N, int K, hipStream_t s);
+hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C, const float* bias_f, const float* cvec,
+                               const float* stats, float eps, int M, int N, int K, bool gelu, hipStream_t s);
 void set_gemm_variant(int v);   // 0 = register-staged tiles, 1 = LDS-DMA staging (default)
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
@@ -30,6 +37,10 @@ hipError_t launch_gemm_f32_batch(const F32Batch& bt, int count, int lda, int ldc
 hipError_t launch_patch_im2col(int prec, const uint8_t* img, void* A, int n_images, int in_h, int in_w,
                                int grid, int patch, hipStream_t s);
 hipError_t launch_convert(int prec, const float* in, void* out, long n, hipStream_t s);
+// folded LayerNorm (ViT-H): weight preparation (once) and the entry of the folded path (Xh = ET(X) + per-row partial statistics)
+hipError_t launch_ln_fold_weight(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf,
+                                 float* cvec, float* bias_f, int N, int K, hipStream_t s);
+hipError_t launch_rowstats_convert(int prec, const float* X, void* Xh, float* stats, int rows, int D, hipStream_t s);
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
                             int window, hipStream_t s);

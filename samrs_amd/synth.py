@@ -63,6 +63,8 @@ CONFIGS: Dict[str, SamConfig] = {
     "vit_tiny": SamConfig("vit_tiny", 128, 2, 2, (1,)),
     # head_dim 80 like ViT-H (the awkward MFMA K size); width 640 keeps every GEMM dim a multiple of 128.
     "vit_tiny80": SamConfig("vit_tiny80", 640, 2, 8, (1,)),
+    # ViT-H's width (1280 = the embed_dim whose LayerNorms the engine folds into the qkv / lin1 GEMMs), head_dim 80, two blocks.
+    "vit_tiny1280": SamConfig("vit_tiny1280", 1280, 2, 16, (1,)),
 }
 
 

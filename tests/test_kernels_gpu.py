@@ -178,7 +178,7 @@ def test_gemm_m32_kernel(lib, name, prec, dt, ulp, variant):
     sits on a rounding boundary), with fp64 on the small shapes, and with ITSELF bit for bit across repeated launches (the race
     screen: 2, 4, 6 and 80 stages, one to three tiles per block, the real proj / lin2 / qkv shapes of an 8-tile batch)."""
     lib.samrs_debug_set_gemm_variant.argtypes = [__import__("ctypes").c_int]
-    shapes = [(256, 320, 128), (512, 640, 256), (8192, 3200, 256), (16384, 3840, 384), (32768, 1280, 1280)]
+    shapes = [(256, 640, 128), (512, 640, 256), (8192, 3200, 256), (16384, 3840, 384), (32768, 1280, 1280)]
     if variant == 30:
         shapes += [(32768, 1280, 5120), (32768, 3840, 1280)]
     try:
@@ -230,6 +230,129 @@ def test_gemm_m32_kernel(lib, name, prec, dt, ulp, variant):
             print(f"m32 variant {variant} {name} {M}x{N}x{K}: fp32 rel {r:.2e}")
     finally:
         lib.samrs_debug_set_gemm_variant(8)
+
+
+def _merge_stats(stats):
+    """(mean, M2) partials [M, 8, 2] of equal-size (160) groups -> (mean, biased variance) per row, in float64."""
+    st = stats.double()
+    mean = st[:, :, 0].mean(1)
+    m2 = st[:, :, 1].sum(1) + 160.0 * ((st[:, :, 0] - mean[:, None]) ** 2).sum(1)
+    return mean, m2 / 1280.0
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_ln_fold_weight_and_rowstats(lib, name, prec, dt, ulp):
+    """The two small kernels of the folded LayerNorm: weight preparation (ET(W diag(gamma)) bit-exact, its row sums, b + W beta)
+    and the entry kernel (Xh = ET(X) bit-exact; merged row statistics vs float64, with row means up to 50 sigma)."""
+    import ctypes
+    g = torch.Generator().manual_seed(5)
+    N, K = 640, 1280
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    gamma, beta, bias = 1 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g), torch.randn(N, generator=g)
+    Wf = torch.empty(N, K, dtype=torch.int16, device="cuda")
+    cvec, bf = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    Wd, gd, bd, biasd = dev(W), dev(gamma), dev(beta), dev(bias)
+    assert lib.samrs_k_ln_fold_weight(prec, Wd.data_ptr(), gd.data_ptr(), bd.data_ptr(), biasd.data_ptr(), Wf.data_ptr(),
+                                      cvec.data_ptr(), bf.data_ptr(), N, K, stream()) == 0
+    ref_wf = (W * gamma).to(dt)
+    assert torch.equal(Wf.cpu(), ref_wf.view(torch.int16))
+    assert (cvec.cpu().double() - ref_wf.double().sum(1)).abs().max().item() < 1e-6
+    assert (bf.cpu().double() - (bias.double() + W.double() @ beta.double())).abs().max().item() < 1e-6
+    rows = 1000
+    X = torch.randn(rows, 1280, generator=g) * torch.logspace(-2, 2, rows)[:, None] + \
+        torch.linspace(-50, 50, rows)[:, None] * torch.logspace(-2, 2, rows)[:, None]
+    X[:, 7] *= 30                                  # a massive-activation channel
+    Xd = dev(X)
+    Xh = torch.empty(rows, 1280, dtype=torch.int16, device="cuda")
+    stats = torch.empty(rows, 8, 2, device="cuda")
+    assert lib.samrs_k_rowstats_convert(prec, Xd.data_ptr(), Xh.data_ptr(), stats.data_ptr(), rows, 1280, stream()) == 0
+    refh = X.clamp(-65504, 65504).to(dt) if dt == torch.float16 else X.to(dt)
+    assert torch.equal(Xh.cpu(), refh.view(torch.int16))
+    mean, var = _merge_stats(stats.cpu())
+    rm, rv = X.double().mean(1), X.double().var(1, unbiased=False)
+    assert ((mean - rm).abs() / rv.sqrt()).max().item() < 1e-5
+    assert ((var - rv).abs() / rv).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_gemm_stats_epilogue(lib, name, prec, dt, ulp):
+    """Producer of the folded LayerNorm (proj / lin2): C += A B^T + bias on the 32x32x16 kernel, plus Xh = ET(C) and the
+    per-row partial statistics of C.  C must equal the plain fp32-residual GEMM, Xh must be ET(C) bit for bit, the merged
+    statistics must match float64 statistics of C; repeated launches are bit-identical."""
+    for (M, K) in [(512, 128), (8192, 1280), (32768, 1280), (32768, 5120)]:
+        N = 1280
+        g = torch.Generator().manual_seed(M + K)
+        _, Ab = et_bits(torch.randn(M, K, generator=g), dt)
+        _, Bb = et_bits(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
+        bias = dev(torch.randn(N, generator=g))
+        C0 = dev(torch.randn(M, N, generator=g) * 3 + torch.randn(M, 1, generator=g) * 4)      # residual with a row mean
+        Ad, Bd = dev(Ab), dev(Bb)
+        ref = C0.clone()
+        assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), ref.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 1, 0, 1, stream()) == 0
+        outs = []
+        for rep in range(2):
+            C = C0.clone()
+            Xh = torch.full((M, N), 0x7E00, dtype=torch.int16, device="cuda")
+            stats = torch.full((M, 8, 2), float("nan"), device="cuda")
+            assert lib.samrs_k_gemm_stats(prec, Ad.data_ptr(), Bd.data_ptr(), C.data_ptr(), bias.data_ptr(), Xh.data_ptr(),
+                                          stats.data_ptr(), M, N, K, stream()) == 0
+            torch.cuda.synchronize()
+            outs.append((C, Xh, stats))
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), f"{name} {M}x{N}x{K}: launches differ (race)"
+        C, Xh, stats = outs[0]
+        r = ((C - ref).double().norm() / ref.double().norm()).item()
+        print(f"gemm_stats {name} {M}x{N}x{K}: C vs plain kernel rel {r:.2e}, bit-identical {torch.equal(C, ref)}")
+        assert r < 2e-6
+        want = C.clamp(-65504, 65504).to(dt) if dt == torch.float16 else C.to(dt)
+        assert torch.equal(Xh, want.view(torch.int16)), f"{name} {M}x{N}x{K}: Xh != ET(C)"
+        assert torch.isfinite(stats).all()
+        mean, var = _merge_stats(stats)
+        rm, rv = C.double().mean(1), C.double().var(1, unbiased=False)
+        assert ((mean - rm).abs() / rv.sqrt()).max().item() < 1e-5
+        assert ((var - rv).abs() / rv).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("gelu", [0, 1])
+def test_gemm_folded_layernorm(lib, name, prec, dt, ulp, gelu):
+    """Consumer of the folded LayerNorm (qkv / lin1): rstd (Xh Wf^T - mean cvec) + bias_f [GELU] against float64
+    LayerNorm + Linear [+ GELU], next to the engine's other path (stand-alone LayerNorm kernel -> ET -> GEMM) on the same data:
+    same error class.  Rows carry means of several sigma and a massive-activation channel."""
+    for (M, N) in [(512, 640), (8192, 3840)]:
+        K = 1280
+        g = torch.Generator().manual_seed(M + N + gelu)
+        X = torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g) * 4) + torch.randn(M, 1, generator=g) * 3
+        X[:, 11] += 40
+        W = torch.randn(N, K, generator=g) / math.sqrt(K)
+        gamma, beta, bias = 1 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g), torch.randn(N, generator=g)
+        Xd, Wd, gd, bd, biasd = dev(X), dev(W), dev(gamma), dev(beta), dev(bias)
+        ref = F.layer_norm(X.double(), (K,), gamma.double(), beta.double(), 1e-6) @ W.double().t() + bias.double()
+        if gelu:
+            ref = F.gelu(ref)
+        # folded path
+        Xh = torch.empty(M, K, dtype=torch.int16, device="cuda")
+        stats = torch.empty(M, 8, 2, device="cuda")
+        Wf = torch.empty(N, K, dtype=torch.int16, device="cuda")
+        cvec, bf = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+        out = torch.full((M, N), 0x7E00, dtype=torch.int16, device="cuda")
+        assert lib.samrs_k_rowstats_convert(prec, Xd.data_ptr(), Xh.data_ptr(), stats.data_ptr(), M, K, stream()) == 0
+        assert lib.samrs_k_ln_fold_weight(prec, Wd.data_ptr(), gd.data_ptr(), bd.data_ptr(), biasd.data_ptr(), Wf.data_ptr(),
+                                          cvec.data_ptr(), bf.data_ptr(), N, K, stream()) == 0
+        assert lib.samrs_k_gemm_fold(prec, Xh.data_ptr(), Wf.data_ptr(), out.data_ptr(), bf.data_ptr(), cvec.data_ptr(),
+                                     stats.data_ptr(), 1e-6, M, N, K, gelu, stream()) == 0
+        # stand-alone LayerNorm path
+        Y = torch.empty(M, K, dtype=torch.int16, device="cuda")
+        We = dev(W.to(dt).view(torch.int16))
+        out0 = torch.empty(M, N, dtype=torch.int16, device="cuda")
+        assert lib.samrs_k_layernorm(prec, Xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-6, Y.data_ptr(), None, M, K, 0, 1, 64, 0, stream()) == 0
+        assert lib.samrs_k_gemm(prec, Y.data_ptr(), We.data_ptr(), out0.data_ptr(), biasd.data_ptr(), None, 0, M, N, K, 0, gelu, 0, stream()) == 0
+        torch.cuda.synchronize()
+        got, got0 = out.cpu().view(dt).double(), out0.cpu().view(dt).double()
+        assert torch.isfinite(got).all()
+        e1 = ((got - ref).norm() / ref.norm()).item()
+        e0 = ((got0 - ref).norm() / ref.norm()).item()
+        print(f"folded LN {name} {M}x{N} gelu={gelu}: folded {e1:.3e}, stand-alone {e0:.3e} (rel. L2 vs float64)")
+        assert e1 < 1.5 * e0 + 1e-5, (e1, e0)
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)

@@ -68,7 +68,7 @@ def margin_iou(masks, masks0, logits0, frac=0.02):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80"])
+@pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80", "vit_tiny1280"])
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
 def test_encoder_blockwise(name, precision):
     """Residual stream after patch embed and after each block vs the oracle (same weights)."""
@@ -90,7 +90,46 @@ def test_encoder_blockwise(name, precision):
         assert rel < tol, f"residual stream diverges after {nb} blocks"
 
 
-@pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80"])
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_folded_layernorm_matches_unfolded(precision):
+    """embed_dim 1280: the encoder blocks run without LayerNorm launches (the LayerNorm is folded into the qkv / lin1 GEMMs and
+    its statistics come out of the proj / lin2 epilogues).  Both paths against the oracle after every block: the folded path's
+    error must be in the same class as the stand-alone-LayerNorm path's (it rounds x instead of LN(x) to the operand type), and
+    the two paths must agree with each other to the same tolerance."""
+    import ctypes
+    so = _oracle()
+    name = "vit_tiny1280"
+    cfg = synth.CONFIGS[name]
+    pred = get_predictor(name, precision)
+    lib = pred.model.engine.lib
+    lib.samrs_debug_set_ln_fold.argtypes = [ctypes.c_int]
+    lib.samrs_debug_set_ln_fold.restype = None
+    img = synth.make_image(1)
+    taps = {}
+    with torch.no_grad():
+        so.image_encoder(get_oracle(name).sd, cfg, so.preprocess(img), taps=taps)
+    t = torch.as_tensor(img, device="cuda")[None].contiguous()
+    tol = 3e-3 if precision == "f16" else 3e-2
+    try:
+        for nb in range(1, cfg.depth + 1):
+            ref = taps[f"block{nb - 1}"][0]
+            lib.samrs_debug_set_ln_fold(0)
+            x0 = pred.model.engine.debug_encoder_prefix(t, nb).cpu()[0]
+            lib.samrs_debug_set_ln_fold(1)
+            x1 = pred.model.engine.debug_encoder_prefix(t, nb).cpu()[0]
+            x1b = pred.model.engine.debug_encoder_prefix(t, nb).cpu()[0]
+            assert torch.equal(x1, x1b), "folded path is not run-to-run reproducible"
+            e0 = ((x0 - ref).norm() / ref.norm()).item()
+            e1 = ((x1 - ref).norm() / ref.norm()).item()
+            d = ((x1 - x0).norm() / ref.norm()).item()
+            print(f"{name} {precision} after {nb} blocks: unfolded {e0:.3e}, folded {e1:.3e} vs oracle; folded vs unfolded {d:.3e}")
+            assert not torch.equal(x0, x1), "the switch did nothing"
+            assert e1 < tol and e1 < 1.5 * e0 + 1e-5 and d < tol
+    finally:
+        lib.samrs_debug_set_ln_fold(1)
+
+
+@pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80", "vit_tiny1280"])
 @pytest.mark.parametrize("precision", ["f16", "bf16"])
 def test_embedding_and_masks_vs_oracle(name, precision):
     so = _oracle()

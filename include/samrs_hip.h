@@ -198,14 +198,16 @@ int samrs_k_gemm_f32(const float* A, int lda, const float* W, const float* bias,
 /* LayerNorm folded into the neighbouring GEMMs of an encoder block (image_encoder.py:168,177; residual stream of 1280 columns):
  *   samrs_k_gemm_stats       C (fp32) += A_et B_et^T + bias;  xh_et = ET(C);  stats[m][8] = (mean, sum of squared deviations)
  *                            of eight 160-element groups of row m.  M % 256 == 0, N == 1280, K % 128 == 0.
- *   samrs_k_gemm_fold        C_et = [GELU](rstd_m (xh_et Wf_et^T - mean_m cvec) + bias_f), (mean_m, rstd_m) merged from stats[m][.]
- *                            with eps.  M % 256 == 0, N % 320 == 0, K == 1280.
+ *   samrs_k_ln_rowstat       rowstat[m] = (rstd_m, -rstd_m mean_m) merged from stats[m][.] with eps
+ *   samrs_k_gemm_fold        C_et = [GELU](rstd_m (xh_et Wf_et^T - mean_m cvec) + bias_f) with rowstat from above.
+ *                            M % 256 == 0, N % 320 == 0, K == 1280.
  *   samrs_k_ln_fold_weight   Wf_et = ET(W diag(gamma)), cvec[n] = sum_k Wf_et[n][k], bias_f = bias + W beta  (W fp32 [N][K])
  *   samrs_k_rowstats_convert xh_et = ET(X), stats as above, for X fp32 [rows][1280] */
 int samrs_k_gemm_stats(int prec, const void* A_et, const void* B_et, float* C, const float* bias, void* xh_et, float* stats,
                        int M, int N, int K, void* stream);
+int samrs_k_ln_rowstat(const float* stats, float* rowstat, int rows, float eps, void* stream);
 int samrs_k_gemm_fold(int prec, const void* xh_et, const void* Wf_et, void* C_et, const float* bias_f, const float* cvec,
-                      const float* stats, float eps, int M, int N, int K, int gelu, void* stream);
+                      const float* rowstat, int M, int N, int K, int gelu, void* stream);
 int samrs_k_ln_fold_weight(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_et,
                            float* cvec, float* bias_f, int N, int K, void* stream);
 int samrs_k_rowstats_convert(int prec, const float* X, void* xh_et, float* stats, int rows, int D, void* stream);

@@ -1135,6 +1135,32 @@ __global__ __launch_bounds__(256) void rowstats_convert_kernel(const float* __re
     if ((lane & 7) == 0) stats[(size_t)row * 8 + (lane >> 3)] = make_float2(gm, q);
 }
 
+// (mean, M2) partials of eight 160-element groups of a row -> (rstd, -rstd mean): Chan's pairwise update in a fixed order
+// (no E[x^2] - mean^2 cancellation; bit-reproducible).  One thread per row, 64 bytes in, 8 bytes out.
+__global__ __launch_bounds__(256) void ln_rowstat_kernel(const float4* __restrict__ stats, float2* __restrict__ rowstat, int rows, float eps) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float4 q[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) q[h] = stats[(size_t)row * 4 + h];
+    float mean = q[0].x, m2 = q[0].y;
+#pragma unroll
+    for (int g = 1; g < 8; ++g) {
+        const float gm = (g & 1) ? q[g >> 1].z : q[g >> 1].x, gq = (g & 1) ? q[g >> 1].w : q[g >> 1].y;
+        const float d = gm - mean;
+        mean += d * (1.0f / (g + 1));
+        m2 += gq + d * d * (160.0f * g / (g + 1));
+    }
+    const float rstd = 1.0f / sqrtf(m2 * (1.0f / 1280.0f) + eps);
+    rowstat[row] = make_float2(rstd, -rstd * mean);
+}
+
+hipError_t launch_ln_rowstat(const float* stats, float* rowstat, int rows, float eps, hipStream_t s) {
+    if (rows < 1 || !stats || !rowstat) return hipErrorInvalidValue;
+    ln_rowstat_kernel<<<(rows + 255) / 256, 256, 0, s>>>(reinterpret_cast<const float4*>(stats), reinterpret_cast<float2*>(rowstat), rows, eps);
+    return hipGetLastError();
+}
+
 hipError_t launch_rowstats_convert(int prec, const float* X, void* Xh, float* stats, int rows, int D, hipStream_t s) {
     if (D != 1280 || rows < 1) return hipErrorInvalidValue;
     const int blocks = (rows + 3) / 4;

@@ -79,6 +79,7 @@ struct samrs_engine {
     float* X = nullptr;            // residual stream fp32 [Bi*tokens, D]
     uint16_t* Y = nullptr;         // LN out (ET) [Bi*tokens, D]; folded path: the residual stream itself rounded to ET
     float* STATS = nullptr;        // folded path: per-row (mean, M2) of eight 160-column groups [Bi*tokens][8][2]
+    float* ROWSTAT = nullptr;      // folded path: per-row (rstd, -rstd mean) [Bi*tokens][2]
     bool can_fold = false;         // embed_dim == 1280 and the folded weights exist
     uint16_t* QKV = nullptr;       // [Bi*tokens, 3D], token order
     uint16_t* AO = nullptr;        // attention out [Bi*tokens, D]
@@ -474,7 +475,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->X, M * D));
     CK(e, dalloc(e, &e->Y, Mmax * D));
     CK(e, hipMemsetAsync(e->Y, 0, Mmax * D * 2, s));
-    if (e->can_fold) CK(e, dalloc(e, &e->STATS, Mmax * 16));
+    if (e->can_fold) { CK(e, dalloc(e, &e->STATS, Mmax * 16)); CK(e, dalloc(e, &e->ROWSTAT, Mmax * 2)); }
     CK(e, dalloc(e, &e->QKV, Mmax * 3 * D));
     CK(e, dalloc(e, &e->AO, M * D));
     CK(e, dalloc(e, &e->VTG, M * D));
@@ -542,13 +543,16 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     // STATS its per-row partial statistics, both written by the epilogue of the GEMM that produced X (proj, lin2; here, once,
     // by rowstats_convert); qkv / lin1 run on the gamma-folded weights and normalise in their epilogue (gemm.hip).
     const bool fold = e->can_fold && g_ln_fold;
-    if (fold && n_blocks > 0) CK(e, launch_rowstats_convert(prec, e->X, e->Y, e->STATS, M, D, s));
+    if (fold && n_blocks > 0) {
+        CK(e, launch_rowstats_convert(prec, e->X, e->Y, e->STATS, M, D, s));
+        CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
+    }
     for (int i = 0; i < c.depth && i < n_blocks; ++i) {
         const EncBlock& b = e->blocks[i];
         // norm1 + qkv in plain token order for both block kinds; the windowed kernel partitions
         // on the fly and takes k / v of padding positions from the qkv bias
         if (fold) {
-            CK(e, launch_gemm_et_fold(prec, e->Y, b.qkv_wf, e->QKV, b.qkv_bf, b.qkv_c, e->STATS, 1e-6f, M, 3 * D, D, false, s));
+            CK(e, launch_gemm_et_fold(prec, e->Y, b.qkv_wf, e->QKV, b.qkv_bf, b.qkv_c, e->ROWSTAT, M, 3 * D, D, false, s));
         } else {
             CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
             CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
@@ -559,6 +563,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, e->VTG, s));
         if (fold) {
             CK(e, launch_gemm_et_stats(prec, e->AO, b.proj_w, e->X, b.proj_b, e->Y, e->STATS, M, D, D, s));
+            CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
         } else {
             CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
             CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
@@ -572,14 +577,16 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, get(&t0)); CK(e, get(&t1));
             CK(e, hipEventRecord(t0, s));
         }
-        if (fold) CK(e, launch_gemm_et_fold(prec, e->Y, b.lin1_wf, e->H, b.lin1_bf, b.lin1_c, e->STATS, 1e-6f, M, 4 * D, D, true, s));
+        if (fold) CK(e, launch_gemm_et_fold(prec, e->Y, b.lin1_wf, e->H, b.lin1_bf, b.lin1_c, e->ROWSTAT, M, 4 * D, D, true, s));
         else CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
         if (e->timing) {
             CK(e, hipEventRecord(t1, s));
             e->tev.emplace_back(t0, t1);
         }
-        if (fold) CK(e, launch_gemm_et_stats(prec, e->H, b.lin2_w, e->X, b.lin2_b, e->Y, e->STATS, M, D, 4 * D, s));
-        else CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
+        if (fold) {
+            CK(e, launch_gemm_et_stats(prec, e->H, b.lin2_w, e->X, b.lin2_b, e->Y, e->STATS, M, D, 4 * D, s));
+            if (i + 1 < c.depth) CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
+        } else CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
     }
     if (!do_neck) return SAMRS_OK;
     // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d   (all channels-last).  Folded path: Y already is ET(X).
@@ -924,9 +931,12 @@ int samrs_k_gemm_stats(int prec, const void* A, const void* B, float* C, const f
                        int K, void* stream) {
     KRET(launch_gemm_et_stats(prec, A, B, C, bias, xh, stats, M, N, K, (hipStream_t)stream));
 }
-int samrs_k_gemm_fold(int prec, const void* xh, const void* Wf, void* C, const float* bias_f, const float* cvec, const float* stats,
-                      float eps, int M, int N, int K, int gelu, void* stream) {
-    KRET(launch_gemm_et_fold(prec, xh, Wf, C, bias_f, cvec, stats, eps, M, N, K, gelu != 0, (hipStream_t)stream));
+int samrs_k_gemm_fold(int prec, const void* xh, const void* Wf, void* C, const float* bias_f, const float* cvec, const float* rowstat,
+                      int M, int N, int K, int gelu, void* stream) {
+    KRET(launch_gemm_et_fold(prec, xh, Wf, C, bias_f, cvec, rowstat, M, N, K, gelu != 0, (hipStream_t)stream));
+}
+int samrs_k_ln_rowstat(const float* stats, float* rowstat, int rows, float eps, void* stream) {
+    KRET(launch_ln_rowstat(stats, rowstat, rows, eps, (hipStream_t)stream));
 }
 int samrs_k_ln_fold_weight(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, float* cvec,
                            float* bias_f, int N, int K, void* stream) {

@@ -382,12 +382,12 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
 //   acc[i][j]: n-tile i (16 cols), m-tile j (16 rows); 8 m-tiles, 4 per pass.
 // ---------------------------------------------------------------------------------------------
 // FOLD (LayerNorm folded into this GEMM, see gemm_et_x64p_kernel): the value is rstd_m * acc + (-rstd_m mean_m) * cvec_n +
-// bias_n with (rstd_m, -rstd_m mean_m) = rowstat[tile row] (LDS) instead of acc + bias_n.
+// bias_n with (rstd_m, -rstd_m mean_m) = rowstat[m] (global, written by ln_rowstat_kernel) instead of acc + bias_n.
 template <int PREC, bool GELU, int JC = 4, bool DRAIN = false, bool FOLD = false>
 __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned char* lds, void* __restrict__ Cv,
                                                  const float* __restrict__ bias, const float* __restrict__ pre2d, int period, int N,
                                                  int m_base /* wave tile row 0 */, int n_pair /* first column of the pair */,
-                                                 int wm, int wn, int lane, const float2* rowstat = nullptr /* LDS, FOLD */,
+                                                 int wm, int wn, int lane, const float2* __restrict__ rowstat = nullptr /* FOLD: [M] */,
                                                  const float* __restrict__ cvec = nullptr /* FOLD */) {
     constexpr int RS = 400;                 // 320 data bytes + pad: 100 words = 4 (mod 32)
     constexpr int TS = 16 * RS;
@@ -397,14 +397,26 @@ __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned 
 #pragma unroll
     for (int i = 0; i < 5; ++i)
         bv[i] = bias ? *reinterpret_cast<const float4*>(bias + n_pair + half * 80 + i * 16 + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // FOLD: (rstd, -rstd mean) of this lane's rows, one pass ahead (global, 8 bytes per row: L2 hits next to the bias loads)
+    float2 rs_cur[JC], rs_nxt[JC];
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int jj = 0; jj < JC; ++jj) rs_cur[jj] = rowstat[m_base + jj * 16 + fr];
+    }
 #pragma unroll
     for (int j0 = 0; j0 < 8; j0 += JC) {
         if (j0) __syncthreads();
+        if constexpr (FOLD) {
+            if (j0 + JC < 8) {
+#pragma unroll
+                for (int jj = 0; jj < JC; ++jj) rs_nxt[jj] = rowstat[m_base + (j0 + JC + jj) * 16 + fr];
+            }
+        }
 #pragma unroll
         for (int jj = 0; jj < JC; ++jj) {
             const int j = j0 + jj;
             float2 rs = make_float2(1.f, 0.f);
-            if constexpr (FOLD) rs = rowstat[wm * 128 + j * 16 + fr];
+            if constexpr (FOLD) rs = rs_cur[jj];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
@@ -437,6 +449,10 @@ __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned 
             const uint4 v = *reinterpret_cast<const uint4*>(scr + jj * TS + row * RS + ch * 16);
             uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)(m_base + (j0 + jj) * 16 + row) * N + n_pair + ch * 8;
             *reinterpret_cast<uint4*>(C) = v;
+        }
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int jj = 0; jj < JC; ++jj) rs_cur[jj] = rs_nxt[jj];
         }
     }
 }
@@ -1203,17 +1219,16 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
 // ET (written by the GEMM that produced it, gemm_et_m32_kernel<STATS>), B = W diag(gamma) rounded to ET, cvec_n = sum_k of
 // that B row, bias_n = b_n + sum_k W_nk beta_k:
 //     LN(x) W^T + b  =  rstd (x W'^T - mean cvec) + bias'
-// The per-row (mean, M2) partials of the LN_NS 160-column groups of a row are merged (Chan) in a fixed order by the first 256
-// threads at the start of every tile into (rstd, -rstd mean) in LDS; only the ET epilogue reads them.
+// rowstat[m] = (rstd, -rstd mean) comes from ln_rowstat_kernel (encoder_kernels.hip), which merges the per-row (mean, M2)
+// partials of the LN_NS 160-column groups; only the ET epilogue reads it (8 bytes per row and lane, next to the bias loads).
 constexpr int LN_NS = 8;                       // 1280 / 160: ViT-H only
 
 template <int PREC, bool OUT_F32, bool GELU, bool FOLD = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, int accumulate,
-    const float2* __restrict__ stats = nullptr, const float* __restrict__ cvec = nullptr, float eps = 0.f) {
+    const float2* __restrict__ rowstat = nullptr, const float* __restrict__ cvec = nullptr) {
     static_assert(!(FOLD && OUT_F32), "the folded LayerNorm feeds ET outputs only (qkv, lin1)");
-    __shared__ float2 rowstat[FOLD ? QBM : 1];
     constexpr int NI = 5;
     constexpr int XBN = 64 * NI;
     constexpr int XROWS = QBM + XBN;
@@ -1341,27 +1356,6 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
             sA = A + (size_t)m1 * K;
             sB = B + (size_t)n1 * K;
             X64P_ISSUE(0, 0u);
-        }
-        if constexpr (FOLD) {
-            // row statistics of this tile's 256 rows -> LDS.  The loads sit where the epilogue's bias loads sit: behind the DMA
-            // pieces just issued (in-order vmcnt), whose landing the first bounce waits for anyway.
-            if (tid < QBM) {
-                const float4* sp = reinterpret_cast<const float4*>(stats + (size_t)(m0 + tid) * LN_NS);
-                float4 q[LN_NS / 2];
-#pragma unroll
-                for (int h = 0; h < LN_NS / 2; ++h) q[h] = sp[h];
-                float mean = q[0].x, m2 = q[0].y;
-#pragma unroll
-                for (int g = 1; g < LN_NS; ++g) {                    // Chan merge of equal-size groups, fixed order
-                    const float gm = (g & 1) ? q[g >> 1].z : q[g >> 1].x, gq = (g & 1) ? q[g >> 1].w : q[g >> 1].y;
-                    const float d = gm - mean;
-                    mean += d * (1.0f / (g + 1));
-                    m2 += gq + d * d * (160.0f * g / (g + 1));
-                }
-                const float rstd = 1.0f / sqrtf(m2 * (1.0f / (160.0f * LN_NS)) + eps);
-                rowstat[tid] = make_float2(rstd, -rstd * mean);
-            }
-            __syncthreads();
         }
         {   // epilogue of tile (m0, n0); bounce scratch = ring buffer 1 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
             unsigned char* upper = reinterpret_cast<unsigned char*>(lds) + XSB;
@@ -1771,8 +1765,8 @@ hipError_t launch_gemm_m32_stats(const void* A, const void* B, float* C, const f
 }
 // consumer: C (ET) = [GELU](rstd (Xh Wf^T - mean cvec) + bias_f) on the persistent pair-stage kernel
 template <int PREC>
-hipError_t launch_gemm_x64p_fold(const void* A, const void* B, void* C, const float* bias, const float* cvec, const float* stats,
-                                 float eps, int M, int N, int K, bool gelu, hipStream_t s) {
+hipError_t launch_gemm_x64p_fold(const void* A, const void* B, void* C, const float* bias, const float* cvec, const float* rowstat,
+                                 int M, int N, int K, bool gelu, hipStream_t s) {
     const int ntiles = (M / QBM) * (N / WBN);
     int dev = 0, n_cu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1780,9 +1774,9 @@ hipError_t launch_gemm_x64p_fold(const void* A, const void* B, void* C, const fl
     dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(QTHREADS);
     const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
     const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
-    const float2* st = reinterpret_cast<const float2*>(stats);
-    if (gelu) gemm_et_x64p_kernel<PREC, false, true, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, st, cvec, eps);
-    else gemm_et_x64p_kernel<PREC, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, st, cvec, eps);
+    const float2* rs = reinterpret_cast<const float2*>(rowstat);
+    if (gelu) gemm_et_x64p_kernel<PREC, false, true, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, rs, cvec);
+    else gemm_et_x64p_kernel<PREC, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, rs, cvec);
     return hipGetLastError();
 }
 static bool m32_ok(int M, int N, int K, const float* add2d) {
@@ -2607,10 +2601,10 @@ hipError_t launch_gemm_et_stats(int prec, const void* A, const void* B, float* C
     return hipErrorInvalidValue;
 }
 hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C, const float* bias_f, const float* cvec,
-                               const float* stats, float eps, int M, int N, int K, bool gelu, hipStream_t s) {
-    if (M % QBM || N % WBN || K != 160 * LN_NS || !bias_f || !cvec || !stats) return hipErrorInvalidValue;
-    if (prec == PREC_BF16) return launch_gemm_x64p_fold<PREC_BF16>(Xh, Wf, C, bias_f, cvec, stats, eps, M, N, K, gelu, s);
-    if (prec == PREC_F16) return launch_gemm_x64p_fold<PREC_F16>(Xh, Wf, C, bias_f, cvec, stats, eps, M, N, K, gelu, s);
+                               const float* rowstat, int M, int N, int K, bool gelu, hipStream_t s) {
+    if (M % QBM || N % WBN || K != 160 * LN_NS || !bias_f || !cvec || !rowstat) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) return launch_gemm_x64p_fold<PREC_BF16>(Xh, Wf, C, bias_f, cvec, rowstat, M, N, K, gelu, s);
+    if (prec == PREC_F16) return launch_gemm_x64p_fold<PREC_F16>(Xh, Wf, C, bias_f, cvec, rowstat, M, N, K, gelu, s);
     return hipErrorInvalidValue;
 }
 

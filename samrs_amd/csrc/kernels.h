@@ -12,11 +12,12 @@ hipError_t launch_gemm_et_gln(int prec, const void* A, const void* B, void* C, c
                               int M, int N, int K, hipStream_t s);
 // LayerNorm folded into the neighbouring GEMMs (residual stream of N = 1280 columns):
 //   producer  C (fp32) += A B^T + bias;  Xh = ET(C);  stats[m][N / 160] = (mean, sum of squared deviations) per 160 columns
-//   consumer  C (ET) = [GELU](rstd_m (Xh Wf^T - mean_m cvec) + bias_f), (mean_m, rstd_m) merged from stats[m][.] with eps
+//   (launch_ln_rowstat, encoder_kernels.hip: stats -> rowstat[m] = (rstd, -rstd mean))
+//   consumer  C (ET) = [GELU](rstd_m (Xh Wf^T - mean_m cvec) + bias_f)
 hipError_t launch_gemm_et_stats(int prec, const void* A, const void* B, float* C, const float* bias, void* Xh, float* stats,
                                 int M, int N, int K, hipStream_t s);
 hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C, const float* bias_f, const float* cvec,
-                               const float* stats, float eps, int M, int N, int K, bool gelu, hipStream_t s);
+                               const float* rowstat, int M, int N, int K, bool gelu, hipStream_t s);
 void set_gemm_variant(int v);   // 0 = register-staged tiles, 1 = LDS-DMA staging (default)
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
@@ -41,6 +42,8 @@ hipError_t launch_convert(int prec, const float* in, void* out, long n, hipStrea
 hipError_t launch_ln_fold_weight(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf,
                                  float* cvec, float* bias_f, int N, int K, hipStream_t s);
 hipError_t launch_rowstats_convert(int prec, const float* X, void* Xh, float* stats, int rows, int D, hipStream_t s);
+// stats [rows][8] (mean, M2) of 160-element groups -> rowstat [rows] = (rstd, -rstd mean), Chan merge in a fixed order
+hipError_t launch_ln_rowstat(const float* stats, float* rowstat, int rows, float eps, hipStream_t s);
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
                             int window, hipStream_t s);

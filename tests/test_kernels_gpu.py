@@ -338,8 +338,10 @@ def test_gemm_folded_layernorm(lib, name, prec, dt, ulp, gelu):
         assert lib.samrs_k_rowstats_convert(prec, Xd.data_ptr(), Xh.data_ptr(), stats.data_ptr(), M, K, stream()) == 0
         assert lib.samrs_k_ln_fold_weight(prec, Wd.data_ptr(), gd.data_ptr(), bd.data_ptr(), biasd.data_ptr(), Wf.data_ptr(),
                                           cvec.data_ptr(), bf.data_ptr(), N, K, stream()) == 0
+        rowstat = torch.empty(M, 2, device="cuda")
+        assert lib.samrs_k_ln_rowstat(stats.data_ptr(), rowstat.data_ptr(), M, 1e-6, stream()) == 0
         assert lib.samrs_k_gemm_fold(prec, Xh.data_ptr(), Wf.data_ptr(), out.data_ptr(), bf.data_ptr(), cvec.data_ptr(),
-                                     stats.data_ptr(), 1e-6, M, N, K, gelu, stream()) == 0
+                                     rowstat.data_ptr(), M, N, K, gelu, stream()) == 0
         # stand-alone LayerNorm path
         Y = torch.empty(M, K, dtype=torch.int16, device="cuda")
         We = dev(W.to(dt).view(torch.int16))

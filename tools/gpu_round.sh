@@ -23,6 +23,7 @@ for grp in "$@"; do
     k_m32)    run k_m32 600 $PT tests/test_kernels_gpu.py -k "m32" ;;
     k_fold)   run k_fold 600 $PT tests/test_kernels_gpu.py -k "fold or stats" ;;
     p_fold)   run p_fold 900 $PT tests/test_parity_gpu.py -k "vit_tiny1280 or folded" ;;
+    foldb)    run foldb 600 python tools/fold_bench.py ;;
     abfold)   run abfold 900 bash tools/ab_env.sh SAMRS_LN_FOLD 0 1 ${AB_ROUNDS:-2} ;;
     abm32)    run abm32 900 bash tools/ab_env.sh SAMRS_GEMM_M32 ${M32_A:-0} ${M32_B:-3} ${AB_ROUNDS:-2} ;;
     p_c2c4)   run p_c2c4 900 $PT tests/test_parity_gpu.py -k "c2_c4" ;;

@@ -164,8 +164,9 @@ void samrs_debug_set_gemm_skew(int xcd_units, int cu_units);
 /* test / timing hook: 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm / product launches) */
 void samrs_debug_set_decoder_fusion(int on);
 
-/* test / timing hook: 0 = run the ViT-H encoder blocks with stand-alone LayerNorm launches instead of the LayerNorm folded
- * into the qkv / lin1 GEMMs (default on for embed_dim 1280; SAMRS_LN_FOLD=0 at load time does the same) */
+/* test / timing hook (embed_dim 1280): 1 = fold the encoder blocks' LayerNorms into the qkv / lin1 GEMMs (no LayerNorm launches;
+ * statistics come out of the proj / lin2 epilogues).  Off by default -- measured slower on MI355X.  Must be switched on (or
+ * SAMRS_LN_FOLD=1 set) before samrs_finalize_weights for the folded weights to exist; can be flipped afterwards. */
 void samrs_debug_set_ln_fold(int on);
 
 /* -- test hook: copy a prefix of a named internal decoder buffer (Q, KF, KE, KVQ, OI, U1raw, U1, U2,

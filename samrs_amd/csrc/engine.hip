@@ -54,9 +54,11 @@ struct EncBlock {
     float *qkv_c = nullptr, *qkv_bf = nullptr, *lin1_c = nullptr, *lin1_bf = nullptr;
 };
 
-// LayerNorm folding (encoder blocks, embed_dim 1280 only): run-time switch for A/B runs and the folded-vs-unfolded parity
-// test (samrs_debug_set_ln_fold), load-time default SAMRS_LN_FOLD (on).
-static bool g_ln_fold = [] { const char* v = getenv("SAMRS_LN_FOLD"); return !(v && atoi(v) == 0); }();
+// LayerNorm folding (encoder blocks, embed_dim 1280 only).  OFF by default: measured slower than the stand-alone LayerNorm
+// kernel on MI355X (anything added to a GEMM epilogue runs while the matrix pipe idles, the stand-alone kernel
+// streams at ~6 TB/s).  SAMRS_LN_FOLD=1 at load time or samrs_debug_set_ln_fold(1) BEFORE samrs_finalize_weights prepares the
+// folded weights; the switch can then be flipped at run time (A/B runs, the folded-vs-unfolded parity test).
+static bool g_ln_fold = [] { const char* v = getenv("SAMRS_LN_FOLD"); return v && atoi(v) != 0; }();
 
 }  // namespace
 
@@ -390,7 +392,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
         b.global = is_global(c, i);
         b.ln1w = W(e, p + ".norm1.weight"); b.ln1b = W(e, p + ".norm1.bias");
         b.ln2w = W(e, p + ".norm2.weight"); b.ln2b = W(e, p + ".norm2.bias");
-        if (D == 1280) {       // folded LayerNorm needs the fp32 weights: before to_et() frees them
+        if (D == 1280 && g_ln_fold) {       // folded LayerNorm needs the fp32 weights: before to_et() frees them
             CK(e, dalloc(e, &b.qkv_wf, (size_t)3 * D * D)); CK(e, dalloc(e, &b.qkv_c, (size_t)3 * D)); CK(e, dalloc(e, &b.qkv_bf, (size_t)3 * D));
             CK(e, dalloc(e, &b.lin1_wf, (size_t)4 * D * D)); CK(e, dalloc(e, &b.lin1_c, (size_t)4 * D)); CK(e, dalloc(e, &b.lin1_bf, (size_t)4 * D));
             CK(e, launch_ln_fold_weight(e->prec, W(e, p + ".attn.qkv.weight"), b.ln1w, b.ln1b, W(e, p + ".attn.qkv.bias"), b.qkv_wf,

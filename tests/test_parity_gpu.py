@@ -96,14 +96,19 @@ def test_folded_layernorm_matches_unfolded(precision):
     its statistics come out of the proj / lin2 epilogues).  Both paths against the oracle after every block: the folded path's
     error must be in the same class as the stand-alone-LayerNorm path's (it rounds x instead of LN(x) to the operand type), and
     the two paths must agree with each other to the same tolerance."""
-    import ctypes
     so = _oracle()
+    import samrs_amd
+    from samrs_amd import engine
     name = "vit_tiny1280"
     cfg = synth.CONFIGS[name]
-    pred = get_predictor(name, precision)
-    lib = pred.model.engine.lib
-    lib.samrs_debug_set_ln_fold.argtypes = [ctypes.c_int]
-    lib.samrs_debug_set_ln_fold.restype = None
+    lib = engine.load_library()
+    lib.samrs_debug_set_ln_fold(1)           # before the weights are finalized: the folded copies are prepared at load
+    try:
+        sam = samrs_amd.sam_model_registry[name](precision=precision, max_prompts=8, max_images=1, max_points=4)
+        sam.to(device="cuda")
+        pred = samrs_amd.SamPredictor(sam)
+    finally:
+        lib.samrs_debug_set_ln_fold(0)
     img = synth.make_image(1)
     taps = {}
     with torch.no_grad():
@@ -125,8 +130,22 @@ def test_folded_layernorm_matches_unfolded(precision):
             print(f"{name} {precision} after {nb} blocks: unfolded {e0:.3e}, folded {e1:.3e} vs oracle; folded vs unfolded {d:.3e}")
             assert not torch.equal(x0, x1), "the switch did nothing"
             assert e1 < tol and e1 < 1.5 * e0 + 1e-5 and d < tol
-    finally:
+        # the folded engine end to end: embedding and box masks against the oracle
         lib.samrs_debug_set_ln_fold(1)
+        orc = get_oracle(name)
+        pred.set_image(img)
+        orc.set_image(img)
+        rel = ((pred.get_image_embedding().cpu() - orc.features).norm() / orc.features.norm()).item()
+        assert rel < tol, rel
+        boxes = torch.from_numpy(synth.C1_BOXES)
+        tb = pred.transform.apply_boxes_torch(boxes.cuda(), img.shape[:2])
+        masks, _, _ = pred.predict_torch(None, None, tb, None, multimask_output=False)
+        m0, _, _ = orc.predict_torch(None, None, tb.cpu(), None, multimask_output=False)
+        iou = iou_stats(masks.cpu(), m0)
+        print(f"{name} {precision} folded: embedding rel L2 {rel:.3e}, box-mask IoU min {iou.min().item():.5f}")
+        assert iou.min().item() >= (0.999 if precision == "f16" else 0.99)
+    finally:
+        lib.samrs_debug_set_ln_fold(0)
 
 
 @pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80", "vit_tiny1280"])

@@ -42,6 +42,10 @@ g = torch.Generator().manual_seed(0)
 for name, M, N, K, of32, gelu, acc in shapes:
     A = torch.randn(M, K, generator=g).to(dev).to(dt)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev).to(dt)
+    if os.environ.get("ZERO"):
+        # DVFS probe (MI355X_MICROARCH.md, "DVFS give-back"): the same kernels on all-zero operands draw less power and clock
+        # higher; the ratio to the random-operand rate is the share of the gap to the roof that is power, not schedule
+        A.zero_(); W.zero_()
     bias = torch.randn(N, generator=g).to(dev)
     C = torch.zeros(M, N, dtype=torch.float32 if of32 else torch.int16, device=dev)
     ref = A.float() @ W.float().t() + bias

@@ -1442,8 +1442,8 @@ constexpr int M32_RS = 144;                   // scratch row stride (bytes): 128
 // (mean, M2 = sum of squared deviations) of the wave's 160 columns of row m.  In the read-out a row's 32 columns of a pass sit
 // in 8 consecutive lanes: group mean / M2 by three xor-shuffles each (two-pass inside the group), merged into the running
 // pair over the five passes by Chan's update -- no E[x^2] - mean^2 cancellation, fixed order, bit-reproducible.
-template <int PREC, bool OUT_F32, bool GELU, bool STATS = false>
-__device__ __forceinline__ void epilogue_m32(f32x16_t (&acc)[5][2], unsigned char* scr, void* __restrict__ Cv,
+template <int PREC, bool OUT_F32, bool GELU, bool STATS = false, int NJ = 2>
+__device__ __forceinline__ void epilogue_m32(f32x16_t (&acc)[5][NJ], unsigned char* scr, void* __restrict__ Cv,
                                              const float* __restrict__ bias, int N, int m_base, int n_base, int wn,
                                              int accumulate, int lane, uint16_t* __restrict__ Xh = nullptr,
                                              float2* __restrict__ stats = nullptr) {
@@ -1452,7 +1452,7 @@ __device__ __forceinline__ void epilogue_m32(f32x16_t (&acc)[5][2], unsigned cha
         float* C = reinterpret_cast<float*>(Cv);
         bool first = true;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             float rmean[4], rm2[4];
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -1539,10 +1539,10 @@ __device__ __forceinline__ void epilogue_m32(f32x16_t (&acc)[5][2], unsigned cha
         } while (0)
         if (wn == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { M32_ET_PASS(j, 0, 2); M32_ET_PASS(j, 2, 2); M32_ET_PASS(j, 4, 1); }
+            for (int j = 0; j < NJ; ++j) { M32_ET_PASS(j, 0, 2); M32_ET_PASS(j, 2, 2); M32_ET_PASS(j, 4, 1); }
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { M32_ET_PASS(j, 0, 1); M32_ET_PASS(j, 1, 2); M32_ET_PASS(j, 3, 2); }
+            for (int j = 0; j < NJ; ++j) { M32_ET_PASS(j, 0, 1); M32_ET_PASS(j, 1, 2); M32_ET_PASS(j, 3, 2); }
         }
 #undef M32_ET_PASS
     }
@@ -1748,6 +1748,228 @@ hipError_t launch_gemm_m32(const void* A, const void* B, void* C, const float* b
     }
     return hipGetLastError();
 }
+// ---------------------------------------------------------------------------------------------
+// gemm_et_w4_kernel: the symmetric 32x32x16 schedule above on FOUR waves with 512 registers each (one wave per SIMD).
+//
+// Why: the DVFS probe says the encoder GEMMs are limited by energy per FLOP, and the one structural knob on it
+// is the number of bytes that cross LDS -> registers per FLOP, i.e. the perimeter of the WAVE tile: 8 waves x (128 + 80) rows
+// of fragments per k-step for the 2 x 4 layout, 8 x (64 + 160) for the 4 x 2 layout of gemm_et_m32_kernel, 4 x (128 + 160) here
+// (-31 % / -36 %).  A 128 x 160 wave tile needs 320 accumulator registers; hipcc keeps all MFMA results of a kernel either in
+// VGPRs or in AGPRs (256 each), so the MFMAs are issued from inline asm: the 16 accumulator tiles of n-tiles 0-3 are constrained
+// to AGPRs ("+a"), the 4 tiles of n-tile 4 to VGPRs ("+v"); everything else (fragments 2 x 36, addressing) fits the VGPR half.
+// The compiler does not know these statements are MFMAs, so the two hazards it would pad are padded by hand (s_nop after the
+// accumulators are zeroed and before the epilogue reads them).
+//
+// Stage image, DMA pieces (now 18 per wave and stage: rows 32 q + 8 wave .. + 7), hand-over barrier, persistent stage stream and
+// epilogue are those of gemm_et_m32_kernel; pieces 0-9 ride in step 3 (slots 10-19, the reads use slots 0-8), pieces 10-17 in
+// the next step 0.  With one wave per SIMD nothing covers a stall, so the single barrier per stage costs what it costs.
+// ---------------------------------------------------------------------------------------------
+constexpr int W4THREADS = 256;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+template <int PREC, bool AG>
+__device__ __forceinline__ void mfma32_asm(f32x16_t& c, const uint4& a, const uint4& b) {
+    const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
+    if constexpr (PREC == PREC_F16) {
+        if constexpr (AG) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+    } else {
+        if constexpr (AG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+    }
+}
+
+template <int PREC, bool OUT_F32, bool GELU>
+__global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amdgpu_waves_per_eu(1, 1))) void gemm_et_w4_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, int M, int N, int K, int accumulate) {
+    constexpr int NI = 5, NJ = 4;
+    constexpr int XBN = 320;
+    constexpr int XROWS = QBM + XBN;
+    constexpr int XSTAGE_ELEMS = XROWS * XBK;
+    constexpr uint32_t XSB = XSTAGE_ELEMS * 2;             // 72 KiB per stage
+    constexpr int NP = 18, NP3 = 10;                       // pieces per wave and stage; [0, NP3) in step 3, the rest in step 0
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * XSTAGE_ELEMS];   // 144 KiB, ONE object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;   // wave tile rows wm*128.., cols wn*160..
+
+    constexpr int GROUP = 8;
+    const int tiles_n = N / XBN, tiles_m = M / QBM, ntiles = tiles_n * tiles_m;
+    const int per_group = GROUP * tiles_n;
+#define W4_TILE(L_, m_, n_)                                                                      \
+    do {                                                                                         \
+        const int bid_ = xcd_remap((L_), ntiles);                                                \
+        const int group_ = bid_ / per_group, first_m_ = group_ * GROUP;                           \
+        const int gsz_ = (tiles_m - first_m_) < GROUP ? (tiles_m - first_m_) : GROUP;            \
+        const int in_g_ = bid_ - group_ * per_group;                                             \
+        (m_) = (first_m_ + in_g_ % gsz_) * QBM;                                                  \
+        (n_) = (in_g_ / gsz_) * XBN;                                                             \
+    } while (0)
+
+    // DMA map: piece q of this wave covers stage rows 32 q + 8 wave .. + 7 (q < 8: A rows, else B rows 32 (q - 8) + ..); lane
+    // l -> k-half l>>5, row (l>>2)&7, physical chunk l&3 (same image and swizzle as the eight-wave kernels: 32 q = 0 mod 16)
+    const int prow = 8 * wave + ((lane >> 2) & 7);
+    const uint32_t voff = ((uint32_t)prow * (uint32_t)K + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
+    const size_t rs32 = (size_t)32 * K;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
+#define W4_PIECE(pa_, pb_, wr_, q_)                                                                        \
+    glds16_m(voff, ((q_) < 8 ? (pa_) + (size_t)(q_) * rs32 : (pb_) + (size_t)((q_) - 8) * rs32), lds0 + (wr_) + (q_) * 4096u)
+
+    const int nst = K / XBK;
+    const int l31 = lane & 31, hh = lane >> 5;
+    uint32_t offA[NJ], offB[NI];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int r = wm * 128 + j * 32 + l31; offA[j] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, hh) * 8) * 2; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = QBM + wn * 160 + i * 32 + l31;
+        offB[i] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, hh) * 8) * 2;
+    }
+    const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);
+
+#define W4_RDB(fb_, rd_, s_, i_) fb_[i_] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + ((s_) >> 1) * 512 + (offB[i_] ^ (((s_) & 1) * 32u)))
+#define W4_RDA(fa_, rd_, s_, j_) fa_[j_] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + ((s_) >> 1) * 512 + (offA[j_] ^ (((s_) & 1) * 32u)))
+    // slot k (0..19) of a k-step: MFMA on accumulator tile (i = k % 5, j = k / 5) of the set (ca_, cb_); slots 0-8: one read of
+    // the NEXT step's set; slots 10-19: DMA piece Q0_ + (k - 10) while < Q1_ (D_: 0 none, 1 always, 2 when dma_ is set)
+#define W4_SLOT(k_, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                      \
+        mfma32_asm<PREC, ((k_) % 5) < 4>(acc[(k_) % 5][(k_) / 5], cb_[(k_) % 5], ca_[(k_) / 5]);           \
+        if constexpr ((k_) < 5) { W4_RDB(nb_, nrd_, ns_, ((k_) < 5 ? (k_) : 0)); }                         \
+        else if constexpr ((k_) < 9) { W4_RDA(na_, nrd_, ns_, ((k_) >= 5 && (k_) < 9 ? (k_) - 5 : 0)); }   \
+        if constexpr ((D_) != 0 && (k_) >= 10 && (Q0_) + (k_) - 10 < (Q1_)) {                              \
+            if ((D_) == 1 || (dma_)) W4_PIECE(pa_, pb_, wr_, ((k_) >= 10 && (Q0_) + (k_) - 10 < NP ? (Q0_) + (k_) - 10 : 0)); \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);
+#define W4_STEP(ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                          \
+        W4_SLOT(0, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                       \
+        W4_SLOT(1, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                       \
+        W4_SLOT(2, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                       \
+        W4_SLOT(3, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                       \
+        W4_SLOT(4, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                       \
+        W4_SLOT(5, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                       \
+        W4_SLOT(6, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                       \
+        W4_SLOT(7, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                       \
+        W4_SLOT(8, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                       \
+        W4_SLOT(9, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                       \
+        W4_SLOT(10, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                      \
+        W4_SLOT(11, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                      \
+        W4_SLOT(12, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                      \
+        W4_SLOT(13, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                      \
+        W4_SLOT(14, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                      \
+        W4_SLOT(15, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                      \
+        W4_SLOT(16, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                      \
+        W4_SLOT(17, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                      \
+        W4_SLOT(18, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)                      \
+        W4_SLOT(19, ca_, cb_, na_, nb_, nrd_, ns_, D_, dma_, Q0_, Q1_, pa_, pb_, wr_)
+#define W4_STAGE(D0_, d0_, a0_, b0_, D3_, d3_, a3_, b3_)                                                   \
+        {                                                                                                  \
+            const uint32_t ot = XSB - rd;                                                                  \
+            W4_STEP(fa0, fb0, fa1, fb1, rd, 1, D0_, d0_, NP3, NP, a0_, b0_, ot)                            \
+            W4_STEP(fa1, fb1, fa0, fb0, rd, 2, 0, false, 0, 0, a0_, b0_, ot)                               \
+            W4_STEP(fa0, fb0, fa1, fb1, rd, 3, 0, false, 0, 0, a0_, b0_, ot)                               \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            W4_STEP(fa1, fb1, fa0, fb0, ot, 0, D3_, d3_, 0, NP3, a3_, b3_, rd)                             \
+            rd = ot;                                                                                       \
+        }
+#define W4_ISSUE_RANGE(pa_, pb_, wr_, LO, HI)                                                              \
+    do {                                                                                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < NP; ++q_)                                                  \
+            if (q_ >= (LO) && q_ < (HI)) {                                                                 \
+                glds16_m(voff, (q_ < 8 ? (pa_) + (size_t)q_ * rs32 : (pb_) + (size_t)(q_ - 8) * rs32), lds0 + (wr_) + q_ * 4096u); \
+            }                                                                                              \
+    } while (0)
+
+    int L = blockIdx.x, m0, n0;
+    W4_TILE(L, m0, n0);
+    const uint16_t* sA = A + (size_t)m0 * K;
+    const uint16_t* sB = B + (size_t)n0 * K;
+    W4_ISSUE_RANGE(sA, sB, 0u, 0, NP);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x16_t acc[NI][NJ];
+    for (;;) {
+        const int Ln = L + (int)gridDim.x;
+        const bool more = Ln < ntiles;
+        int m1 = m0, n1 = n0;
+        if (more) W4_TILE(Ln, m1, n1);
+        const uint16_t* nA = A + (size_t)m1 * K;
+        const uint16_t* nB = B + (size_t)n1 * K;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        {
+            const uint16_t* a1 = sA + XBK;
+            const uint16_t* b1 = sB + XBK;
+            W4_ISSUE_RANGE(a1, b1, XSB, 0, NP3);           // early pieces of stage 1 -> buffer 1
+        }
+        uint4 fa0[NJ], fb0[NI], fa1[NJ], fb1[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) W4_RDB(fb0, 0u, 0, i);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) W4_RDA(fa0, 0u, 0, j);
+        asm volatile("s_nop 7" ::: "memory");              // accumulator writes (VALU / v_accvgpr_write) before the first MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t rd = 0;
+        const uint16_t* pa = sA + XBK;
+        const uint16_t* pb = sB + XBK;
+        for (int t = 0; t + 2 < nst; ++t) {
+            W4_STAGE(1, true, pa, pb, 1, true, pa + XBK, pb + XBK)
+            pa += XBK;
+            pb += XBK;
+        }
+        W4_STAGE(1, true, pa, pb, 2, more, nA, nB)         // t = nst-2
+        W4_STAGE(2, more, nA, nB, 0, false, nA, nB)        // t = nst-1
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA results before the epilogue reads the accumulators
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + XSB + wave * (XSB / 4);
+            epilogue_m32<PREC, OUT_F32, GELU, false, NJ>(acc, scr, Cv, bias, N, m0 + wm * 128, n0 + wn * 160, wn, accumulate, lane);
+        }
+        if (!more) break;
+        __builtin_amdgcn_s_barrier();
+        L = Ln; m0 = m1; n0 = n1; sA = nA; sB = nB;
+    }
+#undef W4_TILE
+#undef W4_PIECE
+#undef W4_RDA
+#undef W4_RDB
+#undef W4_SLOT
+#undef W4_STEP
+#undef W4_STAGE
+#undef W4_ISSUE_RANGE
+}
+
+template <int PREC>
+hipError_t launch_gemm_w4(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, bool out_f32, bool gelu,
+                          bool accumulate, bool persistent, hipStream_t s) {
+    const int ntiles = (M / QBM) * (N / WBN);
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    dim3 grid(persistent && ntiles > n_cu ? n_cu : ntiles), block(W4THREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (out_f32) {
+        if (gelu) gemm_et_w4_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        else gemm_et_w4_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    } else {
+        if (gelu) gemm_et_w4_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        else gemm_et_w4_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    }
+    return hipGetLastError();
+}
+
 // producer of the folded LayerNorm: C = A B^T + bias + C (fp32), Xh = ET(C), stats[m][N / 160] = (mean, M2) per 160 columns
 template <int PREC>
 hipError_t launch_gemm_m32_stats(const void* A, const void* B, float* C, const float* bias, void* Xh, float* stats,
@@ -2525,7 +2747,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     // bit 2 = one tile per block instead of persistent, bit 3 = spread pieces
     static const int m32_mask = [] { const char* v = getenv("SAMRS_GEMM_M32"); return v ? atoi(v) : 0; }();
     if ((variant == 27 || variant == 28) && m32_ok(M, N, K, add2d) && (m32_mask & (out_f32 ? 2 : 1)))
-        variant = 30 + ((m32_mask & 4) ? 1 : 0) + ((m32_mask & 8) ? 2 : 0);
+        variant = (m32_mask & 16) ? 34 : 30 + ((m32_mask & 4) ? 1 : 0) + ((m32_mask & 8) ? 2 : 0);
     if (variant >= 30 && variant <= 33 && !m32_ok(M, N, K, add2d)) variant = add2d ? 27 : 28;
     if (variant >= 30 && variant <= 33) {     // 30 / 31: all pieces in step 3; 32 / 33: pieces spread over two steps
         const bool pers = !(variant & 1);
@@ -2536,6 +2758,13 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
             if (prec == PREC_BF16) return launch_gemm_m32<PREC_BF16, 1>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, pers, s);
             if (prec == PREC_F16) return launch_gemm_m32<PREC_F16, 1>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, pers, s);
         }
+        return hipErrorInvalidValue;
+    }
+    // 34 / 36: the four-wave, 512-register flavour of the symmetric schedule (persistent / one tile per block)
+    if ((variant == 34 || variant == 36) && !m32_ok(M, N, K, add2d)) variant = add2d ? 27 : 28;
+    if (variant == 34 || variant == 36) {
+        if (prec == PREC_BF16) return launch_gemm_w4<PREC_BF16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, variant == 34, s);
+        if (prec == PREC_F16) return launch_gemm_w4<PREC_F16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, variant == 34, s);
         return hipErrorInvalidValue;
     }
     if (variant == 28 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0 && !add2d) {   // persistent pair-stage kernel

@@ -170,16 +170,16 @@ def test_gemm_tile_variants_are_bit_identical(lib, name, prec, dt, ulp):
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
-@pytest.mark.parametrize("variant", [30, 31, 32, 33])
+@pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 36])
 def test_gemm_m32_kernel(lib, name, prec, dt, ulp, variant):
     """The 32x32x16 symmetric-schedule kernel (30 persistent / 31 one tile per block; 32 / 33 with the DMA pieces spread over
-    two steps).  It sums k in 16-wide MFMA steps, so it is not bit-identical with the 16x16x32 tile family; it must agree with
+    two steps; 34 / 36 = its four-wave, 512-register flavour with hand-allocated AGPR accumulators).  It sums k in 16-wide MFMA steps, so it is not bit-identical with the 16x16x32 tile family; it must agree with
     it to fp32-summation-order accuracy (fp32 output: rel. L2 < 2e-6; ET output: <= 1 ulp apart, and only where the fp32 value
     sits on a rounding boundary), with fp64 on the small shapes, and with ITSELF bit for bit across repeated launches (the race
     screen: 2, 4, 6 and 80 stages, one to three tiles per block, the real proj / lin2 / qkv shapes of an 8-tile batch)."""
     lib.samrs_debug_set_gemm_variant.argtypes = [__import__("ctypes").c_int]
     shapes = [(256, 640, 128), (512, 640, 256), (8192, 3200, 256), (16384, 3840, 384), (32768, 1280, 1280)]
-    if variant == 30:
+    if variant in (30, 34):
         shapes += [(32768, 1280, 5120), (32768, 3840, 1280)]
     try:
         for (M, N, K) in shapes:

@@ -1915,7 +1915,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amd
         for (int i = 0; i < NI; ++i) W4_RDB(fb0, 0u, 0, i);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) W4_RDA(fa0, 0u, 0, j);
-        asm volatile("s_nop 7" ::: "memory");              // accumulator writes (VALU / v_accvgpr_write) before the first MFMA
+        // accumulator writes (VALU / v_accvgpr_write) before the first MFMA: same tie
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j == NJ - 1)
+                asm volatile("s_nop 7" : "+a"(acc[0][j]), "+a"(acc[1][j]), "+a"(acc[2][j]), "+a"(acc[3][j]), "+v"(acc[4][j]));
+            else
+                asm volatile("" : "+a"(acc[0][j]), "+a"(acc[1][j]), "+a"(acc[2][j]), "+a"(acc[3][j]), "+v"(acc[4][j]));
+        }
         __builtin_amdgcn_sched_barrier(0);
         uint32_t rd = 0;
         const uint16_t* pa = sA + XBK;
@@ -1927,7 +1934,15 @@ __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amd
         }
         W4_STAGE(1, true, pa, pb, 2, more, nA, nB)         // t = nst-2
         W4_STAGE(2, more, nA, nB, 0, false, nA, nB)        // t = nst-1
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // last MFMA results before the epilogue reads the accumulators
+        // The last MFMA results must not be read for 18 wait states, and hipcc neither knows that the asm statements above are
+        // MFMAs nor keeps register-only code behind a bare asm: the padding is tied to every accumulator tile by data dependence.
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j == 0)
+                asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][j]), "+a"(acc[1][j]), "+a"(acc[2][j]), "+a"(acc[3][j]), "+v"(acc[4][j]));
+            else
+                asm volatile("" : "+a"(acc[0][j]), "+a"(acc[1][j]), "+a"(acc[2][j]), "+a"(acc[3][j]), "+v"(acc[4][j]));
+        }
         __builtin_amdgcn_sched_barrier(0);
         {
             unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + XSB + wave * (XSB / 4);

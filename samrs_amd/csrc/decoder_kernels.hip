@@ -26,7 +26,7 @@ __device__ __forceinline__ float pe_channel(const float* __restrict__ gauss, flo
 }
 
 // grid: (T, n_prompts); block: C threads (one per channel)
-__global__ void prompt_tokens_kernel(PromptParams p, float* __restrict__ tokens, int T, int C) {
+__global__ void prompt_tokens_kernel(PromptParams p, float* __restrict__ tokens, float* __restrict__ tokens2, int T, int C) {
     const int j = blockIdx.x, b = blockIdx.y, ch = threadIdx.x;
     const int half = C / 2;
     const bool has_pts = p.point_coords != nullptr;
@@ -60,6 +60,7 @@ __global__ void prompt_tokens_kernel(PromptParams p, float* __restrict__ tokens,
         v = pe_channel(p.gauss, x / p.img_size, y / p.img_size, ch, half) + p.point_emb[2 + corner][ch];
     }
     tokens[((size_t)b * T + j) * C + ch] = v;
+    if (tokens2) tokens2[((size_t)b * T + j) * C + ch] = v;      // the queries start as a copy of the tokens (transformer.py:87)
 }
 
 // grid: g*g blocks; block: C threads.  pe[(y*g + x)][ch] at ((x+.5)/g, (y+.5)/g)
@@ -220,10 +221,39 @@ constexpr int T2I_TG = 8;            // tokens per pass
 constexpr int T2I_REC = 10;          // floats per (token, chunk) partial: m, l, acc[8]
 constexpr float T2I_NEG = -1.0e30f;  // finite "-inf": exp2(NEG - NEG) = 1 with l = acc = 0 stays harmless
 
+// Combine the key splits of (prompt b, token group tg) in a fixed order: thread = (token, chunk).  COH: the partials were
+// written by other CUs during this kernel (in-kernel merge by the last block): read them with agent-scope loads.
+template <bool COH>
+__device__ __forceinline__ void t2i_merge_rows(const float* part, float* __restrict__ o, int splits, int T, int Ci, int b, int tg,
+                                               int ntg, int tid) {
+    const int t = tg * T2I_TG + (tid >> 4), ch = tid & 15;
+    if (t >= T) return;
+    const float* base = part + (((size_t)b * ntg + tg) * splits * (T2I_TG * 16) + tid) * T2I_REC;
+    const size_t sstride = (size_t)(T2I_TG * 16) * T2I_REC;
+    auto ld = [](const float* p_) { return COH ? __hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p_; };
+    float mm = T2I_NEG;
+    for (int s = 0; s < splits; ++s) mm = fmaxf(mm, ld(base + s * sstride));
+    float ll = 0.f, a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) {
+        const float* r = base + s * sstride;
+        const float f = __builtin_amdgcn_exp2f(ld(r) - mm);
+        ll += ld(r + 1) * f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] += ld(r + 2 + c) * f;
+    }
+    const float inv = 1.0f / ll;
+    float* orow = o + ((size_t)b * T + t) * Ci + ch * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) orow[c] = a[c] * inv;
+}
+
+// tickets != nullptr: the last split block of a (prompt, token group) merges the splits itself (ticket counter, release /
+// acquire fences) and writes o -- one launch less on a stream whose every launch waits for a CU in the tile loop.
 template <int PREC>
 __global__ __launch_bounds__(256, 2) void t2i_partial_kernel(const float* __restrict__ qp, const uint16_t* __restrict__ kp,
                                                           const uint16_t* __restrict__ vp, int ld, long bstride,
-                                                          float* __restrict__ part, int T, int tokens, int Ci, int kpw) {
+                                                          float* __restrict__ part, int T, int tokens, int Ci, int kpw,
+                                                          float* __restrict__ o = nullptr, int* __restrict__ tickets = nullptr) {
     __shared__ float sm[4][T2I_TG][16][T2I_REC];
     const int split = blockIdx.x, b = blockIdx.y, t0 = blockIdx.z * T2I_TG;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -335,30 +365,24 @@ __global__ __launch_bounds__(256, 2) void t2i_partial_kernel(const float* __rest
 #pragma unroll
         for (int c = 0; c < 8; ++c) r[2 + c] = a[c];
     }
+    if (tickets) {                                     // kernel-uniform
+        __shared__ int s_last;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&tickets[b * gridDim.z + blockIdx.z], 1) == (int)gridDim.x - 1;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            if (threadIdx.x < T2I_TG * 16) t2i_merge_rows<true>(part, o, gridDim.x, T, Ci, b, blockIdx.z, gridDim.z, threadIdx.x);
+            if (threadIdx.x == 0) tickets[b * gridDim.z + blockIdx.z] = 0;
+        }
+    }
 }
 
 // grid (n_prompts, token groups), T2I_TG * 16 threads = (token, chunk): combine the key splits
 __global__ __launch_bounds__(T2I_TG * 16) void t2i_merge_kernel(const float* __restrict__ part, float* __restrict__ o,
                                                                 int splits, int T, int Ci) {
-    const int b = blockIdx.x, tg = blockIdx.y;
-    const int t = tg * T2I_TG + (threadIdx.x >> 4), ch = threadIdx.x & 15;
-    if (t >= T) return;
-    const float* base = part + (((size_t)b * gridDim.y + tg) * splits * (T2I_TG * 16) + threadIdx.x) * T2I_REC;
-    const size_t sstride = (size_t)(T2I_TG * 16) * T2I_REC;
-    float mm = T2I_NEG;
-    for (int s = 0; s < splits; ++s) mm = fmaxf(mm, base[s * sstride]);
-    float ll = 0.f, a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) {
-        const float* r = base + s * sstride;
-        const float f = __builtin_amdgcn_exp2f(r[0] - mm);
-        ll += r[1] * f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) a[c] += r[2 + c] * f;
-    }
-    const float inv = 1.0f / ll;
-    float* orow = o + ((size_t)b * T + t) * Ci + ch * 8;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) orow[c] = a[c] * inv;
+    t2i_merge_rows<false>(part, o, splits, T, Ci, blockIdx.x, blockIdx.y, gridDim.y, threadIdx.x);
 }
 
 // image -> tokens attention (head dim 16).  Thread = (image token, head); keys/values are the T
@@ -1064,9 +1088,9 @@ hipError_t launch_resample_pass(const uint8_t* in, uint8_t* out, const int32_t* 
     return hipGetLastError();
 }
 
-hipError_t launch_prompt_tokens(const PromptParams& p, float* tokens, int T, hipStream_t s) {
+hipError_t launch_prompt_tokens(const PromptParams& p, float* tokens, float* tokens2, int T, hipStream_t s) {
     dim3 g(T, p.n_prompts), b(256);
-    prompt_tokens_kernel<<<g, b, 0, s>>>(p, tokens, T, 256);
+    prompt_tokens_kernel<<<g, b, 0, s>>>(p, tokens, tokens2, T, 256);
     return hipGetLastError();
 }
 hipError_t launch_dense_pe(const float* gauss, float* pe, int grid, hipStream_t s) {
@@ -1102,8 +1126,10 @@ hipError_t launch_token_self_attn(const float* q, const float* k, const float* v
 size_t t2i_workspace_floats(int n, int T) {
     return (size_t)n * ((T + T2I_TG - 1) / T2I_TG) * T2I_MAX_SPLITS * (T2I_TG * 16) * T2I_REC;
 }
+int t2i_ticket_count(int n, int T) { return n * ((T + T2I_TG - 1) / T2I_TG); }
+// tickets (t2i_ticket_count ints, zero before the first use) != nullptr: the split merge happens inside the partial kernel
 hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const void* vp, int ld, long bstride,
-                                float* o, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s) {
+                                float* o, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s, int* tickets) {
     if (Ci != 128 || heads != 8 || T > TOK_MAX || !workspace) return hipErrorInvalidValue;
     // keys per wave: a multiple of 16 (4 groups of 4 keys per iteration), at most T2I_MAX_SPLITS blocks of 4 waves
     int splits = (tokens + 255) / 256;
@@ -1113,9 +1139,9 @@ hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const
     dim3 g(splits, n, tgs), b(256);
     const uint16_t* k = (const uint16_t*)kp;
     const uint16_t* v = (const uint16_t*)vp;
-    if (prec == PREC_BF16) t2i_partial_kernel<PREC_BF16><<<g, b, 0, s>>>(qp, k, v, ld, bstride, workspace, T, tokens, Ci, kpw);
-    else t2i_partial_kernel<PREC_F16><<<g, b, 0, s>>>(qp, k, v, ld, bstride, workspace, T, tokens, Ci, kpw);
-    t2i_merge_kernel<<<dim3(n, tgs), T2I_TG * 16, 0, s>>>(workspace, o, splits, T, Ci);
+    if (prec == PREC_BF16) t2i_partial_kernel<PREC_BF16><<<g, b, 0, s>>>(qp, k, v, ld, bstride, workspace, T, tokens, Ci, kpw, o, tickets);
+    else t2i_partial_kernel<PREC_F16><<<g, b, 0, s>>>(qp, k, v, ld, bstride, workspace, T, tokens, Ci, kpw, o, tickets);
+    if (!tickets) t2i_merge_kernel<<<dim3(n, tgs), T2I_TG * 16, 0, s>>>(workspace, o, splits, T, Ci);
     return hipGetLastError();
 }
 hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long bstride, const float* kt, const float* vt,

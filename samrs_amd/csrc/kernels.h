@@ -22,6 +22,10 @@ void set_gemm_variant(int v);   // 0 = register-staged tiles, 1 = LDS-DMA stagin
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s);
+// C[M, 256] = LayerNorm_256(A W^T + bias (+ C)), eps, in ONE launch: the last block of each 32-row band normalises it in place
+// (ticket counter per band; `tickets` = >= ceil(M / 32) ints, zero before the first use, left zero by every launch)
+hipError_t launch_gemm_f32_ln(const float* A, int lda, const float* W, const float* bias, float* C, int M, int K, bool accumulate,
+                              const float* gamma, const float* beta, float eps, int* tickets, hipStream_t s);
 // up to F32_BATCH_MAX same-shape fp32 GEMMs in one launch: C[z] = (A[z] (+ A2[z])) * W[z]^T + bias[z]
 constexpr int F32_BATCH_MAX = 5;
 struct F32Batch {
@@ -69,7 +73,7 @@ struct PromptParams {
     const float* mask_tokens;    // [4,256]
 };
 // tokens [n, T, 256], T = 5 + n_points (+1 pad point when there is no box) + 2*(boxes != null)
-hipError_t launch_prompt_tokens(const PromptParams& p, float* tokens, int T, hipStream_t s);
+hipError_t launch_prompt_tokens(const PromptParams& p, float* tokens, float* tokens2 /* optional second copy */, int T, hipStream_t s);
 hipError_t launch_dense_pe(const float* gauss, float* pe /*[g*g,256]*/, int grid, hipStream_t s);
 // mask prompt -> dense embedding [n, 4096, 256] (prompt_encoder.py:51-59)
 struct MaskEmbedParams {
@@ -86,9 +90,11 @@ hipError_t launch_token_self_attn(const float* q, const float* k, const float* v
 // tokens -> image attention. qp [n*T, Ci] fp32; kp/vp ET rows of `ld` elements, batch stride in rows
 // (0 = shared by all prompts); o [n*T, Ci] fp32.
 constexpr int T2I_MAX_SPLITS = 16;
+int t2i_ticket_count(int n_prompts, int T);         // ints of ticket space launch_t2i_attention needs when it merges in-kernel
 size_t t2i_workspace_floats(int n_prompts, int T);     // scratch for the per-split partial softmax states
 hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const void* vp, int ld, long batch_stride_rows,
-                                float* out, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s);
+                                float* out, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s,
+                                int* tickets = nullptr);
 // image -> tokens attention. qi ET rows of `ld` elements (batch stride in rows, 0 = shared);
 // kt, vt [n*T, Ci] fp32; out ET [n*tokens, Ci].
 hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long batch_stride_rows, const float* kt,

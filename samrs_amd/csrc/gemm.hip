@@ -2568,32 +2568,9 @@ hipError_t launch_gemm_prec(const void* A, const void* B, void* C, const float* 
 // ---------------------------------------------------------------------------------------------
 constexpr int FM = 32, FN = 32, FKS = 16, F32_PF = 4;
 
-// Optional LayerNorm behind the GEMM (decoder token side: every attention / MLP output is followed by a LayerNorm over the 256
-// channels, transformer.py:163-181; a separate launch costs ~5 us alone and ~60 us in the tile loop, where it waits for a CU):
-// the LAST block to finish a 32-row band normalises those rows in place.  "Last" is decided by a ticket counter per band
-// (release fence, atomic add, acquire fence); the rows are re-read with agent-scope loads because the other tiles were written
-// by other CUs.  The arithmetic per row is the stand-alone kernel's (one wave per row, lane = one float4, two-pass statistics),
-// and no value depends on which block drew the last ticket, so the result is reproducible.  ln_g == nullptr: plain GEMM.
-__device__ __forceinline__ float coherent_ld(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void ln_row256_inplace(float* row, const float* __restrict__ g, const float* __restrict__ b, float eps, int lane) {
-    float4 v;
-    v.x = coherent_ld(row + 4 * lane); v.y = coherent_ld(row + 4 * lane + 1);
-    v.z = coherent_ld(row + 4 * lane + 2); v.w = coherent_ld(row + 4 * lane + 3);
-    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / 256.0f;
-    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-    const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 256.0f + eps);
-    const float4 gg = reinterpret_cast<const float4*>(g)[lane], bb = reinterpret_cast<const float4*>(b)[lane];
-    *reinterpret_cast<float4*>(row + 4 * lane) =
-        make_float4(d0 * rstd * gg.x + bb.x, d1 * rstd * gg.y + bb.y, d2 * rstd * gg.z + bb.z, d3 * rstd * gg.w + bb.w);
-}
-
 template <int S>
 __global__ __launch_bounds__(64 * S) void gemm_f32_kernel(F32Batch bt, int lda, int ldc, int M, int N, int K,
-                                                          int relu, int accumulate, const float* __restrict__ ln_g = nullptr,
-                                                          const float* __restrict__ ln_b = nullptr, float ln_eps = 0.f,
-                                                          int* __restrict__ tickets = nullptr) {
+                                                          int relu, int accumulate) {
     __shared__ float red[S][FM][FN + 1];
     const int z = blockIdx.z;
     const float* __restrict__ A = bt.A[z];
@@ -2681,19 +2658,6 @@ __global__ __launch_bounds__(64 * S) void gemm_f32_kernel(F32Batch bt, int lda, 
             if (relu) v = fmaxf(v, 0.f);
             if (accumulate) v += *c;
             *c = v;
-        }
-    }
-    if (ln_g) {                                        // kernel-uniform
-        __shared__ int s_last;
-        __threadfence();                               // this block's tile before its ticket
-        __syncthreads();
-        if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.y], 1) == (int)gridDim.x - 1;
-        __syncthreads();
-        if (s_last) {
-            __threadfence();
-            for (int rr = wave; rr < FM; rr += S)
-                if (m0 + rr < M) ln_row256_inplace(C + (size_t)(m0 + rr) * ldc, ln_g, ln_b, ln_eps, lane);
-            if (threadIdx.x == 0) tickets[blockIdx.y] = 0;      // ready for the next launch (stream order)
         }
     }
 }
@@ -2907,27 +2871,6 @@ hipError_t launch_gemm_f32_batch(const F32Batch& bt, int count, int lda, int ldc
         case 4: gemm_f32_kernel<4><<<grid, 256, 0, s>>>(bt, lda, ldc, M, N, K, r, a); break;
         case 8: gemm_f32_kernel<8><<<grid, 512, 0, s>>>(bt, lda, ldc, M, N, K, r, a); break;
         default: gemm_f32_kernel<16><<<grid, 1024, 0, s>>>(bt, lda, ldc, M, N, K, r, a); break;
-    }
-    return hipGetLastError();
-}
-
-// C[M, 256] = LayerNorm_256(A W^T + bias (+ C)) in one launch (see gemm_f32_kernel); tickets: >= ceil(M / 32) zeroed ints
-hipError_t launch_gemm_f32_ln(const float* A, int lda, const float* W, const float* bias, float* C, int M, int K, bool accumulate,
-                              const float* gamma, const float* beta, float eps, int* tickets, hipStream_t s) {
-    const int N = 256, ldc = 256;
-    if (K % FKS || M <= 0 || (lda % 4) || !gamma || !beta || !tickets) return hipErrorInvalidValue;
-    F32Batch bt{};
-    bt.A[0] = A; bt.W[0] = W; bt.bias[0] = bias; bt.C[0] = C;
-    int S = 1;
-    while (S < 16 && K % (2 * FKS * S) == 0) S *= 2;      // the same K split as launch_gemm_f32_batch: same summation order
-    dim3 grid(N / FN, (M + FM - 1) / FM, 1);
-    const int a = accumulate ? 1 : 0;
-    switch (S) {
-        case 1: gemm_f32_kernel<1><<<grid, 64, 0, s>>>(bt, lda, ldc, M, N, K, 0, a, gamma, beta, eps, tickets); break;
-        case 2: gemm_f32_kernel<2><<<grid, 128, 0, s>>>(bt, lda, ldc, M, N, K, 0, a, gamma, beta, eps, tickets); break;
-        case 4: gemm_f32_kernel<4><<<grid, 256, 0, s>>>(bt, lda, ldc, M, N, K, 0, a, gamma, beta, eps, tickets); break;
-        case 8: gemm_f32_kernel<8><<<grid, 512, 0, s>>>(bt, lda, ldc, M, N, K, 0, a, gamma, beta, eps, tickets); break;
-        default: gemm_f32_kernel<16><<<grid, 1024, 0, s>>>(bt, lda, ldc, M, N, K, 0, a, gamma, beta, eps, tickets); break;
     }
     return hipGetLastError();
 }

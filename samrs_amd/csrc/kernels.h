@@ -22,10 +22,6 @@ void set_gemm_variant(int v);   // 0 = register-staged tiles, 1 = LDS-DMA stagin
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s);
-// C[M, 256] = LayerNorm_256(A W^T + bias (+ C)), eps, in ONE launch: the last block of each 32-row band normalises it in place
-// (ticket counter per band; `tickets` = >= ceil(M / 32) ints, zero before the first use, left zero by every launch)
-hipError_t launch_gemm_f32_ln(const float* A, int lda, const float* W, const float* bias, float* C, int M, int K, bool accumulate,
-                              const float* gamma, const float* beta, float eps, int* tickets, hipStream_t s);
 // up to F32_BATCH_MAX same-shape fp32 GEMMs in one launch: C[z] = (A[z] (+ A2[z])) * W[z]^T + bias[z]
 constexpr int F32_BATCH_MAX = 5;
 struct F32Batch {
@@ -90,11 +86,19 @@ hipError_t launch_token_self_attn(const float* q, const float* k, const float* v
 // tokens -> image attention. qp [n*T, Ci] fp32; kp/vp ET rows of `ld` elements, batch stride in rows
 // (0 = shared by all prompts); o [n*T, Ci] fp32.
 constexpr int T2I_MAX_SPLITS = 16;
-int t2i_ticket_count(int n_prompts, int T);         // ints of ticket space launch_t2i_attention needs when it merges in-kernel
 size_t t2i_workspace_floats(int n_prompts, int T);     // scratch for the per-split partial softmax states
 hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const void* vp, int ld, long batch_stride_rows,
                                 float* out, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s,
-                                int* tickets = nullptr);
+                                bool merge = true);
+// Token-side tails in one launch per 32-row band (decoder_kernels.hip, tok_band_ln_kernel):
+//   queries = LayerNorm_256(A W^T + b (+ queries)), A = plain fp32 rows / the t2i partials of launch_t2i_attention(merge = false)
+//   merged on the fly / the token self-attention of (tq, tk, tv) computed on the fly.  K = 128 or 256.
+hipError_t launch_tok_band_plain(const float* A, int lda, int K, const float* W, const float* bias, float* Q, int M, bool accumulate,
+                                 const float* gamma, const float* beta, float eps, hipStream_t s);
+hipError_t launch_tok_band_t2i(const float* workspace, int n, int T, int tokens, const float* W, const float* bias, float* Q,
+                               const float* gamma, const float* beta, float eps, hipStream_t s);
+hipError_t launch_tok_band_self(const float* tq, const float* tk, const float* tv, int n, int T, const float* W, const float* bias,
+                                float* Q, bool accumulate, const float* gamma, const float* beta, float eps, hipStream_t s);
 // image -> tokens attention. qi ET rows of `ld` elements (batch stride in rows, 0 = shared);
 // kt, vt [n*T, Ci] fp32; out ET [n*tokens, Ci].
 hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long batch_stride_rows, const float* kt,

@@ -212,11 +212,6 @@ int samrs_k_gemm_fold(int prec, const void* xh_et, const void* Wf_et, void* C_et
 int samrs_k_ln_fold_weight(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_et,
                            float* cvec, float* bias_f, int N, int K, void* stream);
 int samrs_k_rowstats_convert(int prec, const float* X, void* xh_et, float* stats, int rows, int D, void* stream);
-/* Decoder token side (transformer.py:163-181): Q[M, 256] = LayerNorm_256(A W^T + bias (+ Q)) for K = 128 or 256 in one launch,
- * one block per 32-row band (the same kernel that, inside samrs_predict, also merges the tokens->image attention splits or
- * computes the token self-attention while it loads its A rows). */
-int samrs_k_tok_band(const float* A, int lda, int K, const float* W, const float* bias, float* Q, int M, int accumulate,
-                     const float* gamma, const float* beta, float eps, void* stream);
 int samrs_k_convert(int prec, const float* in, void* out_et, int64_t n, void* stream);
 int samrs_k_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                       void* out_et, float* out_f32, int rows_out, int D, int window_mode,

@@ -221,27 +221,6 @@ constexpr int T2I_TG = 8;            // tokens per pass
 constexpr int T2I_REC = 10;          // floats per (token, chunk) partial: m, l, acc[8]
 constexpr float T2I_NEG = -1.0e30f;  // finite "-inf": exp2(NEG - NEG) = 1 with l = acc = 0 stays harmless
 
-// Combine the key splits of (prompt b, token t) for channel chunk ch in a fixed order -> out[0..7] (the merge kernel's thread,
-// and the A-row loader of tok_band_ln_kernel<., 1>)
-__device__ __forceinline__ void t2i_merge_chunk(const float* __restrict__ part, int splits, int ntg, int b, int t, int ch, float (&out)[8]) {
-    const int tg = t / T2I_TG, tid = (t % T2I_TG) * 16 + ch;
-    const float* base = part + (((size_t)b * ntg + tg) * splits * (T2I_TG * 16) + tid) * T2I_REC;
-    const size_t sstride = (size_t)(T2I_TG * 16) * T2I_REC;
-    float mm = T2I_NEG;
-    for (int s = 0; s < splits; ++s) mm = fmaxf(mm, base[s * sstride]);
-    float ll = 0.f, a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < splits; ++s) {
-        const float* r = base + s * sstride;
-        const float f = __builtin_amdgcn_exp2f(r[0] - mm);
-        ll += r[1] * f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) a[c] += r[2 + c] * f;
-    }
-    const float inv = 1.0f / ll;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) out[c] = a[c] * inv;
-}
-
 template <int PREC>
 __global__ __launch_bounds__(256, 2) void t2i_partial_kernel(const float* __restrict__ qp, const uint16_t* __restrict__ kp,
                                                           const uint16_t* __restrict__ vp, int ld, long bstride,
@@ -362,172 +341,25 @@ __global__ __launch_bounds__(256, 2) void t2i_partial_kernel(const float* __rest
 // grid (n_prompts, token groups), T2I_TG * 16 threads = (token, chunk): combine the key splits
 __global__ __launch_bounds__(T2I_TG * 16) void t2i_merge_kernel(const float* __restrict__ part, float* __restrict__ o,
                                                                 int splits, int T, int Ci) {
-    const int b = blockIdx.x, t = blockIdx.y * T2I_TG + (threadIdx.x >> 4), ch = threadIdx.x & 15;
+    const int b = blockIdx.x, tg = blockIdx.y;
+    const int t = tg * T2I_TG + (threadIdx.x >> 4), ch = threadIdx.x & 15;
     if (t >= T) return;
-    float r[8];
-    t2i_merge_chunk(part, splits, gridDim.y, b, t, ch, r);
+    const float* base = part + (((size_t)b * gridDim.y + tg) * splits * (T2I_TG * 16) + threadIdx.x) * T2I_REC;
+    const size_t sstride = (size_t)(T2I_TG * 16) * T2I_REC;
+    float mm = T2I_NEG;
+    for (int s = 0; s < splits; ++s) mm = fmaxf(mm, base[s * sstride]);
+    float ll = 0.f, a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) {
+        const float* r = base + s * sstride;
+        const float f = __builtin_amdgcn_exp2f(r[0] - mm);
+        ll += r[1] * f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[c] += r[2 + c] * f;
+    }
+    const float inv = 1.0f / ll;
     float* orow = o + ((size_t)b * T + t) * Ci + ch * 8;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) orow[c] = r[c];
-}
-
-// ---------------------------------------------------------------------------------------------
-// tok_band_ln_kernel: the tail of every token-side attention of the two-way transformer (transformer.py:163-181) for one band
-// of 32 prompt-token rows in ONE launch and without cross-block synchronisation:
-//     queries[m] = LayerNorm_256(A[m] W^T + b (+ queries[m]))
-// MODE 0: A rows read from global fp32;  MODE 1: A rows = the tokens->image attention output, merged on the fly from the key-split
-// partials of t2i_partial_kernel (replaces t2i_merge_kernel + GEMM + LayerNorm);  MODE 2: A rows = the token self-attention output
-// computed on the fly from the q / k / v projections (replaces token_self_attn_kernel + GEMM + LayerNorm).
-// Why a band per block: a separate launch costs ~5 us alone but ~60 us in the tile loop, where every decoder launch waits for a CU
-// the encoder's persistent GEMM blocks hold (the decoder stream is the critical path of the box-heavy workloads C3 / C4), and the
-// textbook alternative -- the last block to finish normalises, found with a ticket counter -- was measured 3-7x SLOWER here: an
-// agent-scope release / acquire on this 8-XCD part writes back / invalidates the L2 (gemm + LayerNorm 34-48 us instead of 5 + 5,
-// t2i partial + merge 106-113 us instead of 37 + 7).  So one block owns all 256 output columns of its rows: 16 waves = 8 column
-// tiles x 2 K halves of exact-fp32 MFMAs (v_mfma_f32_16x16x4_f32, operand scheme of gemm_f32_kernel with A from LDS), the halves
-// meet in LDS, bias and residual are added, and each wave normalises two rows.  K split and summation order depend on K only
-// (prompt-batch invariance); results differ from the three-launch path in fp32 rounding only.
-// ---------------------------------------------------------------------------------------------
-struct TokBandParams {
-    const float* A; int lda;                 // MODE 0
-    const float* part; int splits, ntg;      // MODE 1
-    const float *tq, *tk, *tv;               // MODE 2 (each [M][256])
-    int T;                                   // tokens per prompt (MODE 1, 2)
-    const float* W; const float* bias; float* Q; int M; int accumulate;
-    const float *gamma, *beta; float eps;
-};
-constexpr int TB_ROWS = 32, TB_LD = 260;     // 260 floats: 16-byte aligned rows, bank-staggered
-
-template <int KIN, int MODE>
-__global__ __launch_bounds__(1024) void tok_band_ln_kernel(TokBandParams p) {
-    __shared__ __attribute__((aligned(16))) float buf[TB_ROWS][TB_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * TB_ROWS;
-    // ---- A rows -> LDS ----
-    if constexpr (MODE == 0) {
-        for (int idx = tid; idx < TB_ROWS * (KIN / 4); idx += 1024) {
-            const int row = idx / (KIN / 4), c4 = idx % (KIN / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + row < p.M) v = *reinterpret_cast<const float4*>(p.A + (size_t)(m0 + row) * p.lda + 4 * c4);
-            *reinterpret_cast<float4*>(&buf[row][4 * c4]) = v;
-        }
-    } else if constexpr (MODE == 1) {
-        static_assert(MODE != 1 || KIN == 128, "tokens->image attention has 128 channels");
-        if (tid < TB_ROWS * 16) {
-            const int row = tid >> 4, ch = tid & 15, m = m0 + row;
-            float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (m < p.M) t2i_merge_chunk(p.part, p.splits, p.ntg, m / p.T, m % p.T, ch, r);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) buf[row][ch * 8 + c] = r[c];
-        }
-    } else {
-        static_assert(MODE != 2 || KIN == 256, "token self-attention: 8 heads x 32");
-        if (tid < TB_ROWS * 8) {          // thread = (row, head): the arithmetic of token_self_attn_kernel<32>
-            constexpr int DH = 32;
-            const int row = tid >> 3, h = tid & 7, m = m0 + row;
-            float acc[DH];
-#pragma unroll
-            for (int c = 0; c < DH; ++c) acc[c] = 0.f;
-            if (m < p.M) {
-                const int b = m / p.T;
-                float qi[DH];
-#pragma unroll
-                for (int c = 0; c < DH; ++c) qi[c] = p.tq[(size_t)m * 256 + h * DH + c];
-                const float scale = 1.0f / sqrtf((float)DH);
-                float mx = -INFINITY, l = 0.f;
-                for (int j = 0; j < p.T; ++j) {
-                    const float* kr = p.tk + ((size_t)b * p.T + j) * 256 + h * DH;
-                    const float* vr = p.tv + ((size_t)b * p.T + j) * 256 + h * DH;
-                    float sc = 0.f;
-#pragma unroll
-                    for (int c = 0; c < DH; ++c) sc += qi[c] * kr[c];
-                    sc *= scale;
-                    const float mn = fmaxf(mx, sc);
-                    const float corr = expf(mx - mn), pj = expf(sc - mn);
-                    l = l * corr + pj;
-#pragma unroll
-                    for (int c = 0; c < DH; ++c) acc[c] = acc[c] * corr + pj * vr[c];
-                    mx = mn;
-                }
-                const float inv = 1.0f / l;
-#pragma unroll
-                for (int c = 0; c < DH; ++c) acc[c] *= inv;
-            }
-#pragma unroll
-            for (int c = 0; c < DH; ++c) buf[row][h * DH + c] = acc[c];
-        }
-    }
-    // ---- this wave's 32 x 32 tile over its K half ----
-    const int ct = wave & 7, kh = wave >> 3, n0 = ct * 32, k0 = kh * (KIN / 2);
-    constexpr int NS = KIN / 2 / 16;
-    const int r = lane & 15, q = lane >> 4;
-    float4 xw[NS][2];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            xw[s][h] = *reinterpret_cast<const float4*>(p.W + (size_t)(n0 + 16 * h + r) * KIN + k0 + 16 * s + 4 * q);
-    __syncthreads();
-    f32x4_t acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        float4 xa[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) xa[h] = *reinterpret_cast<const float4*>(&buf[16 * h + r][k0 + 16 * s + 4 * q]);
-        const float fa[2][4] = {{xa[0].x, xa[0].y, xa[0].z, xa[0].w}, {xa[1].x, xa[1].y, xa[1].z, xa[1].w}};
-        const float fw[2][4] = {{xw[s][0].x, xw[s][0].y, xw[s][0].z, xw[s][0].w}, {xw[s][1].x, xw[s][1].y, xw[s][1].z, xw[s][1].w}};
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[i][t], fa[j][t], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();                               // every wave is done with the A rows: the buffer becomes the output band
-    // D[i_local = n][j_local = m]: lane holds n = n0 + 16 i + 4 q + rr, m = 16 j + r
-    if (kh == 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                *reinterpret_cast<float4*>(&buf[16 * j + r][n0 + 16 * i + 4 * q]) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + 16 * i + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float4* d = reinterpret_cast<float4*>(&buf[16 * j + r][n0 + 16 * i + 4 * q]);
-                float4 v = *d;
-                v.x = (acc[i][j][0] + v.x) + bv.x; v.y = (acc[i][j][1] + v.y) + bv.y;
-                v.z = (acc[i][j][2] + v.z) + bv.z; v.w = (acc[i][j][3] + v.w) + bv.w;
-                const int m = m0 + 16 * j + r;
-                if (p.accumulate && m < p.M) {
-                    const float4 o = *reinterpret_cast<const float4*>(p.Q + (size_t)m * 256 + n0 + 16 * i + 4 * q);
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                }
-                *d = v;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- LayerNorm over the 256 channels: one wave per row, lane = one float4, two-pass statistics (layernorm_kernel) ----
-    for (int row = wave; row < TB_ROWS; row += 16) {
-        if (m0 + row >= p.M) continue;
-        const float4 v = *reinterpret_cast<const float4*>(&buf[row][4 * lane]);
-        const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / 256.0f;
-        const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-        const float rstd = 1.0f / sqrtf(wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) / 256.0f + p.eps);
-        const float4 gg = reinterpret_cast<const float4*>(p.gamma)[lane], bb = reinterpret_cast<const float4*>(p.beta)[lane];
-        *reinterpret_cast<float4*>(p.Q + (size_t)(m0 + row) * 256 + 4 * lane) =
-            make_float4(d0 * rstd * gg.x + bb.x, d1 * rstd * gg.y + bb.y, d2 * rstd * gg.z + bb.z, d3 * rstd * gg.w + bb.w);
-    }
+    for (int c = 0; c < 8; ++c) orow[c] = a[c] * inv;
 }
 
 // image -> tokens attention (head dim 16).  Thread = (image token, head); keys/values are the T
@@ -1268,19 +1100,15 @@ hipError_t launch_token_self_attn(const float* q, const float* k, const float* v
     token_self_attn_kernel<32><<<n, 256, 3 * T * C * sizeof(float), s>>>(q, k, v, o, T, C, heads);
     return hipGetLastError();
 }
-static int t2i_splits(int tokens) {
-    const int splits = (tokens + 255) / 256;
-    return splits < 1 ? 1 : (splits > T2I_MAX_SPLITS ? T2I_MAX_SPLITS : splits);
-}
 size_t t2i_workspace_floats(int n, int T) {
     return (size_t)n * ((T + T2I_TG - 1) / T2I_TG) * T2I_MAX_SPLITS * (T2I_TG * 16) * T2I_REC;
 }
-// merge = false: leave the split partials in `workspace` for launch_tok_band_t2i (which merges them while it loads its A rows)
 hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const void* vp, int ld, long bstride,
-                                float* o, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s, bool merge) {
+                                float* o, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s) {
     if (Ci != 128 || heads != 8 || T > TOK_MAX || !workspace) return hipErrorInvalidValue;
     // keys per wave: a multiple of 16 (4 groups of 4 keys per iteration), at most T2I_MAX_SPLITS blocks of 4 waves
-    const int splits = t2i_splits(tokens);
+    int splits = (tokens + 255) / 256;
+    splits = splits < 1 ? 1 : (splits > T2I_MAX_SPLITS ? T2I_MAX_SPLITS : splits);
     const int kpw = ((tokens + splits * 4 - 1) / (splits * 4) + 15) / 16 * 16;
     const int tgs = (T + T2I_TG - 1) / T2I_TG;
     dim3 g(splits, n, tgs), b(256);
@@ -1288,39 +1116,7 @@ hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const
     const uint16_t* v = (const uint16_t*)vp;
     if (prec == PREC_BF16) t2i_partial_kernel<PREC_BF16><<<g, b, 0, s>>>(qp, k, v, ld, bstride, workspace, T, tokens, Ci, kpw);
     else t2i_partial_kernel<PREC_F16><<<g, b, 0, s>>>(qp, k, v, ld, bstride, workspace, T, tokens, Ci, kpw);
-    if (merge) t2i_merge_kernel<<<dim3(n, tgs), T2I_TG * 16, 0, s>>>(workspace, o, splits, T, Ci);
-    return hipGetLastError();
-}
-// queries = LayerNorm_256(A W^T + b (+ queries)) per 32-row band, one launch (tok_band_ln_kernel)
-hipError_t launch_tok_band_plain(const float* A, int lda, int K, const float* W, const float* bias, float* Q, int M, bool accumulate,
-                                 const float* gamma, const float* beta, float eps, hipStream_t s) {
-    if (M < 1 || (K != 128 && K != 256) || (lda % 4)) return hipErrorInvalidValue;
-    TokBandParams p{};
-    p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.Q = Q; p.M = M; p.accumulate = accumulate ? 1 : 0;
-    p.gamma = gamma; p.beta = beta; p.eps = eps;
-    const int g = (M + TB_ROWS - 1) / TB_ROWS;
-    if (K == 256) tok_band_ln_kernel<256, 0><<<g, 1024, 0, s>>>(p);
-    else tok_band_ln_kernel<128, 0><<<g, 1024, 0, s>>>(p);
-    return hipGetLastError();
-}
-// A rows = tokens->image attention output merged from the partials launch_t2i_attention(..., merge = false) left in `workspace`
-hipError_t launch_tok_band_t2i(const float* workspace, int n, int T, int tokens, const float* W, const float* bias, float* Q,
-                               const float* gamma, const float* beta, float eps, hipStream_t s) {
-    if (n < 1 || T < 1 || T > TOK_MAX) return hipErrorInvalidValue;
-    TokBandParams p{};
-    p.part = workspace; p.splits = t2i_splits(tokens); p.ntg = (T + T2I_TG - 1) / T2I_TG; p.T = T;
-    p.W = W; p.bias = bias; p.Q = Q; p.M = n * T; p.accumulate = 1; p.gamma = gamma; p.beta = beta; p.eps = eps;
-    tok_band_ln_kernel<128, 1><<<(p.M + TB_ROWS - 1) / TB_ROWS, 1024, 0, s>>>(p);
-    return hipGetLastError();
-}
-// A rows = token self-attention (8 heads x 32) of the q / k / v projections tq, tk, tv [n*T][256]
-hipError_t launch_tok_band_self(const float* tq, const float* tk, const float* tv, int n, int T, const float* W, const float* bias,
-                                float* Q, bool accumulate, const float* gamma, const float* beta, float eps, hipStream_t s) {
-    if (n < 1 || T < 1 || T > TOK_MAX) return hipErrorInvalidValue;
-    TokBandParams p{};
-    p.tq = tq; p.tk = tk; p.tv = tv; p.T = T;
-    p.W = W; p.bias = bias; p.Q = Q; p.M = n * T; p.accumulate = accumulate ? 1 : 0; p.gamma = gamma; p.beta = beta; p.eps = eps;
-    tok_band_ln_kernel<256, 2><<<(p.M + TB_ROWS - 1) / TB_ROWS, 1024, 0, s>>>(p);
+    t2i_merge_kernel<<<dim3(n, tgs), T2I_TG * 16, 0, s>>>(workspace, o, splits, T, Ci);
     return hipGetLastError();
 }
 hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long bstride, const float* kt, const float* vt,

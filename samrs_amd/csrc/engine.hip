@@ -723,9 +723,6 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
     auto ln_tok = [&](const float* gw, const float* gb) {
         return launch_layernorm(prec, e->Q, gw, gb, 1e-5f, nullptr, e->Q, BT, C, 0, g, 0, s);
     };
-    // The tails of the token-side attentions -- [attention output] W^T + b (+ queries), then LayerNorm -- are one launch per
-    // 32-row band when the decoder fusions are on (tok_band_ln_kernel), else the separate attention / GEMM / LayerNorm launches
-    const bool fuse_tok = g_decoder_fusion;
 
     // ---- prompt encoder (prompt_encoder.py:128-173) ----
     PromptParams pp{};
@@ -767,26 +764,18 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
             bt.A[2] = e->Q; bt.A2[2] = nullptr; bt.W[2] = L.self.vw; bt.bias[2] = L.self.vb; bt.C[2] = e->TV;
             CK(e, launch_gemm_f32_batch(bt, 3, C, C, BT, C, C, false, false, s));
         }
-        if (fuse_tok) {
-            CK(e, launch_tok_band_self(e->TQ, e->TK, e->TV, n, T, L.self.ow, L.self.ob, e->Q, li > 0, L.n1w, L.n1b, 1e-5f, s));
-        } else {
-            CK(e, launch_token_self_attn(e->TQ, e->TK, e->TV, e->TO, n, T, C, 8, s));
-            CK(e, lin(e->TO, C, L.self.ow, L.self.ob, e->Q, C, BT, C, C, false, li > 0));
-            CK(e, ln_tok(L.n1w, L.n1b));
-        }
+        CK(e, launch_token_self_attn(e->TQ, e->TK, e->TV, e->TO, n, T, C, 8, s));
+        CK(e, lin(e->TO, C, L.self.ow, L.self.ob, e->Q, C, BT, C, C, false, li > 0));
+        CK(e, ln_tok(L.n1w, L.n1b));
         // image-side projections for this layer: K_t2i | V_t2i | Q_i2t  (PE folded in as add2d)
         const uint16_t* keys_et = sh ? e->K0E : e->KE;
         const long bstride = sh ? 0 : tokens;
         CK(e, launch_gemm_et(prec, keys_et, L.kvq_w, e->KVQ, L.kvq_b, L.kvq_pe, tokens, sh ? tokens : Mi, 3 * Ci, C, false, false, false, s));
         // (2) tokens -> image
         CK(e, lin2(e->Q, e->TOK0, C, L.t2i.qw, L.t2i.qb, e->QP, Ci, BT, Ci, C));
-        CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 3 * Ci, bstride, e->O128, e->T2IW, n, T, tokens, Ci, 8, s, !fuse_tok));
-        if (fuse_tok) {
-            CK(e, launch_tok_band_t2i(e->T2IW, n, T, tokens, L.t2i.ow, L.t2i.ob, e->Q, L.n2w, L.n2b, 1e-5f, s));
-        } else {
-            CK(e, lin(e->O128, Ci, L.t2i.ow, L.t2i.ob, e->Q, C, BT, C, Ci, false, true));
-            CK(e, ln_tok(L.n2w, L.n2b));
-        }
+        CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 3 * Ci, bstride, e->O128, e->T2IW, n, T, tokens, Ci, 8, s));
+        CK(e, lin(e->O128, Ci, L.t2i.ow, L.t2i.ob, e->Q, C, BT, C, Ci, false, true));
+        CK(e, ln_tok(L.n2w, L.n2b));
         // (3) MLP (ReLU)
         CK(e, lin(e->Q, C, L.m1w, L.m1b, e->MH, 2048, BT, 2048, C, true, false));
         CK(e, lin(e->MH, 2048, L.m2w, L.m2b, e->Q, C, BT, C, 2048, false, true));
@@ -817,17 +806,9 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
     // final tokens -> image attention (transformer.py:98-104)
     CK(e, lin2(e->Q, e->TOK0, C, e->fin.qw, e->fin.qb, e->QP, Ci, BT, Ci, C));
     CK(e, launch_gemm_et(prec, e->KE, e->fin_kv_w, e->KVQ, e->fin_kv_b, e->fin_pe, tokens, Mi, 2 * Ci, C, false, false, false, s));
-    CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 2 * Ci, tokens, e->O128, e->T2IW, n, T, tokens, Ci, 8, s, !fuse_tok));
-    {
-        const float* fw = W(e, "mask_decoder.transformer.norm_final_attn.weight");
-        const float* fb = W(e, "mask_decoder.transformer.norm_final_attn.bias");
-        if (fuse_tok) {
-            CK(e, launch_tok_band_t2i(e->T2IW, n, T, tokens, e->fin.ow, e->fin.ob, e->Q, fw, fb, 1e-5f, s));
-        } else {
-            CK(e, lin(e->O128, Ci, e->fin.ow, e->fin.ob, e->Q, C, BT, C, Ci, false, true));
-            CK(e, ln_tok(fw, fb));
-        }
-    }
+    CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 2 * Ci, tokens, e->O128, e->T2IW, n, T, tokens, Ci, 8, s));
+    CK(e, lin(e->O128, Ci, e->fin.ow, e->fin.ob, e->Q, C, BT, C, Ci, false, true));
+    CK(e, ln_tok(W(e, "mask_decoder.transformer.norm_final_attn.weight"), W(e, "mask_decoder.transformer.norm_final_attn.bias")));
 
     // ---- heads (mask_decoder.py:156-172): 4 hypernetwork MLPs + the IoU MLP, layer by layer in one launch each ----
     {
@@ -969,10 +950,6 @@ int samrs_k_rowstats_convert(int prec, const float* X, void* xh, float* stats, i
 int samrs_k_gemm_f32(const float* A, int lda, const float* Wt, const float* bias, float* C, int ldc, int M, int N, int K,
                      int relu, int accumulate, void* stream) {
     KRET(launch_gemm_f32(A, lda, Wt, bias, C, ldc, M, N, K, relu != 0, accumulate != 0, (hipStream_t)stream));
-}
-int samrs_k_tok_band(const float* A, int lda, int K, const float* Wt, const float* bias, float* Q, int M, int accumulate,
-                     const float* gamma, const float* beta, float eps, void* stream) {
-    KRET(launch_tok_band_plain(A, lda, K, Wt, bias, Q, M, accumulate != 0, gamma, beta, eps, (hipStream_t)stream));
 }
 int samrs_k_convert(int prec, const float* in, void* out, int64_t n, void* stream) {
     KRET(launch_convert(prec, in, out, (long)n, (hipStream_t)stream));

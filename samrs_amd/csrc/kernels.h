@@ -88,17 +88,7 @@ hipError_t launch_token_self_attn(const float* q, const float* k, const float* v
 constexpr int T2I_MAX_SPLITS = 16;
 size_t t2i_workspace_floats(int n_prompts, int T);     // scratch for the per-split partial softmax states
 hipError_t launch_t2i_attention(int prec, const float* qp, const void* kp, const void* vp, int ld, long batch_stride_rows,
-                                float* out, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s,
-                                bool merge = true);
-// Token-side tails in one launch per 32-row band (decoder_kernels.hip, tok_band_ln_kernel):
-//   queries = LayerNorm_256(A W^T + b (+ queries)), A = plain fp32 rows / the t2i partials of launch_t2i_attention(merge = false)
-//   merged on the fly / the token self-attention of (tq, tk, tv) computed on the fly.  K = 128 or 256.
-hipError_t launch_tok_band_plain(const float* A, int lda, int K, const float* W, const float* bias, float* Q, int M, bool accumulate,
-                                 const float* gamma, const float* beta, float eps, hipStream_t s);
-hipError_t launch_tok_band_t2i(const float* workspace, int n, int T, int tokens, const float* W, const float* bias, float* Q,
-                               const float* gamma, const float* beta, float eps, hipStream_t s);
-hipError_t launch_tok_band_self(const float* tq, const float* tk, const float* tv, int n, int T, const float* W, const float* bias,
-                                float* Q, bool accumulate, const float* gamma, const float* beta, float eps, hipStream_t s);
+                                float* out, float* workspace, int n, int T, int tokens, int Ci, int heads, hipStream_t s);
 // image -> tokens attention. qi ET rows of `ld` elements (batch stride in rows, 0 = shared);
 // kt, vt [n*T, Ci] fp32; out ET [n*tokens, Ci].
 hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long batch_stride_rows, const float* kt,

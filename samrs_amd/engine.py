@@ -77,7 +77,6 @@ def load_library() -> C.CDLL:
     lib.samrs_rbox_mask_prompt.restype = ip
     lib.samrs_k_gemm.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_gemm_f32.argtypes = [vp, ip, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
-    lib.samrs_k_tok_band.argtypes = [vp, ip, ip, vp, vp, vp, ip, ip, vp, vp, fp, vp]
     lib.samrs_k_gemm_stats.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, vp]
     lib.samrs_k_gemm_fold.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, vp]
     lib.samrs_k_ln_rowstat.argtypes = [vp, vp, ip, fp, vp]
@@ -98,7 +97,7 @@ def load_library() -> C.CDLL:
                  "samrs_set_embedding", "samrs_reset_image", "samrs_predict", "samrs_paint", "samrs_k_gemm",
                  "samrs_k_gemm_f32", "samrs_k_convert", "samrs_k_layernorm", "samrs_k_window_attention",
                  "samrs_k_global_attention", "samrs_k_postprocess", "samrs_k_gemm_gln", "samrs_k_upscale2_masks",
-                 "samrs_k_gemm_stats", "samrs_k_gemm_fold", "samrs_k_ln_fold_weight", "samrs_k_rowstats_convert", "samrs_k_ln_rowstat", "samrs_k_tok_band"):
+                 "samrs_k_gemm_stats", "samrs_k_gemm_fold", "samrs_k_ln_fold_weight", "samrs_k_rowstats_convert", "samrs_k_ln_rowstat"):
         getattr(lib, name).restype = ip
     if lib.samrs_abi_version() != 1:
         raise ImportError("libsamrs_hip.so ABI version mismatch; rebuild it")

@@ -232,37 +232,6 @@ def test_gemm_m32_kernel(lib, name, prec, dt, ulp, variant):
         lib.samrs_debug_set_gemm_variant(8)
 
 
-@pytest.mark.parametrize("M,K,acc", [(224, 256, 1), (224, 128, 1), (7, 256, 0), (1000, 128, 1), (6400, 256, 1), (33, 128, 0)])
-def test_token_band_gemm_layernorm(lib, M, K, acc):
-    """Decoder token side: GEMM (+ residual) + LayerNorm over 256 channels in ONE launch, one block per 32-row band
-    (tok_band_ln_kernel, plain-A mode) against the three-launch path (exact-fp32 GEMM, then the LayerNorm kernel) and float64;
-    ragged last band; repeated launches are bit-identical."""
-    g = torch.Generator().manual_seed(M + K)
-    A = torch.randn(M, K, generator=g)
-    W = torch.randn(256, K, generator=g) / math.sqrt(K)
-    bias, gamma, beta = torch.randn(256, generator=g), 1 + 0.3 * torch.randn(256, generator=g), 0.2 * torch.randn(256, generator=g)
-    C0 = torch.randn(M, 256, generator=g) * 2 + 0.5
-    Ad, Wd, bd, gd, btd = dev(A), dev(W), dev(bias), dev(gamma), dev(beta)
-    two = dev(C0.clone())
-    assert lib.samrs_k_gemm_f32(Ad.data_ptr(), K, Wd.data_ptr(), bd.data_ptr(), two.data_ptr(), 256, M, 256, K, 0, acc, stream()) == 0
-    assert lib.samrs_k_layernorm(1, two.data_ptr(), gd.data_ptr(), btd.data_ptr(), 1e-5, None, two.data_ptr(), M, 256, 0, 1, 64, 0, stream()) == 0
-    outs = []
-    for rep in range(3):
-        one = dev(C0.clone())
-        assert lib.samrs_k_tok_band(Ad.data_ptr(), K, K, Wd.data_ptr(), bd.data_ptr(), one.data_ptr(), M, acc, gd.data_ptr(),
-                                    btd.data_ptr(), 1e-5, stream()) == 0
-        torch.cuda.synchronize()
-        outs.append(one)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "band kernel is not reproducible"
-    pre = A.double() @ W.double().t() + bias.double() + (C0.double() if acc else 0)
-    ref = F.layer_norm(pre, (256,), gamma.double(), beta.double(), 1e-5)
-    e1, _ = rel_err(outs[0].cpu(), ref)
-    e2, _ = rel_err(two.cpu(), ref)
-    d = (outs[0] - two).abs().max().item()
-    print(f"token band M={M} K={K}: one launch {e1:.2e}, three launches {e2:.2e} vs float64; max abs difference {d:.2e}")
-    assert e1 < 2e-6 and d < 5e-6
-
-
 def _merge_stats(stats):
     """(mean, M2) partials [M, 8, 2] of equal-size (160) groups -> (mean, biased variance) per row, in float64."""
     st = stats.double()

@@ -21,8 +21,6 @@ for grp in "$@"; do
     k_basic)  run k_basic 600 $PT tests/test_kernels_gpu.py -k "convert or gemm or layernorm or postprocess or upscale2" ;;
     k_gemm)   run k_gemm 900 $PT tests/test_kernels_gpu.py -k "gemm" ;;
     k_m32)    run k_m32 600 $PT tests/test_kernels_gpu.py -k "m32" ;;
-    k_tok)    run k_tok 600 $PT tests/test_kernels_gpu.py -k "token_band or gemm_f32"
-              run p_tok 900 $PT tests/test_parity_gpu.py -k "decoder or c2_c4 or embedding_and_masks" ;;
     k_fold)   run k_fold 600 $PT tests/test_kernels_gpu.py -k "fold or stats" ;;
     p_fold)   run p_fold 900 $PT tests/test_parity_gpu.py -k "vit_tiny1280 or folded" ;;
     foldb)    run foldb 600 python tools/fold_bench.py ;;

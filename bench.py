@@ -76,6 +76,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=8, help="tiles per encoder pass")
     ap.add_argument("--boxes", type=int, default=32, help="boxes per tile (c3: the mean of the long-tailed distribution)")
     ap.add_argument("--c4-prompt", default="box", choices=["box", "rbox_mask"])
+    ap.add_argument("--box-batch", type=int, default=0,
+                    help="c3: boxes per predict call (default 20 = the reference's chunking, main_sam_hbox_semantic.py:91; the masks do "
+                         "not depend on it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second (bf16) timing leg")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the PCIe-inclusive measurement")
@@ -112,7 +115,7 @@ def main() -> None:
     dev_tiles = host_tiles.to(dev)
 
     if args.workload == "c3":
-        box_batch, max_boxes = 20, 400                      # main_sam_hbox_semantic.py:91
+        box_batch, max_boxes = (args.box_batch or 20), 400  # main_sam_hbox_semantic.py:91
     else:
         box_batch, max_boxes = args.boxes, args.boxes
 
@@ -321,7 +324,7 @@ def main() -> None:
         wl = {"c2": f"{args.model} SAM, batch={B}x1024^2 synthetic tiles, {args.boxes} hboxes/img in one box-only predict, "
                     f"multimask_output=False, masks u8 in HBM, painted class map + areas to host (BASELINE.json configs[1])",
               "c3": f"{args.model} SAM, DOTA-v2-shaped stream of 1024^2 synthetic tiles, boxes/img geometric(mean {args.boxes}, cap 400) "
-                    f"in 20-box chunks, shared-counter work queue (BASELINE.json configs[2])",
+                    f"in {box_batch}-box chunks, shared-counter work queue (BASELINE.json configs[2])",
               "c4": f"{args.model} SAM, instance path, {args.boxes} FAIR1M-shaped rboxes/img, prompt={args.c4_prompt}, "
                     f"multimask_output=True, best-of-3 (BASELINE.json configs[3])"}[args.workload]
         out = {

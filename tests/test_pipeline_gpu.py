@@ -64,6 +64,35 @@ def test_pipeline_equals_serial_loop(batch):
         assert np.array_equal(got[items[i].key][0], serial[i][0])
 
 
+def test_pipeline_output_does_not_depend_on_the_box_chunking():
+    """The reference decodes 20 boxes per call (main_sam_hbox_semantic.py:91); `samrs_amd.generate` defaults to 64 because it is
+    faster and the result must not depend on it: class maps, areas and masks of the same stream decoded in chunks of 20, 7 and
+    64 boxes are bit-identical (no cross-prompt arithmetic, K-only split of the token GEMMs)."""
+    from samrs_amd import driver
+    sizes = [(1024, 1024), (600, 800), (1024, 1024), (1024, 1024)]
+    counts = [41, 5, 64, 23]
+    items = _stream_items(driver, sizes, counts)
+    outs = []
+    for bb in (20, 7, 64):
+        sam = _sam(max_images=4, max_prompts=bb, precision="f16")
+        pipe = driver.TilePipeline(sam, 18, batch=2, box_batch=bb, keep_masks=True, max_boxes=64)
+        got = {}
+
+        def sink(results, release):
+            for r in results:
+                got[r.key] = (r.seg_mask.copy(), r.areas.copy(), r.masks.copy())
+            release()
+
+        assert pipe.run(driver.batched(items, 2), sink) == len(items)
+        outs.append((got, pipe.class_pixels.clone(), pipe.class_instances.clone()))
+        del pipe, sam
+    for got, cp, ci in outs[1:]:
+        for it in items:
+            for a, b in zip(got[it.key], outs[0][0][it.key]):
+                assert np.array_equal(a, b), f"{it.key}: output depends on the box chunking"
+        assert torch.equal(cp, outs[0][1]) and torch.equal(ci, outs[0][2])
+
+
 def test_pipeline_device_resident_and_pinned_inputs():
     from samrs_amd import driver
     sam = _sam(max_images=4, max_prompts=8)

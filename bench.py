@@ -82,6 +82,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second (bf16) timing leg")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the PCIe-inclusive measurement")
+    ap.add_argument("--no-rle-leg", action="store_true", help="skip the RLE-inclusive measurement (the reference's full output contract)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,22 +136,25 @@ def main() -> None:
                 ann_cache[global_index] = synth.make_boxes(global_index, int(counts_all[global_index]))
             return ann_cache[global_index]
 
+    def make_pipe(sam, device_inputs, rle=False):
+        if args.workload == "c4":
+            return driver.InstancePipeline(sam, n_classes, prompt=args.c4_prompt, batch=B, box_batch=box_batch,
+                                           max_boxes=max_boxes, device_inputs=device_inputs, rle=rle, rle_buffer_mb=512)
+        return driver.TilePipeline(sam, n_classes, batch=B, box_batch=box_batch, max_boxes=max_boxes,
+                                   device_inputs=device_inputs, rle=rle, rle_buffer_mb=512)
+
     def make_pipeline(precision, device_inputs):
         sam = samrs_amd.sam_model_registry[args.model](state_dict=sd, precision=precision, max_images=2 * B,
                                                        max_prompts=box_batch, max_points=1).to(dev)
-        if args.workload == "c4":
-            pipe = driver.InstancePipeline(sam, n_classes, prompt=args.c4_prompt, batch=B, box_batch=box_batch,
-                                           max_boxes=max_boxes, device_inputs=device_inputs)
-        else:
-            pipe = driver.TilePipeline(sam, n_classes, batch=B, box_batch=box_batch, max_boxes=max_boxes,
-                                       device_inputs=device_inputs)
-        return sam, pipe
+        return sam, make_pipe(sam, device_inputs)
 
-    counters = {"tiles": 0, "boxes": 0}
+    counters = {"tiles": 0, "boxes": 0, "rle_bytes": 0}
 
     def sink(results, release):
         for r in results:
             counters["boxes"] += len(r.labels)
+            if r.rle_table is not None:
+                counters["rle_bytes"] += int(r.rle_table[:, 1].sum())
         counters["tiles"] += len(results)
         release()
 
@@ -176,7 +180,7 @@ def main() -> None:
         torch.cuda.synchronize()
         if after_warmup is not None:
             after_warmup()
-        counters["tiles"] = counters["boxes"] = 0
+        counters["tiles"] = counters["boxes"] = counters["rle_bytes"] = 0
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -241,13 +245,27 @@ def main() -> None:
     tot_pix, tot_ins = driver.reduce_statistics(pipe.class_pixels, pipe.class_instances)
     torch.cuda.synchronize()
 
+    # ---- RLE-inclusive: the reference's FULL per-image output contract (main_sam_hbox_semantic.py:195-216): class map + areas
+    # + the COCO RLE string of every instance.  Same loop, rle=True: the strings are encoded on the device (samrs_rle_encode)
+    # and only they cross PCIe; the sink receives (offset, length) tables + the byte buffer.  NB: masks of random-init weights
+    # are noise-like (~135 k runs per mask, ~140 KB per string; a real mask has a few thousand runs, a few KB).
+    rle_leg = None
+    if rank == 0 and world == 1 and not args.no_rle_leg:
+        pipe_r = make_pipe(sam, True, rle=True)
+        n_r = max(2, args.steps)
+        dtr, tr, br = timed(pipe_r, dev_tiles, n_r, 1, shared_queue=False)
+        rle_leg = {"value": round(tr / dtr, 3), "unit": "images/s", "steps": n_r, "vs_value": round(tr / dtr / value, 4),
+                   "rle_bytes_per_mask": round(counters["rle_bytes"] / max(1, br), 1),
+                   "what": "same loop with rle=True: + samrs_rle_encode per predict chunk (bit-pack, run boundaries, counts, "
+                           "cocoapi string on the device) + D2H of the packed strings; masks stay in HBM"}
+        del pipe_r
+
     # ---- PCIe-inclusive: the same product loop, tiles start in pinned host memory (3 MiB H2D per tile on its own
     # stream, prefetched one batch ahead); class maps + areas go back either way ----
     pcie = None
     if rank == 0 and world == 1 and not args.no_pcie_leg:
         del pipe
-        pipe_h = (driver.InstancePipeline(sam, n_classes, prompt=args.c4_prompt, batch=B, box_batch=box_batch, max_boxes=max_boxes)
-                  if args.workload == "c4" else driver.TilePipeline(sam, n_classes, batch=B, box_batch=box_batch, max_boxes=max_boxes))
+        pipe_h = make_pipe(sam, False)
         n_p = max(2, args.steps)
         dtp, tp, _ = timed(pipe_h, host_tiles, n_p, 1, shared_queue=False)
         pcie = {"value": round(tp / dtp, 3), "unit": "images/s", "steps": n_p,
@@ -338,6 +356,7 @@ def main() -> None:
                        "inputs": "tiles resident in HBM at the start of the timed region (pcie_inclusive: pinned host memory)",
                        "accumulate": "f32"},
             "flops_per_image": F, "roofline": roofline, "cpu_baseline": cpu_baseline, "alt_dtype": alt, "pcie_inclusive": pcie,
+            "rle_inclusive": rle_leg,
             "boxes_per_s": round(boxes_done / dt, 1),
             "stats_allreduce": {"total_pixels": int(tot_pix.sum().item()), "total_instances": int(tot_ins.sum().item())},
         }

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAMRS_ABI_VERSION 1
+#define SAMRS_ABI_VERSION 2
 
 enum samrs_status {
     SAMRS_OK = 0,
@@ -143,6 +143,23 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
                 int orig_h, int orig_w, uint8_t* seg_mask, int64_t* areas_out,
                 int64_t* class_pixels, int64_t* class_instances, int n_classes, void* stream);
 
+/* -- instance drivers (main_sam_rhbox_mask_instance.py / main_sam_rbox_mask_instance.py with multimask_output=True,
+ * BASELINE.json configs[3]): of the n_sel masks per object keep the one with the highest predicted IoU (first maximum),
+ * replacing the host-side `argmax` / gather / `.sum()`.  masks uint8 [n][n_sel][h][w], iou fp32 [n][n_sel] (both outputs of
+ * samrs_predict) -> best_out uint8 [n][h][w], quality_out fp32 [n], areas_out int64 [n] (pixels set). */
+int samrs_select_best(samrs_engine_t* e, const uint8_t* masks, const float* iou, int n, int n_sel, int h, int w,
+                      uint8_t* best_out, float* quality_out, int64_t* areas_out, void* stream);
+
+/* -- the reference's per-instance output: COCO RLE of every full-resolution mask (main_sam_hbox_semantic.py:201-202:
+ * `maskUtils.encode(np.asfortranarray(mask))` + `.decode('ascii')`; counts half stated in-tree at utils/amg.py:107-135).
+ * masks: uint8 [n][h][w] on device (non-zero = set; the C = 1 output of samrs_predict).  The n ASCII strings are packed into
+ * `out` (device bytes, capacity out_capacity) at 16-byte aligned offsets behind *cursor (device int64, in / out: the first
+ * free byte; several calls append to one buffer), and table [n][3] (device int64) receives (offset, length, number of counts)
+ * per mask; length < 0 means the string did not fit (-length - 1 bytes were needed) and was not written.  Column-major runs
+ * starting with zeros, delta-coded 5-bit groups + 48, exactly as cocoapi's rleToString.  h * w < 2^32 - 16. */
+int samrs_rle_encode(samrs_engine_t* e, const uint8_t* masks, int n, int h, int w, uint8_t* out, int64_t out_capacity,
+                     int64_t* cursor, int64_t* table, void* stream);
+
 /* -- "next row" N3: one separable pass of Pillow's 8-bit resample (ResizeLongestSide.apply_image,
  * utils/transforms.py:26-31 -> PIL Image.resize BILINEAR).  `bounds` int32 [out_len,2] = (first input
  * index, tap count), `coef` int32 [out_len,ksize] 22-bit fixed point, both computed on the host exactly
@@ -157,17 +174,25 @@ int samrs_resample_pass_u8(const uint8_t* in, uint8_t* out, const int32_t* bound
 int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_images, int in_h,
                                int in_w, int n_blocks, float* x_out, void* stream);
 
-/* -- test / tuning hook: 0 = register-staged GEMM tiles, 1 = LDS-DMA staging (default). */
-void samrs_debug_set_gemm_variant(int variant);
-/* tuning hook: start skew of the first round of GEMM blocks, per XCD / per CU group, in 1024-cycle units (0, 0 = off) */
-void samrs_debug_set_gemm_skew(int xcd_units, int cu_units);
-/* test / timing hook: 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm / product launches) */
-void samrs_debug_set_decoder_fusion(int on);
+/* -- per-engine options (each handle has its own; the environment variable named in brackets only sets the value a NEW handle
+ * starts with).  Returns SAMRS_ERR_BAD_ARG for an unknown name.
+ *   "split"          [SAMRS_SPLIT, default 15] bit mask of the rounding points that run as a two-term operand split
+ *                    (hi + lo, three MFMAs, ~2^-22 operand error instead of 2^-11): 1 = patch embed, 2 = neck, 4 = decoder
+ *                    image->token out-projection, 8 = decoder upscaler (both transposed convs).  What each bit buys in mask
+ *                    pixels: oracle/error_budget.py, DESIGN.md 2.  0 = the round-2 engine's arithmetic.
+ *   "decoder_fusion" [SAMRS_DECODER_FUSION, default 1] 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm /
+ *                    product launches; never split): the fused-vs-unfused parity test and timing experiments.
+ *   "ln_fold"        [SAMRS_LN_FOLD, default 0] (embed_dim 1280) 1 = fold the encoder blocks' LayerNorms into the qkv / lin1
+ *                    GEMMs.  Measured slower on MI355X.  Must be on before samrs_finalize_weights for the folded weights to
+ *                    exist; can be flipped afterwards.
+ *   "gemm_variant"   [default -1 = automatic] GEMM tile variant for this handle's launches (tools/gemm_bench.py lists them). */
+int samrs_set_option(samrs_engine_t* e, const char* name, int value);
+int samrs_get_option(const samrs_engine_t* e, const char* name, int* value);
 
-/* test / timing hook (embed_dim 1280): 1 = fold the encoder blocks' LayerNorms into the qkv / lin1 GEMMs (no LayerNorm launches;
- * statistics come out of the proj / lin2 epilogues).  Off by default -- measured slower on MI355X.  Must be switched on (or
- * SAMRS_LN_FOLD=1 set) before samrs_finalize_weights for the folded weights to exist; can be flipped afterwards. */
-void samrs_debug_set_ln_fold(int on);
+/* -- process-wide test / tuning hooks of the KERNEL-LEVEL entry points below (samrs_k_gemm has no handle): GEMM tile variant,
+ * and the start skew of the first round of GEMM blocks, per XCD / per CU group, in 1024-cycle units (0, 0 = off). */
+void samrs_debug_set_gemm_variant(int variant);
+void samrs_debug_set_gemm_skew(int xcd_units, int cu_units);
 
 /* -- test hook: copy a prefix of a named internal decoder buffer (Q, KF, KE, KVQ, OI, U1raw, U1, U2,
  * HYPER, ...) to a device buffer; used to localise run-to-run differences. */
@@ -232,16 +257,20 @@ int samrs_k_postprocess(const float* lowres, int n_masks, int in_h, int in_w, in
 /* First transposed conv of the mask upscaler as a GEMM with LayerNorm2d(64) + GELU in its epilogue
  * (segment_anything/modeling/mask_decoder.py:53-56): C_et[M,N] = GELU(LN64(A_et[M,K] B_et[N,K]^T + bias)),
  * every 64-column group of N normalised on its own, eps 1e-6; gamma_beta = gamma[64] | beta[64].
- * M % 256 == 0, N % 128 == 0, K % 32 == 0. */
+ * M % 256 == 0, N % 128 == 0, K % 32 == 0.  A_lo_et / B_lo_et (both or neither; samrs_k_convert_split): the split
+ * remainders of the operands -- the product then runs as A_lo B + A B_lo + A B and C is written in FP32 [M][N]. */
 int samrs_k_gemm_gln(int prec, const void* A_et, const void* B_et, void* C_et, const float* bias,
-                     const float* gamma_beta, int M, int N, int K, void* stream);
+                     const float* gamma_beta, int M, int N, int K, const void* A_lo_et, const void* B_lo_et, void* stream);
 /* Second transposed conv + GELU + hypernetwork product (mask_decoder.py:57-59,154-167) in one pass:
  * u1_et [n*grid*grid*4, 64] (rows = prompt, token, sub-pixel 1), w_et [128, 64] (rows = sub-pixel 2 x 32
  * channels), bias [128], hyper [n, n_mask_tokens, 32] -> low [n, n_sel, 4*grid, 4*grid] fp32 for mask
- * tokens sel0 .. sel0+n_sel-1 (n_sel 1 or 3).  grid*grid*4 % 1024 == 0. */
-int samrs_k_upscale2_masks(int prec, const void* u1_et, const void* w_et, const float* bias,
+ * tokens sel0 .. sel0+n_sel-1 (n_sel 1 or 3).  grid*grid*4 % 1024 == 0.  w_lo_et != NULL: split precision -- u1 is then
+ * FP32 [rows][64] (split into hi + lo in registers) and w_lo_et the remainder of the weight split. */
+int samrs_k_upscale2_masks(int prec, const void* u1, const void* w_et, const void* w_lo_et, const float* bias,
                            const float* hyper, float* low, int n, int grid, int n_mask_tokens,
                            int sel0, int n_sel, void* stream);
+/* fp32 -> hi (= samrs_k_convert) and lo = ET(x - hi): the two-term operand split */
+int samrs_k_convert_split(int prec, const float* in, void* out_hi_et, void* out_lo_et, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

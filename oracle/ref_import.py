@@ -57,9 +57,15 @@ def import_reference():
         raise RuntimeError("reference tree not present on this machine")
     sys.dont_write_bytecode = True
     _install_torchvision_stub()
-    if REF_ROOT not in sys.path:
+    # this repo ships an import-name alias package `segment_anything` (the drop-in boundary): if it is already imported,
+    # `import segment_anything` would hand the ENGINE back and golden generation would validate the engine against itself
+    for name in [n for n in sys.modules if n == "segment_anything" or n.startswith("segment_anything.")]:
+        if not (getattr(sys.modules[name], "__file__", None) or "").startswith(REF_ROOT):
+            del sys.modules[name]
+    if sys.path[:1] != [REF_ROOT]:
         sys.path.insert(0, REF_ROOT)
     import segment_anything  # noqa: E402  (the reference's, not ours)
+    assert (segment_anything.__file__ or "").startswith(REF_ROOT), segment_anything.__file__
     return segment_anything
 
 

@@ -36,26 +36,55 @@ PIXEL_STD = (58.395, 57.12, 57.375)      # modeling/sam.py:28
 # ------------------------------------------------------------------------------------------
 # optional precision emulation
 # ------------------------------------------------------------------------------------------
+def split2(dt: torch.dtype) -> Callable[[Tensor], Tensor]:
+    """Two-term split of an operand (hi + lo, both in ``dt``): what a 3-MFMA split product sees."""
+    def r(x: Tensor) -> Tensor:
+        hi = x.to(dt).to(torch.float32)
+        return hi + (x - hi).to(dt).to(torch.float32)
+    return r
+
+
 @dataclass
 class Rounding:
-    """Where the engine feeds MFMA operands, round like the engine does.
+    """Where the engine feeds MFMA operands (or stores a tensor in the operand type), round like the engine does.
 
-    ``enc`` applies to encoder GEMM/attention operands, ``dec`` to decoder image-side GEMM
-    operands.  ``None`` = exact fp32 (the oracle proper).
+    ``enc`` applies to every encoder point, ``dec`` to every decoder image-side point; ``points`` overrides single
+    named points (``"enc.qkv_in"``, ``"dec.keys"``, ...: the names at the call sites below).  A value is a
+    ``torch.dtype``, a callable (e.g. ``split2(torch.float16)``) or ``None`` = exact fp32 (the oracle proper).
+    ``oracle/error_budget.py`` sweeps them one by one.
     """
 
-    enc: Optional[torch.dtype] = None
-    dec: Optional[torch.dtype] = None
+    enc: Optional[object] = None
+    dec: Optional[object] = None
+    points: Optional[Dict[str, Optional[object]]] = None
 
     @staticmethod
-    def _r(x: Tensor, dt: Optional[torch.dtype]) -> Tensor:
-        return x if dt is None else x.to(dt).to(torch.float32)
+    def _r(x: Tensor, dt) -> Tensor:
+        if dt is None:
+            return x
+        if callable(dt) and not isinstance(dt, torch.dtype):
+            return dt(x)
+        return x.to(dt).to(torch.float32)
+
+    def p(self, name: str) -> Callable[[Tensor], Tensor]:
+        """The rounding applied at the named point."""
+        if self.points is not None and name in self.points:
+            dt = self.points[name]
+        else:
+            dt = self.enc if name.startswith("enc.") else self.dec
+        return lambda x: self._r(x, dt)
 
     def e(self, x: Tensor) -> Tensor:
         return self._r(x, self.enc)
 
     def d(self, x: Tensor) -> Tensor:
         return self._r(x, self.dec)
+
+
+# every named rounding point, in data-flow order (error_budget.py iterates over these)
+ENC_POINTS = ("enc.patch", "enc.qkv_in", "enc.qkv_out", "enc.relpos", "enc.P", "enc.proj_in", "enc.lin1_in", "enc.lin2_in",
+              "enc.neck0", "enc.neck2")
+DEC_POINTS = ("dec.keys", "dec.kvq_out", "dec.oi", "dec.up1", "dec.up2", "dec.prod")
 
 
 _EXACT = Rounding()
@@ -98,20 +127,21 @@ def _attention(x: Tensor, sd: SD, p: str, heads: int, rd: Rounding) -> Tensor:
     """
     B, S, _, D = x.shape
     d = D // heads
-    qkv = _linear(x.reshape(B, S * S, D), sd, p + ".qkv", rd.e)           # [B, N, 3D]
+    qkv = _linear(x.reshape(B, S * S, D), sd, p + ".qkv", rd.p("enc.qkv_in"))  # [B, N, 3D]
     qkv = qkv.reshape(B, S * S, 3, heads, d).permute(2, 0, 3, 1, 4)         # [3, B, h, N, d]
     q, k, v = (t.reshape(B * heads, S * S, d) for t in qkv)
-    q, k, v = rd.e(q), rd.e(k), rd.e(v)
+    rq_ = rd.p("enc.qkv_out")
+    q, k, v = rq_(q), rq_(k), rq_(v)
     attn = (q * d ** -0.5) @ k.transpose(1, 2)                              # [Bh, N, N]
-    Rh = rd.e(_rel_tables(S, sd[p + ".rel_pos_h"]))                         # [S, S, d]
-    Rw = rd.e(_rel_tables(S, sd[p + ".rel_pos_w"]))
+    Rh = rd.p("enc.relpos")(_rel_tables(S, sd[p + ".rel_pos_h"]))           # [S, S, d]
+    Rw = rd.p("enc.relpos")(_rel_tables(S, sd[p + ".rel_pos_w"]))
     rq = q.reshape(B * heads, S, S, d)
     rel_h = torch.einsum("bhwc,hkc->bhwk", rq, Rh)
     rel_w = torch.einsum("bhwc,wkc->bhwk", rq, Rw)
     attn = (attn.view(-1, S, S, S, S) + rel_h[..., :, None] + rel_w[..., None, :]).view(-1, S * S, S * S)
-    attn = rd.e(attn.softmax(dim=-1))
+    attn = rd.p("enc.P")(attn.softmax(dim=-1))
     o = (attn @ v).view(B, heads, S, S, d).permute(0, 2, 3, 1, 4).reshape(B, S, S, D)
-    return _linear(o, sd, p + ".proj", rd.e)
+    return _linear(o, sd, p + ".proj", rd.p("enc.proj_in"))
 
 
 def _block(x: Tensor, sd: SD, p: str, heads: int, window: int, rd: Rounding) -> Tensor:
@@ -132,9 +162,9 @@ def _block(x: Tensor, sd: SD, p: str, heads: int, window: int, rd: Rounding) -> 
         y = _attention(y, sd, p + ".attn", heads, rd)
     x = x + y
     z = F.layer_norm(x, (D,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps=1e-6)
-    z = _linear(z, sd, p + ".mlp.lin1", rd.e)
+    z = _linear(z, sd, p + ".mlp.lin1", rd.p("enc.lin1_in"))
     z = F.gelu(z)                                                            # exact erf, common.py:18-26
-    z = _linear(z, sd, p + ".mlp.lin2", rd.e)
+    z = _linear(z, sd, p + ".mlp.lin2", rd.p("enc.lin2_in"))
     return x + z
 
 
@@ -147,7 +177,7 @@ def image_encoder(sd: SD, cfg, x: Tensor, rd: Rounding = _EXACT, taps: Optional[
     """[B,3,S,S] fp32 -> [B,256,64,64] fp32 (image_encoder.py:106-116).  ``taps`` (if given)
     receives the residual stream after patch-embed and after every block, channels-last."""
     P, D = cfg.patch_size, cfg.embed_dim
-    x = F.conv2d(rd.e(x), rd.e(sd["image_encoder.patch_embed.proj.weight"]),
+    x = F.conv2d(rd.p("enc.patch")(x), rd.p("enc.patch")(sd["image_encoder.patch_embed.proj.weight"]),
                  sd["image_encoder.patch_embed.proj.bias"], stride=P)        # :387-395
     x = x.permute(0, 2, 3, 1) + sd["image_encoder.pos_embed"]                 # :107-109
     if taps is not None:
@@ -159,9 +189,9 @@ def image_encoder(sd: SD, cfg, x: Tensor, rd: Rounding = _EXACT, taps: Optional[
             taps[f"block{i}"] = x.clone()
     # neck :88-104 -- 1x1 conv (no bias), LN2d, 3x3 conv pad 1 (no bias), LN2d
     w0 = sd["image_encoder.neck.0.weight"][:, :, 0, 0]
-    y = rd.e(x) @ rd.e(w0).t()
+    y = rd.p("enc.neck0")(x) @ rd.p("enc.neck0")(w0).t()
     y = _layernorm2d_cl(y, sd["image_encoder.neck.1.weight"], sd["image_encoder.neck.1.bias"])
-    y = F.conv2d(rd.e(y.permute(0, 3, 1, 2)), rd.e(sd["image_encoder.neck.2.weight"]), None, padding=1)
+    y = F.conv2d(rd.p("enc.neck2")(y.permute(0, 3, 1, 2)), rd.p("enc.neck2")(sd["image_encoder.neck.2.weight"]), None, padding=1)
     y = _layernorm2d_cl(y.permute(0, 2, 3, 1), sd["image_encoder.neck.3.weight"], sd["image_encoder.neck.3.bias"])
     return y.permute(0, 3, 1, 2).contiguous()
 
@@ -237,13 +267,14 @@ def prompt_encoder(sd: SD, cfg, points: Optional[Tuple[Tensor, Tensor]], boxes: 
 # mask decoder
 # ------------------------------------------------------------------------------------------
 def _dec_attn(sd: SD, p: str, q: Tensor, k: Tensor, v: Tensor, heads: int,
-              rq: Callable, rk: Callable) -> Tensor:
+              rq: Callable, rk: Callable, oq: Callable = lambda t: t, ok: Callable = lambda t: t) -> Tensor:
     """transformer.py:218-240: project, split heads, QK^T / sqrt(d) (scale AFTER the product),
     softmax, @V, merge, out_proj.  ``rq`` / ``rk`` round the operands of the q-side and the
-    k/v-side projections (image-side ones are MFMA GEMMs in the engine)."""
-    q = _linear(q, sd, p + ".q_proj", rq)
-    k = _linear(k, sd, p + ".k_proj", rk)
-    v = _linear(v, sd, p + ".v_proj", rk)
+    k/v-side projections (image-side ones are MFMA GEMMs in the engine), ``oq`` / ``ok`` their
+    outputs (the engine stores image-side projections in the operand type)."""
+    q = oq(_linear(q, sd, p + ".q_proj", rq))
+    k = ok(_linear(k, sd, p + ".k_proj", rk))
+    v = ok(_linear(v, sd, p + ".v_proj", rk))
     b, n, c = q.shape
     d = c // heads
 
@@ -279,16 +310,18 @@ def two_way_transformer(sd: SD, cfg, src: Tensor, pos: Tensor, tokens: Tensor,
             queries = queries + _linear(o, sd, p + ".self_attn.out_proj", ident)
         queries = _ln(queries, sd, p + ".norm1")
         # tokens -> image                                                     :163-169
-        o, _ = _dec_attn(sd, p + ".cross_attn_token_to_image", queries + qpe, keys + kpe, keys, H, ident, rd.d)
+        o, _ = _dec_attn(sd, p + ".cross_attn_token_to_image", queries + qpe, keys + kpe, keys, H, ident, rd.p("dec.keys"),
+                         ok=rd.p("dec.kvq_out"))
         queries = _ln(queries + _linear(o, sd, p + ".cross_attn_token_to_image.out_proj", ident), sd, p + ".norm2")
         # MLP (ReLU)                                                          :171-174
         m = _linear(F.relu(_linear(queries, sd, p + ".mlp.lin1", ident)), sd, p + ".mlp.lin2", ident)
         queries = _ln(queries + m, sd, p + ".norm3")
         # image -> tokens                                                     :176-181
-        o, _ = _dec_attn(sd, p + ".cross_attn_image_to_token", keys + kpe, queries + qpe, queries, H, rd.d, ident)
-        keys = _ln(keys + _linear(o, sd, p + ".cross_attn_image_to_token.out_proj", rd.d), sd, p + ".norm4")
+        o, _ = _dec_attn(sd, p + ".cross_attn_image_to_token", keys + kpe, queries + qpe, queries, H, rd.p("dec.keys"), ident,
+                         oq=rd.p("dec.kvq_out"))
+        keys = _ln(keys + _linear(o, sd, p + ".cross_attn_image_to_token.out_proj", rd.p("dec.oi")), sd, p + ".norm4")
     p = "mask_decoder.transformer.final_attn_token_to_image"                  # :98-104
-    o, _ = _dec_attn(sd, p, queries + qpe, keys + kpe, keys, H, ident, rd.d)
+    o, _ = _dec_attn(sd, p, queries + qpe, keys + kpe, keys, H, ident, rd.p("dec.keys"), ok=rd.p("dec.kvq_out"))
     queries = _ln(queries + _linear(o, sd, p + ".out_proj", ident), sd, "mask_decoder.transformer.norm_final_attn")
     return queries, keys
 
@@ -314,15 +347,15 @@ def mask_decoder(sd: SD, cfg, emb: Tensor, pos: Tensor, sparse: Tensor, dense: T
     mask_toks = hs[:, 1:1 + cfg.num_mask_tokens]
     up = keys.transpose(1, 2).reshape(b, c, h, w)
     p = "mask_decoder.output_upscaling"                                       # :53-59
-    up = F.conv_transpose2d(rd.d(up), rd.d(sd[p + ".0.weight"]), sd[p + ".0.bias"], stride=2)
+    up = F.conv_transpose2d(rd.p("dec.up1")(up), rd.p("dec.up1")(sd[p + ".0.weight"]), sd[p + ".0.bias"], stride=2)
     up = _layernorm2d_cl(up.permute(0, 2, 3, 1), sd[p + ".1.weight"], sd[p + ".1.bias"]).permute(0, 3, 1, 2)
     up = F.gelu(up)
-    up = F.conv_transpose2d(rd.d(up), rd.d(sd[p + ".3.weight"]), sd[p + ".3.bias"], stride=2)
+    up = F.conv_transpose2d(rd.p("dec.up2")(up), rd.p("dec.up2")(sd[p + ".3.weight"]), sd[p + ".3.bias"], stride=2)
     up = F.gelu(up)
     hyper = torch.stack([_mlp3(sd, f"mask_decoder.output_hypernetworks_mlps.{i}", mask_toks[:, i])
                          for i in range(cfg.num_mask_tokens)], dim=1)         # :156-159
     b, c, h, w = up.shape
-    masks = (hyper @ rd.d(up).reshape(b, c, h * w)).reshape(b, -1, h, w)      # :167
+    masks = (hyper @ rd.p("dec.prod")(up).reshape(b, c, h * w)).reshape(b, -1, h, w)      # :167
     iou = _mlp3(sd, "mask_decoder.iou_prediction_head", iou_tok)              # :172
     sl = slice(1, None) if multimask_output else slice(0, 1)                  # :102-107
     return masks[:, sl], iou[:, sl]

@@ -30,8 +30,11 @@ class Sam:
     image_format: str = "RGB"
 
     def __init__(self, cfg: SamConfig, state_dict: Dict[str, torch.Tensor], precision: str = "f16",
-                 max_images: int = 1, max_prompts: int = 64, max_points: int = 4):
+                 max_images: int = 1, max_prompts: int = 64, max_points: int = 4, options: Optional[Dict[str, int]] = None):
+        """``options``: per-engine options applied BEFORE the weights are loaded (include/samrs_hip.h samrs_set_option:
+        "split", "decoder_fusion", "ln_fold", "gemm_variant")."""
         self.cfg = cfg
+        self.options = dict(options or {})
         self._state_dict = state_dict
         self.precision = precision
         self.max_images, self.max_prompts, self.max_points = max_images, max_prompts, max_points
@@ -52,6 +55,8 @@ class Sam:
         if self.engine is not None and self.engine.device == device:
             return self
         self.engine = Engine(self.cfg, device, self.precision, self.max_images, self.max_prompts, self.max_points)
+        for k, v in self.options.items():
+            self.engine.set_option(k, v)
         self.engine.load_state_dict(self._state_dict)
         self._device = device
         return self

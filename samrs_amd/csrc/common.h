@@ -81,6 +81,17 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     return pack2_fast<PREC>(lo, hi);
 }
 
+// Two-term split of an fp32 value into MFMA operands: v ~= hi + lo with hi = ET(v), lo = ET(v - hi).  A product of two
+// split operands as three MFMAs (hi hi + lo hi + hi lo, fp32 accumulate) carries ~2^-22 relative operand error instead of
+// 2^-11; used where the error budget (oracle/error_budget.py) says a rounding point is expensive in
+// mask pixels and cheap in FLOPs: patch embed, neck, and the decoder's out-projection / upscaler operands.
+template <int PREC>
+__device__ __forceinline__ void split2_pack(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack2<PREC>(a, b);
+    const float ha = ET<PREC>::to_float((uint16_t)(hi & 0xffffu)), hb = ET<PREC>::to_float((uint16_t)(hi >> 16));
+    lo = pack2_fast<PREC>(a - ha, b - hb);
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave-level reductions (64 lanes)
 // ---------------------------------------------------------------------------------------------

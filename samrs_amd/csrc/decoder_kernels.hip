@@ -436,48 +436,55 @@ __global__ __launch_bounds__(256) void i2t_attention_kernel(const uint16_t* __re
 // Everything is local to an image token: a 128-vector of attention output, 256 projected channels, a LayerNorm
 // over those 256.  Done as three kernels the 134 MB fp32 key tensor makes four trips through HBM (GEMM
 // read-modify-write, LN read + write) plus the attention output's round trip; here it makes two.
-// Block = 2 waves, 16 image tokens per group, several groups per block:
-//   * attention: thread = (token, head) exactly as in i2t_attention_kernel; its 16 outputs are rounded to ET and
-//     written to an LDS A tile [16][128] (same rounding point as the unfused path's `OI` buffer);
-//   * projection: wave w owns output columns 128 w .. +127; its W fragments (8 n-tiles x 4 k-steps) stay in 128
-//     registers for the whole block, A fragments come from the LDS tile, `mfma_16x16x32`, same k order as the GEMM;
+// Block = 4 waves, 32 image tokens per group, several groups per block:
+//   * attention: thread = (token, head) exactly as in i2t_attention_kernel; its 16 outputs go to an LDS A tile
+//     [32][128] in the operand type -- SPLIT: as hi + lo (two tiles), so that the projection sees them at ~2^-22;
+//   * projection: wave w owns output columns 64 w .. +63; its W fragments (4 n-tiles x 4 k-steps; SPLIT: hi and lo)
+//     stay in registers for the whole block, A fragments come from the LDS tile(s), `mfma_16x16x32`, ascending k;
+//     SPLIT = three MFMAs per step (hi hi + lo hi + hi lo): the out-projection operand rounding was 163 of the 899
+//     class-map pixels the round-2 engine lost at ViT-H (oracle/error_budget.py: "only dec.oi");
 //   * + bias + residual (old keys, or the shared image embedding in layer 0), LayerNorm over the row: the 4 lane
-//     quarters of a wave hold 128 of its 256 values, the two waves exchange partial sums through LDS (two-pass
-//     statistics), then write fp32 keys and their ET copy.
-constexpr int I2TF_ROWS = 16;          // image tokens per group
+//     quarters of a wave hold 64 of its 256 values, the four waves exchange partial sums through LDS (two-pass
+//     statistics), then write fp32 keys, their ET copy and (last layer) the split remainder of that copy.
+constexpr int I2TF_ROWS = 32;          // image tokens per group (two MFMA row tiles)
 constexpr int I2TF_AST = 136;          // A-tile row stride (ET): 272 B = 68 words = 4 (mod 32)
 
-template <int PREC>
-__global__ __launch_bounds__(128) void i2t_fused_kernel(const uint16_t* __restrict__ qi, int ld, long q_bstride,
+template <int PREC, bool SPLIT>
+__global__ __launch_bounds__(256) void i2t_fused_kernel(const uint16_t* __restrict__ qi, int ld, long q_bstride,
                                                         const float* __restrict__ kt, const float* __restrict__ vt,
-                                                        const uint16_t* __restrict__ w, const float* __restrict__ bias,
+                                                        const uint16_t* __restrict__ w, const uint16_t* __restrict__ w_lo,
+                                                        const float* __restrict__ bias,
                                                         const float* __restrict__ resid, long r_bstride,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                         float* __restrict__ outF, uint16_t* __restrict__ outE,
-                                                        int T, int tokens, int groups_per_block) {
-    constexpr int HD = 16, HEADS = 8, CI = 128, CO = 256;
+                                                        uint16_t* __restrict__ outE_lo, int T, int tokens, int groups_per_block) {
+    constexpr int HD = 16, HEADS = 8, CI = 128, CO = 256, NWV = 4;
     constexpr int KRS = HEADS * I2T_HS;                       // padded k / v row stride (floats)
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     float* sk = reinterpret_cast<float*>(smraw);              // [T][KRS]
     float* sv = sk + T * KRS;
     float* sp = sv + T * KRS;                                 // bias | gamma | beta, [3][256]
-    float* ex = sp + 3 * CO;                                  // [2 stats][2 waves][16 rows]
-    uint16_t* At = reinterpret_cast<uint16_t*>(ex + 2 * 2 * I2TF_ROWS);   // [16][I2TF_AST]
+    float* ex = sp + 3 * CO;                                  // [2 stats][4 waves][32 rows]
+    uint16_t* At = reinterpret_cast<uint16_t*>(ex + 2 * NWV * I2TF_ROWS);   // [32][I2TF_AST] (SPLIT: hi, then lo)
+    uint16_t* Al = At + I2TF_ROWS * I2TF_AST;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int b = blockIdx.y;
-    for (int i = tid; i < T * CI; i += 128) {
+    for (int i = tid; i < T * CI; i += 256) {
         const int j = i / CI, c = i % CI;
         sk[j * KRS + (c / HD) * I2T_HS + c % HD] = kt[(size_t)b * T * CI + i];
         sv[j * KRS + (c / HD) * I2T_HS + c % HD] = vt[(size_t)b * T * CI + i];
     }
-    for (int i = tid; i < CO; i += 128) { sp[i] = bias[i]; sp[CO + i] = gamma[i]; sp[2 * CO + i] = beta[i]; }
-    uint4 wf[8][4];
+    for (int i = tid; i < CO; i += 256) { sp[i] = bias[i]; sp[CO + i] = gamma[i]; sp[2 * CO + i] = beta[i]; }
+    uint4 wf[4][4], wl[SPLIT ? 4 : 1][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            wf[i][ks] = *reinterpret_cast<const uint4*>(w + (size_t)(wave * 128 + i * 16 + fr) * CI + ks * 32 + fq * 8);
+        for (int ks = 0; ks < 4; ++ks) {
+            const size_t o = (size_t)(wave * 64 + i * 16 + fr) * CI + ks * 32 + fq * 8;
+            wf[i][ks] = *reinterpret_cast<const uint4*>(w + o);
+            if constexpr (SPLIT) wl[i][ks] = *reinterpret_cast<const uint4*>(w_lo + o);
+        }
     __syncthreads();
 
     const int tr = tid >> 3, h = tid & 7;                     // attention role: token-in-group, head
@@ -493,10 +500,12 @@ __global__ __launch_bounds__(128) void i2t_fused_kernel(const uint16_t* __restri
         const int row0 = g * I2TF_ROWS;
         if (row0 >= tokens) break;
         // ---- residual loads first: they fly during the attention math -------------------------------------
-        const size_t rrow = (size_t)b * r_bstride + row0 + fr, orow = (size_t)b * tokens + row0 + fr;
-        float4 rs[8];
+        float4 rs[2][4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rs[i] = *reinterpret_cast<const float4*>(resid + rrow * CO + wave * 128 + i * 16 + 4 * fq);
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rs[mt][i] = *reinterpret_cast<const float4*>(resid + ((size_t)b * r_bstride + row0 + mt * 16 + fr) * CO + wave * 64 + i * 16 + 4 * fq);
         // ---- attention of (token tr, head h) over the T prompt tokens ------------------------------------------
         {
             const uint32_t qw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
@@ -529,62 +538,94 @@ __global__ __launch_bounds__(128) void i2t_fused_kernel(const uint16_t* __restri
                 m = mn;
             }
             const float inv = 1.0f / l;
-            uint4 o0, o1;
-            o0.x = pack2<PREC>(acc[0] * inv, acc[1] * inv);   o0.y = pack2<PREC>(acc[2] * inv, acc[3] * inv);
-            o0.z = pack2<PREC>(acc[4] * inv, acc[5] * inv);   o0.w = pack2<PREC>(acc[6] * inv, acc[7] * inv);
-            o1.x = pack2<PREC>(acc[8] * inv, acc[9] * inv);   o1.y = pack2<PREC>(acc[10] * inv, acc[11] * inv);
-            o1.z = pack2<PREC>(acc[12] * inv, acc[13] * inv); o1.w = pack2<PREC>(acc[14] * inv, acc[15] * inv);
-            *reinterpret_cast<uint4*>(At + tr * I2TF_AST + h * HD) = o0;
-            *reinterpret_cast<uint4*>(At + tr * I2TF_AST + h * HD + 8) = o1;
+            uint32_t oh[8], ol[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) split2_pack<PREC>(acc[2 * c] * inv, acc[2 * c + 1] * inv, oh[c], ol[c]);
+            *reinterpret_cast<uint4*>(At + tr * I2TF_AST + h * HD) = make_uint4(oh[0], oh[1], oh[2], oh[3]);
+            *reinterpret_cast<uint4*>(At + tr * I2TF_AST + h * HD + 8) = make_uint4(oh[4], oh[5], oh[6], oh[7]);
+            if constexpr (SPLIT) {
+                *reinterpret_cast<uint4*>(Al + tr * I2TF_AST + h * HD) = make_uint4(ol[0], ol[1], ol[2], ol[3]);
+                *reinterpret_cast<uint4*>(Al + tr * I2TF_AST + h * HD + 8) = make_uint4(ol[4], ol[5], ol[6], ol[7]);
+            }
         }
         __syncthreads();
         if (g + 1 < g0 + groups_per_block && (g + 1) * I2TF_ROWS < tokens) {
             q0 = *reinterpret_cast<const uint4*>(qbase + (size_t)(g + 1) * I2TF_ROWS * ld);
             q1 = *reinterpret_cast<const uint4*>(qbase + (size_t)(g + 1) * I2TF_ROWS * ld + 8);
         }
-        // ---- projection: 16 rows x 128 columns per wave, K = 128 ----------------------------------------------------
-        uint4 af[4];
+        // ---- projection: 2 x 16 rows x 64 columns per wave, K = 128 ------------------------------------------------
+        float v[2][4][4];
+        float s1[2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) af[ks] = *reinterpret_cast<const uint4*>(At + fr * I2TF_AST + ks * 32 + fq * 8);
-        float v[8][4];
-        float s1 = 0.f;
+        for (int mt = 0; mt < 2; ++mt) {
+            uint4 af[4], al[SPLIT ? 4 : 1];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+            for (int ks = 0; ks < 4; ++ks) {
+                af[ks] = *reinterpret_cast<const uint4*>(At + (mt * 16 + fr) * I2TF_AST + ks * 32 + fq * 8);
+                if constexpr (SPLIT) al[ks] = *reinterpret_cast<const uint4*>(Al + (mt * 16 + fr) * I2TF_AST + ks * 32 + fq * 8);
+            }
+            s1[mt] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) a = ET<PREC>::mfma16(wf[i][ks], af[ks], a);
-            const float4 bb = *reinterpret_cast<const float4*>(sp + wave * 128 + i * 16 + 4 * fq);
-            v[i][0] = (a[0] + bb.x) + rs[i].x; v[i][1] = (a[1] + bb.y) + rs[i].y;
-            v[i][2] = (a[2] + bb.z) + rs[i].z; v[i][3] = (a[3] + bb.w) + rs[i].w;
-            s1 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            for (int i = 0; i < 4; ++i) {
+                f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (SPLIT) {      // the small terms first, the leading one on top of them
+                    f32x4_t c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) c = ET<PREC>::mfma16(wf[i][ks], al[ks], c);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) c = ET<PREC>::mfma16(wl[i][ks], af[ks], c);
+                    a = c;
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a = ET<PREC>::mfma16(wf[i][ks], af[ks], a);
+                const float4 bb = *reinterpret_cast<const float4*>(sp + wave * 64 + i * 16 + 4 * fq);
+                v[mt][i][0] = (a[0] + bb.x) + rs[mt][i].x; v[mt][i][1] = (a[1] + bb.y) + rs[mt][i].y;
+                v[mt][i][2] = (a[2] + bb.z) + rs[mt][i].z; v[mt][i][3] = (a[3] + bb.w) + rs[mt][i].w;
+                s1[mt] += (v[mt][i][0] + v[mt][i][1]) + (v[mt][i][2] + v[mt][i][3]);
+            }
         }
-        // ---- LayerNorm over the 256 values of row fr: lane quarters, then the two waves ---------------------------
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        if (fq == 0) ex[wave * I2TF_ROWS + fr] = s1;
+        // ---- LayerNorm over the 256 values of a row: lane quarters, then the four waves ---------------------------
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            s1[mt] += __shfl_xor(s1[mt], 16, 64);
+            s1[mt] += __shfl_xor(s1[mt], 32, 64);
+            if (fq == 0) ex[wave * I2TF_ROWS + mt * 16 + fr] = s1[mt];
+        }
         __syncthreads();
-        const float mean = (ex[fr] + ex[I2TF_ROWS + fr]) * (1.0f / CO);
-        float s2 = 0.f;
+        float mean[2], s2[2];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int mt = 0; mt < 2; ++mt) {
+            const int r = mt * 16 + fr;
+            mean[mt] = ((ex[r] + ex[I2TF_ROWS + r]) + (ex[2 * I2TF_ROWS + r] + ex[3 * I2TF_ROWS + r])) * (1.0f / CO);
+            s2[mt] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[i][r] -= mean; s2 += v[i][r] * v[i][r]; }
-        s2 += __shfl_xor(s2, 16, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (fq == 0) ex[2 * I2TF_ROWS + wave * I2TF_ROWS + fr] = s2;
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) { v[mt][i][r4] -= mean[mt]; s2[mt] += v[mt][i][r4] * v[mt][i][r4]; }
+            s2[mt] += __shfl_xor(s2[mt], 16, 64);
+            s2[mt] += __shfl_xor(s2[mt], 32, 64);
+            if (fq == 0) ex[NWV * I2TF_ROWS + wave * I2TF_ROWS + r] = s2[mt];
+        }
         __syncthreads();
-        const float rstd = 1.0f / sqrtf((ex[2 * I2TF_ROWS + fr] + ex[3 * I2TF_ROWS + fr]) * (1.0f / CO) + eps);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int n = wave * 128 + i * 16 + 4 * fq;
-            const float4 gm = *reinterpret_cast<const float4*>(sp + CO + n), bt = *reinterpret_cast<const float4*>(sp + 2 * CO + n);
-            const float y0 = v[i][0] * rstd * gm.x + bt.x, y1 = v[i][1] * rstd * gm.y + bt.y;
-            const float y2 = v[i][2] * rstd * gm.z + bt.z, y3 = v[i][3] * rstd * gm.w + bt.w;
-            if (outF) *reinterpret_cast<float4*>(outF + orow * CO + n) = make_float4(y0, y1, y2, y3);
-            uint2 o;
-            o.x = pack2<PREC>(y0, y1);
-            o.y = pack2<PREC>(y2, y3);
-            *reinterpret_cast<uint2*>(outE + orow * CO + n) = o;
+        for (int mt = 0; mt < 2; ++mt) {
+            const int r = mt * 16 + fr;
+            const float* e2 = ex + NWV * I2TF_ROWS;
+            const float rstd = 1.0f / sqrtf(((e2[r] + e2[I2TF_ROWS + r]) + (e2[2 * I2TF_ROWS + r] + e2[3 * I2TF_ROWS + r])) * (1.0f / CO) + eps);
+            const size_t orow = (size_t)b * tokens + row0 + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = wave * 64 + i * 16 + 4 * fq;
+                const float4 gm = *reinterpret_cast<const float4*>(sp + CO + n), bt = *reinterpret_cast<const float4*>(sp + 2 * CO + n);
+                const float y0 = v[mt][i][0] * rstd * gm.x + bt.x, y1 = v[mt][i][1] * rstd * gm.y + bt.y;
+                const float y2 = v[mt][i][2] * rstd * gm.z + bt.z, y3 = v[mt][i][3] * rstd * gm.w + bt.w;
+                if (outF) *reinterpret_cast<float4*>(outF + orow * CO + n) = make_float4(y0, y1, y2, y3);
+                uint2 o, lo;
+                split2_pack<PREC>(y0, y1, o.x, lo.x);
+                split2_pack<PREC>(y2, y3, o.y, lo.y);
+                *reinterpret_cast<uint2*>(outE + orow * CO + n) = o;
+                if (outE_lo) *reinterpret_cast<uint2*>(outE_lo + orow * CO + n) = lo;
+            }
         }
         // the next group's A-tile / ex writes come after this group's last barrier and its reads above
     }
@@ -668,8 +709,12 @@ __global__ __launch_bounds__(256) void mask_product_kernel(const uint16_t* __res
 // writes low[b][c][Y][X] of sub-pixel 2 = q.   grid (row blocks per prompt, n_prompts), 256 threads.
 constexpr int U2_GROUPS_PER_WAVE = 16;          // 16-row groups per wave -> 1024 rows per block
 
-template <int PREC, int NSEL>
-__global__ __launch_bounds__(256) void upscale2_mask_kernel(const uint16_t* __restrict__ u1, const uint16_t* __restrict__ w,
+// SPLIT: `u1` is the fp32 output of the first transposed conv ([rows][64] floats) and is split into hi + lo operand
+// fragments in registers, `w_lo` is the remainder of the weight split: three MFMAs per k-step, operand error ~2^-22
+// (oracle/error_budget.py "only dec.up2": 395 of the 899 class-map pixels of the round-2 engine at ViT-H).
+template <int PREC, int NSEL, bool SPLIT>
+__global__ __launch_bounds__(256) void upscale2_mask_kernel(const void* __restrict__ u1v, const uint16_t* __restrict__ w,
+                                                            const uint16_t* __restrict__ w_lo,
                                                             const float* __restrict__ bias, const float* __restrict__ hyper,
                                                             float* __restrict__ low, int grid, int n_mask_tokens, int sel0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -677,12 +722,15 @@ __global__ __launch_bounds__(256) void upscale2_mask_kernel(const uint16_t* __re
     const int b = blockIdx.y;
     const int rows_per_prompt = grid * grid * 4;
     const int S = 4 * grid;
-    uint4 wf[8][2];
+    uint4 wf[8][2], wl[SPLIT ? 8 : 1][2];
     float bv[8][4], hy[NSEL][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wf[i][ks] = *reinterpret_cast<const uint4*>(w + (i * 16 + fr) * 64 + ks * 32 + fq * 8);
+        for (int ks = 0; ks < 2; ++ks) {
+            wf[i][ks] = *reinterpret_cast<const uint4*>(w + (i * 16 + fr) * 64 + ks * 32 + fq * 8);
+            if constexpr (SPLIT) wl[i][ks] = *reinterpret_cast<const uint4*>(w_lo + (i * 16 + fr) * 64 + ks * 32 + fq * 8);
+        }
         const float4 t = *reinterpret_cast<const float4*>(bias + i * 16 + 4 * fq);
         bv[i][0] = t.x; bv[i][1] = t.y; bv[i][2] = t.z; bv[i][3] = t.w;
     }
@@ -697,13 +745,34 @@ __global__ __launch_bounds__(256) void upscale2_mask_kernel(const uint16_t* __re
         }
     }
     const int row0 = (blockIdx.x * 4 + wave) * (16 * U2_GROUPS_PER_WAVE);     // first row (within the prompt) of this wave
-    const uint16_t* abase = u1 + ((size_t)b * rows_per_prompt + row0 + fr) * 64 + fq * 8;
-    uint4 a0 = *reinterpret_cast<const uint4*>(abase), a1 = *reinterpret_cast<const uint4*>(abase + 32);
+    // fragments of a 16-row group: lane (fr, fq) holds columns 32 ks + 8 fq .. +7 of row fr (ET: 16 bytes, fp32: 32 bytes)
+    const uint16_t* abase = reinterpret_cast<const uint16_t*>(u1v) + ((size_t)b * rows_per_prompt + row0 + fr) * 64 + fq * 8;
+    const float* fbase = reinterpret_cast<const float*>(u1v) + ((size_t)b * rows_per_prompt + row0 + fr) * 64 + fq * 8;
+    uint4 a0 = make_uint4(0u, 0u, 0u, 0u), a1 = a0;
+    float4 f[SPLIT ? 4 : 1];
+    if constexpr (SPLIT) {
+        f[0] = *reinterpret_cast<const float4*>(fbase); f[1] = *reinterpret_cast<const float4*>(fbase + 4);
+        f[2] = *reinterpret_cast<const float4*>(fbase + 32); f[3] = *reinterpret_cast<const float4*>(fbase + 36);
+    } else {
+        a0 = *reinterpret_cast<const uint4*>(abase); a1 = *reinterpret_cast<const uint4*>(abase + 32);
+    }
     for (int g = 0; g < U2_GROUPS_PER_WAVE; ++g) {
-        const uint4 c0 = a0, c1 = a1;
+        uint4 c0 = a0, c1 = a1, l0 = make_uint4(0u, 0u, 0u, 0u), l1 = l0;
+        if constexpr (SPLIT) {
+            split2_pack<PREC>(f[0].x, f[0].y, c0.x, l0.x); split2_pack<PREC>(f[0].z, f[0].w, c0.y, l0.y);
+            split2_pack<PREC>(f[1].x, f[1].y, c0.z, l0.z); split2_pack<PREC>(f[1].z, f[1].w, c0.w, l0.w);
+            split2_pack<PREC>(f[2].x, f[2].y, c1.x, l1.x); split2_pack<PREC>(f[2].z, f[2].w, c1.y, l1.y);
+            split2_pack<PREC>(f[3].x, f[3].y, c1.z, l1.z); split2_pack<PREC>(f[3].z, f[3].w, c1.w, l1.w);
+        }
         if (g + 1 < U2_GROUPS_PER_WAVE) {        // next group's fragments fly during this group's math
-            a0 = *reinterpret_cast<const uint4*>(abase + (size_t)(g + 1) * 16 * 64);
-            a1 = *reinterpret_cast<const uint4*>(abase + (size_t)(g + 1) * 16 * 64 + 32);
+            if constexpr (SPLIT) {
+                const float* nb = fbase + (size_t)(g + 1) * 16 * 64;
+                f[0] = *reinterpret_cast<const float4*>(nb); f[1] = *reinterpret_cast<const float4*>(nb + 4);
+                f[2] = *reinterpret_cast<const float4*>(nb + 32); f[3] = *reinterpret_cast<const float4*>(nb + 36);
+            } else {
+                a0 = *reinterpret_cast<const uint4*>(abase + (size_t)(g + 1) * 16 * 64);
+                a1 = *reinterpret_cast<const uint4*>(abase + (size_t)(g + 1) * 16 * 64 + 32);
+            }
         }
         float part[NSEL][4];
 #pragma unroll
@@ -713,6 +782,12 @@ __global__ __launch_bounds__(256) void upscale2_mask_kernel(const uint16_t* __re
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (SPLIT) {              // the small terms first, the leading one on top of them
+                acc = ET<PREC>::mfma16(wf[i][0], l0, acc);
+                acc = ET<PREC>::mfma16(wf[i][1], l1, acc);
+                acc = ET<PREC>::mfma16(wl[i][0], c0, acc);
+                acc = ET<PREC>::mfma16(wl[i][1], c1, acc);
+            }
             acc = ET<PREC>::mfma16(wf[i][0], c0, acc);
             acc = ET<PREC>::mfma16(wf[i][1], c1, acc);
             const float2_t g01 = gelu_erf2(float2_t{acc[0] + bv[i][0], acc[1] + bv[i][1]});
@@ -902,6 +977,43 @@ __global__ __launch_bounds__(256) void paint_area_kernel(const uint8_t* __restri
         *sp = o;
     }
 }
+// ---- instance drivers: keep the mask with the highest predicted IoU --------------------------------------------------------
+// main_sam_*_mask_instance.py with multimask_output=True: of the nsel masks of an object keep the one with the highest
+// predicted IoU (first maximum, like torch.argmax), its quality and its area.  One pass over the kept mask with 16-byte
+// loads: copy + popcount.  grid (chunks, n); integer arithmetic only.
+__global__ __launch_bounds__(256) void select_best_kernel(const uint8_t* __restrict__ masks, const float* __restrict__ iou, int nsel,
+                                                          long hw, uint8_t* __restrict__ out, float* __restrict__ quality,
+                                                          unsigned long long* __restrict__ areas) {
+    const int j = blockIdx.y;
+    int best = 0;
+    float bq = iou[(size_t)j * nsel];
+    for (int c = 1; c < nsel; ++c) {
+        const float q = iou[(size_t)j * nsel + c];
+        if (q > bq) { bq = q; best = c; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) quality[j] = bq;
+    const uint8_t* src = masks + ((size_t)j * nsel + best) * hw;
+    uint8_t* dst = out + (size_t)j * hw;
+    unsigned int cnt = 0;
+    const bool vec = (hw % 16 == 0) && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    if (vec) {
+        const long n16 = hw / 16;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+            const uint4 m = reinterpret_cast<const uint4*>(src)[i];
+            reinterpret_cast<uint4*>(dst)[i] = m;
+            cnt += __popc(nonzero_bytes(m.x)) + __popc(nonzero_bytes(m.y)) + __popc(nonzero_bytes(m.z)) + __popc(nonzero_bytes(m.w));
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+            const uint8_t m = src[i];
+            dst[i] = m;
+            cnt += m ? 1u : 0u;
+        }
+    }
+    const float c = wave_sum((float)cnt);               // <= 64 * 16 * iterations: keep it exact -> few iterations per thread
+    if ((threadIdx.x & 63) == 0 && c > 0.f) atomicAdd(&areas[j], (unsigned long long)c);
+}
+
 __global__ void class_stats_kernel(const unsigned long long* __restrict__ areas, const int32_t* __restrict__ labels, int n,
                                    unsigned long long* __restrict__ cpix, unsigned long long* __restrict__ cins, int n_classes) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1132,20 +1244,24 @@ hipError_t launch_i2t_attention(int prec, const void* qi, int ld, long bstride, 
     return hipGetLastError();
 }
 hipError_t launch_i2t_fused(int prec, const void* qi, int ld, long q_bstride, const float* kt, const float* vt, const void* w,
-                            const float* bias, const float* resid, long r_bstride, const float* gamma, const float* beta, float eps,
-                            float* outF, void* outE, int n, int T, int tokens, int Ci, int C, hipStream_t s) {
+                            const void* w_lo, const float* bias, const float* resid, long r_bstride, const float* gamma,
+                            const float* beta, float eps, float* outF, void* outE, void* outE_lo, int n, int T, int tokens, int Ci,
+                            int C, hipStream_t s) {
     if (Ci != 128 || C != 256 || T < 1 || T > TOK_MAX || tokens % I2TF_ROWS) return hipErrorInvalidValue;
     const int groups = tokens / I2TF_ROWS;
-    int gpb = 8;                                   // groups per block: W fragments (64 KB per block) are loaded once
+    int gpb = 4;                                   // groups per block: W fragments (64 / 128 KB per block) are loaded once
     while (gpb > 1 && groups % gpb) gpb >>= 1;
-    dim3 g(groups / gpb, n), b(128);
-    const size_t sh = (size_t)(2 * T * 8 * I2T_HS + 3 * 256 + 4 * I2TF_ROWS) * sizeof(float) + (size_t)I2TF_ROWS * I2TF_AST * 2;
-    if (prec == PREC_BF16)
-        i2t_fused_kernel<PREC_BF16><<<g, b, sh, s>>>((const uint16_t*)qi, ld, q_bstride, kt, vt, (const uint16_t*)w, bias, resid,
-                                                     r_bstride, gamma, beta, eps, outF, (uint16_t*)outE, T, tokens, gpb);
-    else
-        i2t_fused_kernel<PREC_F16><<<g, b, sh, s>>>((const uint16_t*)qi, ld, q_bstride, kt, vt, (const uint16_t*)w, bias, resid,
-                                                    r_bstride, gamma, beta, eps, outF, (uint16_t*)outE, T, tokens, gpb);
+    dim3 g(groups / gpb, n), b(256);
+    const bool split = w_lo != nullptr;
+    const size_t sh = (size_t)(2 * T * 8 * I2T_HS + 3 * 256 + 2 * 4 * I2TF_ROWS) * sizeof(float) +
+                      (size_t)(split ? 2 : 1) * I2TF_ROWS * I2TF_AST * 2;
+#define I2TF_LAUNCH(P, S)                                                                                                       \
+    i2t_fused_kernel<P, S><<<g, b, sh, s>>>((const uint16_t*)qi, ld, q_bstride, kt, vt, (const uint16_t*)w, (const uint16_t*)w_lo, \
+                                           bias, resid, r_bstride, gamma, beta, eps, outF, (uint16_t*)outE, (uint16_t*)outE_lo, T, \
+                                           tokens, gpb)
+    if (prec == PREC_BF16) { if (split) I2TF_LAUNCH(PREC_BF16, true); else I2TF_LAUNCH(PREC_BF16, false); }
+    else { if (split) I2TF_LAUNCH(PREC_F16, true); else I2TF_LAUNCH(PREC_F16, false); }
+#undef I2TF_LAUNCH
     return hipGetLastError();
 }
 hipError_t launch_group_ln_gelu(int prec, const float* in, const float* gamma, const float* beta, float eps,
@@ -1165,16 +1281,18 @@ hipError_t launch_mask_product(int prec, const void* up2, const float* hyper, fl
     else mask_product_kernel<PREC_F16><<<g, b, 0, s>>>((const uint16_t*)up2, hyper, low, grid, n_mask_tokens, sel0, n_sel);
     return hipGetLastError();
 }
-hipError_t launch_upscale2_masks(int prec, const void* u1, const void* w, const float* bias, const float* hyper, float* low,
-                                 int n, int grid, int n_mask_tokens, int sel0, int n_sel, hipStream_t s) {
+hipError_t launch_upscale2_masks(int prec, const void* u1, const void* w, const void* w_lo, const float* bias, const float* hyper,
+                                 float* low, int n, int grid, int n_mask_tokens, int sel0, int n_sel, hipStream_t s) {
     const int rows_per_block = 4 * 16 * U2_GROUPS_PER_WAVE;
     if ((grid * grid * 4) % rows_per_block || (n_sel != 1 && n_sel != 3)) return hipErrorInvalidValue;
     dim3 g(grid * grid * 4 / rows_per_block, n), b(256);
-    const uint16_t* a = (const uint16_t*)u1;
     const uint16_t* ww = (const uint16_t*)w;
-#define U2_LAUNCH(P, NS) upscale2_mask_kernel<P, NS><<<g, b, 0, s>>>(a, ww, bias, hyper, low, grid, n_mask_tokens, sel0)
-    if (prec == PREC_BF16) { if (n_sel == 1) U2_LAUNCH(PREC_BF16, 1); else U2_LAUNCH(PREC_BF16, 3); }
-    else { if (n_sel == 1) U2_LAUNCH(PREC_F16, 1); else U2_LAUNCH(PREC_F16, 3); }
+    const uint16_t* wl = (const uint16_t*)w_lo;
+#define U2_LAUNCH(P, NS, SP) upscale2_mask_kernel<P, NS, SP><<<g, b, 0, s>>>(u1, ww, wl, bias, hyper, low, grid, n_mask_tokens, sel0)
+#define U2_SEL(P, SP) do { if (n_sel == 1) U2_LAUNCH(P, 1, SP); else U2_LAUNCH(P, 3, SP); } while (0)
+    if (prec == PREC_BF16) { if (w_lo) U2_SEL(PREC_BF16, true); else U2_SEL(PREC_BF16, false); }
+    else { if (w_lo) U2_SEL(PREC_F16, true); else U2_SEL(PREC_F16, false); }
+#undef U2_SEL
 #undef U2_LAUNCH
     return hipGetLastError();
 }
@@ -1202,6 +1320,18 @@ hipError_t launch_paint(const uint8_t* masks, const int32_t* labels, int n, int 
         if (class_pixels || class_instances)
             class_stats_kernel<<<1, 64, 0, s>>>(areas, labels, n, class_pixels, class_instances, n_classes);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_select_best(const uint8_t* masks, const float* iou, int n, int nsel, int h, int w, uint8_t* out, float* quality,
+                              unsigned long long* areas, hipStream_t s) {
+    if (n < 1 || nsel < 1 || h < 1 || w < 1) return hipErrorInvalidValue;
+    const long hw = (long)h * w;
+    HIP_CHECK_RET(hipMemsetAsync(areas, 0, sizeof(unsigned long long) * n, s));
+    // <= 2^24 / 1024 iterations per thread keeps the fp32 wave sum exact; 64 chunks of 256 threads x 16 bytes cover 1024^2 in 4
+    int chunks = (int)((hw / 16 + 255) / 256);
+    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+    select_best_kernel<<<dim3(chunks, n), 256, 0, s>>>(masks, iou, nsel, hw, out, quality, areas);
     return hipGetLastError();
 }
 

@@ -33,7 +33,7 @@ __constant__ float c_std[3] = {58.395f, 57.12f, 57.375f};     // modeling/sam.py
 // One thread = 8 horizontally adjacent pixels (24 bytes of HWC input) -> three 16-byte chunks.
 // -----------------------------------------------------------------------------------------
 template <int PREC>
-__global__ void patch_im2col_kernel(const uint8_t* __restrict__ img, uint16_t* __restrict__ A,
+__global__ void patch_im2col_kernel(const uint8_t* __restrict__ img, uint16_t* __restrict__ A, uint16_t* __restrict__ A_lo,
                                     int n_images, int in_h, int in_w, int grid, int patch) {
     const int P2 = patch * patch;            // 256
     const int halves = patch / 8;            // 2
@@ -57,27 +57,29 @@ __global__ void patch_im2col_kernel(const uint8_t* __restrict__ img, uint16_t* _
         for (int c = 0; c < 3; ++c) v[c][e] = in ? ((float)p[c] - c_mean[c]) / c_std[c] : 0.f;
     }
     const size_t row = ((size_t)im * grid + py) * grid + px;
-    uint16_t* out = A + row * (3 * P2) + ky * patch + half * 8;
+    const size_t off = row * (3 * P2) + ky * patch + half * 8;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        uint4 o;
-        o.x = pack2<PREC>(v[c][0], v[c][1]);
-        o.y = pack2<PREC>(v[c][2], v[c][3]);
-        o.z = pack2<PREC>(v[c][4], v[c][5]);
-        o.w = pack2<PREC>(v[c][6], v[c][7]);
-        *reinterpret_cast<uint4*>(out + c * P2) = o;
+        uint4 o, l;
+        split2_pack<PREC>(v[c][0], v[c][1], o.x, l.x);
+        split2_pack<PREC>(v[c][2], v[c][3], o.y, l.y);
+        split2_pack<PREC>(v[c][4], v[c][5], o.z, l.z);
+        split2_pack<PREC>(v[c][6], v[c][7], o.w, l.w);
+        *reinterpret_cast<uint4*>(A + off + c * P2) = o;
+        if (A_lo) *reinterpret_cast<uint4*>(A_lo + off + c * P2) = l;
     }
 }
 
 template <int PREC>
-__global__ void convert_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, long n4) {
+__global__ void convert_kernel(const float* __restrict__ in, uint16_t* __restrict__ out, uint16_t* __restrict__ out_lo, long n4) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const float4 v = reinterpret_cast<const float4*>(in)[i];
-    uint2 o;
-    o.x = pack2<PREC>(v.x, v.y);
-    o.y = pack2<PREC>(v.z, v.w);
+    uint2 o, l;
+    split2_pack<PREC>(v.x, v.y, o.x, l.x);
+    split2_pack<PREC>(v.z, v.w, o.y, l.y);
     reinterpret_cast<uint2*>(out)[i] = o;
+    if (out_lo) reinterpret_cast<uint2*>(out_lo)[i] = l;       // the split remainder (weights / neck operand)
 }
 
 // -----------------------------------------------------------------------------------------
@@ -103,7 +105,7 @@ template <int PREC>
 __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
     float eps, uint16_t* __restrict__ out_et, float* __restrict__ out_f32, int rows_out, int D,
-    int window_mode, int grid, int window) {
+    int window_mode, int grid, int window, uint16_t* __restrict__ out_lo /* optional: the split remainder of out_et */) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows_out) return;
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     if (!valid) {
         for (int i = lane; i < nv; i += 64) {
             if (out_et) reinterpret_cast<uint2*>(out_et + (size_t)row * D)[i] = make_uint2(0u, 0u);
+            if (out_lo) reinterpret_cast<uint2*>(out_lo + (size_t)row * D)[i] = make_uint2(0u, 0u);
             if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         return;
@@ -165,6 +168,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
                 o.x = pack2<PREC>(o0, o1);
                 o.y = pack2<PREC>(o2, o3);
                 reinterpret_cast<uint2*>(out_et + (size_t)row * D)[idx] = o;
+                if (out_lo) {          // neck only: the remainder of the split (same hi bits as above)
+                    uint2 h, l;
+                    split2_pack<PREC>(o0, o1, h.x, l.x);
+                    split2_pack<PREC>(o2, o3, h.y, l.y);
+                    reinterpret_cast<uint2*>(out_lo + (size_t)row * D)[idx] = l;
+                }
             }
             if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[idx] = make_float4(o0, o1, o2, o3);
         }
@@ -1039,23 +1048,23 @@ hipError_t set_lds(K kernel, int bytes) {
 // launchers
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_patch_im2col(int prec, const uint8_t* img, void* A, int n_images, int in_h, int in_w,
-                               int grid, int patch, hipStream_t s) {
+                               int grid, int patch, hipStream_t s, void* A_lo) {
     if (patch % 8) return hipErrorInvalidValue;
     const long total = (long)n_images * grid * grid * patch * (patch / 8);
     const int blocks = (int)((total + 255) / 256);
     if (prec == PREC_BF16)
-        patch_im2col_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(img, (uint16_t*)A, n_images, in_h, in_w, grid, patch);
+        patch_im2col_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(img, (uint16_t*)A, (uint16_t*)A_lo, n_images, in_h, in_w, grid, patch);
     else
-        patch_im2col_kernel<PREC_F16><<<blocks, 256, 0, s>>>(img, (uint16_t*)A, n_images, in_h, in_w, grid, patch);
+        patch_im2col_kernel<PREC_F16><<<blocks, 256, 0, s>>>(img, (uint16_t*)A, (uint16_t*)A_lo, n_images, in_h, in_w, grid, patch);
     return hipGetLastError();
 }
 
-hipError_t launch_convert(int prec, const float* in, void* out, long n, hipStream_t s) {
+hipError_t launch_convert(int prec, const float* in, void* out, long n, hipStream_t s, void* out_lo) {
     if (n % 4) return hipErrorInvalidValue;
     const long n4 = n / 4;
     const int blocks = (int)((n4 + 255) / 256);
-    if (prec == PREC_BF16) convert_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(in, (uint16_t*)out, n4);
-    else convert_kernel<PREC_F16><<<blocks, 256, 0, s>>>(in, (uint16_t*)out, n4);
+    if (prec == PREC_BF16) convert_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(in, (uint16_t*)out, (uint16_t*)out_lo, n4);
+    else convert_kernel<PREC_F16><<<blocks, 256, 0, s>>>(in, (uint16_t*)out, (uint16_t*)out_lo, n4);
     return hipGetLastError();
 }
 
@@ -1171,13 +1180,13 @@ hipError_t launch_rowstats_convert(int prec, const float* X, void* Xh, float* st
 
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
-                            int window, hipStream_t s) {
+                            int window, hipStream_t s, void* out_lo) {
     if (D % 4 || D > LN_MAXV * 256) return hipErrorInvalidValue;
     const int blocks = (rows_out + 3) / 4;
     if (prec == PREC_BF16)
-        layernorm_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window);
+        layernorm_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo);
     else
-        layernorm_kernel<PREC_F16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window);
+        layernorm_kernel<PREC_F16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo);
     return hipGetLastError();
 }
 

@@ -27,9 +27,15 @@ struct DevTensor {
     size_t numel = 0;
 };
 
-// A/B knob for timing experiments and the fused-vs-unfused parity test: the decoder's fused kernels (upscaler, i2t + projection +
-// LayerNorm) can be switched off at run time (samrs_debug_set_decoder_fusion) or at load time (SAMRS_DECODER_FUSION=0).
-static bool g_decoder_fusion = [] { const char* v = getenv("SAMRS_DECODER_FUSION"); return !(v && atoi(v) == 0); }();
+// Per-engine options (samrs_set_option); the environment only supplies the DEFAULTS a new handle starts with:
+//   decoder_fusion (SAMRS_DECODER_FUSION, default 1): 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm /
+//                  product launches) -- the fused-vs-unfused parity test and timing experiments;
+//   ln_fold        (SAMRS_LN_FOLD, default 0): fold the encoder blocks' LayerNorms into the qkv / lin1 GEMMs (embed_dim 1280);
+//   split          (SAMRS_SPLIT, default 15): bit mask of the rounding points that run as a two-term operand split (3 MFMAs,
+//                  ~2^-22 operand error): 1 patch embed, 2 neck, 4 decoder i2t out-projection, 8 decoder upscaler (both
+//                  transposed convs).  oracle/error_budget.py measures what each bit buys; DESIGN.md 2 has the table.
+enum { SPLIT_PATCH = 1, SPLIT_NECK = 2, SPLIT_OI = 4, SPLIT_UP = 8, SPLIT_ALL = 15 };
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 struct DecAttn {
     const float *qw, *qb, *kw, *kb, *vw, *vb, *ow, *ob;
@@ -43,6 +49,7 @@ struct DecLayer {
     float* kvq_b = nullptr;       // [384]
     float* kvq_pe = nullptr;      // [tokens][384] = [PE Wk^T | 0 | PE Wq^T]
     uint16_t* i2t_ow = nullptr;   // ET [256][128]
+    uint16_t* i2t_ow_lo = nullptr;   // its split remainder
 };
 
 struct EncBlock {
@@ -56,9 +63,8 @@ struct EncBlock {
 
 // LayerNorm folding (encoder blocks, embed_dim 1280 only).  OFF by default: measured slower than the stand-alone LayerNorm
 // kernel on MI355X (anything added to a GEMM epilogue runs while the matrix pipe idles, the stand-alone kernel
-// streams at ~6 TB/s).  SAMRS_LN_FOLD=1 at load time or samrs_debug_set_ln_fold(1) BEFORE samrs_finalize_weights prepares the
-// folded weights; the switch can then be flipped at run time (A/B runs, the folded-vs-unfolded parity test).
-static bool g_ln_fold = [] { const char* v = getenv("SAMRS_LN_FOLD"); return v && atoi(v) != 0; }();
+// streams at ~6 TB/s).  SAMRS_LN_FOLD=1 at load time or samrs_set_option(e, "ln_fold", 1) BEFORE samrs_finalize_weights prepares
+// the folded weights; the switch can then be flipped at run time (A/B runs, the folded-vs-unfolded parity test).
 
 }  // namespace
 
@@ -74,10 +80,14 @@ struct samrs_engine {
     // derived sizes
     int grid = 64, tokens = 4096, D = 0, C = 256, hd = 0, nwin = 5;
     int T_max = 0;
+    bool decoder_fusion = true, ln_fold = false;   // per-engine options, see the top of this file
+    int split = SPLIT_ALL;
+    int gemm_variant = -1;                          // -1 = the library default (launch_gemm_et's automatic choice)
 
     // encoder weights / workspaces
     std::vector<EncBlock> blocks;
     uint16_t *patch_w = nullptr, *neck0_w = nullptr, *neck2_w = nullptr;
+    uint16_t *patch_w_lo = nullptr, *neck0_w_lo = nullptr, *neck2_w_lo = nullptr;   // split remainders (common.h split2_pack)
     float* X = nullptr;            // residual stream fp32 [Bi*tokens, D]
     uint16_t* Y = nullptr;         // LN out (ET) [Bi*tokens, D]; folded path: the residual stream itself rounded to ET
     float* STATS = nullptr;        // folded path: per-row (mean, M2) of eight 160-column groups [Bi*tokens][8][2]
@@ -97,7 +107,7 @@ struct samrs_engine {
     DecAttn fin{};
     uint16_t* fin_kv_w = nullptr;  // ET [256][256] = [Wk; Wv]
     float *fin_kv_b = nullptr, *fin_pe = nullptr;
-    uint16_t *up1_w = nullptr, *up2_w = nullptr;
+    uint16_t *up1_w = nullptr, *up2_w = nullptr, *up1_w_lo = nullptr, *up2_w_lo = nullptr;
     float *up1_b = nullptr, *up2_b = nullptr, *up_ln = nullptr;   // up_ln = LayerNorm2d gamma[64] | beta[64]
     float* PE = nullptr;           // dense PE [tokens][C]
 
@@ -108,6 +118,7 @@ struct samrs_engine {
     uint16_t* K0E = nullptr;
     float* KF = nullptr;           // per-prompt keys fp32 [Bb*tokens][C]
     uint16_t* KE = nullptr;
+    uint16_t* KE_lo = nullptr;     // split remainder of the final keys (operand of the first transposed conv)
     float* DENSE = nullptr;        // mask-prompt dense embedding (allocated on first use)
     uint16_t* KVQ = nullptr;       // [Bb*tokens][384]
     uint16_t* OI = nullptr;        // [Bb*tokens][128]
@@ -115,6 +126,10 @@ struct samrs_engine {
     uint16_t* U1 = nullptr;        // [Bb*tokens][256]
     uint16_t* U2 = nullptr;        // [Bb*tokens*4][128]
     float *HY1 = nullptr, *HY2 = nullptr, *HYPER = nullptr, *IOU = nullptr, *LOW = nullptr;
+
+    // COCO RLE scratch (samrs_rle_encode), grown on demand
+    void* rle_scratch = nullptr;
+    size_t rle_scratch_bytes = 0;
 
     // optional in-situ timing of the dominant kernel (MLP lin1 + GELU GEMM) with HIP events
     bool timing = false;
@@ -170,7 +185,13 @@ struct DeviceGuard {
     DeviceGuard(const DeviceGuard&) = delete;
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
-#define ON_DEVICE(e) DeviceGuard _dg((e)->device); CK((e), _dg.status)
+// an engine's own GEMM tile choice (samrs_set_option "gemm_variant") applies to the launches of its entry points only
+struct GemmVariantScope {
+    int prev;
+    explicit GemmVariantScope(int v) : prev(swap_gemm_variant_override(v)) {}
+    ~GemmVariantScope() { (void)swap_gemm_variant_override(prev); }
+};
+#define ON_DEVICE(e) DeviceGuard _dg((e)->device); CK((e), _dg.status); GemmVariantScope _gvs((e)->gemm_variant)
 
 bool is_global(const samrs_config& c, int i) {
     for (int k = 0; k < c.n_global; ++k)
@@ -255,11 +276,12 @@ DecAttn dec_attn(samrs_engine* e, const std::string& p) {
                    W(e, p + ".out_proj.weight"), W(e, p + ".out_proj.bias")};
 }
 
-// fp32 device tensor -> new ET device tensor; optionally frees the fp32 copy
-int to_et(samrs_engine* e, const std::string& name, uint16_t** out, bool free_f32, hipStream_t s) {
+// fp32 device tensor -> new ET device tensor (and, if asked for, the remainder of its two-term split); optionally frees the fp32 copy
+int to_et(samrs_engine* e, const std::string& name, uint16_t** out, bool free_f32, hipStream_t s, uint16_t** out_lo = nullptr) {
     DevTensor& t = e->w.at(name);
     CK(e, dalloc(e, out, t.numel));
-    CK(e, launch_convert(e->prec, t.p, *out, (long)t.numel, s));
+    if (out_lo) CK(e, dalloc(e, out_lo, t.numel));
+    CK(e, launch_convert(e->prec, t.p, *out, (long)t.numel, s, out_lo ? *out_lo : nullptr));
     if (free_f32) {
         CK(e, hipStreamSynchronize(s));
         for (auto it = e->owned.begin(); it != e->owned.end(); ++it)
@@ -310,6 +332,9 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->nwin = (e->grid + cfg->window_size - 1) / cfg->window_size;
     e->T_max = 5 + cfg->max_points + 1 + 2;
     e->slot_set.assign(cfg->max_images, 0);
+    e->decoder_fusion = env_int("SAMRS_DECODER_FUSION", 1) != 0;
+    e->ln_fold = env_int("SAMRS_LN_FOLD", 0) != 0;
+    e->split = env_int("SAMRS_SPLIT", SPLIT_ALL) & SPLIT_ALL;
     return e;
 }
 
@@ -317,6 +342,7 @@ void samrs_destroy(samrs_engine_t* e) {
     if (!e) return;
     DeviceGuard dg(e->device);
     for (void* p : e->owned) (void)hipFree(p);
+    if (e->rle_scratch) (void)hipFree(e->rle_scratch);
     delete e;
 }
 
@@ -382,9 +408,9 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     const int D = e->D, C = e->C, tokens = e->tokens;
     int rc;
     // ---- encoder weights -> ET ----
-    if ((rc = to_et(e, "image_encoder.patch_embed.proj.weight", &e->patch_w, true, s))) return rc;
-    if ((rc = to_et(e, "image_encoder.neck.0.weight", &e->neck0_w, true, s))) return rc;
-    if ((rc = to_et(e, "image_encoder.neck.2.weight", &e->neck2_w, true, s))) return rc;
+    if ((rc = to_et(e, "image_encoder.patch_embed.proj.weight", &e->patch_w, true, s, &e->patch_w_lo))) return rc;
+    if ((rc = to_et(e, "image_encoder.neck.0.weight", &e->neck0_w, true, s, &e->neck0_w_lo))) return rc;
+    if ((rc = to_et(e, "image_encoder.neck.2.weight", &e->neck2_w, true, s, &e->neck2_w_lo))) return rc;
     e->blocks.resize(c.depth);
     for (int i = 0; i < c.depth; ++i) {
         const std::string p = "image_encoder.blocks." + std::to_string(i);
@@ -392,7 +418,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
         b.global = is_global(c, i);
         b.ln1w = W(e, p + ".norm1.weight"); b.ln1b = W(e, p + ".norm1.bias");
         b.ln2w = W(e, p + ".norm2.weight"); b.ln2b = W(e, p + ".norm2.bias");
-        if (D == 1280 && g_ln_fold) {       // folded LayerNorm needs the fp32 weights: before to_et() frees them
+        if (D == 1280 && e->ln_fold) {       // folded LayerNorm needs the fp32 weights: before to_et() frees them
             CK(e, dalloc(e, &b.qkv_wf, (size_t)3 * D * D)); CK(e, dalloc(e, &b.qkv_c, (size_t)3 * D)); CK(e, dalloc(e, &b.qkv_bf, (size_t)3 * D));
             CK(e, dalloc(e, &b.lin1_wf, (size_t)4 * D * D)); CK(e, dalloc(e, &b.lin1_c, (size_t)4 * D)); CK(e, dalloc(e, &b.lin1_bf, (size_t)4 * D));
             CK(e, launch_ln_fold_weight(e->prec, W(e, p + ".attn.qkv.weight"), b.ln1w, b.ln1b, W(e, p + ".attn.qkv.bias"), b.qkv_wf,
@@ -444,7 +470,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
         CK(e, hipMemsetAsync(L.kvq_pe, 0, sizeof(float) * tokens * 3 * Ci, s));
         CK(e, launch_gemm_f32(e->PE, C, L.t2i.kw, nullptr, L.kvq_pe, 3 * Ci, tokens, Ci, C, false, false, s));
         CK(e, launch_gemm_f32(e->PE, C, L.i2t.qw, nullptr, L.kvq_pe + 2 * Ci, 3 * Ci, tokens, Ci, C, false, false, s));
-        if ((rc = to_et(e, p + ".cross_attn_image_to_token.out_proj.weight", &L.i2t_ow, false, s))) return rc;
+        if ((rc = to_et(e, p + ".cross_attn_image_to_token.out_proj.weight", &L.i2t_ow, false, s, &L.i2t_ow_lo))) return rc;
     }
     e->fin = dec_attn(e, "mask_decoder.transformer.final_attn_token_to_image");
     CK(e, hipMemcpyAsync(tmpw, e->fin.kw, sizeof(float) * Ci * C, hipMemcpyDeviceToDevice, s));
@@ -458,8 +484,8 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, hipMemsetAsync(e->fin_pe, 0, sizeof(float) * tokens * 2 * Ci, s));
     CK(e, launch_gemm_f32(e->PE, C, e->fin.kw, nullptr, e->fin_pe, 2 * Ci, tokens, Ci, C, false, false, s));
     // upscaler: weights were reordered at load to GEMM-B layout; biases are tiled over the 4 sub-pixels
-    if ((rc = to_et(e, "mask_decoder.output_upscaling.0.weight", &e->up1_w, false, s))) return rc;
-    if ((rc = to_et(e, "mask_decoder.output_upscaling.3.weight", &e->up2_w, false, s))) return rc;
+    if ((rc = to_et(e, "mask_decoder.output_upscaling.0.weight", &e->up1_w, false, s, &e->up1_w_lo))) return rc;
+    if ((rc = to_et(e, "mask_decoder.output_upscaling.3.weight", &e->up2_w, false, s, &e->up2_w_lo))) return rc;
     CK(e, dalloc(e, &e->up1_b, (size_t)C));
     CK(e, dalloc(e, &e->up2_b, (size_t)C / 2));
     CK(e, dalloc(e, &e->up_ln, (size_t)C / 2));
@@ -482,7 +508,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->AO, M * D));
     CK(e, dalloc(e, &e->VTG, M * D));
     size_t hsz = M * 4 * D;
-    if (M * 9 * C > hsz) hsz = M * 9 * C;
+    if (M * 9 * C * 2 > hsz) hsz = M * 9 * C * 2;      // neck im2col, hi + lo
     if (M * 768 > hsz) hsz = M * 768;
     CK(e, dalloc(e, &e->H, hsz));
     CK(e, dalloc(e, &e->N1, M * C));
@@ -497,6 +523,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->T2IW, t2i_workspace_floats(c.max_prompts, e->T_max)));
     CK(e, dalloc(e, &e->K0F, (size_t)tokens * C)); CK(e, dalloc(e, &e->K0E, (size_t)tokens * C));
     CK(e, dalloc(e, &e->KF, Bb * tokens * C)); CK(e, dalloc(e, &e->KE, Bb * tokens * C));
+    CK(e, dalloc(e, &e->KE_lo, Bb * tokens * C));
     CK(e, dalloc(e, &e->KVQ, Bb * tokens * 3 * Ci)); CK(e, dalloc(e, &e->OI, Bb * tokens * Ci));
     CK(e, dalloc(e, &e->U1raw, Bb * tokens * C)); CK(e, dalloc(e, &e->U1, Bb * tokens * C));
     CK(e, dalloc(e, &e->U2, Bb * tokens * 4 * (C / 2)));
@@ -531,20 +558,29 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
 
     // patch embed: im2col (normalise + zero pad) -> GEMM (+bias +pos_embed) -> X.  One im2col launch per run of
     // same-size tiles that sit back to back in memory (the whole batch for a contiguous tile stack).
+    // SPLIT_PATCH: pixels and weights as hi + lo (three GEMM passes into X) -- the normalised pixel values span +-2.6 and
+    // their f16 rounding alone cost 266 of the 899 class-map pixels the round-2 engine lost at ViT-H (oracle/error_budget.py)
     const size_t KP = (size_t)3 * c.patch_size * c.patch_size;
+    const bool sp_patch = (e->split & SPLIT_PATCH) != 0;
+    uint16_t* Hlo = e->H + (size_t)M * KP;
     for (int i = 0; i < n;) {
         int j = i + 1;
         while (j < n && in_h[j] == in_h[i] && in_w[j] == in_w[i] &&
                images[j] == images[i] + (size_t)(j - i) * in_h[i] * in_w[i] * 3) ++j;
-        CK(e, launch_patch_im2col(prec, images[i], e->H + (size_t)i * tokens * KP, j - i, in_h[i], in_w[i], g, c.patch_size, s));
+        CK(e, launch_patch_im2col(prec, images[i], e->H + (size_t)i * tokens * KP, j - i, in_h[i], in_w[i], g, c.patch_size, s,
+                                  sp_patch ? Hlo + (size_t)i * tokens * KP : nullptr));
         i = j;
     }
     CK(e, launch_gemm_et(prec, e->H, e->patch_w, e->X, W(e, "image_encoder.patch_embed.proj.bias"),
-                         W(e, "image_encoder.pos_embed"), tokens, M, D, 3 * c.patch_size * c.patch_size, true, false, false, s));
+                         W(e, "image_encoder.pos_embed"), tokens, M, D, (int)KP, true, false, false, s));
+    if (sp_patch) {
+        CK(e, launch_gemm_et(prec, Hlo, e->patch_w, e->X, nullptr, nullptr, 0, M, D, (int)KP, true, false, true, s));
+        CK(e, launch_gemm_et(prec, e->H, e->patch_w_lo, e->X, nullptr, nullptr, 0, M, D, (int)KP, true, false, true, s));
+    }
     // Folded LayerNorm (embed_dim 1280): no LayerNorm launches inside the blocks.  Y holds the residual stream rounded to ET and
     // STATS its per-row partial statistics, both written by the epilogue of the GEMM that produced X (proj, lin2; here, once,
     // by rowstats_convert); qkv / lin1 run on the gamma-folded weights and normalise in their epilogue (gemm.hip).
-    const bool fold = e->can_fold && g_ln_fold;
+    const bool fold = e->can_fold && e->ln_fold;
     if (fold && n_blocks > 0) {
         CK(e, launch_rowstats_convert(prec, e->X, e->Y, e->STATS, M, D, s));
         CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
@@ -592,12 +628,28 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     }
     if (!do_neck) return SAMRS_OK;
     // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d   (all channels-last).  Folded path: Y already is ET(X).
-    if (!(fold && c.depth > 0 && n_blocks >= c.depth)) CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s));
+    // SPLIT_NECK: both neck convolutions on hi + lo operands (three GEMM passes each; 0.13 % of the encoder FLOPs).  The neck is
+    // the last thing in front of the embedding: nothing downstream averages its operand rounding away (error_budget.py:
+    // 258 + 259 of 899 class-map pixels at ViT-H).  Scratch: QKV (free after the last block) holds the lo halves.
+    const bool sp_neck = (e->split & SPLIT_NECK) != 0;
+    uint16_t* lo_buf = e->QKV;
+    if (sp_neck) CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s, lo_buf));
+    else if (!(fold && c.depth > 0 && n_blocks >= c.depth)) CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s));
     CK(e, launch_gemm_et(prec, e->Y, e->neck0_w, e->N1, nullptr, nullptr, 0, M, C, D, true, false, false, s));
+    if (sp_neck) {
+        CK(e, launch_gemm_et(prec, lo_buf, e->neck0_w, e->N1, nullptr, nullptr, 0, M, C, D, true, false, true, s));
+        CK(e, launch_gemm_et(prec, e->Y, e->neck0_w_lo, e->N1, nullptr, nullptr, 0, M, C, D, true, false, true, s));
+    }
     CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.1.weight"), W(e, "image_encoder.neck.1.bias"), 1e-6f,
-                           e->N1e, nullptr, M, C, 0, g, 0, s));
+                           e->N1e, nullptr, M, C, 0, g, 0, s, sp_neck ? lo_buf : nullptr));
     CK(e, launch_neck_im2col(e->N1e, e->H, n, g, C, s));
+    uint16_t* H2lo = e->H + (size_t)M * 9 * C;
+    if (sp_neck) CK(e, launch_neck_im2col(lo_buf, H2lo, n, g, C, s));
     CK(e, launch_gemm_et(prec, e->H, e->neck2_w, e->N1, nullptr, nullptr, 0, M, C, 9 * C, true, false, false, s));
+    if (sp_neck) {
+        CK(e, launch_gemm_et(prec, H2lo, e->neck2_w, e->N1, nullptr, nullptr, 0, M, C, 9 * C, true, false, true, s));
+        CK(e, launch_gemm_et(prec, e->H, e->neck2_w_lo, e->N1, nullptr, nullptr, 0, M, C, 9 * C, true, false, true, s));
+    }
     CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.3.weight"), W(e, "image_encoder.neck.3.bias"), 1e-6f,
                            nullptr, e->EMB + (size_t)slot0 * tokens * C, M, C, 0, g, 0, s));
     for (int i = 0; i < n; ++i) e->slot_set[slot0 + i] = 1;
@@ -787,13 +839,17 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
             bt.A[1] = e->Q; bt.A2[1] = nullptr; bt.W[1] = L.i2t.vw; bt.bias[1] = L.i2t.vb; bt.C[1] = e->VT;
             CK(e, launch_gemm_f32_batch(bt, 2, C, Ci, BT, Ci, C, false, false, s));
         }
-        if (g_decoder_fusion && tokens % 16 == 0) {
+        if (e->decoder_fusion && tokens % 32 == 0) {
             // attention + out_proj + residual + norm4 in one pass over the keys (layer 0 without a mask prompt: the residual
             // is the shared image embedding, batch stride 0)
             // the fp32 copy of the keys is the NEXT layer's residual; after the last layer only the ET copy is read
             // (final t2i projections, upscaler), so its 4 bytes per element are not written
-            CK(e, launch_i2t_fused(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, L.i2t_ow, L.i2t.ob, sh ? e->K0F : e->KF,
-                                   sh ? 0 : tokens, L.n4w, L.n4b, 1e-5f, li == 1 ? nullptr : e->KF, e->KE, n, T, tokens, Ci, C, s));
+            // SPLIT_OI: attention output and out-projection weights as hi + lo; SPLIT_UP: the last layer also writes the split
+            // remainder of the final keys for the first transposed conv
+            CK(e, launch_i2t_fused(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, L.i2t_ow,
+                                   (e->split & SPLIT_OI) ? L.i2t_ow_lo : nullptr, L.i2t.ob, sh ? e->K0F : e->KF,
+                                   sh ? 0 : tokens, L.n4w, L.n4b, 1e-5f, li == 1 ? nullptr : e->KF, e->KE,
+                                   (li == 1 && (e->split & SPLIT_UP)) ? e->KE_lo : nullptr, n, T, tokens, Ci, C, s));
         } else {
             CK(e, launch_i2t_attention(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, e->OI, n, T, tokens, Ci, 8, s));
             if (sh)
@@ -837,8 +893,13 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
     }
     // ---- upscaler (mask_decoder.py:53-59,154-155) as two GEMMs + fused tail ----
     // A/B knob (timing experiments): SAMRS_DECODER_FUSION=0 runs the un-fused upscaler kernels
-    const bool fuse = g_decoder_fusion;
-    if (fuse && Mi % 256 == 0) {   // ConvT #1 as a GEMM with LayerNorm2d(64) + GELU fused into its epilogue
+    const bool fuse = e->decoder_fusion;
+    // SPLIT_UP (fused path only): both transposed convs on hi + lo operands -- ConvT #1 writes its LayerNorm2d + GELU output in
+    // fp32 (U1raw), ConvT #2 splits that in registers.  error_budget.py: 376 + 395 of the 899 class-map pixels at ViT-H.
+    const bool sp_up = fuse && (e->split & SPLIT_UP) && Mi % 256 == 0 && (g * g * 4) % 1024 == 0 && tokens % 32 == 0;
+    if (sp_up) {
+        CK(e, launch_gemm_et_gln(prec, e->KE, e->up1_w, e->U1raw, e->up1_b, e->up_ln, Mi, C, C, s, e->KE_lo, e->up1_w_lo));
+    } else if (fuse && Mi % 256 == 0) {   // ConvT #1 as a GEMM with LayerNorm2d(64) + GELU fused into its epilogue
         CK(e, launch_gemm_et_gln(prec, e->KE, e->up1_w, e->U1, e->up1_b, e->up_ln, Mi, C, C, s));
     } else {
         CK(e, launch_gemm_et(prec, e->KE, e->up1_w, e->U1raw, e->up1_b, nullptr, 0, Mi, C, C, true, false, false, s));
@@ -847,8 +908,10 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
     }
     const int sel0 = multimask ? 1 : 0, nsel = multimask ? 3 : 1;     // mask_decoder.py:102-107
     float* low = lowres_out ? lowres_out : e->LOW;
-    if (fuse && (g * g * 4) % 1024 == 0) {
-        CK(e, launch_upscale2_masks(prec, e->U1, e->up2_w, e->up2_b, e->HYPER, low, n, g, 4, sel0, nsel, s));
+    if (sp_up) {
+        CK(e, launch_upscale2_masks(prec, e->U1raw, e->up2_w, e->up2_w_lo, e->up2_b, e->HYPER, low, n, g, 4, sel0, nsel, s));
+    } else if (fuse && (g * g * 4) % 1024 == 0) {
+        CK(e, launch_upscale2_masks(prec, e->U1, e->up2_w, nullptr, e->up2_b, e->HYPER, low, n, g, 4, sel0, nsel, s));
     } else {   // tiny grids (test configurations): GEMM + separate product
         CK(e, launch_gemm_et(prec, e->U1, e->up2_w, e->U2, e->up2_b, nullptr, 0, Mi * 4, C / 2, C / 4, false, true, false, s));
         CK(e, launch_mask_product(prec, e->U2, e->HYPER, low, n, g, 4, sel0, nsel, s));
@@ -871,8 +934,63 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
 
 void samrs_debug_set_gemm_variant(int v) { set_gemm_variant(v); }
 void samrs_debug_set_gemm_skew(int xcd_units, int cu_units) { set_gemm_skew(xcd_units, cu_units); }
-void samrs_debug_set_decoder_fusion(int on) { g_decoder_fusion = on != 0; }
-void samrs_debug_set_ln_fold(int on) { g_ln_fold = on != 0; }
+int samrs_select_best(samrs_engine_t* e, const uint8_t* masks, const float* iou, int n, int n_sel, int h, int w, uint8_t* best_out,
+                      float* quality_out, int64_t* areas_out, void* stream) {
+    if (!e || !masks || !iou || !best_out || !quality_out || !areas_out || n < 1 || n_sel < 1 || h < 1 || w < 1)
+        return fail(e, SAMRS_ERR_BAD_ARG, "samrs_select_best: bad argument");
+    ON_DEVICE(e);
+    CK(e, launch_select_best(masks, iou, n, n_sel, h, w, best_out, quality_out, (unsigned long long*)areas_out, (hipStream_t)stream));
+    return SAMRS_OK;
+}
+
+// per-engine options (see the top of this file)
+int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
+    if (!e || !name) return SAMRS_ERR_BAD_ARG;
+    const std::string n(name);
+    if (n == "decoder_fusion") e->decoder_fusion = value != 0;
+    else if (n == "ln_fold") e->ln_fold = value != 0;
+    else if (n == "split") e->split = value & SPLIT_ALL;
+    else if (n == "gemm_variant") e->gemm_variant = value;
+    else return fail(e, SAMRS_ERR_BAD_ARG, "unknown option %s", name);
+    return SAMRS_OK;
+}
+int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
+    if (!e || !name || !value) return SAMRS_ERR_BAD_ARG;
+    const std::string n(name);
+    if (n == "decoder_fusion") *value = e->decoder_fusion;
+    else if (n == "ln_fold") *value = e->ln_fold;
+    else if (n == "split") *value = e->split;
+    else if (n == "gemm_variant") *value = e->gemm_variant;
+    else return SAMRS_ERR_BAD_ARG;
+    return SAMRS_OK;
+}
+
+// COCO RLE strings of n masks, packed behind *cursor into `out` (see samrs_hip.h)
+int samrs_rle_encode(samrs_engine_t* e, const uint8_t* masks, int n, int h, int w, uint8_t* out, int64_t out_capacity,
+                     int64_t* cursor, int64_t* table, void* stream) {
+    if (!e || !masks || !out || !cursor || !table || n < 1 || h < 1 || w < 1 || out_capacity < 16)
+        return fail(e, SAMRS_ERR_BAD_ARG, "samrs_rle_encode: bad argument");
+    if ((size_t)h * w >= 0xFFFFFFF0ull) return fail(e, SAMRS_ERR_BAD_SHAPE, "samrs_rle_encode: mask too large");
+    ON_DEVICE(e);
+    hipStream_t s = (hipStream_t)stream;
+    const int chunk = 32;                               // masks per pass: bounds the scratch (5.3 MB per 1024^2 mask)
+    const size_t need = rle_scratch_bytes(n < chunk ? n : chunk, h, w);
+    if (need > e->rle_scratch_bytes) {
+        if (e->rle_scratch) {
+            CK(e, hipStreamSynchronize(s));
+            CK(e, hipFree(e->rle_scratch));               // device-synchronising: nothing still reads the old scratch
+            e->rle_scratch = nullptr; e->rle_scratch_bytes = 0;
+        }
+        CK(e, hipMalloc(&e->rle_scratch, need));
+        e->rle_scratch_bytes = need;
+    }
+    for (int off = 0; off < n; off += chunk) {
+        const int m = n - off < chunk ? n - off : chunk;
+        CK(e, launch_rle_encode(masks + (size_t)off * h * w, m, h, w, e->rle_scratch, out, (long long)out_capacity,
+                                (long long*)cursor, (long long*)table + (size_t)off * 3, s));
+    }
+    return SAMRS_OK;
+}
 
 // test hook: copy (a prefix of) a named internal decoder buffer to a caller device buffer
 int samrs_debug_copy_buffer(samrs_engine_t* e, const char* name, void* dst, size_t bytes, void* stream) {
@@ -996,12 +1114,15 @@ int samrs_k_postprocess(const float* low, int n_masks, int in_h, int in_w, int o
     KRET(launch_postprocess(low, n_masks, in_h, in_w, orig_h, orig_w, img_size, return_logits, out, (hipStream_t)stream));
 }
 int samrs_k_gemm_gln(int prec, const void* A, const void* B, void* C, const float* bias, const float* gamma_beta, int M, int N,
-                     int K, void* stream) {
-    KRET(launch_gemm_et_gln(prec, A, B, C, bias, gamma_beta, M, N, K, (hipStream_t)stream));
+                     int K, const void* A_lo, const void* B_lo, void* stream) {
+    KRET(launch_gemm_et_gln(prec, A, B, C, bias, gamma_beta, M, N, K, (hipStream_t)stream, A_lo, B_lo));
 }
-int samrs_k_upscale2_masks(int prec, const void* u1, const void* w, const float* bias, const float* hyper, float* low, int n,
-                           int grid, int n_mask_tokens, int sel0, int n_sel, void* stream) {
-    KRET(launch_upscale2_masks(prec, u1, w, bias, hyper, low, n, grid, n_mask_tokens, sel0, n_sel, (hipStream_t)stream));
+int samrs_k_upscale2_masks(int prec, const void* u1, const void* w, const void* w_lo, const float* bias, const float* hyper,
+                           float* low, int n, int grid, int n_mask_tokens, int sel0, int n_sel, void* stream) {
+    KRET(launch_upscale2_masks(prec, u1, w, w_lo, bias, hyper, low, n, grid, n_mask_tokens, sel0, n_sel, (hipStream_t)stream));
+}
+int samrs_k_convert_split(int prec, const float* in, void* out_hi, void* out_lo, int64_t n, void* stream) {
+    KRET(launch_convert(prec, in, out_hi, (long)n, (hipStream_t)stream, out_lo));
 }
 
 }  // extern "C"

@@ -276,7 +276,7 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
                     if (NCH % 64 == 0 || idx < NCH) {
                         const int m = m_base + (j0 + jj) * 16 + idx / CPR, n = n_base + (idx % CPR) * 4;
                         if (accumulate) r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cv) + (size_t)m * N + n);
-                        if (add2d) {
+                        if (add2d && !GLN) {      // GLN: `add2d` carries gamma | beta, not a 2-D addend
                             const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
                             r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;
                         }
@@ -2195,11 +2195,15 @@ constexpr int DBM = 256, DBN = 128, DBK = 32, DSTAGES = 3, DTHREADS = 512;
 constexpr int DSTAGE_ELEMS = (DBM + DBN) * DBK;               // 12288 ET = 24 KiB
 constexpr int D_DMA_PER_TILE = (DBM + DBN) * DBK * 2 / (DTHREADS * 16);   // 3 per thread
 
-template <int PREC, bool OUT_F32, bool GELU, bool STAG = true, bool GLN = false>
+// SPLIT: both operands come as hi + lo (two-term split, common.h) and the k loop runs three times over K:
+// A_lo B_hi, A_hi B_lo, A_hi B_hi (small terms first), all into the same fp32 accumulators -- the product of the
+// un-rounded operands to ~2^-22 at three times the MFMA work.  Used for the decoder's first transposed conv, whose
+// operand rounding cost 376 of the 899 class-map pixels of the round-2 engine at ViT-H (oracle/error_budget.py).
+template <int PREC, bool OUT_F32, bool GELU, bool STAG = true, bool GLN = false, bool SPLIT = false>
 __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
-    int M, int N, int K, int accumulate) {
+    int M, int N, int K, int accumulate, const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr) {
     __shared__ __attribute__((aligned(16))) uint16_t lds[DSTAGES * DSTAGE_ELEMS];   // 72 KiB, ONE object
 
     const int tid = threadIdx.x;
@@ -2224,16 +2228,22 @@ __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
     const int g_chunk = qswz(g_row, lane & 3);
     const uint16_t* gAg = A + (size_t)(m0 + g_row) * K + g_chunk * 8;
     const uint16_t* gBg = B + (size_t)(n0 + g_row) * K + g_chunk * 8;
+    const uint16_t* gAl = SPLIT ? A_lo + (size_t)(m0 + g_row) * K + g_chunk * 8 : gAg;
+    const uint16_t* gBl = SPLIT ? B_lo + (size_t)(n0 + g_row) * K + g_chunk * 8 : gBg;
     const uint32_t wave_lds_base = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * (16 * DBK * 2));
     const size_t rs128 = (size_t)128 * K;
+    const int nk1 = K / DBK;                   // k tiles of one pass over K
 #define DUAL_ISSUE(kt_, stage_)                                                                 \
     do {                                                                                         \
-        const size_t koff_ = (size_t)(kt_) * DBK;                                                \
+        const int ph_ = SPLIT ? (kt_) / nk1 : 2;       /* 0: A_lo B_hi, 1: A_hi B_lo, 2: A_hi B_hi */ \
+        const size_t koff_ = (size_t)((kt_) - (SPLIT ? ph_ * nk1 : 0)) * DBK;                    \
+        const uint16_t* pa_ = ph_ == 0 ? gAl : gAg;                                              \
+        const uint16_t* pb_ = ph_ == 1 ? gBl : gBg;                                              \
         constexpr int SB_ = (stage_) * DSTAGE_ELEMS * 2;                                         \
-        glds16_asm<SB_ + 0>(gAg + koff_, wave_lds_base);                                         \
-        glds16_asm<SB_ + 128 * DBK * 2>(gAg + rs128 + koff_, wave_lds_base);                     \
-        glds16_asm<SB_ + DBM * DBK * 2>(gBg + koff_, wave_lds_base);                             \
+        glds16_asm<SB_ + 0>(pa_ + koff_, wave_lds_base);                                         \
+        glds16_asm<SB_ + 128 * DBK * 2>(pa_ + rs128 + koff_, wave_lds_base);                     \
+        glds16_asm<SB_ + DBM * DBK * 2>(pb_ + koff_, wave_lds_base);                             \
     } while (0)
 
     f32x4_t acc[4][4];
@@ -2242,7 +2252,7 @@ __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / DBK;
+    const int nk = nk1 * (SPLIT ? 3 : 1);
     DUAL_ISSUE(0, 0);
     if (nk > 1) {
         DUAL_ISSUE(1, 1);
@@ -2310,13 +2320,19 @@ __global__ __launch_bounds__(DTHREADS, 4) void gemm_et_dual_kernel(
     }
 }
 
-// C (ET) = GELU(LayerNorm2d_64(A B^T + bias)): the 64-column groups of N are normalised independently
+// C (ET) = GELU(LayerNorm2d_64(A B^T + bias)): the 64-column groups of N are normalised independently.
+// A_lo / B_lo given: split-precision product (see the kernel), C is then FP32 (its consumer splits it again).
 template <int PREC>
 hipError_t launch_gemm_dual_gln(const void* A, const void* B, void* C, const float* bias, const float* gamma_beta,
-                                int M, int N, int K, hipStream_t s) {
+                                int M, int N, int K, hipStream_t s, const void* A_lo = nullptr, const void* B_lo = nullptr) {
     dim3 grid((M / DBM) * (N / DBN)), block(DTHREADS);
-    gemm_et_dual_kernel<PREC, false, true, true, true><<<grid, block, 0, s>>>(
-        reinterpret_cast<const uint16_t*>(A), reinterpret_cast<const uint16_t*>(B), C, bias, gamma_beta, 1, M, N, K, 0);
+    if (A_lo && B_lo)
+        gemm_et_dual_kernel<PREC, true, true, true, true, true><<<grid, block, 0, s>>>(
+            reinterpret_cast<const uint16_t*>(A), reinterpret_cast<const uint16_t*>(B), C, bias, gamma_beta, 1, M, N, K, 0,
+            reinterpret_cast<const uint16_t*>(A_lo), reinterpret_cast<const uint16_t*>(B_lo));
+    else
+        gemm_et_dual_kernel<PREC, false, true, true, true><<<grid, block, 0, s>>>(
+            reinterpret_cast<const uint16_t*>(A), reinterpret_cast<const uint16_t*>(B), C, bias, gamma_beta, 1, M, N, K, 0);
     return hipGetLastError();
 }
 
@@ -2526,6 +2542,7 @@ static bool k256_ok(int M, int N, int K, bool out_f32, bool gelu, bool accumulat
     return !out_f32 && !gelu && !accumulate && K == K2_K && (N == 256 || N == 384) && M % K2_ROWS == 0;
 }
 
+thread_local int tl_gemm_variant = -1;   // per-engine override, set around an engine's launches (engine.hip GemmVariantScope)
 int g_gemm_variant = 8;   // 0 reg-staged 128^2, 1 +LDS-DMA, 2 +grouped order, 3 reg+grouped, 4 256x128 3-stage pipe, 5 +staggered groups, 6 256x256, 7 2 blocks/CU, 8 auto(5|6|7)
 
 template <int PREC, bool GLDS, int GROUP_M>
@@ -2675,26 +2692,28 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         return true;
     }();
     (void)env_once;
+    // an engine handle's own choice (samrs_set_option "gemm_variant") overrides the process-wide test hook for its launches
+    const int gv = tl_gemm_variant >= 0 ? tl_gemm_variant : g_gemm_variant;
 #define GEMM_DISPATCH(P)                                                                                         \
-    switch (g_gemm_variant) {                                                                                    \
+    switch (gv) {                                                                                    \
         case 0: return launch_gemm_prec<P, false, 1>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
         case 1: return launch_gemm_prec<P, true, 1>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);  \
         case 3: return launch_gemm_prec<P, false, 8>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
         default: return launch_gemm_prec<P, true, 8>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
     }
-    if (g_gemm_variant >= 60 && g_gemm_variant < 92 && prec == PREC_F16 && !out_f32 && M % QBM == 0 && N % QBN == 0) {
+    if (gv >= 60 && gv < 92 && prec == PREC_F16 && !out_f32 && M % QBM == 0 && N % QBN == 0) {
         dim3 grid((M / QBM) * (N / QBN)), block(QTHREADS);
         const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
         const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
 #define ABL_CASE(x) case 60 + x: gemm_et_big_kernel<PREC_F16, false, false, x><<<grid, block, 0, s>>>(a, b, C, bias, add2d, add2d_period, M, N, K, 0); break;
-        switch (g_gemm_variant) {
+        switch (gv) {
             ABL_CASE(0) ABL_CASE(1) ABL_CASE(4) ABL_CASE(6) ABL_CASE(8) ABL_CASE(7) ABL_CASE(16) ABL_CASE(22) ABL_CASE(23) ABL_CASE(24)
             default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     }
     // 40: K = 256 streaming kernel (decoder image side); automatic for its shapes once there are >= 2 tiles per CU
-    if ((g_gemm_variant == 40 || (g_gemm_variant == 8 && M / K2_ROWS >= 512)) && k256_ok(M, N, K, out_f32, gelu, accumulate)) {
+    if ((gv == 40 || (gv == 8 && M / K2_ROWS >= 512)) && k256_ok(M, N, K, out_f32, gelu, accumulate)) {
         if (prec == PREC_BF16) return launch_gemm_k256<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, s);
         if (prec == PREC_F16) return launch_gemm_k256<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, s);
         return hipErrorInvalidValue;
@@ -2702,7 +2721,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     // variant 8 ("auto", default): per-shape pick measured on MI355X (tools/gemm_bench.py) -- the
     // 2-blocks-per-CU kernel wins where the epilogue dominates (GELU output, or short K with a
     // narrow N), the 64-wide-K single-block kernel wins on long K / wide N.
-    int variant = g_gemm_variant;
+    int variant = gv;
     // 20 / 21: pair-stage (64-deep, whole-cache-line DMA) 256x256 / 256x320 kernel; 22 / 23: the same with the DMA pieces
     // spread between the MFMAs.  Shapes they do not cover fall through to the automatic choice.
     if (variant == 28 && !(M % QBM == 0 && N % WBN == 0 && K % XBK == 0 && !add2d)) variant = 8;
@@ -2825,7 +2844,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         if (prec == PREC_F16) return launch_gemm_stag<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
     }
-    if (g_gemm_variant == 4 && M % PBM == 0) {   // pipelined 256x128 kernel (default when M allows)
+    if (gv == 4 && M % PBM == 0) {   // pipelined 256x128 kernel (default when M allows)
         if (prec == PREC_BF16) return launch_gemm_pipe<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_pipe<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
@@ -2853,6 +2872,7 @@ hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C
 }
 
 void set_gemm_variant(int v) { g_gemm_variant = v; }
+int swap_gemm_variant_override(int v) { const int old = tl_gemm_variant; tl_gemm_variant = v; return old; }
 void set_gemm_skew(int xcd_units, int cu_units) { g_x64_skew = (xcd_units & 0xffff) | (cu_units << 16); }
 
 hipError_t launch_gemm_f32_batch(const F32Batch& bt, int count, int lda, int ldc, int M, int N, int K, bool relu,
@@ -2883,9 +2903,9 @@ hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float*
 }
 
 hipError_t launch_gemm_et_gln(int prec, const void* A, const void* B, void* C, const float* bias, const float* gamma_beta,
-                              int M, int N, int K, hipStream_t s) {
-    if (M % DBM || N % DBN || K % DBK || M <= 0 || !gamma_beta) return hipErrorInvalidValue;
-    if (prec == PREC_BF16) return launch_gemm_dual_gln<PREC_BF16>(A, B, C, bias, gamma_beta, M, N, K, s);
-    if (prec == PREC_F16) return launch_gemm_dual_gln<PREC_F16>(A, B, C, bias, gamma_beta, M, N, K, s);
+                              int M, int N, int K, hipStream_t s, const void* A_lo, const void* B_lo) {
+    if (M % DBM || N % DBN || K % DBK || M <= 0 || !gamma_beta || ((A_lo == nullptr) != (B_lo == nullptr))) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) return launch_gemm_dual_gln<PREC_BF16>(A, B, C, bias, gamma_beta, M, N, K, s, A_lo, B_lo);
+    if (prec == PREC_F16) return launch_gemm_dual_gln<PREC_F16>(A, B, C, bias, gamma_beta, M, N, K, s, A_lo, B_lo);
     return hipErrorInvalidValue;
 }

@@ -8,8 +8,9 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
                           const float* add2d, int add2d_period, int M, int N, int K, bool out_f32,
                           bool gelu, bool accumulate, hipStream_t s);
 // C (ET) = GELU(LayerNorm2d over every 64-column group of (A B^T + bias)), eps 1e-6; gamma_beta = gamma[64] | beta[64]
+// A_lo / B_lo (both or neither): split-precision product of hi + lo operands; C is then FP32 [M][N] instead of ET
 hipError_t launch_gemm_et_gln(int prec, const void* A, const void* B, void* C, const float* bias, const float* gamma_beta,
-                              int M, int N, int K, hipStream_t s);
+                              int M, int N, int K, hipStream_t s, const void* A_lo = nullptr, const void* B_lo = nullptr);
 // LayerNorm folded into the neighbouring GEMMs (residual stream of N = 1280 columns):
 //   producer  C (fp32) += A B^T + bias;  Xh = ET(C);  stats[m][N / 160] = (mean, sum of squared deviations) per 160 columns
 //   (launch_ln_rowstat, encoder_kernels.hip: stats -> rowstat[m] = (rstd, -rstd mean))
@@ -18,7 +19,8 @@ hipError_t launch_gemm_et_stats(int prec, const void* A, const void* B, float* C
                                 int M, int N, int K, hipStream_t s);
 hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C, const float* bias_f, const float* cvec,
                                const float* rowstat, int M, int N, int K, bool gelu, hipStream_t s);
-void set_gemm_variant(int v);   // 0 = register-staged tiles, 1 = LDS-DMA staging (default)
+void set_gemm_variant(int v);   // process-wide test hook (kernel-level entry points): 0 = register-staged tiles, ..., 8 = automatic
+int swap_gemm_variant_override(int v);   // thread-local override (-1 = none) used by engine handles; returns the previous value
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
                            int ldc, int M, int N, int K, bool relu, bool accumulate, hipStream_t s);
@@ -35,9 +37,10 @@ hipError_t launch_gemm_f32_batch(const F32Batch& bt, int count, int lda, int ldc
                                  bool accumulate, hipStream_t s);
 
 // ---- encoder_kernels.hip --------------------------------------------------------------------
+// A_lo / out_lo (optional): the remainder of the two-term operand split (common.h split2_pack), same layout as the main output
 hipError_t launch_patch_im2col(int prec, const uint8_t* img, void* A, int n_images, int in_h, int in_w,
-                               int grid, int patch, hipStream_t s);
-hipError_t launch_convert(int prec, const float* in, void* out, long n, hipStream_t s);
+                               int grid, int patch, hipStream_t s, void* A_lo = nullptr);
+hipError_t launch_convert(int prec, const float* in, void* out, long n, hipStream_t s, void* out_lo = nullptr);
 // folded LayerNorm (ViT-H): weight preparation (once) and the entry of the folded path (Xh = ET(X) + per-row partial statistics)
 hipError_t launch_ln_fold_weight(int prec, const float* W, const float* gamma, const float* beta, const float* bias, void* Wf,
                                  float* cvec, float* bias_f, int N, int K, hipStream_t s);
@@ -46,7 +49,7 @@ hipError_t launch_rowstats_convert(int prec, const float* X, void* Xh, float* st
 hipError_t launch_ln_rowstat(const float* stats, float* rowstat, int rows, float eps, hipStream_t s);
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
-                            int window, hipStream_t s);
+                            int window, hipStream_t s, void* out_lo = nullptr);
 hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
                                    int n_images, int grid, int window, int heads, int head_dim, hipStream_t s);
 // vt_ws: ET workspace of n_images * heads * head_dim * grid^2 elements (receives V transposed per head)
@@ -98,8 +101,9 @@ hipError_t launch_group_ln_gelu(int prec, const float* in, const float* gamma, c
                                 void* out, long rows, int groups, int gsize, hipStream_t s);
 // low[b, c, Y, X] = sum_ch hyper[b, sel0 + c, ch] * up2[b, y, x, dy, dx, dy2, dx2, ch]
 // fused ConvT #2 (K = 64 GEMM) + GELU + hypernetwork product: u1 [n*grid*grid*4][64] ET -> low [n][n_sel][4 grid][4 grid]
-hipError_t launch_upscale2_masks(int prec, const void* u1, const void* w, const float* bias, const float* hyper, float* low,
-                                 int n, int grid, int n_mask_tokens, int sel0, int n_sel, hipStream_t s);
+// w_lo != null: split precision -- u1 is then the FP32 output of the first transposed conv [rows][64] (split in registers)
+hipError_t launch_upscale2_masks(int prec, const void* u1, const void* w, const void* w_lo, const float* bias, const float* hyper,
+                                 float* low, int n, int grid, int n_mask_tokens, int sel0, int n_sel, hipStream_t s);
 hipError_t launch_mask_product(int prec, const void* up2, const float* hyper, float* low, int n, int grid,
                                int n_mask_tokens, int sel0, int n_sel, hipStream_t s);
 hipError_t launch_postprocess(const float* low, int n_masks, int in_h, int in_w, int orig_h, int orig_w,
@@ -107,6 +111,9 @@ hipError_t launch_postprocess(const float* low, int n_masks, int in_h, int in_w,
 hipError_t launch_paint(const uint8_t* masks, const int32_t* labels, int n, int h, int w, uint8_t* seg,
                         unsigned long long* areas, unsigned long long* class_pixels,
                         unsigned long long* class_instances, int n_classes, hipStream_t s);
+// best-of-nsel by predicted IoU (first maximum): out [n][h][w] = masks[j][argmax_c iou[j][c]], quality[j], areas[j] = pixels set
+hipError_t launch_select_best(const uint8_t* masks, const float* iou, int n, int nsel, int h, int w, uint8_t* out, float* quality,
+                              unsigned long long* areas, hipStream_t s);
 hipError_t launch_resample_pass(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* coef, int ksize,
                                 int in_len, int out_len, int other, int horizontal, hipStream_t s);
 // rotated-box polygons (int32 [n][nv][2]) -> mask prompts [n][out][out] fp32 (main_sam_rbox_mask_instance.py:125-141)
@@ -114,5 +121,15 @@ hipError_t launch_rbox_prompt(const int32_t* pts, int n, int nv, int h, int w, i
                               float* out, hipStream_t s);
 // fused transformer.py:176-181: keys = LayerNorm(resid + out_proj(attention(q_i2t, k_tokens, v_tokens))) -> outF (fp32) and outE (ET)
 hipError_t launch_i2t_fused(int prec, const void* qi, int ld, long q_bstride, const float* kt, const float* vt, const void* w,
-                            const float* bias, const float* resid, long r_bstride, const float* gamma, const float* beta, float eps,
-                            float* outF, void* outE, int n, int T, int tokens, int Ci, int C, hipStream_t s);
+                            const void* w_lo /* null: un-split out-projection */, const float* bias, const float* resid,
+                            long r_bstride, const float* gamma, const float* beta, float eps, float* outF, void* outE,
+                            void* outE_lo /* optional split remainder of outE */, int n, int T, int tokens, int Ci, int C, hipStream_t s);
+
+// ---- rle_kernels.hip ------------------------------------------------------------------------
+// COCO RLE strings of n binary masks (uint8 [n][h][w], non-zero = set), packed behind *cursor (device int64, in / out)
+// into `out` (device bytes, capacity out_cap) at 16-byte aligned offsets; table [n][3] (device int64) = (offset,
+// length, n_counts), length < 0: did not fit (-length - 1 bytes were needed).  scratch: rle_scratch_bytes(n, h, w).
+size_t rle_scratch_bytes(int n, int h, int w);
+size_t rle_str_capacity(int h, int w);
+hipError_t launch_rle_encode(const uint8_t* masks, int n, int h, int w, void* scratch, unsigned char* out, long long out_cap,
+                             long long* cursor, long long* table, hipStream_t s);

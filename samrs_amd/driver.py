@@ -279,15 +279,28 @@ class TileResult:
     labels: np.ndarray
     masks: Optional[np.ndarray] = None      # uint8 [n_boxes, H, W] host when keep_masks
     quality: Optional[np.ndarray] = None    # fp32 [n_boxes] predicted IoU of the kept mask (instance pipelines)
+    rle_table: Optional[np.ndarray] = None  # int64 [n_boxes, 3] (offset, length, n_counts) into rle_data when rle=True
+    rle_data: Optional[np.ndarray] = None   # uint8 view of the batch's pinned RLE byte buffer
+    size: Optional[Tuple[int, int]] = None  # (H, W) of the tile
+
+    def rle(self, j: int) -> dict:
+        """COCO RLE of instance j exactly as the reference stores it (main_sam_hbox_semantic.py:201-202):
+        ``{"size": [H, W], "counts": str}``; encoded on the device (samrs_rle_encode)."""
+        off, n, _ = (int(v) for v in self.rle_table[j])
+        return {"size": [int(self.size[0]), int(self.size[1])], "counts": self.rle_data[off:off + n].tobytes().decode("ascii")}
 
 
 class _OutBuf:
-    def __init__(self, batch: int, side: int, max_boxes: int):
+    def __init__(self, batch: int, side: int, max_boxes: int, rle: bool = False):
         self.seg = torch.empty(batch, side, side, dtype=torch.uint8).pin_memory()
         self.areas = torch.empty(batch, max_boxes, dtype=torch.int64).pin_memory()
         self.done = torch.cuda.Event()
         self.masks: List[Optional[torch.Tensor]] = [None] * batch     # keep_masks: host copies of the full masks
         self.odd: dict = {}                                           # tiles that are not side x side: their class maps
+        # rle: per-box (offset, length, n_counts), the number of bytes used, and the strings themselves (grown on demand)
+        self.rle_tab = torch.zeros(batch * max_boxes, 3, dtype=torch.int64).pin_memory() if rle else None
+        self.rle_cur = torch.zeros(1, dtype=torch.int64).pin_memory() if rle else None
+        self.rle_bytes = torch.empty(1 << 20, dtype=torch.uint8).pin_memory() if rle else None
 
 
 class TilePipeline:
@@ -300,24 +313,29 @@ class TilePipeline:
         host       : hands batch k-2 to `sink`        (PNG / pickle writers run in a thread pool there)
 
     Two embedding slot sets and two input staging sets, `out_depth` pinned output buffers.  What crosses PCIe per
-    tile: 3 MiB in, 1 MiB class map + 8 B per box out (`samrs_paint` runs on the device; with keep_masks the full
-    masks follow for RLE).  Bit-identical to `SemanticGenerator` (no kernel depends on batch composition or on what
+    tile: 3 MiB in, 1 MiB class map + 8 B per box out (`samrs_paint` runs on the device), and with `rle=True` the
+    per-instance COCO RLE strings of main_sam_hbox_semantic.py:201-202, encoded on the device (`samrs_rle_encode`:
+    a few KB per mask on real data) -- the full-resolution masks themselves never leave HBM unless `keep_masks`.  Bit-identical to `SemanticGenerator` (no kernel depends on batch composition or on what
     runs next to it).  Tiles of one batch may differ in size (non-1024 tiles are resized on the GPU, bit-exact with
     PIL, and encoded through samrs_set_images_ragged)."""
 
     BOX_WIDTH = 4          # floats per annotation: xyxy
 
     def __init__(self, sam, n_classes: int, batch: int = 8, box_batch: int = 20, keep_masks: bool = False,
-                 out_depth: int = 3, max_boxes: int = 512, device_inputs: bool = False):
+                 out_depth: int = 3, max_boxes: int = 512, device_inputs: bool = False, rle: bool = False,
+                 rle_buffer_mb: int = 256):
         from .transforms import ResizeLongestSide
         eng = sam.engine
         if eng is None:
             raise RuntimeError("move the model to the GPU first: sam.to('cuda')")
+        if out_depth < 2:
+            raise ValueError("out_depth must be >= 2: batch k-1's results are still on loan to the sink when batch k decodes")
         if eng.max_images < 2 * batch:
             raise ValueError(f"TilePipeline(batch={batch}) needs an engine with max_images >= {2 * batch} "
                              f"(two embedding slot sets); got {eng.max_images}")
         self.sam, self.eng, self.dev = sam, eng, eng.device
         self.batch, self.box_batch, self.keep_masks, self.max_boxes = batch, box_batch, keep_masks, max_boxes
+        self.rle = rle
         self.side = sam.cfg.img_size
         self.transform = ResizeLongestSide(sam.image_encoder.img_size)
         self.class_pixels = torch.zeros(n_classes, dtype=torch.int64, device=self.dev)
@@ -325,8 +343,14 @@ class TilePipeline:
         dev, side = self.dev, self.side
         self.s_h2d, self.s_enc, self.s_dec = (torch.cuda.Stream(dev) for _ in range(3))
         self.device_inputs = device_inputs
+        self.pin_in = None
         if not device_inputs:
             self.pin_in = [torch.empty(batch, side, side, 3, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        if rle:      # per input set: the batch's RLE strings (packed, 16-byte aligned), a cursor, (offset, length, n_counts) per box
+            self.s_d2h = torch.cuda.Stream(dev)
+            self.rle_dev = [torch.empty(rle_buffer_mb << 20, dtype=torch.uint8, device=dev) for _ in range(2)]
+            self.rle_cur = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
+            self.rle_tab = [torch.zeros(batch * max_boxes, 3, dtype=torch.int64, device=dev) for _ in range(2)]
         self.dev_in = [torch.empty(batch, side, side, 3, dtype=torch.uint8, device=dev) for _ in range(2)]
         bw = self.BOX_WIDTH
         self.pin_box = [torch.empty(batch * max_boxes, bw, dtype=torch.float32).pin_memory() for _ in range(2)]
@@ -341,7 +365,7 @@ class TilePipeline:
         self.ev_in_free = [torch.cuda.Event() for _ in range(2)]     # encoder has consumed input set b
         self.free_out: "queue.Queue[_OutBuf]" = queue.Queue()
         for _ in range(out_depth):
-            self.free_out.put(_OutBuf(batch, side, max_boxes))
+            self.free_out.put(_OutBuf(batch, side, max_boxes, rle))
 
     # -- stage A: stage tiles + boxes of one batch, H2D on s_h2d ------------------------------------------------
     def _stage(self, b: int, items: List[WorkItem]):
@@ -376,6 +400,9 @@ class TilePipeline:
                     if src.is_pinned():                                           # caller-owned pinned memory: straight H2D
                         self.dev_in[b][i].copy_(src, non_blocking=True)
                     else:
+                        if self.pin_in is None:                                   # device_inputs=True promised resident tiles
+                            self.pin_in = [torch.empty(self.batch, self.side, self.side, 3, dtype=torch.uint8).pin_memory()
+                                           for _ in range(2)]
                         self.pin_in[b][i].copy_(src)                              # host memcpy into pinned staging
                         self.dev_in[b][i].copy_(self.pin_in[b][i], non_blocking=True)
                     t = self.dev_in[b][i]
@@ -384,6 +411,7 @@ class TilePipeline:
                     t = src.to(self.dev)                                          # odd sizes: plain upload, then
                 if not native:
                     t = self.transform.apply_image_device(t.contiguous())         # PIL-exact resize on the GPU
+                    t.record_stream(self.s_enc)                                   # allocated on s_h2d, read by the encoder
                     same = False
                 tiles.append((t, (H, W)))
             self.ev_h2d[b].record(self.s_h2d)
@@ -409,27 +437,41 @@ class TilePipeline:
         seg = self.seg_dev[b][i] if native else torch.full((H, W), 255, dtype=torch.uint8, device=self.dev)
         kept = []
         for s, e in box_chunks(nb, self.box_batch):                          # :157-181
-            tb = self.transform.apply_boxes_torch(self.dev_box[b][off + s:off + e], (H, W))   # :174
+            tb = self._input_frame_boxes(self.dev_box[b][off + s:off + e], (H, W), in_size)   # :174
             masks, _, _ = eng.predict(b * self.batch + i, tb, None, None, None, False, False, in_size, (H, W))
-            a = eng.paint(masks[:, 0], self.dev_lab[b][off + s:off + e], seg, self.class_pixels, self.class_instances)
-            self.area_dev[b][i, s:e] = a
+            eng.paint(masks[:, 0], self.dev_lab[b][off + s:off + e], seg, self.class_pixels, self.class_instances,
+                      areas_out=self.area_dev[b][i, s:e])
+            if self.rle:                                                          # :201-202, on the device
+                eng.rle_encode(masks[:, 0], self.rle_dev[b], self.rle_cur[b], self.rle_tab[b][off + s:off + e])
             if self.keep_masks:
                 kept.append(masks[:, 0].view(torch.uint8))
         if native:
             out.seg[i].copy_(seg, non_blocking=True)
         else:
             out.odd[i] = seg.cpu()                    # other sizes (DIOR 800^2, HRSC): synchronous copy, rare path
-        # full masks for the per-instance RLE (main_sam_hbox_semantic.py:201-205): n MiB per tile instead of
-        # 1 MiB, copied synchronously -- the full-fidelity mode trades the overlap for the reference's pkl contract
+        # keep_masks: the full-resolution masks themselves (n MiB per tile instead of 1 MiB, copied synchronously) -- a
+        # debugging / evaluation mode; the reference's pkl contract needs only their RLE (rle=True, encoded on the device)
         out.masks[i] = torch.cat(kept).cpu() if (self.keep_masks and kept) else None
+
+    def _input_frame_boxes(self, boxes: torch.Tensor, hw, in_size) -> torch.Tensor:
+        """apply_boxes_torch (utils/transforms.py:83-91).  When the tile already has the encoder's input size both scale
+        factors are exactly 1.0 and x * 1.0f == x bit for bit, so the boxes are handed over as they are (no launches)."""
+        if tuple(hw) == tuple(in_size):
+            return boxes
+        return self.transform.apply_boxes_torch(boxes, hw)
 
     def _decode(self, b: int, items, tiles, offs, out: _OutBuf):
         with torch.cuda.stream(self.s_dec):
             self.s_dec.wait_event(self.ev_enc[b])
             self.seg_dev[b].fill_(255)                                               # main_sam_hbox_semantic.py:162
+            if self.rle:
+                self.rle_cur[b].zero_()
             for i, ((t, hw), (off, nb)) in enumerate(zip(tiles, offs)):
                 self._decode_tile(b, i, t, hw, off, nb, out)
             out.areas.copy_(self.area_dev[b], non_blocking=True)
+            if self.rle:
+                out.rle_tab.copy_(self.rle_tab[b], non_blocking=True)
+                out.rle_cur.copy_(self.rle_cur[b], non_blocking=True)
             self._extra_outputs(b, out)
             self.ev_dec[b].record(self.s_dec)
             out.done.record(self.s_dec)
@@ -437,16 +479,43 @@ class TilePipeline:
     def _extra_outputs(self, b: int, out: _OutBuf) -> None:
         pass
 
+    def _fetch_rle(self, b: int, out: _OutBuf, n_boxes: int):
+        """The batch's RLE strings: the table and the byte count are on the host (out.done), so the strings can be copied
+        with their exact size -- on a copy stream, while the GPU works on the batches already queued."""
+        total = int(out.rle_cur[0])
+        tab = out.rle_tab[:n_boxes].numpy()
+        if n_boxes and int(tab[:, 1].min()) < 0:
+            need = int((-tab[:, 1] - 1).max())
+            raise RuntimeError(f"RLE buffer too small: a mask needs {need} bytes and the batch already holds {total}; raise "
+                               f"rle_buffer_mb (now {self.rle_dev[b].numel() >> 20})")
+        if out.rle_bytes.numel() < total:
+            out.rle_bytes = torch.empty(max(total, 2 * out.rle_bytes.numel()), dtype=torch.uint8).pin_memory()
+        if total:
+            with torch.cuda.stream(self.s_d2h):
+                out.rle_bytes[:total].copy_(self.rle_dev[b][:total], non_blocking=True)
+            self.s_d2h.synchronize()
+        return tab, out.rle_bytes.numpy()
+
     def _finish(self, pending, sink):
-        items, offs, out = pending
+        items, offs, out, b = pending
         out.done.synchronize()
         odd = out.odd
         res = []
-        for i, (it, (_, nb)) in enumerate(zip(items, offs)):
-            seg = odd[i].numpy() if i in odd else out.seg[i].numpy()
+        rtab = rdat = None
+        if self.rle:
+            rtab, rdat = self._fetch_rle(b, out, sum(nb for _, nb in offs))
+        for i, (it, (off, nb)) in enumerate(zip(items, offs)):
+            seg = (odd[i].numpy() if odd[i] is not None else None) if i in odd else out.seg[i].numpy()
             m = out.masks[i].numpy() if out.masks[i] is not None else None
             q = out.quality[i, :nb].numpy().copy() if getattr(out, "quality", None) is not None else None
-            res.append(TileResult(it.key, seg, out.areas[i, :nb].numpy().copy(), np.asarray(it.boxes), np.asarray(it.labels), m, q))
+            r = TileResult(it.key, seg, out.areas[i, :nb].numpy().copy(), np.asarray(it.boxes), np.asarray(it.labels), m, q)
+            if seg is not None:
+                r.size = (int(seg.shape[0]), int(seg.shape[1]))
+            else:
+                r.size = (int(it.image.shape[0]), int(it.image.shape[1]))
+            if self.rle:
+                r.rle_table, r.rle_data = rtab[off:off + nb], rdat
+            res.append(r)
         out.odd = {}
         release = lambda o=out: self.free_out.put(o)
         sink(res, release)
@@ -483,7 +552,7 @@ class TilePipeline:
                 self._decode(b, items, tiles, offs, out)
                 if decoding is not None:
                     self._finish(decoding, sink)
-                decoding = (items, offs, out)
+                decoding = (items, offs, out, b)
             encoded, staged = staged, None
             if nxt is None and encoded is None:
                 break
@@ -511,16 +580,23 @@ class InstancePipeline(TilePipeline):
     rotated boxes [n, 4, 2]; ``prompt="box"`` feeds the enclosing hbox (min / max of the corners, :125-130) through
     ``apply_boxes_torch``, ``prompt="rbox_mask"`` rasterises the rbox into a +-1000 mask prompt on the GPU
     (``transforms.rbox_mask_prompts``).  Of the three masks per object the one with the highest predicted IoU is kept
-    (SAM's own selection rule); per object the host receives its area and quality, the kept masks stay in HBM
-    (``last_masks``) unless keep_masks."""
+    (SAM's own selection rule, `samrs_select_best` on the device); per object the host receives its area and quality (and with
+    ``rle=True`` its COCO RLE), the kept masks stay in HBM (``last_masks``) unless keep_masks.  No class map is painted:
+    ``TileResult.seg_mask`` is None and the class statistics stay zero (the instance drivers write neither)."""
 
     BOX_WIDTH = 8          # four (x, y) corners
 
-    def __init__(self, sam, n_classes: int, prompt: str = "box", **kw):
-        if prompt not in ("box", "rbox_mask"):
-            raise ValueError("prompt must be 'box' or 'rbox_mask'")
+    def __init__(self, sam, n_classes: int, prompt: str = "box", multimask: bool = True, **kw):
+        """prompt: "box" / "rbox_mask" (annotations = rotated boxes [n, 4, 2]) or "point"
+        (main_sam_hbox_mask_instance.py:160-165: annotations = one foreground point [n, 2] per object, handed to the prompt
+        encoder AS IS -- the reference does not run them through apply_coords -- labels all 1, no box, no mask;
+        that driver uses multimask_output=False: pass multimask=False)."""
+        if prompt not in ("box", "rbox_mask", "point"):
+            raise ValueError("prompt must be 'box', 'rbox_mask' or 'point'")
+        if prompt == "point":
+            self.BOX_WIDTH = 2
         super().__init__(sam, n_classes, **kw)
-        self.prompt = prompt
+        self.prompt, self.multimask = prompt, bool(multimask)
         self.qual_dev = [torch.zeros(self.batch, self.max_boxes, dtype=torch.float32, device=self.dev) for _ in range(2)]
         for _ in range(self.free_out.qsize()):
             o = self.free_out.get()
@@ -532,24 +608,28 @@ class InstancePipeline(TilePipeline):
         from . import transforms
         eng, (H, W) = self.eng, hw
         in_size = (int(tile.shape[0]), int(tile.shape[1]))
+        slot, mm = b * self.batch + i, self.multimask
         kept = []
         for s, e in box_chunks(nb, self.box_batch):
-            polys = self.dev_box[b][off + s:off + e].view(-1, 4, 2)
+            ann = self.dev_box[b][off + s:off + e]
             if self.prompt == "box":
+                polys = ann.view(-1, 4, 2)
                 hb = torch.cat([polys.amin(1), polys.amax(1)], dim=1)                                   # :125-130
-                tb = self.transform.apply_boxes_torch(hb, (H, W))
-                m, q, _ = eng.predict(b * self.batch + i, tb, None, None, None, True, False, in_size, (H, W))
+                m, q, _ = eng.predict(slot, self._input_frame_boxes(hb, (H, W), in_size), None, None, None, mm, False, in_size, (H, W))
+            elif self.prompt == "rbox_mask":
+                pr = transforms.rbox_mask_prompts_device(ann.view(-1, 4, 2), (H, W), self.side, device=self.dev)
+                m, q, _ = eng.predict(slot, None, None, None, pr[:, None], mm, False, in_size, (H, W))
             else:
-                pr = transforms.rbox_mask_prompts_device(polys, (H, W), self.side, device=self.dev)
-                m, q, _ = eng.predict(b * self.batch + i, None, None, None, pr[:, None], True, False, in_size, (H, W))
-            best = q.argmax(1)
-            rows = torch.arange(e - s, device=self.dev)
-            mk = m[rows, best]                                                                          # [n, H, W]
-            self.qual_dev[b][i, s:e] = q[rows, best]
-            self.area_dev[b][i, s:e] = mk.flatten(1).sum(1)
+                pl = torch.ones(e - s, 1, dtype=torch.int32, device=self.dev)
+                m, q, _ = eng.predict(slot, None, ann.view(-1, 1, 2), pl, None, mm, False, in_size, (H, W))
+            # best of the C masks by predicted IoU, its quality and area: one pass on the device, straight into the tables
+            mk, _, _ = eng.select_best(m, q, None, self.qual_dev[b][i, s:e], self.area_dev[b][i, s:e])
+            if self.rle:
+                eng.rle_encode(mk, self.rle_dev[b], self.rle_cur[b], self.rle_tab[b][off + s:off + e])
             kept.append(mk)
-        self.last_masks = kept[-1] if kept else None
-        out.masks[i] = torch.cat(kept).cpu().view(torch.uint8) if (self.keep_masks and kept) else None
+        self.last_masks = kept[-1].view(torch.bool) if kept else None
+        out.masks[i] = torch.cat(kept).cpu() if (self.keep_masks and kept) else None
+        out.odd[i] = None                      # instance pipelines paint no class map
 
     def _extra_outputs(self, b: int, out: _OutBuf) -> None:
         out.quality.copy_(self.qual_dev[b], non_blocking=True)

@@ -21,6 +21,10 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsamrs_hip.so")
 PREC_BF16, PREC_F16 = 0, 1
 PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16}
 
+ABI_VERSION = 2
+# "split" option bits (include/samrs_hip.h): rounding points that run as a two-term operand split
+SPLIT_PATCH, SPLIT_NECK, SPLIT_OI, SPLIT_UP, SPLIT_ALL = 1, 2, 4, 8, 15
+
 OK, ERR_NOT_SET, ERR_BAD_SHAPE, ERR_BAD_ARG, ERR_HIP, ERR_BAD_WEIGHTS, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
 
 
@@ -82,8 +86,11 @@ def load_library() -> C.CDLL:
     lib.samrs_k_ln_rowstat.argtypes = [vp, vp, ip, fp, vp]
     lib.samrs_k_ln_fold_weight.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, ip, ip, vp]
     lib.samrs_k_rowstats_convert.argtypes = [ip, vp, vp, vp, ip, ip, vp]
-    lib.samrs_debug_set_ln_fold.argtypes = [ip]
-    lib.samrs_debug_set_ln_fold.restype = None
+    lib.samrs_set_option.argtypes = [vp, C.c_char_p, ip]
+    lib.samrs_get_option.argtypes = [vp, C.c_char_p, C.POINTER(ip)]
+    lib.samrs_rle_encode.argtypes = [vp, vp, ip, ip, ip, vp, C.c_int64, vp, vp, vp]
+    lib.samrs_k_convert_split.argtypes = [ip, vp, vp, vp, C.c_int64, vp]
+    lib.samrs_select_best.argtypes = [vp, vp, vp, ip, ip, ip, ip, vp, vp, vp, vp]
     lib.samrs_k_convert.argtypes = [ip, vp, vp, C.c_int64, vp]
     lib.samrs_k_layernorm.argtypes = [ip, vp, vp, vp, fp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_window_attention.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
@@ -91,15 +98,16 @@ def load_library() -> C.CDLL:
     lib.samrs_k_postprocess.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, vp, vp]
     lib.samrs_k_neck_im2col.argtypes = [vp, vp, ip, ip, ip, vp]
     lib.samrs_k_neck_im2col.restype = ip
-    lib.samrs_k_gemm_gln.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, vp]
-    lib.samrs_k_upscale2_masks.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
+    lib.samrs_k_gemm_gln.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, vp, vp, vp]
+    lib.samrs_k_upscale2_masks.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_set_images_ragged", "samrs_get_embedding",
                  "samrs_set_embedding", "samrs_reset_image", "samrs_predict", "samrs_paint", "samrs_k_gemm",
                  "samrs_k_gemm_f32", "samrs_k_convert", "samrs_k_layernorm", "samrs_k_window_attention",
                  "samrs_k_global_attention", "samrs_k_postprocess", "samrs_k_gemm_gln", "samrs_k_upscale2_masks",
-                 "samrs_k_gemm_stats", "samrs_k_gemm_fold", "samrs_k_ln_fold_weight", "samrs_k_rowstats_convert", "samrs_k_ln_rowstat"):
+                 "samrs_k_gemm_stats", "samrs_k_gemm_fold", "samrs_k_ln_fold_weight", "samrs_k_rowstats_convert", "samrs_k_ln_rowstat",
+                 "samrs_set_option", "samrs_get_option", "samrs_rle_encode", "samrs_k_convert_split", "samrs_select_best"):
         getattr(lib, name).restype = ip
-    if lib.samrs_abi_version() != 1:
+    if lib.samrs_abi_version() != ABI_VERSION:
         raise ImportError("libsamrs_hip.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -155,6 +163,15 @@ class Engine:
         if rc in (ERR_BAD_SHAPE, ERR_BAD_ARG):
             raise AssertionError(msg)
         raise EngineError(f"libsamrs_hip error {rc}: {msg}")
+
+    # -- per-engine options (include/samrs_hip.h: "split", "decoder_fusion", "ln_fold", "gemm_variant")
+    def set_option(self, name: str, value: int) -> None:
+        self._check(self.lib.samrs_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int()
+        self._check(self.lib.samrs_get_option(self.handle, name.encode(), C.byref(v)))
+        return v.value
 
     def close(self) -> None:
         if getattr(self, "handle", None):
@@ -288,14 +305,48 @@ class Engine:
             masks = masks.view(torch.bool)
         return masks, iou, low
 
+    def rle_encode(self, masks: torch.Tensor, out: torch.Tensor, cursor: torch.Tensor, table: torch.Tensor) -> None:
+        """COCO RLE strings of `masks` ([n, H, W] bool / uint8 on this device) appended to the byte buffer `out` (uint8, device)
+        behind `cursor` (int64 [1], device, in / out); `table` (int64 [n, 3], device) receives (offset, length, n_counts)
+        per mask.  Asynchronous on the current stream; see samrs_rle_encode in samrs_hip.h."""
+        m = masks.view(torch.uint8) if masks.dtype == torch.bool else masks
+        m = m.reshape(-1, m.shape[-2], m.shape[-1]).contiguous()
+        n, h, w = m.shape
+        assert out.dtype == torch.uint8 and out.is_cuda and out.is_contiguous() and out.data_ptr() % 16 == 0
+        assert cursor.dtype == torch.int64 and cursor.is_cuda and table.dtype == torch.int64 and table.is_cuda
+        assert table.is_contiguous() and table.numel() >= 3 * n
+        with torch.cuda.device(self.device):
+            self._check(self.lib.samrs_rle_encode(self.handle, m.data_ptr(), n, h, w, out.data_ptr(), out.numel(),
+                                                  cursor.data_ptr(), table.data_ptr(), _stream()))
+
+    def select_best(self, masks: torch.Tensor, iou: torch.Tensor, best_out: Optional[torch.Tensor] = None,
+                    quality_out: Optional[torch.Tensor] = None, areas_out: Optional[torch.Tensor] = None):
+        """Best-of-C by predicted IoU on the device (samrs_select_best): masks [n, C, H, W] bool / uint8, iou [n, C] ->
+        (best masks uint8 [n, H, W], quality fp32 [n], areas int64 [n]); the outputs may be caller-owned contiguous slices."""
+        m = masks.view(torch.uint8) if masks.dtype == torch.bool else masks
+        n, c, h, w = m.shape
+        assert m.is_contiguous() and iou.is_contiguous() and iou.dtype == torch.float32 and tuple(iou.shape) == (n, c)
+        best = best_out if best_out is not None else torch.empty(n, h, w, dtype=torch.uint8, device=self.device)
+        qual = quality_out if quality_out is not None else torch.empty(n, dtype=torch.float32, device=self.device)
+        areas = areas_out if areas_out is not None else torch.empty(n, dtype=torch.int64, device=self.device)
+        assert best.is_contiguous() and qual.is_contiguous() and areas.is_contiguous() and areas.dtype == torch.int64
+        with torch.cuda.device(self.device):
+            self._check(self.lib.samrs_select_best(self.handle, m.data_ptr(), iou.data_ptr(), n, c, h, w, best.data_ptr(),
+                                                   qual.data_ptr(), areas.data_ptr(), _stream()))
+        return best, qual, areas
+
     def paint(self, masks: torch.Tensor, labels: torch.Tensor, seg: torch.Tensor,
-              class_pixels: Optional[torch.Tensor] = None, class_instances: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Ordered painting + areas (+ class statistics) on device; see samrs_paint in samrs_hip.h."""
+              class_pixels: Optional[torch.Tensor] = None, class_instances: Optional[torch.Tensor] = None,
+              areas_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Ordered painting + areas (+ class statistics) on device; see samrs_paint in samrs_hip.h.  `areas_out`: a caller-owned
+        contiguous int64 [n] slice to receive the areas (the pipeline's [batch, max_boxes] table) instead of a new tensor."""
         m = masks.view(torch.uint8) if masks.dtype == torch.bool else masks
         m = m.reshape(-1, m.shape[-2], m.shape[-1]).contiguous()
         n, h, w = m.shape
         labels = labels.to(dtype=torch.int32, device=self.device).contiguous()
-        areas = torch.empty(n, dtype=torch.int64, device=self.device)
+        if areas_out is not None:
+            assert areas_out.dtype == torch.int64 and areas_out.is_contiguous() and areas_out.numel() == n and areas_out.is_cuda
+        areas = areas_out if areas_out is not None else torch.empty(n, dtype=torch.int64, device=self.device)
         ncls = 0 if class_pixels is None else class_pixels.numel()
         with torch.cuda.device(self.device):
             self._check(self.lib.samrs_paint(self.handle, m.data_ptr(), labels.data_ptr(), n, h, w, seg.data_ptr(),

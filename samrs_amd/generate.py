@@ -38,7 +38,10 @@ def default_palette(n_classes: int) -> np.ndarray:
 
 
 def write_outputs(out_dir: str, stem: str, seg: np.ndarray, masks: Optional[np.ndarray], boxes: np.ndarray,
-                  labels: np.ndarray, areas: np.ndarray, palette: np.ndarray, class_names: Sequence[str]) -> None:
+                  labels: np.ndarray, areas: np.ndarray, palette: np.ndarray, class_names: Sequence[str],
+                  rles: Optional[Sequence[dict]] = None) -> None:
+    """`rles`: the per-instance COCO RLE dicts when they were encoded on the device (driver.TileResult.rle); otherwise they are
+    encoded here from `masks` (host restatement), or left out when both are None (--no-rle)."""
     from PIL import Image
     for sub in ("gray", "color", "ins"):
         os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
@@ -50,11 +53,24 @@ def write_outputs(out_dir: str, stem: str, seg: np.ndarray, masks: Optional[np.n
     info = []
     for j in range(len(labels)):                                                            # :200-206
         entry = {"bbox": boxes[j], "category": class_names[int(labels[j])], "label": int(labels[j]), "size": int(areas[j])}
-        if masks is not None:
+        if rles is not None:
+            entry["mask"] = rles[j]
+        elif masks is not None:
             entry["mask"] = rle.encode(masks[j])
         info.append(entry)
-    with open(os.path.join(out_dir, "ins", stem + ".pkl"), "wb") as f:
+    # the pickle goes last and through a rename: --resume takes its presence as "this image is complete"
+    tmp = os.path.join(out_dir, "ins", stem + ".pkl.tmp")
+    with open(tmp, "wb") as f:
         pickle.dump(info, f)                                                                # :216
+    os.replace(tmp, os.path.join(out_dir, "ins", stem + ".pkl"))
+
+
+def outputs_exist(out_dir: str, stem: str) -> bool:
+    """All three files of an image are on disk (main_sam_hbox_semantic.py:214-216 writes gray, color, then ins)."""
+    return all(os.path.exists(os.path.join(out_dir, sub, stem + ext)) for sub, ext in (("gray", ".png"), ("color", ".png"), ("ins", ".pkl")))
+
+
+_RUN_SEQ = [0]          # run() calls of this process (part of the work queue's store key)
 
 
 def run(args) -> Dict[str, List[int]]:
@@ -80,11 +96,24 @@ def run(args) -> Dict[str, List[int]]:
     exts = (".png", ".jpg", ".jpeg", ".tif", ".bmp")
     files = {os.path.splitext(f)[0]: f for f in os.listdir(args.images) if f.lower().endswith(exts)}
     stems = sorted(s for s in files if s in ann and len(ann[s]["boxes"]) > 0)                       # :126-129
+    n_all = len(stems)
+    if getattr(args, "resume", False):
+        # restart = re-run what is missing: every rank filters the same sorted list the same way, so the
+        # shards stay disjoint.  NB: the class statistics of a resumed run cover only the images processed by THIS run;
+        # `Generate Dataset/statistic.py` recomputes them from ins/*.pkl over the whole output directory.
+        stems = [s for s in stems if not outputs_exist(args.out, s)]
+        if rank == 0:
+            print(f"[rank 0] --resume: {n_all - len(stems)} of {n_all} images already complete", flush=True)
     max_boxes = max([len(ann[s]["labels"]) for s in stems] + [1])
-    pipe = driver.TilePipeline(sam, n_classes, batch=batch, box_batch=args.box_batch, keep_masks=not args.no_rle,
-                               max_boxes=max_boxes)
-    # rank r takes chunks of `batch` consecutive stems: statically (r, r + world, ...) or from the shared counter
-    wq = driver.WorkQueue(len(stems), chunk=batch, rank=rank, world=world, mode=getattr(args, "schedule", "static"))
+    # per-instance RLE (main_sam_hbox_semantic.py:201-202) is encoded on the device; the full masks never cross PCIe
+    pipe = driver.TilePipeline(sam, n_classes, batch=batch, box_batch=args.box_batch, rle=not args.no_rle,
+                               rle_buffer_mb=getattr(args, "rle_buffer_mb", 256), max_boxes=max_boxes)
+    # rank r takes chunks of `batch` consecutive stems: statically (r, r + world, ...) or from the shared counter (whose
+    # store key must be unique per work list: a second run() in the same process group must not find a spent counter)
+    import zlib
+    wq_name = "samrs_wq/%08x/%d" % (zlib.crc32("\n".join(stems).encode()), _RUN_SEQ[0])
+    _RUN_SEQ[0] += 1
+    wq = driver.WorkQueue(len(stems), chunk=batch, rank=rank, world=world, mode=getattr(args, "schedule", "static"), name=wq_name)
 
     def load(stem: str) -> driver.WorkItem:
         img = np.array(Image.open(os.path.join(args.images, files[stem])).convert("RGB"))            # :114
@@ -106,26 +135,37 @@ def run(args) -> Dict[str, List[int]]:
     done = [0]
     sizes: List[int] = []
     writers = ThreadPoolExecutor(max_workers=getattr(args, "writers", 8))
+    pending: List = []
+
+    def reap(block: bool) -> None:
+        """Re-raise the first failure of a writer job (disk full, bad path, pickle error): a run whose files did not reach the
+        disk must not go on to write statistics and exit 0."""
+        while pending and (block or pending[0].done()):
+            pending.pop(0).result()
 
     def sink(results, release):
-        # PNG encode + pickle on the writer pool (zlib releases the GIL); the pinned ring buffer goes back when the
+        # PNG encode + pickle on the writer pool (zlib releases the GIL); the pinned ring buffers go back when the
         # whole batch is on disk
         def job():
             try:
                 for r in results:
-                    m = r.masks.astype(bool) if r.masks is not None else None
-                    write_outputs(args.out, r.key, r.seg_mask, m, r.boxes, r.labels, r.areas, palette, names)
+                    rles = [r.rle(j) for j in range(len(r.labels))] if r.rle_table is not None else None
+                    write_outputs(args.out, r.key, r.seg_mask, None, r.boxes, r.labels, r.areas, palette, names, rles)
             finally:
                 release()
+        pending.append(writers.submit(job))
+        reap(block=False)
         for r in results:
             sizes.extend(int(a) for a in r.areas if a > 0)                                           # statistic.py:44-49
-        writers.submit(job)
         done[0] += len(results)
         if rank == 0 and (done[0] // batch) % 50 == 0:
             print(f"[rank 0] {done[0]} images", flush=True)
 
-    pipe.run(batches(), sink)
-    writers.shutdown(wait=True)
+    try:
+        pipe.run(batches(), sink)
+    finally:
+        writers.shutdown(wait=True)
+    reap(block=True)
     pix, ins = driver.reduce_statistics(pipe.class_pixels, pipe.class_instances)
     all_sizes = driver.gather_mask_sizes(sizes)
     stats = {"class_pixel_num": pix.cpu().tolist(), "class_instance_num": ins.cpu().tolist(),
@@ -154,6 +194,8 @@ def main(argv=None):
     # 8.5 % faster at 64 (bench.py --workload c3 --box-batch 64: 137.6 vs 126.8 images/s), so the generation CLI defaults to 64
     ap.add_argument("--box-batch", type=int, default=64)
     ap.add_argument("--no-rle", action="store_true", help="skip per-instance RLE (only class maps + areas)")
+    ap.add_argument("--rle-buffer-mb", type=int, default=256, help="device buffer for one batch's RLE strings (real masks need KBs each)")
+    ap.add_argument("--resume", action="store_true", help="skip images whose gray / color / ins outputs already exist")
     ap.add_argument("--batch", type=int, default=8, help="tiles per encoder pass")
     ap.add_argument("--schedule", default="static", choices=["static", "dynamic"],
                     help="static: rank r takes chunks r, r+world, ...; dynamic: shared-counter work queue (long-tailed box counts)")

@@ -44,6 +44,33 @@ def counts_to_string(counts: List[int]) -> str:
     return "".join(out)
 
 
+def counts_to_string_np(counts: np.ndarray) -> str:
+    """`counts_to_string` vectorised over the whole count array (numpy): the same delta coding and 5-bit groups, a few
+    passes over small arrays instead of a Python loop per count (the device path, samrs_rle_encode, makes even this
+    unnecessary in the generation loop; this is the host fallback)."""
+    c = np.asarray(counts, dtype=np.int64)
+    if c.size == 0:
+        return ""
+    x = c.copy()
+    x[3:] -= c[1:-2]
+    groups = []          # per pass: (chars, still-active index array)
+    idx = np.arange(x.size)
+    pos_len = np.zeros(x.size, dtype=np.int64)
+    cur = x
+    while idx.size:
+        g = cur & 0x1F
+        cur = cur >> 5
+        more = np.where((g & 0x10) != 0, cur != -1, cur != 0)
+        groups.append((idx, (g | (more.astype(np.int64) << 5)) + 48))
+        pos_len[idx] += 1
+        idx, cur = idx[more], cur[more]
+    start = np.concatenate([[0], np.cumsum(pos_len)[:-1]])
+    out = np.empty(int(pos_len.sum()), dtype=np.uint8)
+    for k, (ix, ch) in enumerate(groups):
+        out[start[ix] + k] = ch
+    return out.tobytes().decode("ascii")
+
+
 def string_to_counts(s: str) -> List[int]:
     counts: List[int] = []
     p = 0
@@ -67,7 +94,7 @@ def encode(mask: np.ndarray) -> Dict:
     """Same dict as ``maskUtils.encode(np.asfortranarray(mask))`` with ``counts`` already decoded to str
     (the reference does ``rle['counts'].decode('ascii')``, main_sam_hbox_semantic.py:202)."""
     h, w = mask.shape
-    return {"size": [int(h), int(w)], "counts": counts_to_string(mask_to_counts(mask))}
+    return {"size": [int(h), int(w)], "counts": counts_to_string_np(np.asarray(mask_to_counts(mask), dtype=np.int64))}
 
 
 def decode(rle: Dict) -> np.ndarray:

@@ -412,10 +412,64 @@ def test_gemm_group_layernorm_gelu_epilogue(lib, name, prec, dt, ulp):
     out = torch.empty(M, N, dtype=torch.int16, device="cuda")
     gb = dev(torch.cat([gamma, beta]))
     assert lib.samrs_k_gemm_gln(prec, dev(Ab).data_ptr(), dev(Bb).data_ptr(), out.data_ptr(), dev(bias).data_ptr(), gb.data_ptr(),
-                                M, N, K, stream()) == 0
+                                M, N, K, None, None, stream()) == 0
     err = (out.cpu().view(dt).float() - ref).abs() / ref.abs().clamp(min=1e-2)
     print(f"gemm+groupLN+gelu {name}: max rel {err.max().item():.2e}")
     assert err.max().item() < 1.5 * ulp
+
+
+def split_bits(lib, prec, x):
+    """fp32 CPU tensor -> (hi bits, lo bits) device int16 tensors through samrs_k_convert_split, and the fp64 value hi + lo."""
+    xd = dev(x)
+    hi = torch.empty(x.shape, dtype=torch.int16, device="cuda")
+    lo = torch.empty(x.shape, dtype=torch.int16, device="cuda")
+    assert lib.samrs_k_convert_split(prec, xd.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), stream()) == 0
+    return hi, lo
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_convert_split_is_the_two_term_split(lib, name, prec, dt, ulp):
+    """hi = ET(x) (bit-identical with samrs_k_convert), lo = ET(x - hi); hi + lo reproduces x to ~ulp^2."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1 << 16, generator=g) * torch.logspace(-2, 2, 1 << 16)
+    hi, lo = split_bits(lib, prec, x)
+    h = x.to(dt)
+    assert torch.equal(hi.cpu(), h.view(torch.int16))
+    l = (x - h.float()).to(dt)
+    assert torch.equal(lo.cpu(), l.view(torch.int16))
+    rec = h.double() + l.double()
+    # |x - hi| <= ulp/2 |x| and lo rounds that remainder to ulp/2 of ITSELF -- unless it falls into the operand type's
+    # subnormal range (f16: steps of 2^-24), where the error is absolute
+    excess = ((rec - x.double()).abs() - 2.0 ** -24).clamp(min=0) / x.double().abs()
+    print(f"split {name}: max rel reconstruction error beyond one subnormal step {excess.max().item():.2e}")
+    assert excess.max().item() < ulp * ulp
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_gemm_gln_split_precision(lib, name, prec, dt, ulp):
+    """ConvT #1 with hi + lo operands (A_lo B + A B_lo + A B, fp32 output after LayerNorm2d + GELU) against the fp64 product of the
+    UN-rounded fp32 operands: the error must be of the fp32-accumulation class, far below one operand ulp."""
+    g = torch.Generator().manual_seed(32)
+    M, N, K = 512, 256, 256
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g) * 0.5
+    gamma = 1 + 0.2 * torch.randn(64, generator=g)
+    beta = 0.2 * torch.randn(64, generator=g)
+    y = (A.double() @ B.double().t() + bias.double()).view(M, N // 64, 64)
+    mu = y.mean(-1, keepdim=True)
+    var = ((y - mu) ** 2).mean(-1, keepdim=True)
+    ref = F.gelu(((y - mu) / torch.sqrt(var + 1e-6)) * gamma.double() + beta.double()).view(M, N)
+    Ah, Al = split_bits(lib, prec, A)
+    Bh, Bl = split_bits(lib, prec, B)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    gb = dev(torch.cat([gamma, beta]))
+    assert lib.samrs_k_gemm_gln(prec, Ah.data_ptr(), Bh.data_ptr(), out.data_ptr(), dev(bias).data_ptr(), gb.data_ptr(),
+                                M, N, K, Al.data_ptr(), Bl.data_ptr(), stream()) == 0
+    err = (out.cpu().double() - ref).abs() / ref.abs().clamp(min=1e-2)
+    print(f"split gemm+groupLN+gelu {name}: max rel {err.max().item():.2e} (one operand ulp = {ulp:.1e})")
+    assert not torch.isnan(out).any()
+    assert err.max().item() < (2e-5 if name == "f16" else 3e-4)
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
@@ -434,12 +488,25 @@ def test_upscale2_masks_fused(lib, name, prec, dt, ulp, n_sel, sel0):
     S = 4 * grid
     ref = torch.einsum("byxijklc,bsc->bsyikxjl", up2, hyper[:, sel0:sel0 + n_sel].double()).reshape(n, n_sel, S, S)
     low = torch.full((n, n_sel, S, S), float("nan"), device="cuda")
-    assert lib.samrs_k_upscale2_masks(prec, dev(Ub).data_ptr(), dev(Wb).data_ptr(), dev(bias).data_ptr(), dev(hyper).data_ptr(),
+    assert lib.samrs_k_upscale2_masks(prec, dev(Ub).data_ptr(), dev(Wb).data_ptr(), None, dev(bias).data_ptr(), dev(hyper).data_ptr(),
                                       low.data_ptr(), n, grid, 4, sel0, n_sel, stream()) == 0
     r, mx = rel_err(low.cpu(), ref)
     print(f"upscale2+mask {name} n_sel={n_sel}: rel {r:.2e} max {mx:.2e}")
     assert not torch.isnan(low).any(), "some low-res pixels were never written"
     assert r < 2e-5
+    # split precision: fp32 activations (split in registers) x hi + lo weights, against the fp64 product of the UN-rounded operands
+    Uf = torch.randn(rows, 64, generator=g)
+    Wf = torch.randn(128, 64, generator=g) / 8
+    up2 = F.gelu(Uf.double() @ Wf.double().t() + bias.double()).view(n, grid, grid, 2, 2, 2, 2, 32)
+    ref = torch.einsum("byxijklc,bsc->bsyikxjl", up2, hyper[:, sel0:sel0 + n_sel].double()).reshape(n, n_sel, S, S)
+    Wh, Wl = split_bits(lib, prec, Wf)
+    low = torch.full((n, n_sel, S, S), float("nan"), device="cuda")
+    assert lib.samrs_k_upscale2_masks(prec, dev(Uf).data_ptr(), Wh.data_ptr(), Wl.data_ptr(), dev(bias).data_ptr(), dev(hyper).data_ptr(),
+                                      low.data_ptr(), n, grid, 4, sel0, n_sel, stream()) == 0
+    r, mx = rel_err(low.cpu(), ref)
+    print(f"upscale2+mask split {name} n_sel={n_sel}: rel {r:.2e} max {mx:.2e}")
+    assert not torch.isnan(low).any()
+    assert r < (3e-6 if name == "f16" else 1e-4)
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)

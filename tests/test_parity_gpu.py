@@ -101,14 +101,11 @@ def test_folded_layernorm_matches_unfolded(precision):
     from samrs_amd import engine
     name = "vit_tiny1280"
     cfg = synth.CONFIGS[name]
-    lib = engine.load_library()
-    lib.samrs_debug_set_ln_fold(1)           # before the weights are finalized: the folded copies are prepared at load
-    try:
-        sam = samrs_amd.sam_model_registry[name](precision=precision, max_prompts=8, max_images=1, max_points=4)
-        sam.to(device="cuda")
-        pred = samrs_amd.SamPredictor(sam)
-    finally:
-        lib.samrs_debug_set_ln_fold(0)
+    # the option must be on before the weights are finalized: the folded copies are prepared at load
+    sam = samrs_amd.sam_model_registry[name](precision=precision, max_prompts=8, max_images=1, max_points=4, options={"ln_fold": 1})
+    sam.to(device="cuda")
+    pred = samrs_amd.SamPredictor(sam)
+    eng = sam.engine
     img = synth.make_image(1)
     taps = {}
     with torch.no_grad():
@@ -118,9 +115,9 @@ def test_folded_layernorm_matches_unfolded(precision):
     try:
         for nb in range(1, cfg.depth + 1):
             ref = taps[f"block{nb - 1}"][0]
-            lib.samrs_debug_set_ln_fold(0)
+            eng.set_option("ln_fold", 0)
             x0 = pred.model.engine.debug_encoder_prefix(t, nb).cpu()[0]
-            lib.samrs_debug_set_ln_fold(1)
+            eng.set_option("ln_fold", 1)
             x1 = pred.model.engine.debug_encoder_prefix(t, nb).cpu()[0]
             x1b = pred.model.engine.debug_encoder_prefix(t, nb).cpu()[0]
             assert torch.equal(x1, x1b), "folded path is not run-to-run reproducible"
@@ -131,7 +128,7 @@ def test_folded_layernorm_matches_unfolded(precision):
             assert not torch.equal(x0, x1), "the switch did nothing"
             assert e1 < tol and e1 < 1.5 * e0 + 1e-5 and d < tol
         # the folded engine end to end: embedding and box masks against the oracle
-        lib.samrs_debug_set_ln_fold(1)
+        eng.set_option("ln_fold", 1)
         orc = get_oracle(name)
         pred.set_image(img)
         orc.set_image(img)
@@ -145,7 +142,8 @@ def test_folded_layernorm_matches_unfolded(precision):
         print(f"{name} {precision} folded: embedding rel L2 {rel:.3e}, box-mask IoU min {iou.min().item():.5f}")
         assert iou.min().item() >= (0.999 if precision == "f16" else 0.99)
     finally:
-        lib.samrs_debug_set_ln_fold(0)
+        eng.set_option("ln_fold", 0)
+        eng.close()
 
 
 @pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80", "vit_tiny1280"])
@@ -209,6 +207,38 @@ def test_decoder_alone_all_prompt_types(precision):
     assert not bad, bad
 
 
+def test_operand_split_buys_what_the_error_budget_says():
+    """The "split" option (two-term operand split of patch embed, neck, decoder out-projection and upscaler): against the fp32
+    oracle the embedding error and the decoder's own error must drop by the factors oracle/error_budget.py predicts for these
+    rounding points, and switching it off must reproduce the round-2 arithmetic's error class."""
+    import samrs_amd
+    so = _oracle()
+    name = "vit_tiny80"
+    sam = samrs_amd.sam_model_registry[name](precision="f16", max_prompts=8, max_points=1).to("cuda")
+    pred = samrs_amd.SamPredictor(sam)
+    eng = sam.engine
+    orc = get_oracle(name)
+    img = synth.make_image(0)
+    orc.set_image(img)
+    boxes = torch.from_numpy(synth.C1_BOXES)
+    tb = so.apply_boxes(boxes, img.shape[:2])
+    _, _, l0 = orc.predict_torch(None, None, tb, None, multimask_output=True)
+    res = {}
+    for split in (0, 15):
+        eng.set_option("split", split)
+        assert eng.get_option("split") == split
+        pred.set_image(img)
+        e_emb = ((pred.get_image_embedding().cpu() - orc.features).norm() / orc.features.norm()).item()
+        eng.set_embedding(orc.features.cuda(), pred.slot)                  # decoder alone on the oracle's embedding
+        _, _, l = pred.predict_torch(None, None, tb.cuda(), None, multimask_output=True)
+        e_dec = ((l.cpu() - l0).norm() / l0.norm()).item()
+        res[split] = (e_emb, e_dec)
+        print(f"split={split}: embedding rel L2 {e_emb:.3e}, decoder-alone low-res rel L2 {e_dec:.3e}")
+    eng.close()
+    assert res[15][0] < 0.75 * res[0][0], res          # two-block encoder: patch embed + neck dominate its operand rounding
+    assert res[15][1] < 0.5 * res[0][1], res           # out-projection + upscaler are ~90 % of the decoder's error variance
+
+
 @pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80", "vit_b", "vit_h"])
 def test_against_reference_golden(name, golden_dir):
     """Replay the committed fixtures produced by the REAL reference (oracle/make_golden.py)."""
@@ -259,8 +289,11 @@ def test_c2_c4_against_reference_golden(name, golden_dir):
     """BASELINE.json configs[1] (32 hboxes on one tile) and configs[3] (rbox -> enclosing hbox / rbox -> mask prompt,
     multimask_output=True) against FULL-RESOLUTION masks produced by the real reference on the realistic-margin weights
     (oracle/make_golden.py `extended`, fixtures tests/golden/<name>_c2c4.npz).  Asserted, at ViT-H too:
-      * per-mask IoU >= 0.999 on the C2 path (north_star; >= 0.998 for the three multimask tokens of C4) and relative
-        area error <= 1.5e-3; every MASK pixel whose reference logit has a margin of tau is reproduced exactly;
+      * per-mask IoU >= 0.9995 on the C2 path (north_star asks 0.999) and relative area error <= 1.5e-3; C4 (the three
+        multimask tokens: smaller masks with as many near-threshold pixels): >= 0.999 at ViT-B, >= 0.9985 at ViT-H -- the
+        four block GEMMs of the 32-block encoder in f16, with EVERYTHING else exact, already cost 0.99878 there
+        (oracle/error_budget.py vit_h plans2, row "floor"), so no 1x-rate f16 path can promise 0.999 on
+        this fixture; every MASK pixel whose reference logit has a margin of tau is reproduced exactly;
       * the painted class map is IDENTICAL to the reference's on every pixel whose reference decision has a margin of
         tau = 1 % of the logit spread (`c2_unstable` = the complement, computed from the reference's own logits), and
         the engine's logit error stays below tau -- i.e. the only pixels that may differ are the ones where the
@@ -312,7 +345,7 @@ def test_c2_c4_against_reference_golden(name, golden_dir):
     # ---- C2: 32 hboxes, one call here == the reference's 20 + 12 chunks (bit-identical by construction, tested above) ----
     tb = pred.transform.apply_boxes_torch(torch.from_numpy(inp["boxes"]).cuda(), hw)
     m, q, l = pred.predict_torch(None, None, tb, None, multimask_output=False)
-    check("c2", m, q, l)
+    check("c2", m, q, l, iou_floor=0.9995)
     seg = torch.full(hw, 255, dtype=torch.uint8, device="cuda")
     eng.paint(m[:, 0], torch.from_numpy(inp["labels"]), seg)
     seg = seg.cpu().numpy()
@@ -321,19 +354,22 @@ def test_c2_c4_against_reference_golden(name, golden_dir):
     print(f"c2c4 {name} class map: {int(diff.sum())} of {diff.size} pixels differ ({diff.mean():.2e}); reference-unstable pixels "
           f"{int(unstable.sum())} ({unstable.mean():.2e}); differing pixels outside the unstable set: {int((diff & ~unstable).sum())}")
     assert np.array_equal(seg[~unstable], g["c2_seg"][~unstable]), "class map differs where the reference's decision has margin"
-    assert diff.mean() < 1.5e-3
+    # round 2 (no operand split): 849 / 896 pixels at ViT-B / ViT-H; with the split rounding points the error budget
+    # predicts 394 / 476 (oracle/error_budget.py plans2, row E1)
+    assert diff.sum() <= 620, int(diff.sum())
     # ---- C4: enclosing hbox prompt, multimask ----
+    c4_floor = 0.999 if name == "vit_b" else 0.9985
     tb = pred.transform.apply_boxes_torch(torch.from_numpy(inp["hboxes"]).cuda(), hw)
     m, q, l = pred.predict_torch(None, None, tb, None, multimask_output=True)
     assert m.shape[1] == 3
-    # the three multimask tokens: smaller, noisier masks than token 0 on random weights -- measured min 0.9982 at ViT-H,
-    # 0.9994 at ViT-B; the zero-tolerance statement is the margin one inside check()
-    check("c4box", m, q, l, iou_floor=0.998)
+    # the three multimask tokens: smaller, noisier masks than token 0 on random weights; the zero-tolerance statement is
+    # the margin one inside check()
+    check("c4box", m, q, l, iou_floor=c4_floor)
     # ---- C4: rbox mask prompt (GPU rasteriser; bit-exact with the oracle that built the golden input), multimask ----
     prompts = transforms.rbox_mask_prompts(inp["polys"], hw, img_size=1024, device=torch.device("cuda"))
     assert abs(prompts.double().sum().item() - float(g["c4mask_prompt_sum"])) < 1e-6 * abs(float(g["c4mask_prompt_sum"])) + 1e-3
     m, q, l = pred.predict_torch(None, None, None, prompts[:, None], multimask_output=True)
-    check("c4mask", m, q, l, iou_floor=0.998)
+    check("c4mask", m, q, l, iou_floor=c4_floor)
     sam.engine.close()
 
 
@@ -483,6 +519,18 @@ def test_generation_driver_end_to_end(tmp_path):
             if d["size"] > 0:
                 tot_pix[d["label"]] += d["size"]
     assert stats["class_pixel_num"] == tot_pix.tolist()
+    # --resume: nothing is missing -> nothing is recomputed, nothing is rewritten; remove one pickle -> exactly that image
+    # (a second run() in the same process also exercises the per-run work-queue key)
+    before = {p: os.stat(p).st_mtime_ns for p in sorted(str(x) for x in out_dir.rglob("*.p*"))}
+    ns = generate.argparse.Namespace(
+        images=str(img_dir), boxes=str(tmp_path / "boxes.json"), out=str(out_dir), model="vit_tiny", checkpoint=None,
+        precision="f16", classes=None, n_classes=18, palette=None, box_batch=20, no_rle=False, resume=True)
+    s2 = generate.run(ns)
+    assert s2["mask_num"] == 0 and before == {p: os.stat(p).st_mtime_ns for p in before}
+    os.remove(out_dir / "ins" / "P0001.pkl")
+    s3 = generate.run(ns)
+    assert s3["mask_num"] == sum(1 for d in pickle.load(open(out_dir / "ins" / "P0001.pkl", "rb")) if d["size"] > 0)
+    assert os.stat(out_dir / "ins" / "P0000.pkl").st_mtime_ns == before[str(out_dir / "ins" / "P0000.pkl")]
 
 
 def test_vit_h_full_size_properties():
@@ -533,20 +581,24 @@ def test_decoder_fused_kernels_match_unfused():
     output in the last product."""
     pred = get_predictor("vit_h", "f16", max_prompts=32, max_images=8)
     eng = pred.model.engine
-    from samrs_amd import engine as E
-    lib = E.load_library()
     tile = torch.as_tensor(synth.make_noise_image(40))[None].cuda()
     eng.set_images(tile, 0)
     boxes, _ = synth.make_boxes(40, 32)
     b = torch.from_numpy(boxes).cuda()
     size = (1024, 1024)
+    split = eng.get_option("split")
     try:
-        lib.samrs_debug_set_decoder_fusion(0)
+        # like with like: the un-fused kernels never split their operands, so the fused ones run un-split here too
+        # (the split itself is tested kernel by kernel and against the oracle / the reference fixtures)
+        eng.set_option("split", split & 3)
+        eng.set_option("decoder_fusion", 0)
         m0, q0, l0 = eng.predict(0, b, None, None, None, False, False, size, size)
         m0, q0, l0 = m0.clone(), q0.clone(), l0.clone()
+        eng.set_option("decoder_fusion", 1)
+        m1, q1, l1 = eng.predict(0, b, None, None, None, False, False, size, size)
     finally:
-        lib.samrs_debug_set_decoder_fusion(1)
-    m1, q1, l1 = eng.predict(0, b, None, None, None, False, False, size, size)
+        eng.set_option("decoder_fusion", 1)
+        eng.set_option("split", split)
     rel = ((l1 - l0).norm() / l0.norm()).item()
     mx = ((l1 - l0).abs().max() / l0.std()).item()
     diff = (m1 != m0).sum().item()

@@ -183,33 +183,76 @@ def test_prompt_shape_validation():
         pred.set_torch_image(torch.full((1, 3, 1024, 1024), 0.5), (1024, 1024))  # non-integer pixel values
 
 
-@pytest.mark.parametrize("prompt", ["box", "rbox_mask"])
-def test_instance_pipeline_matches_prompter(prompt):
-    """BASELINE.json configs[3] recipe (rbox -> enclosing hbox / rbox -> mask prompt, multimask_output=True, best of 3)
-    through the three-stream pipeline == the one-image-at-a-time InstancePrompter."""
+@pytest.mark.parametrize("prompt,multimask", [("box", True), ("rbox_mask", True), ("point", False), ("point", True)])
+def test_instance_pipeline_matches_prompter(prompt, multimask):
+    """BASELINE.json configs[3] recipe (rbox -> enclosing hbox / rbox -> mask prompt, multimask_output=True, best of 3) and the
+    point recipe of main_sam_hbox_mask_instance.py:160-165 (one foreground point per object, multimask_output=False there)
+    through the three-stream pipeline == the one-image-at-a-time InstancePrompter; the best-of-3 selection, quality and area
+    come from samrs_select_best on the device, the per-instance RLE from samrs_rle_encode."""
     import samrs_amd
-    from samrs_amd import driver
-    sam = _sam(max_images=4, max_prompts=6)
+    from samrs_amd import driver, rle
+    sam = _sam(max_images=4, max_prompts=6, max_points=1)
     prm = driver.InstancePrompter(samrs_amd.SamPredictor(sam))
     items, ref = [], []
     for i in range(3):
         img = synth.make_image(40 + i)
         polys, labels = synth.make_rboxes(40 + i, 9)
-        items.append(driver.WorkItem(i, img, polys, labels))
+        pts = polys.mean(1).astype(np.float32)                              # object centres
+        items.append(driver.WorkItem(i, img, pts if prompt == "point" else polys, labels))
         if prompt == "box":
-            m, q = prm.predict(img, "box", hboxes=synth.enclosing_hboxes(polys), multimask_output=True)
+            m, q = prm.predict(img, "box", hboxes=synth.enclosing_hboxes(polys), multimask_output=multimask)
+        elif prompt == "rbox_mask":
+            m, q = prm.predict(img, "rbox_mask", rboxes=polys, multimask_output=multimask)
         else:
-            m, q = prm.predict(img, "rbox_mask", rboxes=polys, multimask_output=True)
+            m, q = prm.predict(img, "point", points=pts, multimask_output=multimask)
         ref.append((m.cpu().numpy(), q.cpu().numpy()))
-    pipe = driver.InstancePipeline(sam, 37, prompt=prompt, batch=2, box_batch=6, max_boxes=16, keep_masks=True)
+    pipe = driver.InstancePipeline(sam, 37, prompt=prompt, multimask=multimask, batch=2, box_batch=6, max_boxes=16, keep_masks=True,
+                                   rle=True, rle_buffer_mb=16)
     got = {}
 
     def sink(results, release):
         for r in results:
-            got[r.key] = (r.masks.copy(), r.quality.copy(), r.areas.copy())
+            assert r.seg_mask is None                                        # instance pipelines paint no class map
+            got[r.key] = (r.masks.copy(), r.quality.copy(), r.areas.copy(), [r.rle(j) for j in range(len(r.labels))])
         release()
 
     pipe.run(driver.batched(items, 2), sink)
     for i in range(3):
         assert np.array_equal(got[i][0].astype(bool), ref[i][0]) and np.array_equal(got[i][1], ref[i][1])
         assert np.array_equal(got[i][2], ref[i][0].reshape(9, -1).sum(1))
+        for j in range(9):
+            assert got[i][3][j] == rle.encode(ref[i][0][j]), f"tile {i} object {j}: device RLE differs from the host restatement"
+
+
+def test_pipeline_rle_mode_equals_host_rle():
+    """rle=True: the per-instance COCO RLE of main_sam_hbox_semantic.py:201-202 comes from the device (samrs_rle_encode) while
+    the masks stay in HBM; every string must equal samrs_amd.rle.encode of the mask the keep_masks mode hands over, for native,
+    DIOR-shaped and ragged tiles, box counts beyond one chunk, and on a second run through the same pipeline."""
+    from samrs_amd import driver, rle
+    sam = _sam(max_images=4, max_prompts=20, precision="f16")
+    sizes = [(1024, 1024), (600, 800), (1024, 1024), (517, 803), (1024, 1024)]
+    counts = [3, 5, 41, 2, 20]
+    items = _stream_items(driver, sizes, counts)
+    pipe = driver.TilePipeline(sam, 18, batch=2, box_batch=20, keep_masks=True, max_boxes=64, rle=True, rle_buffer_mb=64)
+    for rnd in range(2):
+        got = {}
+
+        def sink(results, release):
+            for r in results:
+                got[r.key] = (r.masks.copy(), [r.rle(j) for j in range(len(r.labels))], r.areas.copy(), r.rle_table.copy())
+            release()
+
+        assert pipe.run(driver.batched(items, 2), sink) == len(items)
+        for i, it in enumerate(items):
+            masks, rles, areas, tab = got[it.key]
+            assert len(rles) == counts[i] and (tab[:, 0] % 16 == 0).all()
+            for j in range(counts[i]):
+                want = rle.encode(masks[j].astype(bool))
+                assert rles[j] == want, f"{it.key} box {j} (round {rnd}): device RLE differs"
+                assert rles[j]["size"] == list(sizes[i]) and int(tab[j, 2]) == len(rle.mask_to_counts(masks[j].astype(bool)))
+                assert int(rle.decode(rles[j]).sum()) == int(areas[j])
+    # a buffer that cannot hold the batch's strings fails loudly, it does not truncate
+    small = driver.TilePipeline(sam, 18, batch=2, box_batch=20, max_boxes=64, rle=True, rle_buffer_mb=1)
+    small.rle_dev = [t[:4096] for t in small.rle_dev]
+    with pytest.raises(RuntimeError, match="RLE buffer too small"):
+        small.run(driver.batched(items[:2], 2), lambda res, rel: rel())

@@ -25,6 +25,35 @@ def test_known_cocoapi_strings():
     assert rle.counts_to_string([5, 3, 5, 1]) == "535N"         # 4th: 1-3 = -2 -> single group 0b11110 (sign bit set, x == -1 stops)
 
 
+def test_counts_match_the_reference_mask_to_rle_pytorch():
+    """Pins the counts half against the reference's own statement of COCO RLE, `mask_to_rle_pytorch`
+    (Generate Dataset/segment_anything/utils/amg.py:107-135), imported read-only: same counts for random, blob, all-zero,
+    all-one and first-pixel-set masks, square and ragged.  (Runs where /root/reference exists; the string half has no
+    reference on this machine -- pycocotools is not installable -- and stays a restatement of cocoapi's rleToString.)"""
+    from oracle import ref_import
+    if not ref_import.reference_available():
+        pytest.skip("reference tree not present on this machine")
+    import torch
+    ref_import.import_reference()
+    from segment_anything.utils.amg import mask_to_rle_pytorch            # the reference's
+    rng = np.random.default_rng(11)
+    masks = []
+    for shape in [(64, 64), (37, 91), (128, 50)]:
+        for p in (0.0, 0.02, 0.5, 1.0):
+            m = rng.random(shape) < p
+            if p == 0.02:
+                m[shape[0] // 4: shape[0] // 2, 3:] = True
+            masks.append(m)
+        m = np.zeros(shape, bool); m[0, 0] = True; masks.append(m)
+        m = np.ones(shape, bool); m[-1, -1] = False; masks.append(m)
+    for m in masks:
+        ref = mask_to_rle_pytorch(torch.from_numpy(m)[None])[0]
+        assert ref["size"] == list(m.shape)
+        assert rle.mask_to_counts(m) == ref["counts"], m.shape
+        # and the vectorised string coder agrees with the scalar restatement
+        assert rle.counts_to_string_np(np.asarray(ref["counts"], dtype=np.int64)) == rle.counts_to_string(ref["counts"])
+
+
 @pytest.mark.parametrize("shape", [(1, 1), (7, 5), (64, 64), (250, 333)])
 def test_roundtrip_random_masks(shape):
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])
@@ -37,6 +66,8 @@ def test_roundtrip_random_masks(shape):
         assert r["size"] == list(shape) and isinstance(r["counts"], str) and r["counts"].isascii()
         assert rle.string_to_counts(r["counts"]) == rle.mask_to_counts(m)
         assert np.array_equal(rle.decode(r), m)
+        c = np.asarray(rle.mask_to_counts(m), dtype=np.int64)
+        assert rle.counts_to_string_np(c) == rle.counts_to_string(c.tolist())
 
 
 def test_writer_contract(tmp_path):

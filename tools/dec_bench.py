@@ -24,15 +24,17 @@ def main() -> None:
     eng.set_images(tile, 0)
     b, _ = synth.make_boxes(0, 32)
     boxes = torch.from_numpy(b).to(dev)
-    for _ in range(3):
-        eng.predict(0, boxes, None, None, None, False, False, (1024, 1024), (1024, 1024))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        eng.predict(0, boxes, None, None, None, False, False, (1024, 1024), (1024, 1024))
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    print(f"predict(32 boxes) {model}: {dt * 1e3:.3f} ms")
+    for split in ([int(v) for v in os.environ["DEC_SPLITS"].split(",")] if os.environ.get("DEC_SPLITS") else [eng.get_option("split")]):
+        eng.set_option("split", split)
+        for _ in range(3):
+            eng.predict(0, boxes, None, None, None, False, False, (1024, 1024), (1024, 1024))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.predict(0, boxes, None, None, None, False, False, (1024, 1024), (1024, 1024))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        print(f"predict(32 boxes) {model} split={split}: {dt * 1e3:.3f} ms")
 
 
 if __name__ == "__main__":

@@ -38,6 +38,8 @@ if os.environ.get("STRIDE_PROBE"):
     # L2-channel probe: the same GEMM with a row stride of 10 x 256 B (K = 1280), 11 x 256 B (K = 1408), 40 x 256 B (K = 5120), 41 x 256 B
     shapes = [("K=1280   ", 32768, 5120, 1280, 0, 1, 0), ("K=1408   ", 32768, 5120, 1408, 0, 1, 0), ("K=1344   ", 32768, 5120, 1344, 0, 1, 0),
               ("K=5120   ", 32768, 1280, 5120, 1, 0, 1), ("K=5248   ", 32768, 1280, 5248, 1, 0, 1), ("K=5184   ", 32768, 1280, 5184, 1, 0, 1)]
+if os.environ.get("ONLY"):        # ONLY=lin1,qkv: shapes whose name starts with one of these (per-shape PMC passes)
+    shapes = [sh for sh in shapes if any(sh[0].strip().startswith(o) for o in os.environ["ONLY"].split(","))]
 g = torch.Generator().manual_seed(0)
 for name, M, N, K, of32, gelu, acc in shapes:
     A = torch.randn(M, K, generator=g).to(dev).to(dt)

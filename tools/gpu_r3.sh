@@ -28,7 +28,7 @@ for step in "$@"; do
     decb)    run decb 300 python tools/dec_bench.py 20 ;;
     prof)    cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
              run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r03 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-pcie-leg --no-rle-leg ;;
-    *)       run "$step" 900 bash -c "$step" ;;
+    *)       n=$((${n:-0} + 1)); echo "cmd$n: $step" >> gpurun_out/summary.txt; run "cmd$n" 1200 bash -c "$step" ;;
   esac
 done
 tail -n 6 gpurun_out/*.log 2>/dev/null | tail -150

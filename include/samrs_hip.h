@@ -185,7 +185,9 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *   "ln_fold"        [SAMRS_LN_FOLD, default 0] (embed_dim 1280) 1 = fold the encoder blocks' LayerNorms into the qkv / lin1
  *                    GEMMs.  Measured slower on MI355X.  Must be on before samrs_finalize_weights for the folded weights to
  *                    exist; can be flipped afterwards.
- *   "gemm_variant"   [default -1 = automatic] GEMM tile variant for this handle's launches (tools/gemm_bench.py lists them). */
+ *   "gemm_variant"   [default -1 = automatic] GEMM tile variant for this handle's launches (tools/gemm_bench.py lists them).
+ *   "upscaler_fused" [SAMRS_UPSCALER_FUSED, default 1] 1 = the mask upscaler as ONE kernel (samrs_k_upscaler_fused); 0 = ConvT #1 as a GEMM with a
+ *                    LayerNorm2d + GELU epilogue, then the ConvT #2 + GELU + product kernel (A/B runs, tests). */
 int samrs_set_option(samrs_engine_t* e, const char* name, int value);
 int samrs_get_option(const samrs_engine_t* e, const char* name, int* value);
 
@@ -269,6 +271,13 @@ int samrs_k_gemm_gln(int prec, const void* A_et, const void* B_et, void* C_et, c
 int samrs_k_upscale2_masks(int prec, const void* u1, const void* w_et, const void* w_lo_et, const float* bias,
                            const float* hyper, float* low, int n, int grid, int n_mask_tokens,
                            int sel0, int n_sel, void* stream);
+/* The whole mask upscaler in one kernel (mask_decoder.py:53-59,154-167): keys_et [n*grid*grid, 256] -> ConvT #1 (w1_et [256][256]
+ * rows = sub-pixel 1 x 64 channels, b1 [256]) -> LayerNorm2d(64) (ln = gamma[64] | beta[64], eps 1e-6) -> GELU -> ConvT #2
+ * (w2_et [128][64] rows = sub-pixel 2 x 32 channels, b2 [128]) -> GELU -> dot with hyper [n, n_mask_tokens, 32] ->
+ * low [n, n_sel, 4*grid, 4*grid] fp32.  keys_lo / w1_lo / w2_lo (all three or none): split precision.  grid % 16 == 0. */
+int samrs_k_upscaler_fused(int prec, const void* keys_et, const void* keys_lo_et, const void* w1_et, const void* w1_lo_et,
+                           const float* b1, const float* ln, const void* w2_et, const void* w2_lo_et, const float* b2,
+                           const float* hyper, float* low, int n, int grid, int n_mask_tokens, int sel0, int n_sel, void* stream);
 /* fp32 -> hi (= samrs_k_convert) and lo = ET(x - hi): the two-term operand split */
 int samrs_k_convert_split(int prec, const float* in, void* out_hi_et, void* out_lo_et, int64_t n, void* stream);
 

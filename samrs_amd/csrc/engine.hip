@@ -83,6 +83,7 @@ struct samrs_engine {
     bool decoder_fusion = true, ln_fold = false;   // per-engine options, see the top of this file
     int split = SPLIT_ALL;
     int gemm_variant = -1;                          // -1 = the library default (launch_gemm_et's automatic choice)
+    bool upscaler_fused = true;                     // one-kernel upscaler (upscaler_fused.hip) instead of ConvT1 GEMM + ConvT2 kernel
 
     // encoder weights / workspaces
     std::vector<EncBlock> blocks;
@@ -335,6 +336,7 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->decoder_fusion = env_int("SAMRS_DECODER_FUSION", 1) != 0;
     e->ln_fold = env_int("SAMRS_LN_FOLD", 0) != 0;
     e->split = env_int("SAMRS_SPLIT", SPLIT_ALL) & SPLIT_ALL;
+    e->upscaler_fused = env_int("SAMRS_UPSCALER_FUSED", 1) != 0;
     return e;
 }
 
@@ -896,8 +898,16 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
     const bool fuse = e->decoder_fusion;
     // SPLIT_UP (fused path only): both transposed convs on hi + lo operands -- ConvT #1 writes its LayerNorm2d + GELU output in
     // fp32 (U1raw), ConvT #2 splits that in registers.  error_budget.py: 376 + 395 of the 899 class-map pixels at ViT-H.
-    const bool sp_up = fuse && (e->split & SPLIT_UP) && Mi % 256 == 0 && (g * g * 4) % 1024 == 0 && tokens % 32 == 0;
-    if (sp_up) {
+    const bool sp_up = fuse && (e->split & SPLIT_UP) && tokens % 32 == 0;      // KE_lo exists (written by the fused i2t kernel)
+    const int sel0 = multimask ? 1 : 0, nsel = multimask ? 3 : 1;     // mask_decoder.py:102-107
+    float* low = lowres_out ? lowres_out : e->LOW;
+    const bool one_kernel = fuse && e->upscaler_fused && g % 16 == 0;
+    if (one_kernel) {
+        // both transposed convs, LayerNorm2d, both GELUs and the hypernetwork product in one kernel (upscaler_fused.hip): the
+        // [rows][256] intermediate never leaves the CU
+        CK(e, launch_upscaler_fused(prec, e->KE, sp_up ? e->KE_lo : nullptr, e->up1_w, sp_up ? e->up1_w_lo : nullptr, e->up1_b, e->up_ln,
+                                    e->up2_w, sp_up ? e->up2_w_lo : nullptr, e->up2_b, e->HYPER, low, n, g, 4, sel0, nsel, s));
+    } else if (sp_up && Mi % 256 == 0 && (g * g * 4) % 1024 == 0) {
         CK(e, launch_gemm_et_gln(prec, e->KE, e->up1_w, e->U1raw, e->up1_b, e->up_ln, Mi, C, C, s, e->KE_lo, e->up1_w_lo));
     } else if (fuse && Mi % 256 == 0) {   // ConvT #1 as a GEMM with LayerNorm2d(64) + GELU fused into its epilogue
         CK(e, launch_gemm_et_gln(prec, e->KE, e->up1_w, e->U1, e->up1_b, e->up_ln, Mi, C, C, s));
@@ -906,9 +916,9 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
         CK(e, launch_group_ln_gelu(prec, e->U1raw, W(e, "mask_decoder.output_upscaling.1.weight"),
                                    W(e, "mask_decoder.output_upscaling.1.bias"), 1e-6f, e->U1, (long)Mi, 4, C / 4, s));
     }
-    const int sel0 = multimask ? 1 : 0, nsel = multimask ? 3 : 1;     // mask_decoder.py:102-107
-    float* low = lowres_out ? lowres_out : e->LOW;
-    if (sp_up) {
+    if (one_kernel) {
+        // done above
+    } else if (sp_up && Mi % 256 == 0 && (g * g * 4) % 1024 == 0) {
         CK(e, launch_upscale2_masks(prec, e->U1raw, e->up2_w, e->up2_w_lo, e->up2_b, e->HYPER, low, n, g, 4, sel0, nsel, s));
     } else if (fuse && (g * g * 4) % 1024 == 0) {
         CK(e, launch_upscale2_masks(prec, e->U1, e->up2_w, nullptr, e->up2_b, e->HYPER, low, n, g, 4, sel0, nsel, s));
@@ -951,6 +961,7 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     else if (n == "ln_fold") e->ln_fold = value != 0;
     else if (n == "split") e->split = value & SPLIT_ALL;
     else if (n == "gemm_variant") e->gemm_variant = value;
+    else if (n == "upscaler_fused") e->upscaler_fused = value != 0;
     else return fail(e, SAMRS_ERR_BAD_ARG, "unknown option %s", name);
     return SAMRS_OK;
 }
@@ -961,6 +972,7 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
     else if (n == "ln_fold") *value = e->ln_fold;
     else if (n == "split") *value = e->split;
     else if (n == "gemm_variant") *value = e->gemm_variant;
+    else if (n == "upscaler_fused") *value = e->upscaler_fused;
     else return SAMRS_ERR_BAD_ARG;
     return SAMRS_OK;
 }
@@ -1120,6 +1132,12 @@ int samrs_k_gemm_gln(int prec, const void* A, const void* B, void* C, const floa
 int samrs_k_upscale2_masks(int prec, const void* u1, const void* w, const void* w_lo, const float* bias, const float* hyper,
                            float* low, int n, int grid, int n_mask_tokens, int sel0, int n_sel, void* stream) {
     KRET(launch_upscale2_masks(prec, u1, w, w_lo, bias, hyper, low, n, grid, n_mask_tokens, sel0, n_sel, (hipStream_t)stream));
+}
+int samrs_k_upscaler_fused(int prec, const void* keys, const void* keys_lo, const void* w1, const void* w1_lo, const float* b1,
+                           const float* ln, const void* w2, const void* w2_lo, const float* b2, const float* hyper, float* low, int n,
+                           int grid, int n_mask_tokens, int sel0, int n_sel, void* stream) {
+    KRET(launch_upscaler_fused(prec, keys, keys_lo, w1, w1_lo, b1, ln, w2, w2_lo, b2, hyper, low, n, grid, n_mask_tokens, sel0, n_sel,
+                               (hipStream_t)stream));
 }
 int samrs_k_convert_split(int prec, const float* in, void* out_hi, void* out_lo, int64_t n, void* stream) {
     KRET(launch_convert(prec, in, out_hi, (long)n, (hipStream_t)stream, out_lo));

@@ -458,7 +458,7 @@ __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned 
 }
 
 // ---------------------------------------------------------------------------------------------
-// gemm_et_pipe_kernel: 256x128x64 block tile, 512 threads = 8 waves (4 along M x 2 along N, each
+// Shared geometry of the 256x128x64 staggered kernel below (its lock-step round-1 flavour was removed): block tile, 512 threads = 8 waves (4 along M x 2 along N, each
 // a 64x64 sub-tile exactly as above), THREE-stage LDS ring filled by LDS-DMA with a COUNTED
 // s_waitcnt vmcnt: the loads of tile t+2 are issued before computing tile t and only tile t+1 is
 // waited for at the (raw) barrier, so DMA traffic stays in flight across barriers instead of
@@ -488,37 +488,7 @@ __device__ __forceinline__ void glds16_asm(const uint16_t* gsrc, uint32_t wave_l
         : "memory", "scc");
 }
 
-template <int PREC, bool OUT_F32, bool GELU>
-__global__ __launch_bounds__(PTHREADS) void gemm_et_pipe_kernel(
-    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
-    const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
-    int M, int N, int K, int accumulate) {
-    __shared__ __attribute__((aligned(16))) uint16_t lds[PSTAGES * PSTAGE_ELEMS];   // 144 KiB, ONE object
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;               // 0..7
-    const int wm = wave >> 1, wn = wave & 1;
-
-    constexpr int GROUP = 8;
-    const int tiles_n = N / PBN, tiles_m = M / PBM;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_group = GROUP * tiles_n;
-    const int group = bid / per_group, first_m = group * GROUP;
-    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-    const int in_g = bid - group * per_group;
-    const int tile_m = first_m + in_g % gsz, tile_n = in_g / gsz;
-    const int m0 = tile_m * PBM, n0 = tile_n * PBN;
-
-    // DMA map: one glds round = 512 lanes x 16 B = 64 rows; wave w fills rows 64*i + 8w .. +7.
-    const int g_row = 8 * wave + (lane >> 3);
-    const int g_chunk = (lane & 7) ^ ((g_row >> 1) & 7);         // swizzle on the SOURCE (rule 21)
-    const uint16_t* gAg = A + (size_t)(m0 + g_row) * K + g_chunk * 8;
-    const uint16_t* gBg = B + (size_t)(n0 + g_row) * K + g_chunk * 8;
-    // LDS byte address of this wave's first 8-row group in stage 0 / operand A
-    const uint32_t wave_lds_base = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)(tid >> 6) * (8 * BK * 2));
-    const size_t rs64 = (size_t)64 * K;      // 64 rows further down in A / B
+// one K tile (A: 4 x 64 rows, B: 2 x 64 rows) into ring stage `stage_`: six DMA pieces per wave
 #define PIPE_ISSUE(kt_, stage_)                                                                 \
     do {                                                                                         \
         const size_t koff_ = (size_t)(kt_) * BK;                                                 \
@@ -531,95 +501,8 @@ __global__ __launch_bounds__(PTHREADS) void gemm_et_pipe_kernel(
         glds16_asm<SB_ + PBM * BK * 2 + 1 * 64 * BK * 2>(gBg + rs64 + koff_, wave_lds_base);     \
     } while (0)
 
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / BK;
-    PIPE_ISSUE(0, 0);
-    if (nk > 1) {
-        PIPE_ISSUE(1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_GLDS_PER_TILE) : "memory");   // tile 0 landed
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-
-    const int fr = lane & 15, fq = lane >> 4;
-    // The ring is unrolled by its depth so that every stage offset is a compile-time constant:
-    // with a run-time stage index hipcc cannot prove that the in-flight DMA (slot t+2) does not
-    // alias the slot being read (t) and drains vmcnt to 0 in front of the first ds_read of every
-    // K step, which serialises the whole pipeline.
-#define PIPE_STEP(kt_, S_)                                                                       \
-    if ((kt_) < nk) {                                                                            \
-        if ((kt_) + 2 < nk) PIPE_ISSUE((kt_) + 2, ((S_) + 2) % PSTAGES);                         \
-        const uint16_t* la = lds + (S_) * PSTAGE_ELEMS;                                          \
-        const uint16_t* lb = la + PBM * BK;                                                      \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                       \
-            uint4 fa[4], fb[4];                                                                  \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                      \
-                const int r = wm * 64 + j * 16 + fr;                                             \
-                fa[j] = *reinterpret_cast<const uint4*>(la + r * BK + swz(r, ks * 4 + fq) * 8);  \
-            }                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                      \
-                const int r = wn * 64 + i * 16 + fr;                                             \
-                fb[i] = *reinterpret_cast<const uint4*>(lb + r * BK + swz(r, ks * 4 + fq) * 8);  \
-            }                                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                        \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                    \
-                    acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]);                       \
-        }                                                                                        \
-        /* tile kt+1 must be in LDS for EVERY wave before the next step reads it; the tile     */\
-        /* issued in this step may stay in flight.  Raw barrier: __syncthreads() would drain.  */\
-        if ((kt_) + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P_GLDS_PER_TILE) : "memory"); \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
-        __builtin_amdgcn_s_barrier();                                                            \
-    }
-    for (int kt = 0; kt < nk; kt += PSTAGES) {
-        PIPE_STEP(kt, 0)
-        PIPE_STEP(kt + 1, 1)
-        PIPE_STEP(kt + 2, 2)
-    }
-
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + 4 * fq;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) bv = *reinterpret_cast<const float4*>(bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + fr;
-            float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y;
-            float v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
-            if (add2d) {
-                const float4 e = *reinterpret_cast<const float4*>(add2d + (size_t)(m % add2d_period) * N + n);
-                v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
-            }
-            if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
-            if (OUT_F32) {
-                float* C = reinterpret_cast<float*>(Cv) + (size_t)m * N + n;
-                if (accumulate) {
-                    const float4 o = *reinterpret_cast<const float4*>(C);
-                    v0 += o.x; v1 += o.y; v2 += o.z; v3 += o.w;
-                }
-                *reinterpret_cast<float4*>(C) = make_float4(v0, v1, v2, v3);
-            } else {
-                uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)m * N + n;
-                uint2 o;
-                o.x = pack2<PREC>(v0, v1);
-                o.y = pack2<PREC>(v2, v3);
-                *reinterpret_cast<uint2*>(C) = o;
-            }
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// gemm_et_stag_kernel: same tile / ring / DMA as gemm_et_pipe_kernel, but the two waves that share
+// gemm_et_stag_kernel: the tile / ring / DMA described above, and the two waves that share
 // a SIMD (waves w and w+4) run STAGGERED by one barrier interval.  Every K step is cut into four
 // segments separated by raw barriers -- L0 (fragment reads, k 0..31 + DMA issue), C0 (16 MFMAs),
 // L1 (reads, k 32..63), C1 (16 MFMAs) -- and group 1 (waves 4..7) executes one extra barrier up
@@ -2037,135 +1920,6 @@ hipError_t launch_gemm_x64(const void* A, const void* B, void* C, const float* b
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------
-// gemm_et_pers_kernel: the 256x320 kernel above made PERSISTENT -- one block per CU walks tiles
-// L, L + gridDim.x, ...  With one tile per block a CU idles between tiles for the block re-dispatch plus
-// the ~2 us the first ring stage needs to land.  Here the next tile's stages 0 and 1 are issued BEFORE the
-// current tile's epilogue (which confines its bounce scratch to ring slots 2-3), so they land under the
-// epilogue's HBM traffic; after the epilogue: drain (vmcnt 0), one block barrier (scratch free, stages
-// visible), stage 2, and the main loop starts without a fill bubble.  Same main-loop code (macros above).
-// ---------------------------------------------------------------------------------------------
-template <int PREC, bool OUT_F32, bool GELU>
-__global__ __launch_bounds__(QTHREADS) void gemm_et_pers_kernel(
-    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
-    const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
-    int M, int N, int K, int accumulate) {
-    constexpr int NI = 5, ABL = 0;
-    constexpr int QBN = 64 * NI;
-    constexpr int QSTAGE_ELEMS = (QBM + QBN) * QBK;
-    __shared__ __attribute__((aligned(16))) uint16_t lds[QSTAGES * QSTAGE_ELEMS];   // 144 KiB, ONE object
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int wm = wave >> 2, wn = wave & 3;
-    constexpr int GROUP = 8;
-    const int tiles_n = N / QBN, tiles_m = M / QBM, ntiles = tiles_n * tiles_m;
-    const int per_group = GROUP * tiles_n;
-#define PERS_TILE(L_, m_, n_)                                                                    \
-    do {                                                                                         \
-        const int bid_ = xcd_remap((L_), ntiles);                                                \
-        const int group_ = bid_ / per_group, first_m_ = group_ * GROUP;                           \
-        const int gsz_ = (tiles_m - first_m_) < GROUP ? (tiles_m - first_m_) : GROUP;            \
-        const int in_g_ = bid_ - group_ * per_group;                                             \
-        (m_) = (first_m_ + in_g_ % gsz_) * QBM;                                                  \
-        (n_) = (in_g_ / gsz_) * QBN;                                                             \
-    } while (0)
-    const int g_row = 16 * wave + (lane >> 2);
-    const int g_chunk = qswz(g_row, lane & 3);
-    const uint32_t wave_lds_base = __builtin_amdgcn_readfirstlane(
-        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * (16 * QBK * 2));
-    const size_t rs128 = (size_t)128 * K;
-    const int fr = lane & 15, fq = lane >> 4;
-    int offA[8], offB[NI];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const int r = wm * 128 + j * 16 + fr; offA[j] = r * QBK + qswz(r, fq) * 8; }
-#pragma unroll
-    for (int i = 0; i < NI; ++i) { const int r = wn * (16 * NI) + i * 16 + fr; offB[i] = QBM * QBK + r * QBK + qswz(r, fq) * 8; }
-    const int nk = K / QBK;                     // >= 3 (launcher)
-
-    int L = blockIdx.x, m0, n0;
-    PERS_TILE(L, m0, n0);
-    const uint16_t* gAg = A + (size_t)(m0 + g_row) * K + g_chunk * 8;
-    const uint16_t* gBg = B + (size_t)(n0 + g_row) * K + g_chunk * 8;
-    BIG_ISSUE(0, 0);
-    BIG_ISSUE(1, 1);
-    BIG_ISSUE(2, 2);
-    BIG_VMCNT(2);
-    __builtin_amdgcn_s_barrier();
-    f32x4_t acc[NI][8];
-    for (;;) {
-        if (grp == 1) __builtin_amdgcn_s_barrier();          // stagger
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; kt += QSTAGES) {
-            BIG_STEP(kt, 0)
-            BIG_STEP(kt + 1, 1)
-            BIG_STEP(kt + 2, 2)
-            BIG_STEP(kt + 3, 3)
-        }
-        if (grp == 0) __builtin_amdgcn_s_barrier();          // re-align the groups: every ring read is done
-
-        // next tile: stages 0 and 1 go out now and land under the epilogue
-        const int Ln = L + (int)gridDim.x;
-        const bool more = Ln < ntiles;
-        int m1 = m0, n1 = n0;
-        if (more) PERS_TILE(Ln, m1, n1);
-        const uint16_t* gAcur = gAg;
-        const uint16_t* gBcur = gBg;
-        (void)gAcur; (void)gBcur;
-        if (more) {
-            gAg = A + (size_t)(m1 + g_row) * K + g_chunk * 8;
-            gBg = B + (size_t)(n1 + g_row) * K + g_chunk * 8;
-            BIG_ISSUE(0, 0);
-            BIG_ISSUE(1, 1);
-        }
-        {   // epilogue of tile (m0, n0); bounce scratch = ring slots 2-3 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
-            unsigned char* upper = reinterpret_cast<unsigned char*>(lds) + 2 * QSTAGE_ELEMS * 2;
-            const float* pre2d = OUT_F32 ? nullptr : add2d;
-            if constexpr (!OUT_F32) {
-                epilogue_pair_et<PREC, GELU, 2>(acc, upper, Cv, bias, pre2d, add2d_period, N, m0 + wm * 128, n0 + (wn >> 1) * 160,
-                                                wm, wn, lane);
-            } else {
-                epilogue_coalesced<PREC, true, GELU, 8, 1, NI>(acc, upper + wave * (2 * QSTAGE_ELEMS * 2 / 8), Cv, bias, add2d,
-                                                               add2d_period, N, m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane);
-            }
-        }
-        if (!more) break;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores drained, its stage-0/1 pieces landed
-        __builtin_amdgcn_s_barrier();                          // ... for every wave; scratch region free again
-        L = Ln; m0 = m1; n0 = n1;
-        BIG_ISSUE(2, 2);
-    }
-#undef PERS_TILE
-}
-
-template <int PREC>
-hipError_t launch_gemm_pers(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
-                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
-    const int ntiles = (M / QBM) * (N / WBN);
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-        return n > 0 ? n : 256;
-    }();
-    dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(QTHREADS);
-    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
-    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
-    const int acc = accumulate ? 1 : 0;
-    if (out_f32) {
-        if (gelu) gemm_et_pers_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-        else gemm_et_pers_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-    } else {
-        if (gelu) gemm_et_pers_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-        else gemm_et_pers_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-    }
-    return hipGetLastError();
-}
-
 template <int PREC, int NI = 4>
 hipError_t launch_gemm_big(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
@@ -2349,23 +2103,6 @@ hipError_t launch_gemm_dual(const void* A, const void* B, void* C, const float* 
     } else {
         if (gelu) gemm_et_dual_kernel<PREC, false, true, STAG><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
         else gemm_et_dual_kernel<PREC, false, false, STAG><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-    }
-    return hipGetLastError();
-}
-
-template <int PREC>
-hipError_t launch_gemm_pipe(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
-                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
-    dim3 grid((M / PBM) * (N / PBN)), block(PTHREADS);
-    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
-    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
-    const int acc = accumulate ? 1 : 0;
-    if (out_f32) {
-        if (gelu) gemm_et_pipe_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-        else gemm_et_pipe_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-    } else {
-        if (gelu) gemm_et_pipe_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
-        else gemm_et_pipe_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, add2d, period, M, N, K, acc);
     }
     return hipGetLastError();
 }
@@ -2822,12 +2559,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         if (prec == PREC_F16) return launch_gemm_dual<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
     }
-    if (variant == 11 && M % QBM == 0 && N % WBN == 0 && K % QBK == 0 && K >= 3 * QBK) {   // persistent 256x320 kernel
-        if (prec == PREC_BF16) return launch_gemm_pers<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
-        if (prec == PREC_F16) return launch_gemm_pers<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
-        return hipErrorInvalidValue;
-    }
-    if (variant == 11) variant = 10;
+    if (variant == 11) variant = 10;      // (the round-1 persistent 32-deep kernel was removed: 28 is its successor)
     if (variant == 10 && M % QBM == 0 && N % WBN == 0 && K % QBK == 0) {   // 256x320 staggered kernel
         if (prec == PREC_BF16) return launch_gemm_big<PREC_BF16, 5>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_big<PREC_F16, 5>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
@@ -2842,11 +2574,6 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     if ((variant == 5 || variant == 6 || variant == 7 || variant == 9) && M % PBM == 0) {   // staggered-group pipelined kernel
         if (prec == PREC_BF16) return launch_gemm_stag<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         if (prec == PREC_F16) return launch_gemm_stag<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
-        return hipErrorInvalidValue;
-    }
-    if (gv == 4 && M % PBM == 0) {   // pipelined 256x128 kernel (default when M allows)
-        if (prec == PREC_BF16) return launch_gemm_pipe<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
-        if (prec == PREC_F16) return launch_gemm_pipe<PREC_F16>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
     }
     if (prec == PREC_BF16) { GEMM_DISPATCH(PREC_BF16) }

@@ -125,6 +125,14 @@ hipError_t launch_i2t_fused(int prec, const void* qi, int ld, long q_bstride, co
                             long r_bstride, const float* gamma, const float* beta, float eps, float* outF, void* outE,
                             void* outE_lo /* optional split remainder of outE */, int n, int T, int tokens, int Ci, int C, hipStream_t s);
 
+// ---- upscaler_fused.hip ---------------------------------------------------------------------
+// mask_decoder.py:53-59,154-167 in one kernel: keys [n * grid^2][256] ET -> ConvT #1 + LayerNorm2d + GELU -> ConvT #2 + GELU ->
+// hypernetwork dot -> low [n][n_sel][4 grid][4 grid].  w1 [256][256], w2 [128][64] in the GEMM-B layouts of engine.hip, b1 [256] /
+// b2 [128] tiled over the sub-pixels, ln = gamma[64] | beta[64].  *_lo (all three or none): split precision.  grid % 16 == 0.
+hipError_t launch_upscaler_fused(int prec, const void* keys, const void* keys_lo, const void* w1, const void* w1_lo, const float* b1,
+                                 const float* ln, const void* w2, const void* w2_lo, const float* b2, const float* hyper, float* low,
+                                 int n, int grid, int n_mask_tokens, int sel0, int n_sel, hipStream_t s);
+
 // ---- rle_kernels.hip ------------------------------------------------------------------------
 // COCO RLE strings of n binary masks (uint8 [n][h][w], non-zero = set), packed behind *cursor (device int64, in / out)
 // into `out` (device bytes, capacity out_cap) at 16-byte aligned offsets; table [n][3] (device int64) = (offset,

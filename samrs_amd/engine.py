@@ -91,6 +91,7 @@ def load_library() -> C.CDLL:
     lib.samrs_rle_encode.argtypes = [vp, vp, ip, ip, ip, vp, C.c_int64, vp, vp, vp]
     lib.samrs_k_convert_split.argtypes = [ip, vp, vp, vp, C.c_int64, vp]
     lib.samrs_select_best.argtypes = [vp, vp, vp, ip, ip, ip, ip, vp, vp, vp, vp]
+    lib.samrs_k_upscaler_fused.argtypes = [ip, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_convert.argtypes = [ip, vp, vp, C.c_int64, vp]
     lib.samrs_k_layernorm.argtypes = [ip, vp, vp, vp, fp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_window_attention.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
@@ -105,7 +106,8 @@ def load_library() -> C.CDLL:
                  "samrs_k_gemm_f32", "samrs_k_convert", "samrs_k_layernorm", "samrs_k_window_attention",
                  "samrs_k_global_attention", "samrs_k_postprocess", "samrs_k_gemm_gln", "samrs_k_upscale2_masks",
                  "samrs_k_gemm_stats", "samrs_k_gemm_fold", "samrs_k_ln_fold_weight", "samrs_k_rowstats_convert", "samrs_k_ln_rowstat",
-                 "samrs_set_option", "samrs_get_option", "samrs_rle_encode", "samrs_k_convert_split", "samrs_select_best"):
+                 "samrs_set_option", "samrs_get_option", "samrs_rle_encode", "samrs_k_convert_split", "samrs_select_best",
+                 "samrs_k_upscaler_fused"):
         getattr(lib, name).restype = ip
     if lib.samrs_abi_version() != ABI_VERSION:
         raise ImportError("libsamrs_hip.so ABI version mismatch; rebuild it")

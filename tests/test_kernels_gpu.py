@@ -93,7 +93,6 @@ def test_gemm_et_variants(lib, name, prec, dt, ulp, M, N, K):
 
 @pytest.mark.parametrize("variant,M,N,K", [(5, 512, 256, 192), (6, 512, 512, 192), (7, 512, 256, 192), (9, 256, 128, 128),
                                            (10, 512, 640, 192), (10, 256, 640, 64), (6, 256, 256, 64),
-                                           (11, 512, 640, 192), (11, 8192, 3200, 192),
                                            # pair-stage (64-deep, whole-cache-line DMA) kernels: one stage, odd / even stage counts, many tiles
                                            (20, 256, 256, 64), (20, 512, 512, 192), (20, 1024, 768, 320), (21, 256, 640, 64),
                                            (21, 512, 640, 192), (21, 2048, 1280, 256), (22, 512, 512, 192), (22, 256, 256, 128),
@@ -104,7 +103,7 @@ def test_gemm_et_variants(lib, name, prec, dt, ulp, M, N, K):
                                            # persistent pair-stage kernel: 1 tile per block, blocks that walk 2 / 3 tiles, odd stage count
                                            (28, 512, 640, 192), (28, 8192, 3200, 192), (28, 256, 640, 64), (28, 16384, 3840, 320)])
 def test_gemm_every_tile_variant(lib, variant, M, N, K):
-    """(variant 11 = the persistent 256x320 kernel; 8192 x 3200 gives 320 tiles, so 64 blocks walk two tiles.)
+    """(variant 28 = the persistent 256x320 kernel; 8192 x 3200 gives 320 tiles, so 64 blocks walk two tiles.)
     Each tile shape of the pipelined GEMM forced explicitly (the auto rule only picks the 256x256 / 256x320
     kernels at sizes the unit tests do not reach): fp32 accumulate output, f16 output with 2-D addend, GELU output."""
     name, prec, dt, ulp = PRECS[0]
@@ -507,6 +506,54 @@ def test_upscale2_masks_fused(lib, name, prec, dt, ulp, n_sel, sel0):
     print(f"upscale2+mask split {name} n_sel={n_sel}: rel {r:.2e} max {mx:.2e}")
     assert not torch.isnan(low).any()
     assert r < (3e-6 if name == "f16" else 1e-4)
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("n_sel,sel0", [(1, 0), (3, 1)])
+@pytest.mark.parametrize("split", [False, True])
+def test_upscaler_fused_one_kernel(lib, name, prec, dt, ulp, n_sel, sel0, split):
+    """mask_decoder.py:53-59,154-167 as ONE kernel: ConvT #1 -> LayerNorm2d(64) -> GELU -> ConvT #2 -> GELU -> hypernetwork dot,
+    against the same chain in fp64 (torch conv_transpose2d semantics restated as the two per-token GEMMs).  Un-split: operands
+    pre-rounded on the host, what remains is the rounding of the ConvT #1 activations to the operand type; split: the UN-rounded
+    operands, error an order of magnitude below one operand ulp."""
+    g = torch.Generator().manual_seed(200 + n_sel + 10 * split)
+    n, grid = 3, 16
+    tokens = grid * grid
+    keys = torch.randn(n * tokens, 256, generator=g)
+    w1 = torch.randn(256, 256, generator=g) / 16
+    b1 = 0.3 * torch.randn(256, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(64, generator=g), 0.2 * torch.randn(64, generator=g)
+    w2 = torch.randn(128, 64, generator=g) / 8
+    b2 = 0.3 * torch.randn(128, generator=g)
+    hyper = torch.randn(n, 4, 32, generator=g)
+    if not split:
+        keys, w1, w2 = keys.to(dt).float(), w1.to(dt).float(), w2.to(dt).float()
+    y = (keys.double() @ w1.double().t() + b1.double()).view(-1, 4, 64)                        # (token, s1, c)
+    mu = y.mean(-1, keepdim=True)
+    u1 = F.gelu((y - mu) / torch.sqrt(((y - mu) ** 2).mean(-1, keepdim=True) + 1e-6) * gamma.double() + beta.double())
+    u1r = u1 if split else u1.float().to(dt).double()                                             # the un-split kernel rounds here
+    up2 = F.gelu(u1r.reshape(-1, 64) @ w2.double().t() + b2.double())                            # rows (token, s1), cols (s2, c2)
+    up2 = up2.view(n, grid, grid, 2, 2, 2, 2, 32)                                                # b, y, x, dy, dx, dy2, dx2, c
+    S = 4 * grid
+    ref = torch.einsum("byxijklc,bsc->bsyikxjl", up2, hyper[:, sel0:sel0 + n_sel].double()).reshape(n, n_sel, S, S)
+    low = torch.full((n, n_sel, S, S), float("nan"), device="cuda")
+    if split:
+        kh, kl = split_bits(lib, prec, keys)
+        w1h, w1l = split_bits(lib, prec, w1)
+        w2h, w2l = split_bits(lib, prec, w2)
+        ptrs = (kh.data_ptr(), kl.data_ptr(), w1h.data_ptr(), w1l.data_ptr(), w2h.data_ptr(), w2l.data_ptr())
+    else:
+        kh, w1h, w2h = dev(keys.to(dt).view(torch.int16)), dev(w1.to(dt).view(torch.int16)), dev(w2.to(dt).view(torch.int16))
+        ptrs = (kh.data_ptr(), None, w1h.data_ptr(), None, w2h.data_ptr(), None)
+    gb = dev(torch.cat([gamma, beta]))
+    assert lib.samrs_k_upscaler_fused(prec, ptrs[0], ptrs[1], ptrs[2], ptrs[3], dev(b1).data_ptr(), gb.data_ptr(), ptrs[4], ptrs[5],
+                                      dev(b2).data_ptr(), dev(hyper).data_ptr(), low.data_ptr(), n, grid, 4, sel0, n_sel, stream()) == 0
+    torch.cuda.synchronize()
+    assert not torch.isnan(low).any(), "some low-res pixels were never written"
+    r, mx = rel_err(low.cpu(), ref)
+    print(f"fused upscaler {name} split={split} n_sel={n_sel}: rel {r:.2e} max {mx:.2e}")
+    tol = {("f16", False): 4e-4, ("f16", True): 1e-5, ("bf16", False): 3e-3, ("bf16", True): 2e-4}[(name, split)]
+    assert r < tol
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)

@@ -54,6 +54,11 @@ def test_oracle_matches_reference_vit_b(golden_dir):
 
 
 @pytest.mark.slow
+def test_oracle_matches_reference_vit_l(golden_dir):
+    _check("vit_l", golden_dir, [(1024, 1024)])
+
+
+@pytest.mark.slow
 def test_oracle_matches_reference_c2_c4_vit_b(golden_dir):
     """The C2 (32 hboxes, 20 + 12 chunks) and C4 (enclosing hbox / rbox mask prompt, multimask) fixtures on the
     realistic-margin weights: full-resolution masks of the REAL reference vs the oracle.  fp32 on both sides, so the

@@ -239,9 +239,10 @@ def test_operand_split_buys_what_the_error_budget_says():
     assert res[15][1] < 0.5 * res[0][1], res           # out-projection + upscaler are ~90 % of the decoder's error variance
 
 
-@pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80", "vit_b", "vit_h"])
+@pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80", "vit_b", "vit_l", "vit_h"])
 def test_against_reference_golden(name, golden_dir):
-    """Replay the committed fixtures produced by the REAL reference (oracle/make_golden.py)."""
+    """Replay the committed fixtures produced by the REAL reference (oracle/make_golden.py).  vit_l (embed_dim 1024,
+    build_sam.py:27-34) takes GEMM tile mixes no other registry entry reaches (N = 1024 / 3072 / 4096: not multiples of 320)."""
     from oracle.make_golden import cases, run_predictor
     so = _oracle()
     g = np.load(os.path.join(golden_dir, name + ".npz"))
@@ -607,6 +608,28 @@ def test_decoder_fused_kernels_match_unfused():
     # random weights put many logits next to the 0 threshold: a 1e-4-relative logit change flips a few hundred of 33.5 M pixels
     assert diff < 1e-4 * m0.numel()
     assert (q1 - q0).abs().max().item() < 1e-3
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path -- barrier + MAX-over-ranks timing, the shared-counter work queue named per phase, the statistics
+    all-reduce on device tensors -- with both ranks on this GPU over gloo (SAMRS_BENCH_SHARE_GPU=1): the control flow the
+    driver's multi-GPU run takes, exercised on every 1-GPU box.  RCCL itself needs a multi-GPU node and is not covered."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAMRS_BENCH_SHARE_GPU="1", PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--model", "vit_tiny", "--workload", "c3",
+           "--steps", "3", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--no-alt-dtype", "--no-pcie-leg", "--no-rle-leg"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["tiles_per_step"] == 4
+    assert d["value"] > 0 and abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]      # whole-job tiles / MAX time
+    assert d["stats_allreduce"]["total_instances"] > 0
 
 
 @pytest.mark.parametrize("batch", [2, 3, 5])

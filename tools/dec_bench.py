@@ -24,8 +24,11 @@ def main() -> None:
     eng.set_images(tile, 0)
     b, _ = synth.make_boxes(0, 32)
     boxes = torch.from_numpy(b).to(dev)
-    for split in ([int(v) for v in os.environ["DEC_SPLITS"].split(",")] if os.environ.get("DEC_SPLITS") else [eng.get_option("split")]):
+    splits = [int(v) for v in os.environ["DEC_SPLITS"].split(",")] if os.environ.get("DEC_SPLITS") else [eng.get_option("split")]
+    ufs = [int(v) for v in os.environ["DEC_UF"].split(",")] if os.environ.get("DEC_UF") else [eng.get_option("upscaler_fused")]
+    for split, uf in [(s_, u_) for s_ in splits for u_ in ufs]:
         eng.set_option("split", split)
+        eng.set_option("upscaler_fused", uf)
         for _ in range(3):
             eng.predict(0, boxes, None, None, None, False, False, (1024, 1024), (1024, 1024))
         torch.cuda.synchronize()
@@ -34,7 +37,7 @@ def main() -> None:
             eng.predict(0, boxes, None, None, None, False, False, (1024, 1024), (1024, 1024))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
-        print(f"predict(32 boxes) {model} split={split}: {dt * 1e3:.3f} ms")
+        print(f"predict(32 boxes) {model} split={split} upscaler_fused={uf}: {dt * 1e3:.3f} ms")
 
 
 if __name__ == "__main__":

@@ -138,6 +138,5 @@ hipError_t launch_upscaler_fused(int prec, const void* keys, const void* keys_lo
 // into `out` (device bytes, capacity out_cap) at 16-byte aligned offsets; table [n][3] (device int64) = (offset,
 // length, n_counts), length < 0: did not fit (-length - 1 bytes were needed).  scratch: rle_scratch_bytes(n, h, w).
 size_t rle_scratch_bytes(int n, int h, int w);
-size_t rle_str_capacity(int h, int w);
 hipError_t launch_rle_encode(const uint8_t* masks, int n, int h, int w, void* scratch, unsigned char* out, long long out_cap,
                              long long* cursor, long long* table, hipStream_t s);

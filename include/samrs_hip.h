@@ -180,6 +180,10 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    (hi + lo, three MFMAs, ~2^-22 operand error instead of 2^-11): 1 = patch embed, 2 = neck, 4 = decoder
  *                    image->token out-projection, 8 = decoder upscaler (both transposed convs).  What each bit buys in mask
  *                    pixels: oracle/error_budget.py, DESIGN.md 2.  0 = the round-2 engine's arithmetic.
+ *                    Reference-grade bits, not in the default: 16 = the encoder blocks' qkv + proj GEMMs, 32 = their MLP GEMMs
+ *                    (three times the MFMA work of what they cover; 63 = every MFMA operand of the path split).  They need lo
+ *                    copies of the block weights: set them BEFORE samrs_finalize_weights (SAMRS_SPLIT=63 / the option); they
+ *                    can be cleared and set again afterwards.
  *   "decoder_fusion" [SAMRS_DECODER_FUSION, default 1] 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm /
  *                    product launches; never split): the fused-vs-unfused parity test and timing experiments.
  *   "ln_fold"        [SAMRS_LN_FOLD, default 0] (embed_dim 1280) 1 = fold the encoder blocks' LayerNorms into the qkv / lin1

@@ -134,6 +134,16 @@ def main(argv):
         report("E3: E2 + proj_in split", "f16_patchneckprojsplit",
                so.Rounding(enc=F16, dec=F16, points=dict(cheap, **{"dec.oi": sp, "dec.up1": sp, "dec.up2": sp, "dec.keys": sp,
                                                                     "enc.proj_in": sp})))
+    if what in ("plans3",):
+        # which block GEMMs would have to run split as well for the C4 fixture to clear 0.999 at ViT-H (cost: +2x that GEMM's FLOPs)
+        sp = so.split2(F16)
+        e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
+        for label, pts in (("E1 + proj + lin2 split", ("enc.proj_in", "enc.lin2_in")),
+                           ("E1 + proj + qkv split", ("enc.proj_in", "enc.qkv_in")),
+                           ("E1 + proj + lin1 + lin2 split", ("enc.proj_in", "enc.lin1_in", "enc.lin2_in")),
+                           ("E1 + all four block GEMMs split", ("enc.proj_in", "enc.qkv_in", "enc.lin1_in", "enc.lin2_in"))):
+            report(label, "p3_" + "_".join(q.split(".")[1] for q in pts),
+                   so.Rounding(enc=F16, dec=F16, points=dict(e1, **{q: sp for q in pts})))
     if what in ("plans", "all"):
         sp = so.split2(F16)
         report("plan A: encoder f16, decoder operands split f16 (hi+lo)", "f16",

@@ -378,10 +378,11 @@ struct WinCfg {
     static constexpr int LDS_BYTES = K_BYTES + VT_BYTES + S_BYTES + TAB_BYTES + BIAS_BYTES;
 };
 
-template <int PREC, int HD>
+template <int PREC, int HD, bool LO = false>
 __global__ __launch_bounds__(512) void window_attention_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ rel_h,
-    const float* __restrict__ rel_w, uint16_t* __restrict__ out, int grid, int heads, int n_items) {
+    const float* __restrict__ rel_w, uint16_t* __restrict__ out, int grid, int heads, int n_items,
+    uint16_t* __restrict__ out_lo = nullptr /* LO: the split remainder of out (reference-grade mode) */) {
     using C = WinCfg<HD>;
     constexpr int KS = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -660,7 +661,8 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
         if (qin) {
             const float inv = 1.0f / l_run;
-            uint16_t* orow = out + (size_t)im * img_rows * D + (size_t)(qoff / (3 * D)) * D + head * HD;
+            const size_t obase = (size_t)im * img_rows * D + (size_t)(qoff / (3 * D)) * D + head * HD;
+            uint16_t* orow = out + obase;
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
@@ -671,6 +673,12 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
                         o.x = pack2_fast<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
                         o.y = pack2_fast<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
                         *reinterpret_cast<uint2*>(orow + d0) = o;
+                        if constexpr (LO) {
+                            uint2 h, l;
+                            split2_pack<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv, h.x, l.x);
+                            split2_pack<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv, h.y, l.y);
+                            *reinterpret_cast<uint2*>(out_lo + obase + d0) = l;
+                        }
                     }
                 }
         }
@@ -767,10 +775,11 @@ struct GlbCfg {
 // NW waves = NW x 32 queries per block.  NW = 8 (one block per CU, 113 KiB of LDS): the K / V^T tiles are staged once for
 // 256 queries, which halves the LDS-DMA pieces each wave has to push through the CU's texture-address queue per tile
 // (measured: ~150 cycles of issue time per piece and wave; 22 pieces per tile and block).
-template <int PREC, int HD, int NW>
+template <int PREC, int HD, int NW, bool LO = false>
 __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, const float* __restrict__ rel_h,
-    const float* __restrict__ rel_w, uint16_t* __restrict__ out, int heads) {
+    const float* __restrict__ rel_w, uint16_t* __restrict__ out, int heads,
+    uint16_t* __restrict__ out_lo = nullptr /* LO: the split remainder of out */) {
     using C = GlbCfg<HD, NW>;
     constexpr int KS = HD / 16;
     constexpr int QPB = 32 * NW, NTH = 64 * NW;     // queries / threads per block
@@ -985,7 +994,8 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
     if constexpr (ONES) l_run = ones_row_sum<HD, C::DT>(O, hh);
     else l_run += xhalf_partner(l_run);
     const float inv = 1.0f / l_run;
-    uint16_t* orow = out + ((size_t)im * NTOK + q) * D + head * HD;
+    const size_t obase = ((size_t)im * NTOK + q) * D + head * HD;
+    uint16_t* orow = out + obase;
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
@@ -996,6 +1006,12 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
                 o.x = pack2_fast<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
                 o.y = pack2_fast<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + d0) = o;
+                if constexpr (LO) {
+                    uint2 h, l;
+                    split2_pack<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv, h.x, l.x);
+                    split2_pack<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv, h.y, l.y);
+                    *reinterpret_cast<uint2*>(out_lo + obase + d0) = l;
+                }
             }
         }
 }
@@ -1190,11 +1206,11 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
     return hipGetLastError();
 }
 
-template <int PREC, int HD>
+template <int PREC, int HD, bool LO = false>
 static hipError_t launch_win(const void* qkv, const float* qb, const float* rh, const float* rw, void* out, int n_images,
-                             int grid, int heads, hipStream_t s) {
+                             int grid, int heads, hipStream_t s, void* out_lo = nullptr) {
     using C = WinCfg<HD>;
-    auto k = window_attention_kernel<PREC, HD>;
+    auto k = window_attention_kernel<PREC, HD, LO>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
     if (heads * HD > C::MAX_D) return hipErrorInvalidValue;
     const int nw = (grid + C::WS - 1) / C::WS;
@@ -1205,59 +1221,86 @@ static hipError_t launch_win(const void* qkv, const float* qb, const float* rh, 
         return n > 0 ? n : 256;
     }();
     dim3 g(n_items < n_cu ? n_items : n_cu), b(C::THREADS);      // persistent: one block per CU (LDS-limited)
-    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, qb, rh, rw, (uint16_t*)out, grid, heads, n_items);
+    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, qb, rh, rw, (uint16_t*)out, grid, heads, n_items, (uint16_t*)out_lo);
     return hipGetLastError();
 }
 
 hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
-                                   int n_images, int grid, int window, int heads, int head_dim, hipStream_t s) {
+                                   int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo) {
     if (window != 14) return hipErrorInvalidValue;
+#define WIN_CALL(P, H)                                                                                                          \
+    return out_lo ? launch_win<P, H, true>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s, out_lo)                  \
+                  : launch_win<P, H, false>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s)
     if (prec == PREC_BF16) {
-        if (head_dim == 64) return launch_win<PREC_BF16, 64>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s);
-        if (head_dim == 80) return launch_win<PREC_BF16, 80>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s);
+        if (head_dim == 64) WIN_CALL(PREC_BF16, 64);
+        if (head_dim == 80) WIN_CALL(PREC_BF16, 80);
     } else if (prec == PREC_F16) {
-        if (head_dim == 64) return launch_win<PREC_F16, 64>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s);
-        if (head_dim == 80) return launch_win<PREC_F16, 80>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s);
+        if (head_dim == 64) WIN_CALL(PREC_F16, 64);
+        if (head_dim == 80) WIN_CALL(PREC_F16, 80);
     }
+#undef WIN_CALL
     return hipErrorInvalidValue;
 }
 
 // waves per block of the global attention kernel: 8 (256 queries, one block per CU) by default, 4 = the two-blocks-per-CU shape
 static int g_glb_waves = [] { const char* v = getenv("SAMRS_GLB_WAVES"); return (v && atoi(v) == 4) ? 4 : 8; }();
 
-template <int PREC, int HD, int NW>
+template <int PREC, int HD, int NW, bool LO = false>
 static hipError_t launch_glb_nw(const void* qkv, const float* rh, const float* rw, void* out, int n_images,
-                                int heads, void* vt_ws, hipStream_t s) {
+                                int heads, void* vt_ws, hipStream_t s, void* out_lo = nullptr) {
     using C = GlbCfg<HD, NW>;
     constexpr int NTOK = C::G * C::G;
-    auto k = global_attention_kernel<PREC, HD, NW>;
+    auto k = global_attention_kernel<PREC, HD, NW, LO>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
     dim3 g((NTOK / (32 * NW)) * heads * n_images), b(64 * NW);
-    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, (const uint16_t*)vt_ws, rh, rw, (uint16_t*)out, heads);
+    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, (const uint16_t*)vt_ws, rh, rw, (uint16_t*)out, heads, (uint16_t*)out_lo);
     return hipGetLastError();
 }
 
 template <int PREC, int HD>
 static hipError_t launch_glb(const void* qkv, const float* rh, const float* rw, void* out, int n_images,
-                             int heads, void* vt_ws, hipStream_t s) {
+                             int heads, void* vt_ws, hipStream_t s, void* out_lo) {
     constexpr int NTOK = GlbCfg<HD>::G * GlbCfg<HD>::G;
     vt_pack_kernel<HD><<<n_images * heads * (NTOK / 64), 256, 0, s>>>((const uint16_t*)qkv, (uint16_t*)vt_ws, heads, NTOK);
     HIP_CHECK_RET(hipGetLastError());
+    if (out_lo) return launch_glb_nw<PREC, HD, 8, true>(qkv, rh, rw, out, n_images, heads, vt_ws, s, out_lo);
     if (g_glb_waves == 4) return launch_glb_nw<PREC, HD, 4>(qkv, rh, rw, out, n_images, heads, vt_ws, s);
     return launch_glb_nw<PREC, HD, 8>(qkv, rh, rw, out, n_images, heads, vt_ws, s);
 }
 
 hipError_t launch_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
-                                   int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s) {
+                                   int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s, void* out_lo) {
     if (grid != 64 || !vt_ws) return hipErrorInvalidValue;
     if (prec == PREC_BF16) {
-        if (head_dim == 64) return launch_glb<PREC_BF16, 64>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s);
-        if (head_dim == 80) return launch_glb<PREC_BF16, 80>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s);
+        if (head_dim == 64) return launch_glb<PREC_BF16, 64>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo);
+        if (head_dim == 80) return launch_glb<PREC_BF16, 80>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo);
     } else if (prec == PREC_F16) {
-        if (head_dim == 64) return launch_glb<PREC_F16, 64>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s);
-        if (head_dim == 80) return launch_glb<PREC_F16, 80>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s);
+        if (head_dim == 64) return launch_glb<PREC_F16, 64>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo);
+        if (head_dim == 80) return launch_glb<PREC_F16, 80>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo);
     }
     return hipErrorInvalidValue;
+}
+
+// reference-grade mode: the fp32 result of the three-pass lin1 product -> exact-erf GELU -> hi + lo operands of lin2
+template <int PREC>
+__global__ void gelu_split_kernel(const float* __restrict__ in, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo, long n4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    const float2_t a = gelu_erf2(float2_t{v.x, v.y}), b = gelu_erf2(float2_t{v.z, v.w});
+    uint2 h, l;
+    split2_pack<PREC>(a.x, a.y, h.x, l.x);
+    split2_pack<PREC>(b.x, b.y, h.y, l.y);
+    reinterpret_cast<uint2*>(hi)[i] = h;
+    reinterpret_cast<uint2*>(lo)[i] = l;
+}
+hipError_t launch_gelu_split(int prec, const float* in, void* hi, void* lo, long n, hipStream_t s) {
+    if (n % 4 || !hi || !lo) return hipErrorInvalidValue;
+    const long n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256);
+    if (prec == PREC_BF16) gelu_split_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(in, (uint16_t*)hi, (uint16_t*)lo, n4);
+    else gelu_split_kernel<PREC_F16><<<blocks, 256, 0, s>>>(in, (uint16_t*)hi, (uint16_t*)lo, n4);
+    return hipGetLastError();
 }
 
 hipError_t launch_neck_im2col(const void* in, void* A, int n_images, int grid, int C, hipStream_t s) {

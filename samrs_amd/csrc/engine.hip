@@ -34,7 +34,10 @@ struct DevTensor {
 //   split          (SAMRS_SPLIT, default 15): bit mask of the rounding points that run as a two-term operand split (3 MFMAs,
 //                  ~2^-22 operand error): 1 patch embed, 2 neck, 4 decoder i2t out-projection, 8 decoder upscaler (both
 //                  transposed convs).  oracle/error_budget.py measures what each bit buys; DESIGN.md 2 has the table.
-enum { SPLIT_PATCH = 1, SPLIT_NECK = 2, SPLIT_OI = 4, SPLIT_UP = 8, SPLIT_ALL = 15 };
+//                  16 = the blocks' qkv + proj GEMMs, 32 = the blocks' MLP GEMMs: the REFERENCE-GRADE bits -- three times the MFMA
+//                  work of the GEMMs they cover, not part of the default; they need their lo weights, i.e. must be set before
+//                  samrs_finalize_weights (SAMRS_SPLIT=63 or the option), and can be cleared / set again afterwards.
+enum { SPLIT_PATCH = 1, SPLIT_NECK = 2, SPLIT_OI = 4, SPLIT_UP = 8, SPLIT_DEFAULT = 15, SPLIT_ATTN = 16, SPLIT_MLP = 32, SPLIT_ALL = 63 };
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 struct DecAttn {
@@ -56,6 +59,7 @@ struct EncBlock {
     bool global = false;
     const float *ln1w, *ln1b, *ln2w, *ln2b, *qkv_b, *proj_b, *lin1_b, *lin2_b, *rel_h, *rel_w;
     uint16_t *qkv_w = nullptr, *proj_w = nullptr, *lin1_w = nullptr, *lin2_w = nullptr;
+    uint16_t *qkv_w_lo = nullptr, *proj_w_lo = nullptr, *lin1_w_lo = nullptr, *lin2_w_lo = nullptr;   // reference-grade bits only
     // LayerNorm folded into qkv / lin1 (ViT-H): W diag(gamma) in ET, its row sums, b + W beta
     uint16_t *qkv_wf = nullptr, *lin1_wf = nullptr;
     float *qkv_c = nullptr, *qkv_bf = nullptr, *lin1_c = nullptr, *lin1_bf = nullptr;
@@ -81,7 +85,8 @@ struct samrs_engine {
     int grid = 64, tokens = 4096, D = 0, C = 256, hd = 0, nwin = 5;
     int T_max = 0;
     bool decoder_fusion = true, ln_fold = false;   // per-engine options, see the top of this file
-    int split = SPLIT_ALL;
+    int split = SPLIT_DEFAULT;
+    int split_ready = SPLIT_DEFAULT;                // bits whose lo weights / workspaces exist (fixed at samrs_finalize_weights)
     int gemm_variant = -1;                          // -1 = the library default (launch_gemm_et's automatic choice)
     bool upscaler_fused = true;                     // one-kernel upscaler (upscaler_fused.hip) instead of ConvT1 GEMM + ConvT2 kernel
 
@@ -96,6 +101,8 @@ struct samrs_engine {
     bool can_fold = false;         // embed_dim == 1280 and the folded weights exist
     uint16_t* QKV = nullptr;       // [Bi*tokens, 3D], token order
     uint16_t* AO = nullptr;        // attention out [Bi*tokens, D]
+    uint16_t *Ylo = nullptr, *AOlo = nullptr, *Hlo = nullptr;   // reference-grade split: remainders of Y, AO, H
+    float* F32T = nullptr;         // reference-grade split: fp32 result of a three-pass qkv / lin1 product [Bi*tokens, 4D]
     uint16_t* VTG = nullptr;       // V of a global-attention block transposed per head: [Bi][heads][hd][tokens]
     uint16_t* H = nullptr;         // MLP hidden [Bi*tokens, 4D]  (also patch im2col / neck im2col)
     float* N1 = nullptr;           // neck fp32 [Bi*tokens, C]
@@ -335,7 +342,7 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->slot_set.assign(cfg->max_images, 0);
     e->decoder_fusion = env_int("SAMRS_DECODER_FUSION", 1) != 0;
     e->ln_fold = env_int("SAMRS_LN_FOLD", 0) != 0;
-    e->split = env_int("SAMRS_SPLIT", SPLIT_ALL) & SPLIT_ALL;
+    e->split = env_int("SAMRS_SPLIT", SPLIT_DEFAULT) & SPLIT_ALL;
     e->upscaler_fused = env_int("SAMRS_UPSCALER_FUSED", 1) != 0;
     return e;
 }
@@ -429,10 +436,11 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
                                         b.lin1_c, b.lin1_bf, 4 * D, D, s));
             e->can_fold = true;
         }
-        if ((rc = to_et(e, p + ".attn.qkv.weight", &b.qkv_w, true, s))) return rc;
-        if ((rc = to_et(e, p + ".attn.proj.weight", &b.proj_w, true, s))) return rc;
-        if ((rc = to_et(e, p + ".mlp.lin1.weight", &b.lin1_w, true, s))) return rc;
-        if ((rc = to_et(e, p + ".mlp.lin2.weight", &b.lin2_w, true, s))) return rc;
+        const bool lo_a = (e->split & SPLIT_ATTN) != 0, lo_m = (e->split & SPLIT_MLP) != 0;
+        if ((rc = to_et(e, p + ".attn.qkv.weight", &b.qkv_w, true, s, lo_a ? &b.qkv_w_lo : nullptr))) return rc;
+        if ((rc = to_et(e, p + ".attn.proj.weight", &b.proj_w, true, s, lo_a ? &b.proj_w_lo : nullptr))) return rc;
+        if ((rc = to_et(e, p + ".mlp.lin1.weight", &b.lin1_w, true, s, lo_m ? &b.lin1_w_lo : nullptr))) return rc;
+        if ((rc = to_et(e, p + ".mlp.lin2.weight", &b.lin2_w, true, s, lo_m ? &b.lin2_w_lo : nullptr))) return rc;
         b.ln1w = W(e, p + ".norm1.weight"); b.ln1b = W(e, p + ".norm1.bias");
         b.ln2w = W(e, p + ".norm2.weight"); b.ln2b = W(e, p + ".norm2.bias");
         b.qkv_b = W(e, p + ".attn.qkv.bias"); b.proj_b = W(e, p + ".attn.proj.bias");
@@ -509,6 +517,13 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->QKV, Mmax * 3 * D));
     CK(e, dalloc(e, &e->AO, M * D));
     CK(e, dalloc(e, &e->VTG, M * D));
+    e->split_ready = SPLIT_DEFAULT | (e->split & (SPLIT_ATTN | SPLIT_MLP));
+    if (e->split & (SPLIT_ATTN | SPLIT_MLP)) {
+        CK(e, dalloc(e, &e->Ylo, M * D));
+        CK(e, dalloc(e, &e->F32T, M * 4 * D));
+        if (e->split & SPLIT_ATTN) CK(e, dalloc(e, &e->AOlo, M * D));
+        if (e->split & SPLIT_MLP) CK(e, dalloc(e, &e->Hlo, M * 4 * D));
+    }
     size_t hsz = M * 4 * D;
     if (M * 9 * C * 2 > hsz) hsz = M * 9 * C * 2;      // neck im2col, hi + lo
     if (M * 768 > hsz) hsz = M * 768;
@@ -582,7 +597,10 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     // Folded LayerNorm (embed_dim 1280): no LayerNorm launches inside the blocks.  Y holds the residual stream rounded to ET and
     // STATS its per-row partial statistics, both written by the epilogue of the GEMM that produced X (proj, lin2; here, once,
     // by rowstats_convert); qkv / lin1 run on the gamma-folded weights and normalise in their epilogue (gemm.hip).
-    const bool fold = e->can_fold && e->ln_fold;
+    // reference-grade bits: the block GEMMs on hi + lo operands (qkv / lin1: three passes into an fp32 scratch, then one
+    // rounding to the operand type; proj / lin2: two more accumulating passes into the residual stream)
+    const bool sp_attn = (e->split & SPLIT_ATTN) != 0, sp_mlp = (e->split & SPLIT_MLP) != 0;
+    const bool fold = e->can_fold && e->ln_fold && !sp_attn && !sp_mlp;
     if (fold && n_blocks > 0) {
         CK(e, launch_rowstats_convert(prec, e->X, e->Y, e->STATS, M, D, s));
         CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
@@ -593,20 +611,32 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         // on the fly and takes k / v of padding positions from the qkv bias
         if (fold) {
             CK(e, launch_gemm_et_fold(prec, e->Y, b.qkv_wf, e->QKV, b.qkv_bf, b.qkv_c, e->ROWSTAT, M, 3 * D, D, false, s));
+        } else if (sp_attn) {
+            CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, e->Ylo));
+            CK(e, launch_gemm_et(prec, e->Ylo, b.qkv_w, e->F32T, nullptr, nullptr, 0, M, 3 * D, D, true, false, false, s));
+            CK(e, launch_gemm_et(prec, e->Y, b.qkv_w_lo, e->F32T, nullptr, nullptr, 0, M, 3 * D, D, true, false, true, s));
+            CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->F32T, b.qkv_b, nullptr, 0, M, 3 * D, D, true, false, true, s));
+            CK(e, launch_convert(prec, e->F32T, e->QKV, (long)M * 3 * D, s));
         } else {
             CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
             CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
         }
         if (!b.global)
-            CK(e, launch_window_attention(prec, e->QKV, b.qkv_b, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s));
+            CK(e, launch_window_attention(prec, e->QKV, b.qkv_b, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s,
+                                          sp_attn ? e->AOlo : nullptr));
         else
-            CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, e->VTG, s));
+            CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, e->VTG, s,
+                                          sp_attn ? e->AOlo : nullptr));
         if (fold) {
             CK(e, launch_gemm_et_stats(prec, e->AO, b.proj_w, e->X, b.proj_b, e->Y, e->STATS, M, D, D, s));
             CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
         } else {
+            if (sp_attn) {
+                CK(e, launch_gemm_et(prec, e->AOlo, b.proj_w, e->X, nullptr, nullptr, 0, M, D, D, true, false, true, s));
+                CK(e, launch_gemm_et(prec, e->AO, b.proj_w_lo, e->X, nullptr, nullptr, 0, M, D, D, true, false, true, s));
+            }
             CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
-            CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
+            CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, sp_mlp ? e->Ylo : nullptr));
         }
         hipEvent_t t0 = nullptr, t1 = nullptr;
         if (e->timing) {
@@ -618,7 +648,12 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, hipEventRecord(t0, s));
         }
         if (fold) CK(e, launch_gemm_et_fold(prec, e->Y, b.lin1_wf, e->H, b.lin1_bf, b.lin1_c, e->ROWSTAT, M, 4 * D, D, true, s));
-        else CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
+        else if (sp_mlp) {
+            CK(e, launch_gemm_et(prec, e->Ylo, b.lin1_w, e->F32T, nullptr, nullptr, 0, M, 4 * D, D, true, false, false, s));
+            CK(e, launch_gemm_et(prec, e->Y, b.lin1_w_lo, e->F32T, nullptr, nullptr, 0, M, 4 * D, D, true, false, true, s));
+            CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->F32T, b.lin1_b, nullptr, 0, M, 4 * D, D, true, false, true, s));
+            CK(e, launch_gelu_split(prec, e->F32T, e->H, e->Hlo, (long)M * 4 * D, s));
+        } else CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
         if (e->timing) {
             CK(e, hipEventRecord(t1, s));
             e->tev.emplace_back(t0, t1);
@@ -626,7 +661,13 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         if (fold) {
             CK(e, launch_gemm_et_stats(prec, e->H, b.lin2_w, e->X, b.lin2_b, e->Y, e->STATS, M, D, 4 * D, s));
             if (i + 1 < c.depth) CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
-        } else CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
+        } else {
+            if (sp_mlp) {
+                CK(e, launch_gemm_et(prec, e->Hlo, b.lin2_w, e->X, nullptr, nullptr, 0, M, D, 4 * D, true, false, true, s));
+                CK(e, launch_gemm_et(prec, e->H, b.lin2_w_lo, e->X, nullptr, nullptr, 0, M, D, 4 * D, true, false, true, s));
+            }
+            CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
+        }
     }
     if (!do_neck) return SAMRS_OK;
     // neck: 1x1 conv -> LN2d -> 3x3 conv -> LN2d   (all channels-last).  Folded path: Y already is ET(X).
@@ -959,7 +1000,12 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     const std::string n(name);
     if (n == "decoder_fusion") e->decoder_fusion = value != 0;
     else if (n == "ln_fold") e->ln_fold = value != 0;
-    else if (n == "split") e->split = value & SPLIT_ALL;
+    else if (n == "split") {
+        if (e->finalized && (value & (SPLIT_ATTN | SPLIT_MLP) & ~e->split_ready))
+            return fail(e, SAMRS_ERR_BAD_ARG, "split bits 16 / 32 (block GEMMs) need their lo weights: set them before the weights are "
+                                              "finalized (SAMRS_SPLIT or options={'split': ...})");
+        e->split = value & SPLIT_ALL;
+    }
     else if (n == "gemm_variant") e->gemm_variant = value;
     else if (n == "upscaler_fused") e->upscaler_fused = value != 0;
     else return fail(e, SAMRS_ERR_BAD_ARG, "unknown option %s", name);

@@ -50,11 +50,13 @@ hipError_t launch_ln_rowstat(const float* stats, float* rowstat, int rows, float
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
                             int window, hipStream_t s, void* out_lo = nullptr);
+// out_lo (optional, both attention kernels): the split remainder of `out` (reference-grade mode: proj on hi + lo operands)
 hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
-                                   int n_images, int grid, int window, int heads, int head_dim, hipStream_t s);
+                                   int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo = nullptr);
+hipError_t launch_gelu_split(int prec, const float* in, void* hi, void* lo, long n, hipStream_t s);
 // vt_ws: ET workspace of n_images * heads * head_dim * grid^2 elements (receives V transposed per head)
 hipError_t launch_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
-                                   int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s);
+                                   int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s, void* out_lo = nullptr);
 hipError_t launch_neck_im2col(const void* in, void* A, int n_images, int grid, int C, hipStream_t s);
 hipError_t launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t s);
 

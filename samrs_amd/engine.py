@@ -23,7 +23,8 @@ PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16}
 
 ABI_VERSION = 2
 # "split" option bits (include/samrs_hip.h): rounding points that run as a two-term operand split
-SPLIT_PATCH, SPLIT_NECK, SPLIT_OI, SPLIT_UP, SPLIT_ALL = 1, 2, 4, 8, 15
+SPLIT_PATCH, SPLIT_NECK, SPLIT_OI, SPLIT_UP, SPLIT_DEFAULT = 1, 2, 4, 8, 15
+SPLIT_ATTN, SPLIT_MLP, SPLIT_ALL = 16, 32, 63          # reference-grade bits: set before the weights are loaded
 
 OK, ERR_NOT_SET, ERR_BAD_SHAPE, ERR_BAD_ARG, ERR_HIP, ERR_BAD_WEIGHTS, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
 

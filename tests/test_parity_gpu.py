@@ -285,8 +285,8 @@ def _unpack(bits, shape):
     return np.unpackbits(bits, axis=-1).reshape(*bits.shape[:-1], *shape).astype(bool)
 
 
-@pytest.mark.parametrize("name", ["vit_b", "vit_h"])
-def test_c2_c4_against_reference_golden(name, golden_dir):
+@pytest.mark.parametrize("name,split", [("vit_b", 15), ("vit_h", 15), ("vit_h", 31), ("vit_h", 63)])
+def test_c2_c4_against_reference_golden(name, split, golden_dir):
     """BASELINE.json configs[1] (32 hboxes on one tile) and configs[3] (rbox -> enclosing hbox / rbox -> mask prompt,
     multimask_output=True) against FULL-RESOLUTION masks produced by the real reference on the realistic-margin weights
     (oracle/make_golden.py `extended`, fixtures tests/golden/<name>_c2c4.npz).  Asserted, at ViT-H too:
@@ -300,16 +300,22 @@ def test_c2_c4_against_reference_golden(name, golden_dir):
         the engine's logit error stays below tau -- i.e. the only pixels that may differ are the ones where the
         reference's own answer is decided by less than the f16 operand rounding noise (identity on ALL
         pixels is not attainable by any reduced-precision path on a continuous logit field; the count is printed);
-      * low-res logits and IoU predictions within the f16 tolerances of this file's header."""
+      * low-res logits and IoU predictions within the f16 tolerances of this file's header.
+    `split` = the engine's operand-split option: 15 is the default (patch embed, neck, decoder out-projection and upscaler on
+    hi + lo operands); 31 adds the blocks' qkv + proj GEMMs, 63 every block GEMM (the reference-grade bits: three times the
+    MFMA work of what they cover) -- from 31 on the C4 fixture clears the north star's 0.999 at ViT-H too, which shows that
+    the default's 0.9987 is the price of running the four block GEMMs at the 1x f16 rate and nothing else."""
     import samrs_amd
     from samrs_amd import transforms
     from oracle.make_golden import extended_inputs
     g = np.load(os.path.join(golden_dir, name + "_c2c4.npz"))
     cfg = synth.CONFIGS[name]
     sd = synth.make_state_dict(cfg, 0, logit_scale=float(g["logit_scale"]))
-    sam = samrs_amd.sam_model_registry[name](state_dict=sd, precision="f16", max_prompts=32, max_points=1).to("cuda")
+    sam = samrs_amd.sam_model_registry[name](state_dict=sd, precision="f16", max_prompts=32, max_points=1,
+                                             options={"split": split}).to("cuda")
     pred = samrs_amd.SamPredictor(sam)
     eng = sam.engine
+    assert eng.get_option("split") == split
     inp = extended_inputs()
     img = synth.make_image(0)
     hw = img.shape[:2]
@@ -335,7 +341,7 @@ def test_c2_c4_against_reference_golden(name, golden_dir):
         flips = flip.flatten(2).sum(-1)
         near = torch.from_numpy(_unpack(g[tag + "_nearmask"], hw))          # reference pixels with |logit| < tau
         outside = int((flip & ~near).sum())
-        print(f"c2c4 {name} {tag}: IoU min {ious.min():.5f} mean {ious.mean():.5f}; max rel area diff {rel_area:.2e}; low-res rel L2 {l2:.2e} "
+        print(f"c2c4 {name} split={split} {tag}: IoU min {ious.min():.5f} mean {ious.mean():.5f}; max rel area diff {rel_area:.2e}; low-res rel L2 {l2:.2e} "
               f"max err/std {err:.2e} (tau {tau_frac:.0e}); iou-pred err {qerr:.2e}; flipped pixels per mask max {int(flips.max())} "
               f"(reference pixels within tau: max {int(g[tag + '_near'].max())})")
         assert outside == 0, f"{tag}: {outside} mask pixels differ where the reference's logit has margin"
@@ -352,14 +358,17 @@ def test_c2_c4_against_reference_golden(name, golden_dir):
     seg = seg.cpu().numpy()
     unstable = _unpack(g["c2_unstable"], hw)
     diff = seg != g["c2_seg"]
-    print(f"c2c4 {name} class map: {int(diff.sum())} of {diff.size} pixels differ ({diff.mean():.2e}); reference-unstable pixels "
+    print(f"c2c4 {name} split={split} class map: {int(diff.sum())} of {diff.size} pixels differ ({diff.mean():.2e}); reference-unstable pixels "
           f"{int(unstable.sum())} ({unstable.mean():.2e}); differing pixels outside the unstable set: {int((diff & ~unstable).sum())}")
     assert np.array_equal(seg[~unstable], g["c2_seg"][~unstable]), "class map differs where the reference's decision has margin"
     # round 2 (no operand split): 849 / 896 pixels at ViT-B / ViT-H; with the split rounding points the error budget
     # predicts 394 / 476 (oracle/error_budget.py plans2, row E1)
-    assert diff.sum() <= 620, int(diff.sum())
+    # (error budget at ViT-H: 307 with the qkv + proj GEMMs split as well, 89 with every block GEMM split)
+    assert diff.sum() <= {15: 620, 31: 420, 63: 160}[split], int(diff.sum())
     # ---- C4: enclosing hbox prompt, multimask ----
-    c4_floor = 0.999 if name == "vit_b" else 0.9985
+    # measured at ViT-H: 0.99874 / 0.99877 (split 15), 0.99911 / 0.99927 (31), 0.99974 / 0.99984 (63); the error budget
+    # predicted 0.99886 / 0.99881, 0.99919 / 0.99928, 0.99976 / 0.99984
+    c4_floor = 0.999 if (name == "vit_b" or split >= 31) else 0.9985
     tb = pred.transform.apply_boxes_torch(torch.from_numpy(inp["hboxes"]).cuda(), hw)
     m, q, l = pred.predict_torch(None, None, tb, None, multimask_output=True)
     assert m.shape[1] == 3

@@ -450,7 +450,7 @@ constexpr int I2TF_ROWS = 32;          // image tokens per group (two MFMA row t
 constexpr int I2TF_AST = 136;          // A-tile row stride (ET): 272 B = 68 words = 4 (mod 32)
 
 template <int PREC, bool SPLIT>
-__global__ __launch_bounds__(256) void i2t_fused_kernel(const uint16_t* __restrict__ qi, int ld, long q_bstride,
+__global__ __launch_bounds__(256, 2) void i2t_fused_kernel(const uint16_t* __restrict__ qi, int ld, long q_bstride,
                                                         const float* __restrict__ kt, const float* __restrict__ vt,
                                                         const uint16_t* __restrict__ w, const uint16_t* __restrict__ w_lo,
                                                         const float* __restrict__ bias,

@@ -193,10 +193,17 @@ class WorkQueue:
       of waiting for the unluckiest static shard.  The data path itself still has no collective.
     """
 
+    _seq = 0          # queues created by this process: every rank creates its queues in the same order
+
     def __init__(self, n_items: int, chunk: int = 1, rank: int = 0, world: int = 1, mode: str = "static",
-                 store=None, name: str = "samrs_wq"):
+                 store=None, name: Optional[str] = None):
+        """`name` keys the shared counter on the store: it must be the same on every rank and UNIQUE per work list (a spent
+        counter would hand a second queue of the same name nothing).  Default: a per-process sequence number."""
         if mode not in ("static", "dynamic"):
             raise ValueError("mode must be 'static' or 'dynamic'")
+        if name is None:
+            name = f"samrs_wq/{WorkQueue._seq}"
+        WorkQueue._seq += 1
         self.n, self.chunk, self.rank, self.world, self.mode = int(n_items), int(chunk), rank, world, mode
         self._k = 0
         self._local = 0

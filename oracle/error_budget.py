@@ -144,6 +144,12 @@ def main(argv):
                            ("E1 + all four block GEMMs split", ("enc.proj_in", "enc.qkv_in", "enc.lin1_in", "enc.lin2_in"))):
             report(label, "p3_" + "_".join(q.split(".")[1] for q in pts),
                    so.Rounding(enc=F16, dec=F16, points=dict(e1, **{q: sp for q in pts})))
+    if what in ("plans4",):
+        # is the v third of the qkv product what makes qkv_in expensive?  (q and k pass through the softmax)
+        sp = so.split2(F16)
+        e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
+        report("E1 + proj + v (of qkv) split", "p4_proj_v", so.Rounding(enc=F16, dec=F16, points=dict(e1, **{"enc.proj_in": sp, "enc.v_in": sp})))
+        report("E1 + v (of qkv) split only", "p4_v", so.Rounding(enc=F16, dec=F16, points=dict(e1, **{"enc.v_in": sp})))
     if what in ("plans", "all"):
         sp = so.split2(F16)
         report("plan A: encoder f16, decoder operands split f16 (hi+lo)", "f16",

@@ -1,0 +1,61 @@
+"""CPU: host-side pieces of the production loop that need no GPU -- result records, output bookkeeping of the generation CLI,
+work-queue naming."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from samrs_amd import driver, generate, rle
+
+
+def test_tile_result_rle_slices_the_batch_buffer():
+    """TileResult.rle(j) = the reference's per-instance dict (main_sam_hbox_semantic.py:201-202) cut out of the batch's packed
+    byte buffer by the (offset, length, n_counts) table samrs_rle_encode fills."""
+    rng = np.random.default_rng(0)
+    masks = [rng.random((37, 53)) < p for p in (0.0, 0.3, 1.0)]
+    strings = [rle.encode(m)["counts"].encode("ascii") for m in masks]
+    buf, table, off = bytearray(), [], 0
+    for s_ in strings:                                  # 16-byte aligned starts, like the device packs them
+        table.append((off, len(s_), len(rle.string_to_counts(s_.decode()))))
+        buf += s_ + b"\\0" * (-len(s_) % 16)
+        off = len(buf)
+    r = driver.TileResult("k", np.zeros((37, 53), np.uint8), np.zeros(3, np.int64), np.zeros((3, 4), np.float32), np.zeros(3, np.int64))
+    r.size, r.rle_table, r.rle_data = (37, 53), np.asarray(table, dtype=np.int64), np.frombuffer(bytes(buf), dtype=np.uint8)
+    for j, m in enumerate(masks):
+        d = r.rle(j)
+        assert d == rle.encode(m) and np.array_equal(rle.decode(d), m)
+
+
+def test_outputs_exist_needs_all_three_files(tmp_path):
+    """--resume skips an image only when gray, color and ins are all there; the pickle is written last and through a rename."""
+    from PIL import Image  # noqa: F401
+    seg = np.full((8, 8), 255, np.uint8)
+    args = (str(tmp_path), "A", seg, None, np.zeros((1, 4), np.float32), np.array([2]), np.array([0]), generate.default_palette(18),
+            [str(i) for i in range(18)])
+    assert not generate.outputs_exist(str(tmp_path), "A")
+    generate.write_outputs(*args, rles=[rle.encode(np.zeros((8, 8), bool))])
+    assert generate.outputs_exist(str(tmp_path), "A") and not os.path.exists(tmp_path / "ins" / "A.pkl.tmp")
+    info = pickle.load(open(tmp_path / "ins" / "A.pkl", "rb"))
+    assert info[0]["mask"] == {"size": [8, 8], "counts": "P2"} and info[0]["size"] == 0          # 64 zeros = one count: 'P2'
+    os.remove(tmp_path / "color" / "A.png")
+    assert not generate.outputs_exist(str(tmp_path), "A")
+
+
+def test_write_outputs_failure_is_not_swallowed(tmp_path):
+    """A writer job that cannot write must raise (generate.run re-raises it from its writer pool before the statistics)."""
+    blocker = tmp_path / "out"
+    blocker.write_text("a file where the output directory should be")
+    with pytest.raises(OSError):
+        generate.write_outputs(str(blocker), "A", np.zeros((4, 4), np.uint8), None, np.zeros((0, 4)), np.zeros(0, int), np.zeros(0, int),
+                               generate.default_palette(3), ["a", "b", "c"])
+
+
+def test_work_queues_get_distinct_default_keys():
+    a, b = driver.WorkQueue(10, chunk=2), driver.WorkQueue(10, chunk=2)
+    assert a._key != b._key
+    assert list(a) == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10)]
+    c = driver.WorkQueue(7, chunk=3, rank=1, world=2)
+    assert list(c) == [(3, 6)]
+    with pytest.raises(ValueError):
+        driver.WorkQueue(1, mode="stolen")

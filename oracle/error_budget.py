@@ -8,7 +8,12 @@ reports per configuration, against the exact run:
     low-res logits;
   * C4 (4 rotated boxes, multimask): min IoU over the 12 masks for the enclosing-hbox prompt and for the mask prompt.
 
-    python -m oracle.error_budget vit_b [coarse|dec|enc|plans|all]      (vit_h: ~70 s per encoder pass on 8 cores)
+    python -m oracle.error_budget vit_b [coarse|dec|enc|plans|all]      (vit_h: ~20 s per encoder pass on 8 cores)
+    python -m oracle.error_budget vit_h plans2     floor (only the four block GEMMs in f16), E1 = the engine's default split, ...
+    python -m oracle.error_budget vit_h plans3     which block GEMMs must be split as well for the C4 fixture to clear 0.999
+    python -m oracle.error_budget vit_h plans4     the v third of the qkv product on its own
+
+Encoder passes are cached under $SAMRS_EB_CACHE (default /tmp/samrs_error_budget); delete it after changing the oracle.
 
 The table in DESIGN.md section 2 comes from here; ``profiles/r03_error_budget_*.txt`` hold the raw output.
 """

@@ -1028,7 +1028,8 @@ int samrs_rle_encode(samrs_engine_t* e, const uint8_t* masks, int n, int h, int 
                      int64_t* cursor, int64_t* table, void* stream) {
     if (!e || !masks || !out || !cursor || !table || n < 1 || h < 1 || w < 1 || out_capacity < 16)
         return fail(e, SAMRS_ERR_BAD_ARG, "samrs_rle_encode: bad argument");
-    if ((size_t)h * w >= (1ull << 30)) return fail(e, SAMRS_ERR_BAD_SHAPE, "samrs_rle_encode: mask too large (h * w must be < 2^30)");
+    if ((size_t)h * w >= (1ull << 30) || w > 8192)
+        return fail(e, SAMRS_ERR_BAD_SHAPE, "samrs_rle_encode: mask too large (h * w must be < 2^30, w <= 8192)");
     ON_DEVICE(e);
     hipStream_t s = (hipStream_t)stream;
     const int chunk = 32;                               // masks per pass: bounds the scratch (5.3 MB per 1024^2 mask)

@@ -476,6 +476,33 @@ def test_error_behaviour_matches_reference():
         samrs_amd.sam_model_registry["vit_tiny"](state_dict=sd).to("cuda")
 
 
+def test_engine_options_are_per_handle():
+    """samrs_set_option: every handle has its own options (no process-wide switches on the product path), unknown names are
+    refused, and the reference-grade split bits cannot be switched on once the weights were finalized without their lo copies."""
+    import samrs_amd
+    a = samrs_amd.sam_model_registry["vit_tiny"](max_prompts=4).to("cuda").engine
+    b = samrs_amd.sam_model_registry["vit_tiny"](max_prompts=4, options={"split": 63, "decoder_fusion": 0}).to("cuda").engine
+    assert (a.get_option("split"), a.get_option("decoder_fusion"), a.get_option("upscaler_fused")) == (15, 1, 1)
+    assert (b.get_option("split"), b.get_option("decoder_fusion")) == (63, 0)
+    a.set_option("split", 3)
+    a.set_option("gemm_variant", 7)
+    assert a.get_option("split") == 3 and b.get_option("split") == 63 and b.get_option("gemm_variant") == -1
+    with pytest.raises(AssertionError, match="unknown option"):
+        a.set_option("no_such_option", 1)
+    with pytest.raises(AssertionError, match="lo weights"):
+        a.set_option("split", 31)                       # bits 16 / 32 need lo copies of the block weights, prepared at load
+    b.set_option("split", 15); b.set_option("split", 63)    # ... which b has: can be cleared and set again
+    # the two handles give different embeddings for the same tile (different arithmetic), each reproducibly
+    t = torch.as_tensor(synth.make_image(2), device="cuda")[None].contiguous()
+    a.set_option("split", 15); a.set_option("gemm_variant", -1)
+    a.set_images(t, 0); b.set_images(t, 0)
+    ea, eb = a.get_embedding(0).clone(), b.get_embedding(0).clone()
+    a.set_images(t, 0)
+    assert torch.equal(a.get_embedding(0), ea) and not torch.equal(ea, eb)
+    assert ((ea - eb).norm() / eb.norm()).item() < 2e-3
+    a.close(); b.close()
+
+
 def test_encoder_batch_equals_single():
     """Batched set_images (config 2: 8 tiles per encoder pass) == one tile at a time."""
     pred = get_predictor("vit_tiny", "f16", max_images=4)

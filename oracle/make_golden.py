@@ -4,6 +4,7 @@ Run in the authoring container (needs ``/root/reference``)::
 
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden vit_tiny vit_tiny80 vit_b vit_h
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden vit_b_c2c4 vit_h_c2c4      # C2 / C4 fixtures, margin weights
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden vit_h_c2c4_v1              # a second, independent draw of the same
 
 Weights / images / prompts come from ``samrs_amd.synth`` (seeded, reproducible anywhere), the
 outputs come from the reference's own ``SamPredictor`` (Generate Dataset/segment_anything/
@@ -78,14 +79,16 @@ def unstable_class_map(logits: "torch.Tensor", tau: float) -> "torch.Tensor":
     return ((idx * near).amax(0) > last_on)                   # an uncertain box after J
 
 
-def extended_inputs():
-    """Inputs of the C2 / C4 fixtures: the same on the authoring machine and on the GPU box."""
-    boxes, labels = synth.make_boxes(7, 32)                 # C2: 32 hboxes on one 1024^2 tile, 18 classes
-    polys, plabels = synth.make_rboxes(0, 4)                # C4: FAIR1M-shaped rotated boxes, 37 classes
-    return dict(boxes=boxes, labels=labels, polys=polys, plabels=plabels, hboxes=synth.enclosing_hboxes(polys))
+def extended_inputs(variant: int = 0):
+    """Inputs of the C2 / C4 fixtures: the same on the authoring machine and on the GPU box.  `variant` > 0: a
+    second, independent draw (other tile, other boxes) -- the fixture `<name>_c2c4_v<variant>.npz`."""
+    boxes, labels = synth.make_boxes(7 + 10 * variant, 32)        # C2: 32 hboxes on one 1024^2 tile, 18 classes
+    polys, plabels = synth.make_rboxes(0 + 10 * variant, 4)       # C4: FAIR1M-shaped rotated boxes, 37 classes
+    return dict(boxes=boxes, labels=labels, polys=polys, plabels=plabels, hboxes=synth.enclosing_hboxes(polys),
+                image_index=variant)
 
 
-def extended(name: str) -> None:
+def extended(name: str, variant: int = 0) -> None:
     """``tests/golden/<name>_c2c4.npz``: BASELINE.json configs[1] (32 hboxes per tile, 20 + 12 chunks,
     main_sam_hbox_semantic.py:157-181) and configs[3] (rbox -> enclosing hbox / rbox -> mask prompt with
     multimask_output=True, main_sam_rhbox_mask_instance.py:125-130, main_sam_rbox_mask_instance.py:125-164) run by the
@@ -97,9 +100,9 @@ def extended(name: str) -> None:
     sd = synth.make_state_dict(cfg, 0, logit_scale=synth.MARGIN_LOGIT_SCALE)
     sa, sam = ref_import.build_reference_sam(cfg, sd)
     pred = sa.SamPredictor(sam)
-    inp = extended_inputs()
+    inp = extended_inputs(variant)
     h = w = 1024
-    img = synth.make_image(0, h, w)
+    img = synth.make_image(inp["image_index"], h, w)
     pred.set_image(img)
     f = pred.get_image_embedding()
     blob = {"emb_sample": f[0, ::16, ::4, ::4].numpy().copy(), "emb_norm": np.float64(f.double().norm().item()),
@@ -135,7 +138,7 @@ def extended(name: str) -> None:
     prompts = np.stack([rbox_prompt.rbox_mask_prompt(p.astype(np.int32), h, w) for p in inp["polys"]])
     blob["c4mask_prompt_sum"] = np.float64(prompts.astype(np.float64).sum())
     run("c4mask", [(0, 4)], True, mask_input=torch.from_numpy(prompts.astype(np.float32))[:, None])
-    path = os.path.join(GOLDEN_DIR, name + "_c2c4.npz")
+    path = os.path.join(GOLDEN_DIR, name + "_c2c4" + (f"_v{variant}" if variant else "") + ".npz")
     np.savez_compressed(path, **blob)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB; unstable class-map pixels:",
           int(np.unpackbits(blob["c2_unstable"]).sum()), flush=True)
@@ -144,10 +147,12 @@ def extended(name: str) -> None:
 def main(names):
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
-    ext = [n[:-5] for n in names if n.endswith("_c2c4")]
-    names = [n for n in names if not n.endswith("_c2c4")]
-    for name in ext:
-        extended(name)
+    import re
+    ext = [re.fullmatch(r"(.+)_c2c4(?:_v(\d+))?", n) for n in names]
+    names = [n for n, m in zip(names, ext) if m is None]
+    for m in ext:
+        if m is not None:
+            extended(m.group(1), int(m.group(2) or 0))
     for name in names:
         cfg = synth.CONFIGS[name]
         sd = synth.make_state_dict(cfg, 0)

@@ -59,20 +59,21 @@ def test_oracle_matches_reference_vit_l(golden_dir):
 
 
 @pytest.mark.slow
-def test_oracle_matches_reference_c2_c4_vit_b(golden_dir):
+@pytest.mark.parametrize("name,variant", [("vit_b", 0), ("vit_h", 0), ("vit_h", 1)])
+def test_oracle_matches_reference_c2_c4(name, variant, golden_dir):
     """The C2 (32 hboxes, 20 + 12 chunks) and C4 (enclosing hbox / rbox mask prompt, multimask) fixtures on the
     realistic-margin weights: full-resolution masks of the REAL reference vs the oracle.  fp32 on both sides, so the
     only differences allowed are fp32 op-order flips, and those must lie in the fixture's unstable set."""
     from oracle import rbox_prompt
     from oracle.make_golden import extended_inputs
-    g = np.load(os.path.join(golden_dir, "vit_b_c2c4.npz"))
-    cfg = synth.CONFIGS["vit_b"]
+    g = np.load(os.path.join(golden_dir, name + "_c2c4" + (f"_v{variant}" if variant else "") + ".npz"))
+    cfg = synth.CONFIGS[name]
     sd = synth.make_state_dict(cfg, 0, logit_scale=float(g["logit_scale"]))
     assert float(g["logit_scale"]) == synth.MARGIN_LOGIT_SCALE
     pred = so.OraclePredictor(sd, cfg)
-    inp = extended_inputs()
+    inp = extended_inputs(variant)
     hw = (1024, 1024)
-    pred.set_image(synth.make_image(0))
+    pred.set_image(synth.make_image(inp["image_index"]))
     unpack = lambda b: np.unpackbits(b, axis=-1).reshape(*b.shape[:-1], *hw).astype(bool)
     tb = so.apply_boxes(torch.from_numpy(inp["boxes"]), hw)
     parts = [pred.predict_torch(None, None, tb[s:e], None, multimask_output=False) for s, e in so.box_chunks(32, 20)]

@@ -410,7 +410,9 @@ class TilePipeline:
                         if self.pin_in is None:                                   # device_inputs=True promised resident tiles
                             self.pin_in = [torch.empty(self.batch, self.side, self.side, 3, dtype=torch.uint8).pin_memory()
                                            for _ in range(2)]
-                        self.pin_in[b][i].copy_(src)                              # host memcpy into pinned staging
+                        # host memcpy into pinned staging: numpy's (one thread, lock released), not Tensor.copy_, which fans a
+                        # 3 MiB copy out over every OpenMP thread -- 5.6 ms instead of 0.1 ms on a 16-CPU slice of a 256-thread host
+                        np.copyto(self.pin_in[b][i].numpy(), src.numpy())
                         self.dev_in[b][i].copy_(self.pin_in[b][i], non_blocking=True)
                     t = self.dev_in[b][i]
                 else:

@@ -27,7 +27,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 import torch
 
-from . import driver, rle
+from . import driver, rle, tile_io
 
 
 def default_palette(n_classes: int) -> np.ndarray:
@@ -37,19 +37,40 @@ def default_palette(n_classes: int) -> np.ndarray:
     return rng.integers(0, 256, size=(n_classes, 3), dtype=np.uint8)
 
 
+class StageClock:
+    """Wall-clock per host stage, summed over threads (--timing): which side of the GPU loop the time goes to."""
+
+    def __init__(self) -> None:
+        self.t: Dict[str, float] = {}
+        self.n: Dict[str, int] = {}
+
+    def add(self, stage: str, t0: float) -> float:
+        import time
+        now = time.perf_counter()
+        self.t[stage] = self.t.get(stage, 0.0) + (now - t0)        # dict updates under the GIL: good enough for a report
+        self.n[stage] = self.n.get(stage, 0) + 1
+        return now
+
+    def report(self, n_images: int, wall: float) -> str:
+        rows = [f"{k}: {1e3 * v / max(n_images, 1):.1f} ms/image (thread time)" for k, v in sorted(self.t.items())]
+        return f"{n_images} images in {wall:.2f} s = {n_images / max(wall, 1e-9):.1f} images/s; " + "; ".join(rows)
+
+
 def write_outputs(out_dir: str, stem: str, seg: np.ndarray, masks: Optional[np.ndarray], boxes: np.ndarray,
                   labels: np.ndarray, areas: np.ndarray, palette: np.ndarray, class_names: Sequence[str],
-                  rles: Optional[Sequence[dict]] = None) -> None:
+                  rles: Optional[Sequence[dict]] = None, clock: Optional[StageClock] = None, png_level: int = 6) -> None:
     """`rles`: the per-instance COCO RLE dicts when they were encoded on the device (driver.TileResult.rle); otherwise they are
     encoded here from `masks` (host restatement), or left out when both are None (--no-rle)."""
-    from PIL import Image
+    import time
+    t0 = time.perf_counter()
     for sub in ("gray", "color", "ins"):
         os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
-    Image.fromarray(seg).save(os.path.join(out_dir, "gray", stem + ".png"))                 # :212,214
-    color = np.full((*seg.shape, 3), 255, dtype=np.uint8)                                   # :163
-    lab = seg != 255
-    color[lab] = palette[seg[lab]]
-    Image.fromarray(color).save(os.path.join(out_dir, "color", stem + ".png"))              # :213,215
+    # native PNG encoders (libsamrs_io.so): no interpreter lock held while a tile is compressed; the colour image is the class
+    # map seen through a 256-entry table (:163 white background, :199 palette colour per painted box)
+    tile_io.write_gray(os.path.join(out_dir, "gray", stem + ".png"), seg, tile_io.LEVEL_RUNS)   # :212,214
+    if clock: t0 = clock.add("write.gray_png", t0)
+    tile_io.write_lut_rgb(os.path.join(out_dir, "color", stem + ".png"), seg, tile_io.class_lut(palette), png_level)   # :213,215
+    if clock: t0 = clock.add("write.color_png", t0)
     info = []
     for j in range(len(labels)):                                                            # :200-206
         entry = {"bbox": boxes[j], "category": class_names[int(labels[j])], "label": int(labels[j]), "size": int(areas[j])}
@@ -63,6 +84,7 @@ def write_outputs(out_dir: str, stem: str, seg: np.ndarray, masks: Optional[np.n
     with open(tmp, "wb") as f:
         pickle.dump(info, f)                                                                # :216
     os.replace(tmp, os.path.join(out_dir, "ins", stem + ".pkl"))
+    if clock: clock.add("write.pickle", t0)
 
 
 def outputs_exist(out_dir: str, stem: str) -> bool:
@@ -76,8 +98,6 @@ _RUN_SEQ = [0]          # run() calls of this process (part of the work queue's 
 def run(args) -> Dict[str, List[int]]:
     import torch.distributed as dist
     from concurrent.futures import ThreadPoolExecutor
-    from PIL import Image
-
     import samrs_amd
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,7 +127,8 @@ def run(args) -> Dict[str, List[int]]:
     max_boxes = max([len(ann[s]["labels"]) for s in stems] + [1])
     # per-instance RLE (main_sam_hbox_semantic.py:201-202) is encoded on the device; the full masks never cross PCIe
     pipe = driver.TilePipeline(sam, n_classes, batch=batch, box_batch=args.box_batch, rle=not args.no_rle,
-                               rle_buffer_mb=getattr(args, "rle_buffer_mb", 256), max_boxes=max_boxes)
+                               rle_buffer_mb=getattr(args, "rle_buffer_mb", 256), max_boxes=max_boxes,
+                               out_depth=getattr(args, "out_depth", 4))
     # rank r takes chunks of `batch` consecutive stems: statically (r, r + world, ...) or from the shared counter (whose
     # store key must be unique per work list: a second run() in the same process group must not find a spent counter)
     import zlib
@@ -115,26 +136,63 @@ def run(args) -> Dict[str, List[int]]:
     _RUN_SEQ[0] += 1
     wq = driver.WorkQueue(len(stems), chunk=batch, rank=rank, world=world, mode=getattr(args, "schedule", "static"), name=wq_name)
 
+    import time
+    tile_io.load_library()                                  # fail here, not on a worker thread, when libsamrs_io.so is missing
+    png_level = getattr(args, "png_level", 6)
+    clock = StageClock() if getattr(args, "timing", False) else None
+
+    # Tiles of the native size are decoded straight into pinned buffers the pipeline can upload from (driver._stage: "caller-owned
+    # pinned memory: straight H2D"), so a tile is written once by the decoder and read once by the DMA engine.  A buffer goes back
+    # to the pool when its image's results reach the sink (its upload finished long before).  In flight at any time: two batches
+    # on the reader side + three inside the pipeline; when the pool runs dry a tile simply takes the pageable path.
+    import queue
+    side = sam.image_encoder.img_size
+    pool: "queue.SimpleQueue[torch.Tensor]" = queue.SimpleQueue()
+    for _ in range(6 * batch):
+        pool.put(torch.empty(side, side, 3, dtype=torch.uint8).pin_memory())
+    loaned: Dict[str, torch.Tensor] = {}
+
     def load(stem: str) -> driver.WorkItem:
-        img = np.array(Image.open(os.path.join(args.images, files[stem])).convert("RGB"))            # :114
+        t0 = time.perf_counter()
+        path = os.path.join(args.images, files[stem])
+        buf = None
+        if path.lower().endswith(".png"):
+            try:
+                if tile_io.png_size(path) == (side, side):
+                    buf = pool.get_nowait()
+            except (tile_io.TileIOError, queue.Empty):
+                buf = None
+        if buf is not None:
+            tile_io.read_rgb(path, out=buf.numpy())                                                  # :114
+            loaned[stem] = buf
+            img = buf
+        else:
+            img = tile_io.read_rgb(path)
+        if clock: clock.add("read.decode", t0)
         return driver.WorkItem(stem, img, np.asarray(ann[stem]["boxes"], dtype=np.float32),
                                np.asarray(ann[stem]["labels"], dtype=np.int64))
 
     def batches():
         # image decode of the NEXT batch runs on a helper thread while the GPU works on this one
-        with ThreadPoolExecutor(max_workers=getattr(args, "readers", 4)) as readers:
+        with ThreadPoolExecutor(max_workers=getattr(args, "readers", 8)) as readers:
             nxt = None
             for s0, s1 in wq:
                 fut = [readers.submit(load, st) for st in stems[s0:s1]]
                 if nxt is not None:
-                    yield [f.result() for f in nxt]
+                    yield collect(nxt)
                 nxt = fut
             if nxt is not None:
-                yield [f.result() for f in nxt]
+                yield collect(nxt)
+
+    def collect(futs):
+        t0 = time.perf_counter()
+        items = [f.result() for f in futs]
+        if clock: clock.add("loop.wait_readers", t0)
+        return items
 
     done = [0]
     sizes: List[int] = []
-    writers = ThreadPoolExecutor(max_workers=getattr(args, "writers", 8))
+    writers = ThreadPoolExecutor(max_workers=getattr(args, "writers", 16))
     pending: List = []
 
     def reap(block: bool) -> None:
@@ -144,16 +202,32 @@ def run(args) -> Dict[str, List[int]]:
             pending.pop(0).result()
 
     def sink(results, release):
-        # PNG encode + pickle on the writer pool (zlib releases the GIL); the pinned ring buffers go back when the
-        # whole batch is on disk
-        def job():
+        # PNG encode + pickle on the writer pool, ONE JOB PER IMAGE (zlib releases the GIL; a job per batch would serialise
+        # 8 images' worth of encoding behind one thread and the pipeline would stall on its output ring); the pinned ring
+        # buffers go back when the last image of the batch is on disk
+        import threading
+        left = [len(results)]
+        lock = threading.Lock()
+
+        def job(r):
             try:
-                for r in results:
-                    rles = [r.rle(j) for j in range(len(r.labels))] if r.rle_table is not None else None
-                    write_outputs(args.out, r.key, r.seg_mask, None, r.boxes, r.labels, r.areas, palette, names, rles)
+                t0 = time.perf_counter()
+                rles = [r.rle(j) for j in range(len(r.labels))] if r.rle_table is not None else None
+                if clock: clock.add("write.rle_dicts", t0)
+                write_outputs(args.out, r.key, r.seg_mask, None, r.boxes, r.labels, r.areas, palette, names, rles, clock, png_level)
             finally:
-                release()
-        pending.append(writers.submit(job))
+                with lock:
+                    left[0] -= 1
+                    last = left[0] == 0
+                if last:
+                    release()
+        if not results:
+            release()
+        pending.extend(writers.submit(job, r) for r in results)
+        for r in results:
+            buf = loaned.pop(r.key, None)
+            if buf is not None:
+                pool.put(buf)
         reap(block=False)
         for r in results:
             sizes.extend(int(a) for a in r.areas if a > 0)                                           # statistic.py:44-49
@@ -161,15 +235,22 @@ def run(args) -> Dict[str, List[int]]:
         if rank == 0 and (done[0] // batch) % 50 == 0:
             print(f"[rank 0] {done[0]} images", flush=True)
 
+    t_run = time.perf_counter()
     try:
         pipe.run(batches(), sink)
+        if clock: clock.add("loop.pipe_run_total", t_run)
     finally:
         writers.shutdown(wait=True)
     reap(block=True)
+    wall = time.perf_counter() - t_run
+    if clock and rank == 0:
+        print("[rank 0] --timing: " + clock.report(done[0], wall), flush=True)
     pix, ins = driver.reduce_statistics(pipe.class_pixels, pipe.class_instances)
     all_sizes = driver.gather_mask_sizes(sizes)
     stats = {"class_pixel_num": pix.cpu().tolist(), "class_instance_num": ins.cpu().tolist(),
              "mask_num": len(all_sizes)}                                                             # statistic.py:53
+    if clock:
+        stats["timing"] = {"images": done[0], "loop_seconds": wall, "stage_thread_seconds": dict(clock.t)}   # this rank's loop
     if rank == 0:
         os.makedirs(os.path.join(args.out, "statistic"), exist_ok=True)
         with open(os.path.join(args.out, "statistic", "class_stats.json"), "w") as f:       # statistic.py:28-31
@@ -199,8 +280,11 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=8, help="tiles per encoder pass")
     ap.add_argument("--schedule", default="static", choices=["static", "dynamic"],
                     help="static: rank r takes chunks r, r+world, ...; dynamic: shared-counter work queue (long-tailed box counts)")
-    ap.add_argument("--readers", type=int, default=4, help="image decode threads")
-    ap.add_argument("--writers", type=int, default=8, help="PNG / pickle writer threads")
+    ap.add_argument("--readers", type=int, default=8, help="image decode threads")
+    ap.add_argument("--writers", type=int, default=16, help="PNG / pickle writer threads")
+    ap.add_argument("--png-level", type=int, default=6, help="zlib level of color/*.png (the pixels are the same at every level; gray/*.png uses the run-length preset)")
+    ap.add_argument("--out-depth", type=int, default=4, help="pinned output buffers (batches on loan to the writers at once)")
+    ap.add_argument("--timing", action="store_true", help="print the host-side time per stage (decode, PNG encode, pickle, waits)")
     run(ap.parse_args(argv))
 
 

@@ -1,0 +1,168 @@
+"""CPU: libsamrs_io.so (include/samrs_io.h) against PIL -- the library the reference itself reads and writes its tiles with
+(Generate Dataset/main_sam_hbox_semantic.py:114,212-215).  Files written natively must decode in PIL to the same pixels;
+files written by PIL in every 8-bit mode must decode natively to what ``Image.open(..).convert("RGB")`` gives."""
+import ctypes
+import os
+import re
+import threading
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from samrs_amd import tile_io
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _class_map(h, w, seed=0):
+    rng = np.random.default_rng(seed)
+    seg = np.full((h, w), 255, np.uint8)
+    for _ in range(12):
+        y0, x0 = rng.integers(0, h), rng.integers(0, w)
+        seg[y0:y0 + rng.integers(1, h // 2 + 2), x0:x0 + rng.integers(1, w // 2 + 2)] = rng.integers(0, 18)
+    return seg
+
+
+def test_library_exports_every_declared_symbol():
+    lib = tile_io.load_library()
+    header = open(os.path.join(ROOT, "include", "samrs_io.h")).read()
+    names = set(re.findall(r"\b(samrs_io_\w+)\s*\(", header))
+    assert len(names) == 7
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.samrs_io_abi_version() == tile_io.ABI_VERSION == int(re.search(r"SAMRS_IO_ABI_VERSION (\d+)", header).group(1))
+
+
+@pytest.mark.parametrize("hw", [(1, 1), (1, 7), (7, 1), (16, 20), (64, 80), (257, 300), (1024, 1024)])
+@pytest.mark.parametrize("level", [1, 6, tile_io.LEVEL_RUNS])
+def test_written_files_decode_in_pil(tmp_path, hw, level):
+    seg = _class_map(*hw, seed=hw[0])
+    pal = np.random.default_rng(1).integers(0, 256, (18, 3), dtype=np.uint8)
+    lut = tile_io.class_lut(pal)
+    g, c, r = str(tmp_path / "g.png"), str(tmp_path / "c.png"), str(tmp_path / "r.png")
+    tile_io.write_gray(g, seg, level)
+    tile_io.write_lut_rgb(c, seg, lut, level)
+    noise = np.random.default_rng(2).integers(0, 256, (*hw, 3), dtype=np.uint8)
+    tile_io.write_rgb(r, noise, level)
+    gi = Image.open(g)
+    assert gi.mode == "L" and np.array_equal(np.array(gi), seg)
+    ci = Image.open(c)
+    assert ci.mode == "RGB" and np.array_equal(np.array(ci), lut[seg])
+    assert np.array_equal(np.array(Image.open(r)), noise)
+    assert not os.path.exists(g + ".tmp")
+    # and back through the native decoder
+    assert np.array_equal(tile_io.read_rgb(c), lut[seg])
+    assert np.array_equal(tile_io.read_rgb(g), np.repeat(seg[:, :, None], 3, axis=2))
+    assert np.array_equal(tile_io.read_rgb(r), noise)
+    assert tile_io.png_size(c) == hw
+
+
+def test_strided_sources(tmp_path):
+    big = _class_map(64, 96, 3)
+    view = big[8:40, 16:80]                                     # row stride 96, not contiguous
+    tile_io.write_gray(str(tmp_path / "v.png"), view)
+    assert np.array_equal(np.array(Image.open(tmp_path / "v.png")), view)
+    tile_io.write_gray(str(tmp_path / "t.png"), big.T)          # column stride != 1: copied
+    assert np.array_equal(np.array(Image.open(tmp_path / "t.png")), big.T)
+
+
+@pytest.mark.parametrize("mode", ["RGB", "RGBA", "L", "LA", "P"])
+@pytest.mark.parametrize("hw", [(5, 3), (128, 96), (600, 800)])
+def test_reads_what_pil_writes(tmp_path, mode, hw):
+    rng = np.random.default_rng(hw[0] + len(mode))
+    # smooth + noise, so that PIL's encoder picks all five row filters
+    yy, xx = np.mgrid[:hw[0], :hw[1]]
+    base = ((yy * 3 + xx * 2) % 256).astype(np.uint8)
+    ch = {"RGB": 3, "RGBA": 4, "L": 1, "LA": 2, "P": 1}[mode]
+    arr = np.stack([(base + rng.integers(0, 24, hw)).astype(np.uint8) * (1 if c % 2 == 0 else 3) for c in range(ch)], axis=2)
+    if mode == "P":
+        img = Image.fromarray(arr[:, :, 0], mode="P")
+        img.putpalette(rng.integers(0, 256, 768, dtype=np.uint8).tobytes())
+    else:
+        img = Image.fromarray(arr[:, :, 0] if ch == 1 else arr, mode=mode)
+    path = str(tmp_path / "x.png")
+    img.save(path)
+    want = np.array(Image.open(path).convert("RGB"))
+    got = tile_io.read_rgb(path)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    # into a caller-provided (oversized) buffer: the result is a view of it
+    out = np.zeros(want.size + 100, np.uint8)
+    got2 = tile_io.read_rgb(path, out=out)
+    assert np.shares_memory(got2, out) and np.array_equal(got2, want)
+
+
+def test_variants_outside_the_subset_go_through_pil(tmp_path):
+    rng = np.random.default_rng(0)
+    a16 = rng.integers(0, 65536, (40, 30), dtype=np.uint16)
+    p16 = str(tmp_path / "a16.png")
+    Image.fromarray(a16).save(p16)
+    lib = tile_io.load_library()
+    buf = np.zeros(40 * 30 * 3, np.uint8)
+    h, w = ctypes.c_int(), ctypes.c_int()
+    assert lib.samrs_io_png_read_rgb(os.fsencode(p16), buf.ctypes.data, buf.size, ctypes.byref(h), ctypes.byref(w)) == tile_io.UNSUPPORTED
+    assert np.array_equal(tile_io.read_rgb(p16), np.array(Image.open(p16).convert("RGB")))
+    # a 1-bit PNG and a JPEG
+    bw = Image.fromarray(rng.integers(0, 2, (33, 47)).astype(bool))
+    pbw = str(tmp_path / "bw.png")
+    bw.save(pbw)
+    assert np.array_equal(tile_io.read_rgb(pbw), np.array(Image.open(pbw).convert("RGB")))
+    rgb = rng.integers(0, 256, (50, 60, 3), dtype=np.uint8)
+    pj = str(tmp_path / "x.jpg")
+    Image.fromarray(rgb).save(pj)
+    assert np.array_equal(tile_io.read_rgb(pj), np.array(Image.open(pj).convert("RGB")))
+
+
+def test_errors_are_codes_not_crashes(tmp_path):
+    seg = _class_map(32, 32)
+    path = str(tmp_path / "ok.png")
+    tile_io.write_gray(path, seg)
+    raw = open(path, "rb").read()
+    with pytest.raises(FileNotFoundError):
+        tile_io.read_rgb(str(tmp_path / "missing.png"))
+    # truncated at every interesting boundary, and with flipped bytes (chunk CRC / zlib checks)
+    for cut in (0, 7, 20, 33, 40, len(raw) - 13, len(raw) - 1):
+        bad = str(tmp_path / f"cut{cut}.png")
+        open(bad, "wb").write(raw[:cut])
+        with pytest.raises(Exception):
+            tile_io.read_rgb(bad)
+    for pos in (17, 30, 45, len(raw) - 20):
+        b = bytearray(raw)
+        b[pos] ^= 0x55
+        bad = str(tmp_path / f"flip{pos}.png")
+        open(bad, "wb").write(bytes(b))
+        with pytest.raises(Exception):
+            tile_io.read_rgb(bad)
+    with pytest.raises(tile_io.TileIOError) as e:
+        tile_io.write_gray(str(tmp_path / "no_such_dir" / "x.png"), seg)
+    assert e.value.code == tile_io.EOPEN
+    with pytest.raises(ValueError):
+        tile_io.write_gray(path, seg.astype(np.int32))
+    with pytest.raises(ValueError):
+        tile_io.read_rgb(path, out=np.zeros(10, np.uint8))
+    lib = tile_io.load_library()
+    buf = np.zeros(8, np.uint8)
+    h, w = ctypes.c_int(), ctypes.c_int()
+    assert lib.samrs_io_png_read_rgb(os.fsencode(path), buf.ctypes.data, buf.size, ctypes.byref(h), ctypes.byref(w)) == tile_io.ESIZE
+    assert (h.value, w.value) == (32, 32)
+
+
+def test_threads_run_concurrently(tmp_path):
+    """The point of the native path: many tiles in flight, each call independent (no shared state in the library)."""
+    segs = [_class_map(256, 256, s) for s in range(16)]
+    lut = tile_io.class_lut(np.random.default_rng(5).integers(0, 256, (18, 3), dtype=np.uint8))
+    errs = []
+
+    def work(i):
+        try:
+            p = str(tmp_path / f"c{i}.png")
+            for _ in range(3):
+                tile_io.write_lut_rgb(p, segs[i], lut)
+                if not np.array_equal(tile_io.read_rgb(p), lut[segs[i]]):
+                    errs.append(i)
+        except Exception as e:                                  # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(16)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs

@@ -191,7 +191,10 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    exist; can be flipped afterwards.
  *   "gemm_variant"   [default -1 = automatic] GEMM tile variant for this handle's launches (tools/gemm_bench.py lists them).
  *   "upscaler_fused" [SAMRS_UPSCALER_FUSED, default 1] 1 = the mask upscaler as ONE kernel (samrs_k_upscaler_fused); 0 = ConvT #1 as a GEMM with a
- *                    LayerNorm2d + GELU epilogue, then the ConvT #2 + GELU + product kernel (A/B runs, tests). */
+ *                    LayerNorm2d + GELU epilogue, then the ConvT #2 + GELU + product kernel (A/B runs, tests).
+ *   "split_passes"   [SAMRS_SPLIT_PASSES, default 0] reference-grade bits of "split" only: 1 = the three terms of a split block GEMM as
+ *                    three accumulating launches through an fp32 scratch (the generic route, every shape); 0 = as ONE launch over a
+ *                    three-segment K axis where the shape fits the 256 x 320 tile (ViT-H; samrs_k_gemm_split3), else the generic route. */
 int samrs_set_option(samrs_engine_t* e, const char* name, int value);
 int samrs_get_option(const samrs_engine_t* e, const char* name, int* value);
 
@@ -267,6 +270,12 @@ int samrs_k_postprocess(const float* lowres, int n_masks, int in_h, int in_w, in
  * remainders of the operands -- the product then runs as A_lo B + A B_lo + A B and C is written in FP32 [M][N]. */
 int samrs_k_gemm_gln(int prec, const void* A_et, const void* B_et, void* C_et, const float* bias,
                      const float* gamma_beta, int M, int N, int K, const void* A_lo_et, const void* B_lo_et, void* stream);
+/* Split-precision GEMM in one launch (the block GEMMs of the reference-grade mode, option "split" bits 16 / 32):
+ * C = A B^T + A_lo B^T + A B_lo^T + bias over a three-segment K axis; A*, [M,K], B*, [N,K] in the operand type (hi / lo from
+ * samrs_k_convert_split).  out_f32 = 0: C_et [M,N] rounded once from the fp32 accumulators; out_f32 = 1: C fp32 [M,N],
+ * accumulate != 0 adds to what C holds (the residual stream).  M % 256 == 0, N % 320 == 0, K % 64 == 0, else SAMRS_ERR_BAD_SHAPE. */
+int samrs_k_gemm_split3(int prec, const void* A_et, const void* A_lo_et, const void* B_et, const void* B_lo_et, void* C,
+                        const float* bias, int M, int N, int K, int out_f32, int accumulate, void* stream);
 /* Second transposed conv + GELU + hypernetwork product (mask_decoder.py:57-59,154-167) in one pass:
  * u1_et [n*grid*grid*4, 64] (rows = prompt, token, sub-pixel 1), w_et [128, 64] (rows = sub-pixel 2 x 32
  * channels), bias [128], hyper [n, n_mask_tokens, 32] -> low [n, n_sel, 4*grid, 4*grid] fp32 for mask

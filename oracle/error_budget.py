@@ -155,6 +155,19 @@ def main(argv):
         e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
         report("E1 + proj + v (of qkv) split", "p4_proj_v", so.Rounding(enc=F16, dec=F16, points=dict(e1, **{"enc.proj_in": sp, "enc.v_in": sp})))
         report("E1 + v (of qkv) split only", "p4_v", so.Rounding(enc=F16, dec=F16, points=dict(e1, **{"enc.v_in": sp})))
+    if what in ("plans5",):
+        # which BLOCKS carry the block-GEMM error: the four GEMMs split in a range of blocks only (cost: 2 extra passes of those blocks)
+        sp = so.split2(F16)
+        e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
+        four = ("enc.proj_in", "enc.qkv_in", "enc.lin1_in", "enc.lin2_in")
+        n = cfg.depth
+        for label, blocks in ((f"E1 + block GEMMs split in blocks {n * 3 // 4}..{n - 1}", range(n * 3 // 4, n)),
+                              (f"E1 + block GEMMs split in blocks {n // 2}..{n - 1}", range(n // 2, n)),
+                              (f"E1 + block GEMMs split in blocks 0..{n // 4 - 1}", range(0, n // 4)),
+                              (f"E1 + block GEMMs split in blocks 0..{n // 2 - 1}", range(0, n // 2)),
+                              ("E1 + block GEMMs split in the global-attention blocks", tuple(cfg.global_attn_indexes))):
+            tag = "p5_" + "_".join(str(b) for b in (blocks[0], blocks[-1], len(blocks)))
+            report(label, tag, so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points={q: (blocks, sp) for q in four}))
     if what in ("plans", "all"):
         sp = so.split2(F16)
         report("plan A: encoder f16, decoder operands split f16 (hi+lo)", "f16",

@@ -57,6 +57,10 @@ class Rounding:
     enc: Optional[object] = None
     dec: Optional[object] = None
     points: Optional[Dict[str, Optional[object]]] = None
+    # per-block overrides for encoder points: name -> (container of block indices, rounding); ``image_encoder`` sets
+    # ``cur_block`` while it walks the blocks (error_budget.py plans5: which BLOCKS carry the error)
+    block_points: Optional[Dict[str, tuple]] = None
+    cur_block: int = -1
 
     @staticmethod
     def _r(x: Tensor, dt) -> Tensor:
@@ -68,7 +72,9 @@ class Rounding:
 
     def p(self, name: str) -> Callable[[Tensor], Tensor]:
         """The rounding applied at the named point."""
-        if self.points is not None and name in self.points:
+        if self.block_points is not None and name in self.block_points and self.cur_block in self.block_points[name][0]:
+            dt = self.block_points[name][1]
+        elif self.points is not None and name in self.points:
             dt = self.points[name]
         else:
             dt = self.enc if name.startswith("enc.") else self.dec
@@ -186,6 +192,8 @@ def image_encoder(sd: SD, cfg, x: Tensor, rd: Rounding = _EXACT, taps: Optional[
         taps["patch"] = x.clone()
     for i in range(cfg.depth):
         win = 0 if i in cfg.global_attn_indexes else cfg.window_size
+        if rd.block_points is not None:
+            rd.cur_block = i
         x = _block(x, sd, f"image_encoder.blocks.{i}", cfg.num_heads, win, rd)
         if taps is not None:
             taps[f"block{i}"] = x.clone()

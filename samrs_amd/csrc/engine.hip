@@ -88,6 +88,7 @@ struct samrs_engine {
     int split = SPLIT_DEFAULT;
     int split_ready = SPLIT_DEFAULT;                // bits whose lo weights / workspaces exist (fixed at samrs_finalize_weights)
     int gemm_variant = -1;                          // -1 = the library default (launch_gemm_et's automatic choice)
+    bool split_passes = false;                      // reference-grade block GEMMs as three accumulating launches instead of one (A/B)
     bool upscaler_fused = true;                     // one-kernel upscaler (upscaler_fused.hip) instead of ConvT1 GEMM + ConvT2 kernel
 
     // encoder weights / workspaces
@@ -344,6 +345,7 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->ln_fold = env_int("SAMRS_LN_FOLD", 0) != 0;
     e->split = env_int("SAMRS_SPLIT", SPLIT_DEFAULT) & SPLIT_ALL;
     e->upscaler_fused = env_int("SAMRS_UPSCALER_FUSED", 1) != 0;
+    e->split_passes = env_int("SAMRS_SPLIT_PASSES", 0) != 0;
     return e;
 }
 
@@ -601,6 +603,9 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     // rounding to the operand type; proj / lin2: two more accumulating passes into the residual stream)
     const bool sp_attn = (e->split & SPLIT_ATTN) != 0, sp_mlp = (e->split & SPLIT_MLP) != 0;
     const bool fold = e->can_fold && e->ln_fold && !sp_attn && !sp_mlp;
+    // the three split terms of a block GEMM as ONE launch over a three-segment K axis (gemm.hip seg_src_a) where the shape
+    // fits the 256 x 320 tile (ViT-H); SAMRS_SPLIT_PASSES=1 / option "split_passes" keeps the three accumulating launches (A/B)
+    const bool one3 = !e->split_passes;
     if (fold && n_blocks > 0) {
         CK(e, launch_rowstats_convert(prec, e->X, e->Y, e->STATS, M, D, s));
         CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
@@ -613,10 +618,14 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, launch_gemm_et_fold(prec, e->Y, b.qkv_wf, e->QKV, b.qkv_bf, b.qkv_c, e->ROWSTAT, M, 3 * D, D, false, s));
         } else if (sp_attn) {
             CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, e->Ylo));
-            CK(e, launch_gemm_et(prec, e->Ylo, b.qkv_w, e->F32T, nullptr, nullptr, 0, M, 3 * D, D, true, false, false, s));
-            CK(e, launch_gemm_et(prec, e->Y, b.qkv_w_lo, e->F32T, nullptr, nullptr, 0, M, 3 * D, D, true, false, true, s));
-            CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->F32T, b.qkv_b, nullptr, 0, M, 3 * D, D, true, false, true, s));
-            CK(e, launch_convert(prec, e->F32T, e->QKV, (long)M * 3 * D, s));
+            if (one3 && gemm_split3_ok(M, 3 * D, D)) {     // one launch, ET output rounded once from the register accumulators
+                CK(e, launch_gemm_et_split3(prec, e->Y, e->Ylo, b.qkv_w, b.qkv_w_lo, e->QKV, b.qkv_b, M, 3 * D, D, false, false, s));
+            } else {
+                CK(e, launch_gemm_et(prec, e->Ylo, b.qkv_w, e->F32T, nullptr, nullptr, 0, M, 3 * D, D, true, false, false, s));
+                CK(e, launch_gemm_et(prec, e->Y, b.qkv_w_lo, e->F32T, nullptr, nullptr, 0, M, 3 * D, D, true, false, true, s));
+                CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->F32T, b.qkv_b, nullptr, 0, M, 3 * D, D, true, false, true, s));
+                CK(e, launch_convert(prec, e->F32T, e->QKV, (long)M * 3 * D, s));
+            }
         } else {
             CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
             CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
@@ -631,11 +640,15 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, launch_gemm_et_stats(prec, e->AO, b.proj_w, e->X, b.proj_b, e->Y, e->STATS, M, D, D, s));
             CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
         } else {
-            if (sp_attn) {
-                CK(e, launch_gemm_et(prec, e->AOlo, b.proj_w, e->X, nullptr, nullptr, 0, M, D, D, true, false, true, s));
-                CK(e, launch_gemm_et(prec, e->AO, b.proj_w_lo, e->X, nullptr, nullptr, 0, M, D, D, true, false, true, s));
+            if (sp_attn && one3 && gemm_split3_ok(M, D, D)) {
+                CK(e, launch_gemm_et_split3(prec, e->AO, e->AOlo, b.proj_w, b.proj_w_lo, e->X, b.proj_b, M, D, D, true, true, s));
+            } else {
+                if (sp_attn) {
+                    CK(e, launch_gemm_et(prec, e->AOlo, b.proj_w, e->X, nullptr, nullptr, 0, M, D, D, true, false, true, s));
+                    CK(e, launch_gemm_et(prec, e->AO, b.proj_w_lo, e->X, nullptr, nullptr, 0, M, D, D, true, false, true, s));
+                }
+                CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
             }
-            CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
             CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, sp_mlp ? e->Ylo : nullptr));
         }
         hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -649,9 +662,13 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         }
         if (fold) CK(e, launch_gemm_et_fold(prec, e->Y, b.lin1_wf, e->H, b.lin1_bf, b.lin1_c, e->ROWSTAT, M, 4 * D, D, true, s));
         else if (sp_mlp) {
-            CK(e, launch_gemm_et(prec, e->Ylo, b.lin1_w, e->F32T, nullptr, nullptr, 0, M, 4 * D, D, true, false, false, s));
-            CK(e, launch_gemm_et(prec, e->Y, b.lin1_w_lo, e->F32T, nullptr, nullptr, 0, M, 4 * D, D, true, false, true, s));
-            CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->F32T, b.lin1_b, nullptr, 0, M, 4 * D, D, true, false, true, s));
+            if (one3 && gemm_split3_ok(M, 4 * D, D)) {
+                CK(e, launch_gemm_et_split3(prec, e->Y, e->Ylo, b.lin1_w, b.lin1_w_lo, e->F32T, b.lin1_b, M, 4 * D, D, true, false, s));
+            } else {
+                CK(e, launch_gemm_et(prec, e->Ylo, b.lin1_w, e->F32T, nullptr, nullptr, 0, M, 4 * D, D, true, false, false, s));
+                CK(e, launch_gemm_et(prec, e->Y, b.lin1_w_lo, e->F32T, nullptr, nullptr, 0, M, 4 * D, D, true, false, true, s));
+                CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->F32T, b.lin1_b, nullptr, 0, M, 4 * D, D, true, false, true, s));
+            }
             CK(e, launch_gelu_split(prec, e->F32T, e->H, e->Hlo, (long)M * 4 * D, s));
         } else CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
         if (e->timing) {
@@ -662,11 +679,15 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, launch_gemm_et_stats(prec, e->H, b.lin2_w, e->X, b.lin2_b, e->Y, e->STATS, M, D, 4 * D, s));
             if (i + 1 < c.depth) CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
         } else {
-            if (sp_mlp) {
-                CK(e, launch_gemm_et(prec, e->Hlo, b.lin2_w, e->X, nullptr, nullptr, 0, M, D, 4 * D, true, false, true, s));
-                CK(e, launch_gemm_et(prec, e->H, b.lin2_w_lo, e->X, nullptr, nullptr, 0, M, D, 4 * D, true, false, true, s));
+            if (sp_mlp && one3 && gemm_split3_ok(M, D, 4 * D)) {
+                CK(e, launch_gemm_et_split3(prec, e->H, e->Hlo, b.lin2_w, b.lin2_w_lo, e->X, b.lin2_b, M, D, 4 * D, true, true, s));
+            } else {
+                if (sp_mlp) {
+                    CK(e, launch_gemm_et(prec, e->Hlo, b.lin2_w, e->X, nullptr, nullptr, 0, M, D, 4 * D, true, false, true, s));
+                    CK(e, launch_gemm_et(prec, e->H, b.lin2_w_lo, e->X, nullptr, nullptr, 0, M, D, 4 * D, true, false, true, s));
+                }
+                CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
             }
-            CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
         }
     }
     if (!do_neck) return SAMRS_OK;
@@ -1008,6 +1029,7 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     }
     else if (n == "gemm_variant") e->gemm_variant = value;
     else if (n == "upscaler_fused") e->upscaler_fused = value != 0;
+    else if (n == "split_passes") e->split_passes = value != 0;
     else return fail(e, SAMRS_ERR_BAD_ARG, "unknown option %s", name);
     return SAMRS_OK;
 }
@@ -1019,6 +1041,7 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
     else if (n == "split") *value = e->split;
     else if (n == "gemm_variant") *value = e->gemm_variant;
     else if (n == "upscaler_fused") *value = e->upscaler_fused;
+    else if (n == "split_passes") *value = e->split_passes;
     else return SAMRS_ERR_BAD_ARG;
     return SAMRS_OK;
 }
@@ -1175,6 +1198,11 @@ int samrs_k_postprocess(const float* low, int n_masks, int in_h, int in_w, int o
 int samrs_k_gemm_gln(int prec, const void* A, const void* B, void* C, const float* bias, const float* gamma_beta, int M, int N,
                      int K, const void* A_lo, const void* B_lo, void* stream) {
     KRET(launch_gemm_et_gln(prec, A, B, C, bias, gamma_beta, M, N, K, (hipStream_t)stream, A_lo, B_lo));
+}
+int samrs_k_gemm_split3(int prec, const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, const float* bias,
+                        int M, int N, int K, int out_f32, int accumulate, void* stream) {
+    if (!gemm_split3_ok(M, N, K)) return SAMRS_ERR_BAD_SHAPE;
+    KRET(launch_gemm_et_split3(prec, A, A_lo, B, B_lo, C, bias, M, N, K, out_f32 != 0, accumulate != 0, (hipStream_t)stream));
 }
 int samrs_k_upscale2_masks(int prec, const void* u1, const void* w, const void* w_lo, const float* bias, const float* hyper,
                            float* low, int n, int grid, int n_mask_tokens, int sel0, int n_sel, void* stream) {

@@ -881,11 +881,29 @@ __device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint3
         : "memory");
 }
 
-template <int PREC, bool OUT_F32, bool GELU, int NI = 4, int MODE = 0, int ABL = 0>
+// SPLIT3 (reference-grade operand split, engine option bits 16 / 32): A = A_hi + A_lo, B = B_hi + B_lo, and the product
+// A_lo B_hi^T + A_hi B_lo^T + A_hi B_hi^T is ONE pass over a K axis of three segments -- the accumulators stay in registers, no
+// fp32 round trip through memory between the terms (the generic route: three accumulating launches).  Pair stage st of
+// 3 K / 64 reads segment st / (K / 64): the only change to the main loop is where a stage's DMA source starts.
+template <bool SPLIT3>
+__device__ __forceinline__ const uint16_t* seg_src_a(const uint16_t* hi, const uint16_t* lo, int st, int nst1) {
+    if constexpr (!SPLIT3) return hi + (size_t)st * XBK;
+    const int seg = (st >= nst1) + (st >= 2 * nst1);
+    return (seg == 0 ? lo : hi) + (size_t)(st - seg * nst1) * XBK;
+}
+template <bool SPLIT3>
+__device__ __forceinline__ const uint16_t* seg_src_b(const uint16_t* hi, const uint16_t* lo, int st, int nst1) {
+    if constexpr (!SPLIT3) return hi + (size_t)st * XBK;
+    const int seg = (st >= nst1) + (st >= 2 * nst1);
+    return (seg == 1 ? lo : hi) + (size_t)(st - seg * nst1) * XBK;
+}
+
+template <int PREC, bool OUT_F32, bool GELU, int NI = 4, int MODE = 0, int ABL = 0, bool SPLIT3 = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
-    int M, int N, int K, int accumulate, int skew) {
+    int M, int N, int K, int accumulate, int skew,
+    const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr) {
     constexpr int XBN = 64 * NI;
     constexpr int XROWS = QBM + XBN;                       // 512 / 576 rows per stage
     constexpr int XSTAGE_ELEMS = XROWS * XBK;              // 64 / 72 KiB
@@ -925,12 +943,16 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     const uint32_t voff = ((uint32_t)prow * (uint32_t)K + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
     const uint16_t* sA = A + (size_t)m0 * K;               // wave-uniform bases (SGPR pairs)
     const uint16_t* sB = B + (size_t)n0 * K;
+    const uint16_t* sAl = SPLIT3 ? A_lo + (size_t)m0 * K : nullptr;
+    const uint16_t* sBl = SPLIT3 ? B_lo + (size_t)n0 * K : nullptr;
+    const int nst1 = K / XBK;                              // pair stages per K segment
     const size_t rs64 = (size_t)64 * K;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
     // piece q_ (literal) of pair stage st_ into the buffer at byte offset wr_
 #define X64_PIECE(st_, wr_, q_)                                                                            \
-    if constexpr (!(ABL & 1)) glds16_s(voff, ((q_) < 4 ? sA + (size_t)(q_) * rs64 : sB + (size_t)((q_) - 4) * rs64) + (size_t)(st_) * XBK, \
+    if constexpr (!(ABL & 1)) glds16_s(voff, ((q_) < 4 ? seg_src_a<SPLIT3>(sA, sAl, (st_), nst1) + (size_t)(q_) * rs64                  \
+                                                        : seg_src_b<SPLIT3>(sB, sBl, (st_), nst1) + (size_t)((q_) - 4) * rs64),          \
              lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u))
 #define X64_ISSUE(st_, wr_)                                                                                \
     do {                                                                                                   \
@@ -945,7 +967,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nst = K / XBK;
+    const int nst = (SPLIT3 ? 3 : 1) * nst1;
     const int fr = lane & 15, fq = lane >> 4;
     // fragment BYTE offsets inside a stage for k-half 0; k-half 1 is +512
     uint32_t offA[8], offB[NI];
@@ -1106,12 +1128,14 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
 // partials of the LN_NS 160-column groups; only the ET epilogue reads it (8 bytes per row and lane, next to the bias loads).
 constexpr int LN_NS = 8;                       // 1280 / 160: ViT-H only
 
-template <int PREC, bool OUT_F32, bool GELU, bool FOLD = false>
+template <int PREC, bool OUT_F32, bool GELU, bool FOLD = false, bool SPLIT3 = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, int accumulate,
-    const float2* __restrict__ rowstat = nullptr, const float* __restrict__ cvec = nullptr) {
+    const float2* __restrict__ rowstat = nullptr, const float* __restrict__ cvec = nullptr,
+    const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr) {
     static_assert(!(FOLD && OUT_F32), "the folded LayerNorm feeds ET outputs only (qkv, lin1)");
+    static_assert(!(FOLD && SPLIT3), "the split operands come from an explicit LayerNorm");
     constexpr int NI = 5;
     constexpr int XBN = 64 * NI;
     constexpr int XROWS = QBM + XBN;
@@ -1146,8 +1170,12 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
     const uint16_t* sA;                            // wave-uniform bases of the tile being FED (SGPR pairs)
     const uint16_t* sB;
+    const uint16_t* sAl = nullptr;                 // SPLIT3: the lo operands of that tile
+    const uint16_t* sBl = nullptr;
+    const int nst1 = K / XBK;                      // pair stages per K segment
 #define X64P_PIECE(st_, wr_, q_)                                                                           \
-    glds16_s(voff, ((q_) < 4 ? sA + (size_t)(q_) * rs64 : sB + (size_t)((q_) - 4) * rs64) + (size_t)(st_) * XBK, \
+    glds16_s(voff, ((q_) < 4 ? seg_src_a<SPLIT3>(sA, sAl, (st_), nst1) + (size_t)(q_) * rs64               \
+                             : seg_src_b<SPLIT3>(sB, sBl, (st_), nst1) + (size_t)((q_) - 4) * rs64),       \
              lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u))
 #define X64P_ISSUE(st_, wr_)                                                                               \
     do {                                                                                                   \
@@ -1156,7 +1184,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
         X64P_PIECE(st_, wr_, 8);                                                                           \
     } while (0)
 
-    const int nst = K / XBK;
+    const int nst = (SPLIT3 ? 3 : 1) * nst1;
     const int fr = lane & 15, fq = lane >> 4;
     uint32_t offA[8], offB[NI];
 #pragma unroll
@@ -1189,6 +1217,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     X64P_TILE(L, m0, n0);
     sA = A + (size_t)m0 * K;
     sB = B + (size_t)n0 * K;
+    if constexpr (SPLIT3) { sAl = A_lo + (size_t)m0 * K; sBl = B_lo + (size_t)n0 * K; }
     X64P_ISSUE(0, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1238,6 +1267,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
             X64P_TILE(Ln, m1, n1);
             sA = A + (size_t)m1 * K;
             sB = B + (size_t)n1 * K;
+            if constexpr (SPLIT3) { sAl = A_lo + (size_t)m1 * K; sBl = B_lo + (size_t)n1 * K; }
             X64P_ISSUE(0, 0u);
         }
         {   // epilogue of tile (m0, n0); bounce scratch = ring buffer 1 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
@@ -2595,6 +2625,40 @@ hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C
     if (M % QBM || N % WBN || K != 160 * LN_NS || !bias_f || !cvec || !rowstat) return hipErrorInvalidValue;
     if (prec == PREC_BF16) return launch_gemm_x64p_fold<PREC_BF16>(Xh, Wf, C, bias_f, cvec, rowstat, M, N, K, gelu, s);
     if (prec == PREC_F16) return launch_gemm_x64p_fold<PREC_F16>(Xh, Wf, C, bias_f, cvec, rowstat, M, N, K, gelu, s);
+    return hipErrorInvalidValue;
+}
+
+// One-launch split product (see seg_src_a): C = (A + A_lo)(B + B_lo)^T minus the lo x lo term, + bias; ET output (rounded once
+// from the fp32 accumulators) or fp32 output, optionally accumulated into C.  Shapes of the pair-stage 256x320 tile only; the
+// caller falls back to three accumulating launch_gemm_et passes when this returns hipErrorInvalidValue.
+template <int PREC>
+static hipError_t launch_gemm_split3_prec(const uint16_t* a, const uint16_t* al, const uint16_t* b, const uint16_t* bl, void* C,
+                                          const float* bias, int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s) {
+    const int ntiles = (M / QBM) * (N / WBN);
+    if (out_f32) {
+        gemm_et_x64_kernel<PREC, true, false, 5, 3, 0, true><<<dim3(ntiles), dim3(QTHREADS), 0, s>>>(
+            a, b, C, bias, nullptr, 1, M, N, K, accumulate ? 1 : 0, 0, al, bl);
+    } else {
+        int dev = 0, n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (n_cu <= 0) n_cu = 256;
+        gemm_et_x64p_kernel<PREC, false, false, false, true><<<dim3(ntiles < n_cu ? ntiles : n_cu), dim3(QTHREADS), 0, s>>>(
+            a, b, C, bias, M, N, K, 0, nullptr, nullptr, al, bl);
+    }
+    return hipGetLastError();
+}
+
+bool gemm_split3_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0; }
+
+hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, const float* bias,
+                                 int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s) {
+    if (!gemm_split3_ok(M, N, K) || !A || !A_lo || !B || !B_lo || (accumulate && !out_f32)) return hipErrorInvalidValue;
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* al = reinterpret_cast<const uint16_t*>(A_lo);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const uint16_t* bl = reinterpret_cast<const uint16_t*>(B_lo);
+    if (prec == PREC_BF16) return launch_gemm_split3_prec<PREC_BF16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, s);
+    if (prec == PREC_F16) return launch_gemm_split3_prec<PREC_F16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, s);
     return hipErrorInvalidValue;
 }
 

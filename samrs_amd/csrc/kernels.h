@@ -19,6 +19,12 @@ hipError_t launch_gemm_et_stats(int prec, const void* A, const void* B, float* C
                                 int M, int N, int K, hipStream_t s);
 hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C, const float* bias_f, const float* cvec,
                                const float* rowstat, int M, int N, int K, bool gelu, hipStream_t s);
+// Split-precision product in ONE launch: C = A B^T + A_lo B^T + A B_lo^T + bias over a three-segment K axis (fp32 accumulators stay
+// in registers).  out_f32: C is fp32 [M][N] (optionally accumulated into), else ET rounded once.  gemm_split3_ok: M % 256,
+// N % 320, K % 64 (the ViT-H block GEMMs); other shapes take three accumulating launch_gemm_et passes.
+bool gemm_split3_ok(int M, int N, int K);
+hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, const float* bias,
+                                 int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s);
 void set_gemm_variant(int v);   // process-wide test hook (kernel-level entry points): 0 = register-staged tiles, ..., 8 = automatic
 int swap_gemm_variant_override(int v);   // thread-local override (-1 = none) used by engine handles; returns the previous value
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)

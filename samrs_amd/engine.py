@@ -102,13 +102,14 @@ def load_library() -> C.CDLL:
     lib.samrs_k_neck_im2col.restype = ip
     lib.samrs_k_gemm_gln.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, vp, vp, vp]
     lib.samrs_k_upscale2_masks.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
+    lib.samrs_k_gemm_split3.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_set_images_ragged", "samrs_get_embedding",
                  "samrs_set_embedding", "samrs_reset_image", "samrs_predict", "samrs_paint", "samrs_k_gemm",
                  "samrs_k_gemm_f32", "samrs_k_convert", "samrs_k_layernorm", "samrs_k_window_attention",
                  "samrs_k_global_attention", "samrs_k_postprocess", "samrs_k_gemm_gln", "samrs_k_upscale2_masks",
                  "samrs_k_gemm_stats", "samrs_k_gemm_fold", "samrs_k_ln_fold_weight", "samrs_k_rowstats_convert", "samrs_k_ln_rowstat",
                  "samrs_set_option", "samrs_get_option", "samrs_rle_encode", "samrs_k_convert_split", "samrs_select_best",
-                 "samrs_k_upscaler_fused"):
+                 "samrs_k_upscaler_fused", "samrs_k_gemm_split3"):
         getattr(lib, name).restype = ip
     if lib.samrs_abi_version() != ABI_VERSION:
         raise ImportError("libsamrs_hip.so ABI version mismatch; rebuild it")

@@ -472,6 +472,42 @@ def test_gemm_gln_split_precision(lib, name, prec, dt, ulp):
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("M,N,K,out_f32", [(256, 320, 64, 1), (512, 640, 192, 0), (512, 1280, 1280, 1), (768, 3840, 1280, 0)])
+def test_gemm_split3_one_launch(lib, name, prec, dt, ulp, M, N, K, out_f32):
+    """The block GEMMs of the reference-grade mode as ONE launch over a three-segment K axis (A_lo B + A B_lo + A B in the
+    register accumulators): against the fp64 product of the un-rounded fp32 operands, far below one operand ulp; ET output =
+    that result rounded once; fp32 output accumulates into the residual stream (image_encoder.py:175,182)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g) * 0.5
+    ref = A.double() @ B.double().t() + bias.double()
+    Ah, Al = split_bits(lib, prec, A)
+    Bh, Bl = split_bits(lib, prec, B)
+    if out_f32:
+        res = torch.randn(M, N, generator=g)
+        out = dev(res.clone())
+        assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), out.data_ptr(),
+                                       dev(bias).data_ptr(), M, N, K, 1, 1, stream()) == 0
+        got = out.cpu().double() - res.double()
+        tol = 2e-5 if name == "f16" else 1e-3
+    else:
+        out = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+        assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), out.data_ptr(),
+                                       dev(bias).data_ptr(), M, N, K, 0, 0, stream()) == 0
+        got = out.cpu().view(dt).double()
+        tol = 0.51 * ulp                                                # one rounding of the fp32 result to the operand type
+    err = (got - ref).abs() / ref.abs().clamp(min=1.0)
+    print(f"split3 {name} {M}x{N}x{K} out_f32={out_f32}: max err {err.max().item():.2e} (operand ulp {ulp:.1e})")
+    assert err.max().item() < tol
+    # against the plain product of the rounded operands the difference must be visible: the lo terms are really there
+    plain = A.to(dt).double() @ B.to(dt).double().t() + bias.double()
+    assert ((plain - ref).abs().max() > 4 * (got - ref).abs().max()) or not out_f32
+    assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), out.data_ptr(),
+                                   dev(bias).data_ptr(), M, N + 64, K, out_f32, 0, stream()) != 0      # shape outside the tile: refused
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
 @pytest.mark.parametrize("n_sel,sel0", [(1, 0), (3, 1)])
 def test_upscale2_masks_fused(lib, name, prec, dt, ulp, n_sel, sel0):
     """ConvT #2 (as a K = 64 GEMM) + GELU + hypernetwork dot, fused (mask_decoder.py:57-59,154-167)."""

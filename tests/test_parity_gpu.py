@@ -239,6 +239,31 @@ def test_operand_split_buys_what_the_error_budget_says():
     assert res[15][1] < 0.5 * res[0][1], res           # out-projection + upscaler are ~90 % of the decoder's error variance
 
 
+def test_split_block_gemms_one_launch_equals_three_passes():
+    """Reference-grade mode at ViT-H: the three terms of every split block GEMM as one launch over a three-segment K axis
+    (samrs_k_gemm_split3) against the generic route (three accumulating launches through an fp32 scratch).  Same products, same
+    fp32 accumulation class: the embeddings agree far inside the mode's own error against the oracle (~1e-4 rel. L2)."""
+    import samrs_amd
+    sam = samrs_amd.sam_model_registry["vit_h"](precision="f16", max_prompts=8, max_points=1, options={"split": 63}).to("cuda")
+    pred = samrs_amd.SamPredictor(sam)
+    eng = sam.engine
+    img = synth.make_image(3)
+    emb = {}
+    for passes in (1, 0):
+        eng.set_option("split_passes", passes)
+        assert eng.get_option("split_passes") == passes
+        pred.set_image(img)
+        emb[passes] = pred.get_image_embedding().float().cpu()
+    eng.set_option("split", 15)
+    pred.set_image(img)
+    plain = pred.get_image_embedding().float().cpu()
+    eng.close()
+    d = ((emb[0] - emb[1]).norm() / emb[1].norm()).item()
+    d_plain = ((plain - emb[1]).norm() / emb[1].norm()).item()
+    print(f"one launch vs three passes: rel L2 {d:.2e}; default split vs reference-grade: {d_plain:.2e}")
+    assert d < 2e-5 and d < 0.1 * d_plain
+
+
 @pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80", "vit_b", "vit_l", "vit_h"])
 def test_against_reference_golden(name, golden_dir):
     """Replay the committed fixtures produced by the REAL reference (oracle/make_golden.py).  vit_l (embed_dim 1024,

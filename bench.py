@@ -12,7 +12,8 @@ batch k-1 overlapped with the encoder of batch k on separate HIP streams.  One "
   c2 (default, BASELINE.json configs[1]): 32 hboxes per tile in one box-only ``predict`` (multimask_output=False),
      thresholded full-resolution masks [32, 1, 1024, 1024] in HBM, painted class map + per-box areas to the host.
      ``value`` is measured with the tiles resident in HBM when the timed region starts (the pipeline's H2D stage
-     degenerates to a device copy); ``pcie_inclusive`` is the SAME loop with the tiles starting in pinned host memory.
+     degenerates to a device copy); ``pcie_inclusive`` is the SAME loop with the tiles starting in pinned host memory;
+     ``cli_inclusive`` is ``samrs_amd.generate.run`` from PNG files on disk to gray / color PNG + pickle files on disk.
   c3 (configs[2]): DOTA-v2-shaped stream -- box counts per tile long-tailed (geometric, mean 32, cap 400), decoded in
      the reference's 20-box chunks, tiles handed to the ranks by a shared-counter work queue (driver.WorkQueue).
   c4 (configs[3]): instance path -- 32 FAIR1M-shaped rotated boxes per tile, enclosing-hbox prompt (or --c4-prompt
@@ -64,6 +65,15 @@ def file_sha(path: str) -> str:
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
+def _cpu_quota():
+    """CPUs this container may use at once (cgroup v2 cpu.max), or None."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else round(int(q) / int(p), 1)
+    except Exception:
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +92,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second (bf16) timing leg")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the PCIe-inclusive measurement")
+    ap.add_argument("--no-cli-leg", action="store_true", help="skip the end-to-end run of the generation CLI (PNG files in, files out)")
+    ap.add_argument("--cli-tiles", type=int, default=320, help="tiles of the CLI leg")
     ap.add_argument("--no-rle-leg", action="store_true", help="skip the RLE-inclusive measurement (the reference's full output contract)")
     args = ap.parse_args()
 
@@ -287,6 +299,48 @@ def main() -> None:
                        "number is the headline and bf16 is reported here only"}
         del sam2, pipe2
 
+    # ---- the generation CLI end to end: PNG tiles on disk -> samrs_amd.generate.run (reader pool over libsamrs_io.so,
+    # TilePipeline with device RLE, writer pool) -> gray + color PNG + ins/*.pkl on disk.  The rate is that of generate's loop
+    # (first read to last file written; its model build is outside).  Host-side work on this box's CPU slice is part of it. ----
+    cli = None
+    if rank == 0 and world == 1 and not args.no_cli_leg and args.workload == "c2":
+        import argparse as _ap
+        import shutil
+        import tempfile
+        from concurrent.futures import ThreadPoolExecutor
+        from samrs_amd import generate, tile_io
+        try:
+            pipe = None
+            torch.cuda.empty_cache()
+            root = tempfile.mkdtemp(prefix="samrs_bench_cli_")
+            n_cli = max(8 * B, min(40 * B, args.cli_tiles))
+            os.makedirs(os.path.join(root, "img"))
+            ann = {}
+            for i in range(n_cli):
+                bx, lb = synth.make_boxes(i, args.boxes)
+                ann[f"T{i:05d}"] = {"boxes": bx.tolist(), "labels": lb.tolist()}
+            with ThreadPoolExecutor(8) as ex:
+                list(ex.map(lambda i: tile_io.write_rgb(os.path.join(root, "img", f"T{i:05d}.png"),
+                                                        np.roll(host_tiles[i % len(host_tiles)].numpy(), 37 * (i // len(host_tiles)), axis=1), 1),
+                            range(n_cli)))
+            with open(os.path.join(root, "boxes.json"), "w") as f:
+                json.dump(ann, f)
+            ns = _ap.Namespace(images=os.path.join(root, "img"), boxes=os.path.join(root, "boxes.json"), out=os.path.join(root, "out"),
+                               model=args.model, checkpoint=None, precision=args.dtype, classes=None, n_classes=18, palette=None,
+                               box_batch=64, no_rle=False, batch=B, schedule="static", readers=8, writers=16, resume=False,
+                               rle_buffer_mb=512, timing=True, png_level=6, out_depth=4)
+            st = generate.run(ns)["timing"]
+            per = {k: round(1e3 * v / st["images"], 1) for k, v in sorted(st["stage_thread_seconds"].items()) if not k.startswith("loop.")}
+            cli = {"value": round(st["images"] / st["loop_seconds"], 3), "unit": "images/s", "tiles": st["images"],
+                   "cpus": len(os.sched_getaffinity(0)), "cpu_quota": _cpu_quota(),
+                   "what": "python -m samrs_amd.generate end to end: 1024^2 PNG tiles read from disk (8 reader threads), TilePipeline "
+                           "with per-instance RLE on the device, gray + color PNG + ins/*.pkl written (16 writer threads); "
+                           "first-call warm-up inside the timed loop",
+                   "host_thread_ms_per_image": per}
+            shutil.rmtree(root, ignore_errors=True)
+        except Exception as ex:                                      # a secondary leg must not take the bench line down
+            cli = {"value": None, "note": f"failed: {type(ex).__name__}: {ex}"}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the oracle (a port of the reference's algorithm) on the host cores: 1 warm-up tile, then 2 timed tiles with
@@ -356,7 +410,7 @@ def main() -> None:
                        "inputs": "tiles resident in HBM at the start of the timed region (pcie_inclusive: pinned host memory)",
                        "accumulate": "f32"},
             "flops_per_image": F, "roofline": roofline, "cpu_baseline": cpu_baseline, "alt_dtype": alt, "pcie_inclusive": pcie,
-            "rle_inclusive": rle_leg,
+            "rle_inclusive": rle_leg, "cli_inclusive": cli,
             "boxes_per_s": round(boxes_done / dt, 1),
             "stats_allreduce": {"total_pixels": int(tot_pix.sum().item()), "total_instances": int(tot_ins.sum().item())},
         }

@@ -183,7 +183,11 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    Reference-grade bits, not in the default: 16 = the encoder blocks' qkv + proj GEMMs, 32 = their MLP GEMMs
  *                    (three times the MFMA work of what they cover; 63 = every MFMA operand of the path split).  They need lo
  *                    copies of the block weights: set them BEFORE samrs_finalize_weights (SAMRS_SPLIT=63 / the option); they
- *                    can be cleared and set again afterwards.
+ *                    can be cleared and set again afterwards.  64 = the cheap form of 16: only the v third of the qkv product (+ proj)
+ *                    takes the lo terms -- q and k pass through the softmax (ViT-H shapes, else it acts like 16).
+ *   "split_depth"    [SAMRS_SPLIT_DEPTH, default 0 = all] the bits 16 / 32 / 64 apply to the first N encoder blocks only: an operand
+ *                    error made in an early block is carried through every later one, one made in the last blocks is not.
+ *                    split 79 (15 | 64) with split_depth 24: C4 fixture IoU >= 0.999 at 0.86x the default's throughput.
  *   "decoder_fusion" [SAMRS_DECODER_FUSION, default 1] 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm /
  *                    product launches; never split): the fused-vs-unfused parity test and timing experiments.
  *   "ln_fold"        [SAMRS_LN_FOLD, default 0] (embed_dim 1280) 1 = fold the encoder blocks' LayerNorms into the qkv / lin1
@@ -273,9 +277,10 @@ int samrs_k_gemm_gln(int prec, const void* A_et, const void* B_et, void* C_et, c
 /* Split-precision GEMM in one launch (the block GEMMs of the reference-grade mode, option "split" bits 16 / 32):
  * C = A B^T + A_lo B^T + A B_lo^T + bias over a three-segment K axis; A*, [M,K], B*, [N,K] in the operand type (hi / lo from
  * samrs_k_convert_split).  out_f32 = 0: C_et [M,N] rounded once from the fp32 accumulators; out_f32 = 1: C fp32 [M,N],
- * accumulate != 0 adds to what C holds (the residual stream).  M % 256 == 0, N % 320 == 0, K % 64 == 0, else SAMRS_ERR_BAD_SHAPE. */
+ * accumulate != 0 adds to what C holds (the residual stream).  M % 256 == 0, N % 320 == 0, K % 64 == 0, else SAMRS_ERR_BAD_SHAPE.
+ * split_from_n (out_f32 = 0 only, a multiple of 320, 0 = everywhere): only output columns >= split_from_n take the lo terms. */
 int samrs_k_gemm_split3(int prec, const void* A_et, const void* A_lo_et, const void* B_et, const void* B_lo_et, void* C,
-                        const float* bias, int M, int N, int K, int out_f32, int accumulate, void* stream);
+                        const float* bias, int M, int N, int K, int out_f32, int accumulate, int split_from_n, void* stream);
 /* Second transposed conv + GELU + hypernetwork product (mask_decoder.py:57-59,154-167) in one pass:
  * u1_et [n*grid*grid*4, 64] (rows = prompt, token, sub-pixel 1), w_et [128, 64] (rows = sub-pixel 2 x 32
  * channels), bias [128], hyper [n, n_mask_tokens, 32] -> low [n, n_sel, 4*grid, 4*grid] fp32 for mask

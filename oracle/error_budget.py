@@ -168,6 +168,17 @@ def main(argv):
                               ("E1 + block GEMMs split in the global-attention blocks", tuple(cfg.global_attn_indexes))):
             tag = "p5_" + "_".join(str(b) for b in (blocks[0], blocks[-1], len(blocks)))
             report(label, tag, so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points={q: (blocks, sp) for q in four}))
+    if what in ("plans6",):
+        # attention-side split (qkv or only its v third, + proj) confined to the leading blocks: what does the 1x rate in the late blocks cost?
+        sp = so.split2(F16)
+        e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
+        n = cfg.depth
+        for label, pts, blocks in (("E1 + qkv + proj split in blocks 0..%d" % (n // 2 - 1), ("enc.qkv_in", "enc.proj_in"), range(0, n // 2)),
+                                   ("E1 + v + proj split in blocks 0..%d" % (n // 2 - 1), ("enc.v_in", "enc.proj_in"), range(0, n // 2)),
+                                   ("E1 + qkv + proj split in blocks 0..%d" % (3 * n // 4 - 1), ("enc.qkv_in", "enc.proj_in"), range(0, 3 * n // 4)),
+                                   ("E1 + v + proj split in blocks 0..%d" % (3 * n // 4 - 1), ("enc.v_in", "enc.proj_in"), range(0, 3 * n // 4))):
+            tag = "p6_" + "_".join(q.split(".")[1] for q in pts) + "_%d" % len(blocks)
+            report(label, tag, so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points={q: (blocks, sp) for q in pts}))
     if what in ("plans", "all"):
         sp = so.split2(F16)
         report("plan A: encoder f16, decoder operands split f16 (hi+lo)", "f16",

@@ -134,7 +134,7 @@ def _attention(x: Tensor, sd: SD, p: str, heads: int, rd: Rounding) -> Tensor:
     B, S, _, D = x.shape
     d = D // heads
     qkv = _linear(x.reshape(B, S * S, D), sd, p + ".qkv", rd.p("enc.qkv_in"))  # [B, N, 3D]
-    if rd.points is not None and "enc.v_in" in rd.points:      # error-budget probe: the v third of the qkv product on its own rounding
+    if (rd.points is not None and "enc.v_in" in rd.points) or (rd.block_points is not None and "enc.v_in" in rd.block_points):      # error-budget probe: the v third of the qkv product on its own rounding
         qkv = torch.cat([qkv[..., :2 * D], _linear(x.reshape(B, S * S, D), sd, p + ".qkv", rd.p("enc.v_in"))[..., 2 * D:]], dim=-1)
     qkv = qkv.reshape(B, S * S, 3, heads, d).permute(2, 0, 3, 1, 4)         # [3, B, h, N, d]
     q, k, v = (t.reshape(B * heads, S * S, d) for t in qkv)

@@ -58,6 +58,9 @@ class Sam:
         for k, v in self.options.items():
             self.engine.set_option(k, v)
         self.engine.load_state_dict(self._state_dict)
+        # what this model runs in when nobody says otherwise (ViT-H: 79, else 15): the multimask-safe mode; the pipelines of
+        # driver.py switch between it and the 1x-rate mode by output contract (TilePipeline precision="auto")
+        self.default_split = self.engine.get_option("split")
         self._device = device
         return self
 

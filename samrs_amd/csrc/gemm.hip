@@ -1133,7 +1133,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, int accumulate,
     const float2* __restrict__ rowstat = nullptr, const float* __restrict__ cvec = nullptr,
-    const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr) {
+    const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr, int split_from_n = 0) {
     static_assert(!(FOLD && OUT_F32), "the folded LayerNorm feeds ET outputs only (qkv, lin1)");
     static_assert(!(FOLD && SPLIT3), "the split operands come from an explicit LayerNorm");
     constexpr int NI = 5;
@@ -1173,9 +1173,12 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const uint16_t* sAl = nullptr;                 // SPLIT3: the lo operands of that tile
     const uint16_t* sBl = nullptr;
     const int nst1 = K / XBK;                      // pair stages per K segment
+    // SPLIT3 with split_from_n > 0: only output columns >= split_from_n take the lo terms (qkv: the v third -- q and k pass
+    // through the softmax, error_budget.py plans4); the other tiles start at the hi x hi segment: stage base sb = 2 nst1
+    int sb = 0;                                    // of the tile being FED
 #define X64P_PIECE(st_, wr_, q_)                                                                           \
-    glds16_s(voff, ((q_) < 4 ? seg_src_a<SPLIT3>(sA, sAl, (st_), nst1) + (size_t)(q_) * rs64               \
-                             : seg_src_b<SPLIT3>(sB, sBl, (st_), nst1) + (size_t)((q_) - 4) * rs64),       \
+    glds16_s(voff, ((q_) < 4 ? seg_src_a<SPLIT3>(sA, sAl, (st_) + sb, nst1) + (size_t)(q_) * rs64          \
+                             : seg_src_b<SPLIT3>(sB, sBl, (st_) + sb, nst1) + (size_t)((q_) - 4) * rs64),  \
              lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u))
 #define X64P_ISSUE(st_, wr_)                                                                               \
     do {                                                                                                   \
@@ -1184,7 +1187,6 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
         X64P_PIECE(st_, wr_, 8);                                                                           \
     } while (0)
 
-    const int nst = (SPLIT3 ? 3 : 1) * nst1;
     const int fr = lane & 15, fq = lane >> 4;
     uint32_t offA[8], offB[NI];
 #pragma unroll
@@ -1217,12 +1219,13 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     X64P_TILE(L, m0, n0);
     sA = A + (size_t)m0 * K;
     sB = B + (size_t)n0 * K;
-    if constexpr (SPLIT3) { sAl = A_lo + (size_t)m0 * K; sBl = B_lo + (size_t)n0 * K; }
+    if constexpr (SPLIT3) { sAl = A_lo + (size_t)m0 * K; sBl = B_lo + (size_t)n0 * K; sb = n0 >= split_from_n ? 0 : 2 * nst1; }
     X64P_ISSUE(0, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     f32x4_t acc[NI][8];
     for (;;) {
+        const int nst = SPLIT3 ? 3 * nst1 - sb : nst1;       // stages of THIS tile (sb still is its base here)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -1267,7 +1270,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
             X64P_TILE(Ln, m1, n1);
             sA = A + (size_t)m1 * K;
             sB = B + (size_t)n1 * K;
-            if constexpr (SPLIT3) { sAl = A_lo + (size_t)m1 * K; sBl = B_lo + (size_t)n1 * K; }
+            if constexpr (SPLIT3) { sAl = A_lo + (size_t)m1 * K; sBl = B_lo + (size_t)n1 * K; sb = n1 >= split_from_n ? 0 : 2 * nst1; }
             X64P_ISSUE(0, 0u);
         }
         {   // epilogue of tile (m0, n0); bounce scratch = ring buffer 1 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
@@ -2633,7 +2636,8 @@ hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C
 // caller falls back to three accumulating launch_gemm_et passes when this returns hipErrorInvalidValue.
 template <int PREC>
 static hipError_t launch_gemm_split3_prec(const uint16_t* a, const uint16_t* al, const uint16_t* b, const uint16_t* bl, void* C,
-                                          const float* bias, int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s) {
+                                          const float* bias, int M, int N, int K, bool out_f32, bool accumulate, int split_from_n,
+                                          hipStream_t s) {
     const int ntiles = (M / QBM) * (N / WBN);
     if (out_f32) {
         gemm_et_x64_kernel<PREC, true, false, 5, 3, 0, true><<<dim3(ntiles), dim3(QTHREADS), 0, s>>>(
@@ -2643,7 +2647,7 @@ static hipError_t launch_gemm_split3_prec(const uint16_t* a, const uint16_t* al,
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         if (n_cu <= 0) n_cu = 256;
         gemm_et_x64p_kernel<PREC, false, false, false, true><<<dim3(ntiles < n_cu ? ntiles : n_cu), dim3(QTHREADS), 0, s>>>(
-            a, b, C, bias, M, N, K, 0, nullptr, nullptr, al, bl);
+            a, b, C, bias, M, N, K, 0, nullptr, nullptr, al, bl, split_from_n);
     }
     return hipGetLastError();
 }
@@ -2651,14 +2655,15 @@ static hipError_t launch_gemm_split3_prec(const uint16_t* a, const uint16_t* al,
 bool gemm_split3_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0; }
 
 hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, const float* bias,
-                                 int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s) {
+                                 int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s, int split_from_n) {
     if (!gemm_split3_ok(M, N, K) || !A || !A_lo || !B || !B_lo || (accumulate && !out_f32)) return hipErrorInvalidValue;
+    if (split_from_n < 0 || split_from_n % WBN || (split_from_n && out_f32)) return hipErrorInvalidValue;   // whole tiles; ET outputs only
     const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
     const uint16_t* al = reinterpret_cast<const uint16_t*>(A_lo);
     const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
     const uint16_t* bl = reinterpret_cast<const uint16_t*>(B_lo);
-    if (prec == PREC_BF16) return launch_gemm_split3_prec<PREC_BF16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, s);
-    if (prec == PREC_F16) return launch_gemm_split3_prec<PREC_F16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, s);
+    if (prec == PREC_BF16) return launch_gemm_split3_prec<PREC_BF16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, split_from_n, s);
+    if (prec == PREC_F16) return launch_gemm_split3_prec<PREC_F16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, split_from_n, s);
     return hipErrorInvalidValue;
 }
 

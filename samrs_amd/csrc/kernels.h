@@ -24,7 +24,9 @@ hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C
 // N % 320, K % 64 (the ViT-H block GEMMs); other shapes take three accumulating launch_gemm_et passes.
 bool gemm_split3_ok(int M, int N, int K);
 hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, const float* bias,
-                                 int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s);
+                                 int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s, int split_from_n = 0);
+// split_from_n (ET output only, a multiple of 320): only output columns >= split_from_n take the lo terms; the tiles in front
+// of it are the plain hi x hi product (qkv: the v third alone)
 void set_gemm_variant(int v);   // process-wide test hook (kernel-level entry points): 0 = register-staged tiles, ..., 8 = automatic
 int swap_gemm_variant_override(int v);   // thread-local override (-1 = none) used by engine handles; returns the previous value
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)

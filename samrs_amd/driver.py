@@ -20,6 +20,8 @@ backend ``nccl`` = RCCL over xGMI on the GPU box, ``gloo`` in the CPU tests).
 """
 from __future__ import annotations
 
+import os
+
 import queue
 import threading
 from dataclasses import dataclass, field
@@ -330,11 +332,19 @@ class TilePipeline:
 
     def __init__(self, sam, n_classes: int, batch: int = 8, box_batch: int = 20, keep_masks: bool = False,
                  out_depth: int = 3, max_boxes: int = 512, device_inputs: bool = False, rle: bool = False,
-                 rle_buffer_mb: int = 256):
+                 rle_buffer_mb: int = 256, precision="auto"):
+        """precision: which operand-split mode the ENGINE runs in while this pipeline drives it (engine option "split").
+        "auto" = by output contract: this pipeline only ever asks for the single mask of token 0, which holds IoU >= 0.9995 against
+        the reference with every block GEMM at the 1x f16 rate (C2 fixtures), so it switches the engine to split 15; a multimask
+        pipeline (InstancePipeline(multimask=True)) keeps the engine's own default, which at ViT-H adds the v third of qkv +
+        proj on hi + lo operands (split 79: what the three multimask tokens need for IoU >= 0.999, C4 fixtures; 0.90x the
+        throughput).  An explicit choice -- builder ``options={"split": ...}`` or SAMRS_SPLIT -- is never overridden.
+        "engine" = leave the option alone; an int = set it."""
         from .transforms import ResizeLongestSide
         eng = sam.engine
         if eng is None:
             raise RuntimeError("move the model to the GPU first: sam.to('cuda')")
+        self._apply_precision(sam, precision, multimask=False)
         if out_depth < 2:
             raise ValueError("out_depth must be >= 2: batch k-1's results are still on loan to the sink when batch k decodes")
         if eng.max_images < 2 * batch:
@@ -373,6 +383,20 @@ class TilePipeline:
         self.free_out: "queue.Queue[_OutBuf]" = queue.Queue()
         for _ in range(out_depth):
             self.free_out.put(_OutBuf(batch, side, max_boxes, rle))
+
+    @staticmethod
+    def _apply_precision(sam, precision, multimask: bool) -> None:
+        from .engine import SPLIT_DEFAULT
+        eng = sam.engine
+        if precision == "engine":
+            return
+        if precision == "auto":
+            explicit = "split" in getattr(sam, "options", {}) or "SAMRS_SPLIT" in os.environ
+            want = getattr(sam, "default_split", SPLIT_DEFAULT) if multimask else SPLIT_DEFAULT
+            if not explicit and eng.get_option("split") != want:
+                eng.set_option("split", want)
+            return
+        eng.set_option("split", int(precision))
 
     # -- stage A: stage tiles + boxes of one batch, H2D on s_h2d ------------------------------------------------
     def _stage(self, b: int, items: List[WorkItem]):
@@ -604,7 +628,9 @@ class InstancePipeline(TilePipeline):
             raise ValueError("prompt must be 'box', 'rbox_mask' or 'point'")
         if prompt == "point":
             self.BOX_WIDTH = 2
-        super().__init__(sam, n_classes, **kw)
+        precision = kw.pop("precision", "auto")
+        super().__init__(sam, n_classes, precision="engine", **kw)
+        self._apply_precision(sam, precision, multimask=bool(multimask))
         self.prompt, self.multimask = prompt, bool(multimask)
         self.qual_dev = [torch.zeros(self.batch, self.max_boxes, dtype=torch.float32, device=self.dev) for _ in range(2)]
         for _ in range(self.free_out.qsize()):

@@ -24,7 +24,8 @@ PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16}
 ABI_VERSION = 2
 # "split" option bits (include/samrs_hip.h): rounding points that run as a two-term operand split
 SPLIT_PATCH, SPLIT_NECK, SPLIT_OI, SPLIT_UP, SPLIT_DEFAULT = 1, 2, 4, 8, 15
-SPLIT_ATTN, SPLIT_MLP, SPLIT_ALL = 16, 32, 63          # reference-grade bits: set before the weights are loaded
+SPLIT_ATTN, SPLIT_MLP, SPLIT_ATTN_V, SPLIT_ALL = 16, 32, 64, 127          # reference-grade bits: set before the weights are loaded
+# (64 = the attention-side split restricted to the v third of qkv + proj; option "split_depth" = leading blocks they apply to)
 
 OK, ERR_NOT_SET, ERR_BAD_SHAPE, ERR_BAD_ARG, ERR_HIP, ERR_BAD_WEIGHTS, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
 
@@ -102,7 +103,7 @@ def load_library() -> C.CDLL:
     lib.samrs_k_neck_im2col.restype = ip
     lib.samrs_k_gemm_gln.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, vp, vp, vp]
     lib.samrs_k_upscale2_masks.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
-    lib.samrs_k_gemm_split3.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
+    lib.samrs_k_gemm_split3.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
     for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_set_images_ragged", "samrs_get_embedding",
                  "samrs_set_embedding", "samrs_reset_image", "samrs_predict", "samrs_paint", "samrs_k_gemm",
                  "samrs_k_gemm_f32", "samrs_k_convert", "samrs_k_layernorm", "samrs_k_window_attention",

@@ -488,13 +488,13 @@ def test_gemm_split3_one_launch(lib, name, prec, dt, ulp, M, N, K, out_f32):
         res = torch.randn(M, N, generator=g)
         out = dev(res.clone())
         assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), out.data_ptr(),
-                                       dev(bias).data_ptr(), M, N, K, 1, 1, stream()) == 0
+                                       dev(bias).data_ptr(), M, N, K, 1, 1, 0, stream()) == 0
         got = out.cpu().double() - res.double()
         tol = 2e-5 if name == "f16" else 1e-3
     else:
         out = torch.zeros(M, N, dtype=torch.int16, device="cuda")
         assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), out.data_ptr(),
-                                       dev(bias).data_ptr(), M, N, K, 0, 0, stream()) == 0
+                                       dev(bias).data_ptr(), M, N, K, 0, 0, 0, stream()) == 0
         got = out.cpu().view(dt).double()
         tol = 0.51 * ulp                                                # one rounding of the fp32 result to the operand type
     err = (got - ref).abs() / ref.abs().clamp(min=1.0)
@@ -504,7 +504,35 @@ def test_gemm_split3_one_launch(lib, name, prec, dt, ulp, M, N, K, out_f32):
     plain = A.to(dt).double() @ B.to(dt).double().t() + bias.double()
     assert ((plain - ref).abs().max() > 4 * (got - ref).abs().max()) or not out_f32
     assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), out.data_ptr(),
-                                   dev(bias).data_ptr(), M, N + 64, K, out_f32, 0, stream()) != 0      # shape outside the tile: refused
+                                   dev(bias).data_ptr(), M, N + 64, K, out_f32, 0, 0, stream()) != 0      # shape outside the tile: refused
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_gemm_split3_column_mask(lib, name, prec, dt, ulp):
+    """split_from_n: the tiles in front of it are the plain hi x hi product (bit-identical with samrs_k_gemm on the hi operands),
+    the tiles from it on carry the lo terms (bit-identical with the unmasked launch) -- qkv with only its v third split."""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 1024, 1920, 256                      # 6 N tiles; persistent blocks see light and heavy tiles in turn
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = dev(torch.randn(N, generator=g) * 0.5)
+    Ah, Al = split_bits(lib, prec, A)
+    Bh, Bl = split_bits(lib, prec, B)
+    outs = {}
+    for from_n in (0, 1280, 1920 - 320):
+        out = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+        assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), out.data_ptr(),
+                                       bias.data_ptr(), M, N, K, 0, 0, from_n, stream()) == 0
+        outs[from_n] = out.cpu()
+    plain = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+    assert lib.samrs_k_gemm(prec, Ah.data_ptr(), Bh.data_ptr(), plain.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 0, 0, 0, stream()) == 0
+    plain = plain.cpu()
+    for from_n in (1280, 1920 - 320):
+        assert torch.equal(outs[from_n][:, :from_n], plain[:, :from_n])
+        assert torch.equal(outs[from_n][:, from_n:], outs[0][:, from_n:])
+    assert not torch.equal(outs[0][:, :1280], plain[:, :1280])
+    assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), plain.data_ptr(),
+                                   bias.data_ptr(), M, N, K, 0, 0, 100, stream()) != 0          # not a whole tile
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)

@@ -310,8 +310,13 @@ def _unpack(bits, shape):
     return np.unpackbits(bits, axis=-1).reshape(*bits.shape[:-1], *shape).astype(bool)
 
 
+# split 79 = 15 | 64 = the ViT-H DEFAULT: the cheap rounding points + the v third of qkv and proj on hi + lo operands in the
+# leading three quarters of the blocks (split_depth 0 = automatic); built here WITHOUT options, so the default is what is tested
+VIT_H_DEFAULT_SPLIT = 79
+
+
 @pytest.mark.parametrize("name,split,variant", [("vit_b", 15, 0), ("vit_h", 15, 0), ("vit_h", 31, 0), ("vit_h", 63, 0),
-                                                ("vit_h", 15, 1), ("vit_h", 31, 1)])
+                                                ("vit_h", 15, 1), ("vit_h", 31, 1), ("vit_h", 79, 0), ("vit_h", 79, 1)])
 def test_c2_c4_against_reference_golden(name, split, variant, golden_dir):
     """BASELINE.json configs[1] (32 hboxes on one tile) and configs[3] (rbox -> enclosing hbox / rbox -> mask prompt,
     multimask_output=True) against FULL-RESOLUTION masks produced by the real reference on the realistic-margin weights
@@ -327,10 +332,11 @@ def test_c2_c4_against_reference_golden(name, split, variant, golden_dir):
         reference's own answer is decided by less than the f16 operand rounding noise (identity on ALL
         pixels is not attainable by any reduced-precision path on a continuous logit field; the count is printed);
       * low-res logits and IoU predictions within the f16 tolerances of this file's header.
-    `split` = the engine's operand-split option: 15 is the default (patch embed, neck, decoder out-projection and upscaler on
-    hi + lo operands); 31 adds the blocks' qkv + proj GEMMs, 63 every block GEMM (the reference-grade bits: three times the
-    MFMA work of what they cover) -- from 31 on the C4 fixture clears the north star's 0.999 at ViT-H too, which shows that
-    the default's 0.9983 - 0.9992 is the price of running the four block GEMMs at the 1x f16 rate and nothing else."""
+    `split` = the engine's operand-split option: 15 = the cheap rounding points (patch embed, neck, decoder out-projection and
+    upscaler on hi + lo operands: the default below ViT-H, and the "1x rate" mode at ViT-H); 79 = the ViT-H default = 15 + the v
+    third of qkv and proj in the leading 24 blocks; 31 adds all of qkv + proj in every block, 63 every block GEMM.  From 79 on the C4
+    fixtures clear the north star's 0.999 at ViT-H too, which shows that the 0.9983 - 0.9992 of split 15 is the price of running
+    the block GEMMs at the 1x f16 rate and nothing else."""
     import samrs_amd
     from samrs_amd import transforms
     from oracle.make_golden import extended_inputs
@@ -339,10 +345,10 @@ def test_c2_c4_against_reference_golden(name, split, variant, golden_dir):
     cfg = synth.CONFIGS[name]
     sd = synth.make_state_dict(cfg, 0, logit_scale=float(g["logit_scale"]))
     sam = samrs_amd.sam_model_registry[name](state_dict=sd, precision="f16", max_prompts=32, max_points=1,
-                                             options={"split": split}).to("cuda")
+                                             options=None if split == VIT_H_DEFAULT_SPLIT else {"split": split}).to("cuda")
     pred = samrs_amd.SamPredictor(sam)
     eng = sam.engine
-    assert eng.get_option("split") == split
+    assert eng.get_option("split") == split and eng.get_option("split_depth") == 0
     inp = extended_inputs(variant)
     img = synth.make_image(inp["image_index"])
     hw = img.shape[:2]
@@ -391,12 +397,14 @@ def test_c2_c4_against_reference_golden(name, split, variant, golden_dir):
     # round 2 (no operand split): 849 / 896 pixels at ViT-B / ViT-H; with the split rounding points the error budget
     # predicts 394 / 476 (oracle/error_budget.py plans2, row E1)
     # (error budget at ViT-H: 307 with the qkv + proj GEMMs split as well, 89 with every block GEMM split)
-    assert diff.sum() <= {0: 1000, 15: 620, 31: 420, 63: 160}[split], int(diff.sum())
+    assert diff.sum() <= {0: 1000, 15: 620, 31: 420, 63: 160, 79: 480}[split], int(diff.sum())
     # ---- C4: enclosing hbox prompt, multimask ----
     # measured at ViT-H: 0.99874 / 0.99877 (split 15), 0.99911 / 0.99927 (31), 0.99974 / 0.99984 (63); the error budget
     # predicted 0.99886 / 0.99881, 0.99919 / 0.99928, 0.99976 / 0.99984
     # second draw (variant 1): 0.99924 / 0.99834 (split 15; round-2 arithmetic = split 0: see profiles/r03_ab.txt), 0.99952 / 0.99929 (31):
     # the C4 minimum is set by one small mask and moves by +-5e-4 between draws, so the default's floor is 0.998
+    # split 79 (v + proj, 24 leading blocks; error budget plans6: 0.99911 / 0.99926; measured 0.99920 / 0.99928 and, second draw,
+    # 0.99951 / 0.99914, at +6.7 ms per step instead of +21.6 for split 31): the ViT-H default holds the north star's 0.999 on C4
     c4_floor = 0.999 if (name == "vit_b" or split >= 31) else 0.998
     tb = pred.transform.apply_boxes_torch(torch.from_numpy(inp["hboxes"]).cuda(), hw)
     m, q, l = pred.predict_torch(None, None, tb, None, multimask_output=True)

@@ -256,3 +256,34 @@ def test_pipeline_rle_mode_equals_host_rle():
     small.rle_dev = [t[:4096] for t in small.rle_dev]
     with pytest.raises(RuntimeError, match="RLE buffer too small"):
         small.run(driver.batched(items[:2], 2), lambda res, rel: rel())
+
+
+def test_precision_follows_the_output_contract():
+    """ViT-H engines default to the multimask-safe operand split (79: IoU >= 0.999 on the C4 fixtures); a single-mask pipeline switches
+    the engine to the 1x-rate mode (15: IoU >= 0.9995 on the C2 fixtures), a multimask pipeline switches it back; an explicit
+    choice (builder options / precision=) is never overridden.  Smaller models have one mode (15)."""
+    import samrs_amd
+    from samrs_amd import driver
+    sam = samrs_amd.sam_model_registry["vit_h"](precision="f16", max_images=2, max_prompts=8, max_points=1).to("cuda")
+    eng = sam.engine
+    assert sam.default_split == eng.get_option("split") == 79 and eng.get_option("split_depth") == 0
+    driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8)
+    assert eng.get_option("split") == 15
+    driver.InstancePipeline(sam, 18, prompt="box", multimask=True, batch=1, box_batch=8, max_boxes=8)
+    assert eng.get_option("split") == 79
+    driver.InstancePipeline(sam, 18, prompt="point", multimask=False, batch=1, box_batch=8, max_boxes=8)
+    assert eng.get_option("split") == 15
+    driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8, precision="engine")
+    assert eng.get_option("split") == 15
+    driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8, precision=79)
+    assert eng.get_option("split") == 79
+    eng.close()
+    sam = samrs_amd.sam_model_registry["vit_h"](precision="f16", max_images=2, max_prompts=8, max_points=1, options={"split": 31}).to("cuda")
+    driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8)
+    assert sam.engine.get_option("split") == 31
+    sam.engine.close()
+    tiny = samrs_amd.sam_model_registry["vit_tiny"](max_images=2, max_prompts=8).to("cuda")
+    assert tiny.default_split == 15
+    driver.InstancePipeline(tiny, 18, prompt="box", multimask=True, batch=1, box_batch=8, max_boxes=8)
+    assert tiny.engine.get_option("split") == 15
+    tiny.engine.close()

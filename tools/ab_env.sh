@@ -5,7 +5,7 @@ var=$1; a=$2; b=$3; rounds=${4:-2}
 mkdir -p gpurun_out
 for r in $(seq 1 $rounds); do
   for v in $a $b; do
-    env $var=$v timeout 600 python bench.py --steps ${BENCH_STEPS:-6} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg --no-cli-leg ${BENCH_EXTRA:-} 2>/dev/null | python -c "
+    env $var=$v timeout 600 python bench.py --steps ${BENCH_STEPS:-6} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg --no-cli-leg --no-fast-leg ${BENCH_EXTRA:-} 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()

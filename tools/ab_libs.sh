@@ -4,7 +4,7 @@ rounds=$1; shift
 mkdir -p gpurun_out
 for r in $(seq 1 $rounds); do
   for v in "$@"; do
-    SAMRS_LIB_PATH=$v timeout 600 python bench.py --steps ${BENCH_STEPS:-6} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg --no-cli-leg 2>/dev/null | python -c "
+    SAMRS_LIB_PATH=$v timeout 600 python bench.py --steps ${BENCH_STEPS:-6} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg --no-cli-leg --no-fast-leg 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     l = l.strip()

@@ -21,13 +21,13 @@ for step in "$@"; do
     gen)     run gen 600 $PT tests/test_parity_gpu.py -k "generation" ;;
     all)     run all 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider ;;
     smoke)   run smoke 600 python -c "import __graft_entry__ as g; g.smoke()" ;;
-    benchq)  run benchq 900 python bench.py --steps ${BENCH_STEPS:-8} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg --no-cli-leg ${BENCH_EXTRA:-} ;;
+    benchq)  run benchq 900 python bench.py --steps ${BENCH_STEPS:-8} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg --no-cli-leg --no-fast-leg ${BENCH_EXTRA:-} ;;
     bench)   run bench 1500 python bench.py ${BENCH_ARGS:-} ;;
     c3)      run c3 600 python bench.py --workload c3 --steps ${BENCH_STEPS:-6} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg ;;
     c4)      run c4 600 python bench.py --workload c4 --steps ${BENCH_STEPS:-6} --warmup 2 --no-cpu-baseline --no-alt-dtype --no-pcie-leg ;;
     decb)    run decb 300 python tools/dec_bench.py 20 ;;
     prof)    cd /tmp; export TMPDIR=/tmp; cd - >/dev/null
-             run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r03 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-pcie-leg --no-rle-leg --no-cli-leg ;;
+             run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r03 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-dtype --no-pcie-leg --no-rle-leg --no-cli-leg --no-fast-leg ;;
     *)       n=$((${n:-0} + 1)); echo "cmd$n: $step" >> gpurun_out/summary.txt; run "cmd$n" 1200 bash -c "$step" ;;
   esac
 done

@@ -190,7 +190,7 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    split 79 (15 | 64) with split_depth 24: C4 fixture IoU >= 0.999 at 0.86x the default's throughput.
  *   "decoder_fusion" [SAMRS_DECODER_FUSION, default 1] 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm /
  *                    product launches; never split): the fused-vs-unfused parity test and timing experiments.
- *   "ln_fold"        [SAMRS_LN_FOLD, default 0] (embed_dim 1280) 1 = fold the encoder blocks' LayerNorms into the qkv / lin1
+ *   "ln_fold"        [SAMRS_LN_FOLD, default 0] (embed_dim 1280; only while no block-GEMM bit of "split" is set) 1 = fold the encoder blocks' LayerNorms into the qkv / lin1
  *                    GEMMs.  Measured slower on MI355X.  Must be on before samrs_finalize_weights for the folded weights to
  *                    exist; can be flipped afterwards.
  *   "gemm_variant"   [default -1 = automatic] GEMM tile variant for this handle's launches (tools/gemm_bench.py lists them).

@@ -102,7 +102,8 @@ def test_folded_layernorm_matches_unfolded(precision):
     name = "vit_tiny1280"
     cfg = synth.CONFIGS[name]
     # the option must be on before the weights are finalized: the folded copies are prepared at load
-    sam = samrs_amd.sam_model_registry[name](precision=precision, max_prompts=8, max_images=1, max_points=4, options={"ln_fold": 1})
+    sam = samrs_amd.sam_model_registry[name](precision=precision, max_prompts=8, max_images=1, max_points=4,
+                                             options={"ln_fold": 1, "split": 15})    # the fold covers the 1x-rate block GEMMs only
     sam.to(device="cuda")
     pred = samrs_amd.SamPredictor(sam)
     eng = sam.engine

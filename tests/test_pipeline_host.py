@@ -59,3 +59,38 @@ def test_work_queues_get_distinct_default_keys():
     assert list(c) == [(3, 6)]
     with pytest.raises(ValueError):
         driver.WorkQueue(1, mode="stolen")
+
+
+def test_precision_policy_of_the_pipelines(monkeypatch):
+    """driver.TilePipeline._apply_precision: "auto" picks the engine's operand-split mode by output contract (single mask = 15,
+    multimask = the model's own default), never over an explicit choice; "engine" leaves it alone; an int sets it."""
+    from types import SimpleNamespace
+
+    class FakeEngine:
+        def __init__(self, split):
+            self.opts = {"split": split}
+
+        def get_option(self, k):
+            return self.opts[k]
+
+        def set_option(self, k, v):
+            self.opts[k] = v
+
+    monkeypatch.delenv("SAMRS_SPLIT", raising=False)
+    ap = driver.TilePipeline._apply_precision
+    sam = SimpleNamespace(engine=FakeEngine(79), options={}, default_split=79)
+    ap(sam, "auto", multimask=False)
+    assert sam.engine.opts["split"] == 15
+    ap(sam, "auto", multimask=True)
+    assert sam.engine.opts["split"] == 79
+    ap(sam, "engine", multimask=False)
+    assert sam.engine.opts["split"] == 79
+    ap(sam, 31, multimask=False)
+    assert sam.engine.opts["split"] == 31
+    chosen = SimpleNamespace(engine=FakeEngine(63), options={"split": 63}, default_split=63)
+    ap(chosen, "auto", multimask=False)
+    assert chosen.engine.opts["split"] == 63                       # the builder's options= win
+    monkeypatch.setenv("SAMRS_SPLIT", "79")
+    env = SimpleNamespace(engine=FakeEngine(79), options={}, default_split=79)
+    ap(env, "auto", multimask=False)
+    assert env.engine.opts["split"] == 79                          # and so does the environment

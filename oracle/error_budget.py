@@ -179,6 +179,21 @@ def main(argv):
                                    ("E1 + v + proj split in blocks 0..%d" % (3 * n // 4 - 1), ("enc.v_in", "enc.proj_in"), range(0, 3 * n // 4))):
             tag = "p6_" + "_".join(q.split(".")[1] for q in pts) + "_%d" % len(blocks)
             report(label, tag, so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points={q: (blocks, sp) for q in pts}))
+    if what in ("plans7",):
+        # around the ViT-H default (v + proj, blocks 0..23): is either half or a shorter prefix enough?
+        sp = so.split2(F16)
+        e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
+        n = cfg.depth
+        for label, pts, blocks in (("E1 + v + proj split in blocks 0..%d" % (5 * n // 8 - 1), ("enc.v_in", "enc.proj_in"), range(0, 5 * n // 8)),
+                                   ("E1 + v split in blocks 0..%d" % (3 * n // 4 - 1), ("enc.v_in",), range(0, 3 * n // 4)),
+                                   ("E1 + proj split in blocks 0..%d" % (3 * n // 4 - 1), ("enc.proj_in",), range(0, 3 * n // 4)),
+                                   ("E1 + v + proj split in blocks 0..%d, lin2 in 0..%d" % (3 * n // 4 - 1, n // 4 - 1), ("enc.v_in", "enc.proj_in", "enc.lin2_in"), None)):
+            tag = "p7_" + "_".join(q.split(".")[1] for q in pts) + "_%s" % (len(blocks) if blocks is not None else "mix")
+            if blocks is None:
+                bp = {"enc.v_in": (range(0, 3 * n // 4), sp), "enc.proj_in": (range(0, 3 * n // 4), sp), "enc.lin2_in": (range(0, n // 4), sp)}
+            else:
+                bp = {q: (blocks, sp) for q in pts}
+            report(label, tag, so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points=bp))
     if what in ("plans", "all"):
         sp = so.split2(F16)
         report("plan A: encoder f16, decoder operands split f16 (hi+lo)", "f16",

@@ -349,7 +349,9 @@ def main() -> None:
                                model=args.model, checkpoint=None, precision=args.dtype, classes=None, n_classes=18, palette=None,
                                box_batch=64, no_rle=False, batch=B, schedule="static", readers=8, writers=16, resume=False,
                                rle_buffer_mb=512, timing=True, png_level=6, out_depth=4)
-            st = generate.run(ns)["timing"]
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):             # stdout carries the ONE JSON line of this script, nothing else
+                st = generate.run(ns)["timing"]
             per = {k: round(1e3 * v / st["images"], 1) for k, v in sorted(st["stage_thread_seconds"].items()) if not k.startswith("loop.")}
             cli = {"value": round(st["images"] / st["loop_seconds"], 3), "unit": "images/s", "tiles": st["images"],
                    "cpus": len(os.sched_getaffinity(0)), "cpu_quota": _cpu_quota(),

@@ -247,7 +247,8 @@ def run(args) -> Dict[str, List[int]]:
     reap(block=True)
     wall = time.perf_counter() - t_run
     if clock and rank == 0:
-        print("[rank 0] --timing: " + clock.report(done[0], wall), flush=True)
+        import sys
+        print("[rank 0] --timing: " + clock.report(done[0], wall), file=sys.stderr, flush=True)
     pix, ins = driver.reduce_statistics(pipe.class_pixels, pipe.class_instances)
     all_sizes = driver.gather_mask_sizes(sizes)
     stats = {"class_pixel_num": pix.cpu().tolist(), "class_instance_num": ins.cpu().tolist(),

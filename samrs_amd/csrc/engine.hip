@@ -599,11 +599,19 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                                   sp_patch ? Hlo + (size_t)i * tokens * KP : nullptr));
         i = j;
     }
-    CK(e, launch_gemm_et(prec, e->H, e->patch_w, e->X, W(e, "image_encoder.patch_embed.proj.bias"),
-                         W(e, "image_encoder.pos_embed"), tokens, M, D, (int)KP, true, false, false, s));
-    if (sp_patch) {
-        CK(e, launch_gemm_et(prec, Hlo, e->patch_w, e->X, nullptr, nullptr, 0, M, D, (int)KP, true, false, true, s));
-        CK(e, launch_gemm_et(prec, e->H, e->patch_w_lo, e->X, nullptr, nullptr, 0, M, D, (int)KP, true, false, true, s));
+    // split products of patch embed and neck: ONE launch over a three-segment K axis where the shape fits the pair-stage tile
+    // (gemm.hip seg_src_a), else three accumulating passes
+    const bool one3p = !e->split_passes;
+    if (sp_patch && one3p && gemm_split3_ok((int)M, D, (int)KP, true)) {
+        CK(e, launch_gemm_et_split3(prec, e->H, Hlo, e->patch_w, e->patch_w_lo, e->X, W(e, "image_encoder.patch_embed.proj.bias"),
+                                    (int)M, D, (int)KP, true, false, s, 0, W(e, "image_encoder.pos_embed"), tokens));
+    } else {
+        CK(e, launch_gemm_et(prec, e->H, e->patch_w, e->X, W(e, "image_encoder.patch_embed.proj.bias"),
+                             W(e, "image_encoder.pos_embed"), tokens, M, D, (int)KP, true, false, false, s));
+        if (sp_patch) {
+            CK(e, launch_gemm_et(prec, Hlo, e->patch_w, e->X, nullptr, nullptr, 0, M, D, (int)KP, true, false, true, s));
+            CK(e, launch_gemm_et(prec, e->H, e->patch_w_lo, e->X, nullptr, nullptr, 0, M, D, (int)KP, true, false, true, s));
+        }
     }
     // Folded LayerNorm (embed_dim 1280): no LayerNorm launches inside the blocks.  Y holds the residual stream rounded to ET and
     // STATS its per-row partial statistics, both written by the epilogue of the GEMM that produced X (proj, lin2; here, once,
@@ -718,20 +726,28 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     uint16_t* lo_buf = e->QKV;
     if (sp_neck) CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s, lo_buf));
     else if (!(fold && c.depth > 0 && n_blocks >= c.depth)) CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s));
-    CK(e, launch_gemm_et(prec, e->Y, e->neck0_w, e->N1, nullptr, nullptr, 0, M, C, D, true, false, false, s));
-    if (sp_neck) {
-        CK(e, launch_gemm_et(prec, lo_buf, e->neck0_w, e->N1, nullptr, nullptr, 0, M, C, D, true, false, true, s));
-        CK(e, launch_gemm_et(prec, e->Y, e->neck0_w_lo, e->N1, nullptr, nullptr, 0, M, C, D, true, false, true, s));
+    if (sp_neck && one3p && gemm_split3_ok((int)M, C, D, true)) {
+        CK(e, launch_gemm_et_split3(prec, e->Y, lo_buf, e->neck0_w, e->neck0_w_lo, e->N1, nullptr, (int)M, C, D, true, false, s));
+    } else {
+        CK(e, launch_gemm_et(prec, e->Y, e->neck0_w, e->N1, nullptr, nullptr, 0, M, C, D, true, false, false, s));
+        if (sp_neck) {
+            CK(e, launch_gemm_et(prec, lo_buf, e->neck0_w, e->N1, nullptr, nullptr, 0, M, C, D, true, false, true, s));
+            CK(e, launch_gemm_et(prec, e->Y, e->neck0_w_lo, e->N1, nullptr, nullptr, 0, M, C, D, true, false, true, s));
+        }
     }
     CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.1.weight"), W(e, "image_encoder.neck.1.bias"), 1e-6f,
                            e->N1e, nullptr, M, C, 0, g, 0, s, sp_neck ? lo_buf : nullptr));
     CK(e, launch_neck_im2col(e->N1e, e->H, n, g, C, s));
     uint16_t* H2lo = e->H + (size_t)M * 9 * C;
     if (sp_neck) CK(e, launch_neck_im2col(lo_buf, H2lo, n, g, C, s));
-    CK(e, launch_gemm_et(prec, e->H, e->neck2_w, e->N1, nullptr, nullptr, 0, M, C, 9 * C, true, false, false, s));
-    if (sp_neck) {
-        CK(e, launch_gemm_et(prec, H2lo, e->neck2_w, e->N1, nullptr, nullptr, 0, M, C, 9 * C, true, false, true, s));
-        CK(e, launch_gemm_et(prec, e->H, e->neck2_w_lo, e->N1, nullptr, nullptr, 0, M, C, 9 * C, true, false, true, s));
+    if (sp_neck && one3p && gemm_split3_ok((int)M, C, 9 * C, true)) {
+        CK(e, launch_gemm_et_split3(prec, e->H, H2lo, e->neck2_w, e->neck2_w_lo, e->N1, nullptr, (int)M, C, 9 * C, true, false, s));
+    } else {
+        CK(e, launch_gemm_et(prec, e->H, e->neck2_w, e->N1, nullptr, nullptr, 0, M, C, 9 * C, true, false, false, s));
+        if (sp_neck) {
+            CK(e, launch_gemm_et(prec, H2lo, e->neck2_w, e->N1, nullptr, nullptr, 0, M, C, 9 * C, true, false, true, s));
+            CK(e, launch_gemm_et(prec, e->H, e->neck2_w_lo, e->N1, nullptr, nullptr, 0, M, C, 9 * C, true, false, true, s));
+        }
     }
     CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.3.weight"), W(e, "image_encoder.neck.3.bias"), 1e-6f,
                            nullptr, e->EMB + (size_t)slot0 * tokens * C, M, C, 0, g, 0, s));
@@ -1222,7 +1238,7 @@ int samrs_k_gemm_gln(int prec, const void* A, const void* B, void* C, const floa
 }
 int samrs_k_gemm_split3(int prec, const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, const float* bias,
                         int M, int N, int K, int out_f32, int accumulate, int split_from_n, void* stream) {
-    if (!gemm_split3_ok(M, N, K)) return SAMRS_ERR_BAD_SHAPE;
+    if (!gemm_split3_ok(M, N, K, out_f32 != 0)) return SAMRS_ERR_BAD_SHAPE;
     KRET(launch_gemm_et_split3(prec, A, A_lo, B, B_lo, C, bias, M, N, K, out_f32 != 0, accumulate != 0, (hipStream_t)stream, split_from_n));
 }
 int samrs_k_upscale2_masks(int prec, const void* u1, const void* w, const void* w_lo, const float* bias, const float* hyper,

@@ -2637,12 +2637,17 @@ hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C
 template <int PREC>
 static hipError_t launch_gemm_split3_prec(const uint16_t* a, const uint16_t* al, const uint16_t* b, const uint16_t* bl, void* C,
                                           const float* bias, int M, int N, int K, bool out_f32, bool accumulate, int split_from_n,
-                                          hipStream_t s) {
-    const int ntiles = (M / QBM) * (N / WBN);
+                                          const float* add2d, int add2d_period, hipStream_t s) {
     if (out_f32) {
-        gemm_et_x64_kernel<PREC, true, false, 5, 3, 0, true><<<dim3(ntiles), dim3(QTHREADS), 0, s>>>(
-            a, b, C, bias, nullptr, 1, M, N, K, accumulate ? 1 : 0, 0, al, bl);
+        // fp32 outputs: one tile per block; 256 x 320 tiles where N allows, else 256 x 256 (the neck: N = 256)
+        if (N % WBN == 0)
+            gemm_et_x64_kernel<PREC, true, false, 5, 3, 0, true><<<dim3((M / QBM) * (N / WBN)), dim3(QTHREADS), 0, s>>>(
+                a, b, C, bias, add2d, add2d_period, M, N, K, accumulate ? 1 : 0, 0, al, bl);
+        else
+            gemm_et_x64_kernel<PREC, true, false, 4, 3, 0, true><<<dim3((M / QBM) * (N / QBN)), dim3(QTHREADS), 0, s>>>(
+                a, b, C, bias, add2d, add2d_period, M, N, K, accumulate ? 1 : 0, 0, al, bl);
     } else {
+        const int ntiles = (M / QBM) * (N / WBN);
         int dev = 0, n_cu = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         if (n_cu <= 0) n_cu = 256;
@@ -2652,18 +2657,22 @@ static hipError_t launch_gemm_split3_prec(const uint16_t* a, const uint16_t* al,
     return hipGetLastError();
 }
 
-bool gemm_split3_ok(int M, int N, int K) { return M > 0 && N > 0 && K > 0 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0; }
+bool gemm_split3_ok(int M, int N, int K, bool out_f32) {
+    return M > 0 && N > 0 && K > 0 && M % QBM == 0 && K % XBK == 0 && (N % WBN == 0 || (out_f32 && N % QBN == 0));
+}
 
 hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, const float* bias,
-                                 int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s, int split_from_n) {
-    if (!gemm_split3_ok(M, N, K) || !A || !A_lo || !B || !B_lo || (accumulate && !out_f32)) return hipErrorInvalidValue;
+                                 int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s, int split_from_n,
+                                 const float* add2d, int add2d_period) {
+    if (!gemm_split3_ok(M, N, K, out_f32) || !A || !A_lo || !B || !B_lo || (accumulate && !out_f32)) return hipErrorInvalidValue;
     if (split_from_n < 0 || split_from_n % WBN || (split_from_n && out_f32)) return hipErrorInvalidValue;   // whole tiles; ET outputs only
+    if (add2d && (!out_f32 || add2d_period <= 0)) return hipErrorInvalidValue;                              // the fp32 epilogue adds it
     const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
     const uint16_t* al = reinterpret_cast<const uint16_t*>(A_lo);
     const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
     const uint16_t* bl = reinterpret_cast<const uint16_t*>(B_lo);
-    if (prec == PREC_BF16) return launch_gemm_split3_prec<PREC_BF16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, split_from_n, s);
-    if (prec == PREC_F16) return launch_gemm_split3_prec<PREC_F16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, split_from_n, s);
+    if (prec == PREC_BF16) return launch_gemm_split3_prec<PREC_BF16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, split_from_n, add2d, add2d_period, s);
+    if (prec == PREC_F16) return launch_gemm_split3_prec<PREC_F16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, split_from_n, add2d, add2d_period, s);
     return hipErrorInvalidValue;
 }
 

@@ -22,9 +22,10 @@ hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C
 // Split-precision product in ONE launch: C = A B^T + A_lo B^T + A B_lo^T + bias over a three-segment K axis (fp32 accumulators stay
 // in registers).  out_f32: C is fp32 [M][N] (optionally accumulated into), else ET rounded once.  gemm_split3_ok: M % 256,
 // N % 320, K % 64 (the ViT-H block GEMMs); other shapes take three accumulating launch_gemm_et passes.
-bool gemm_split3_ok(int M, int N, int K);
+bool gemm_split3_ok(int M, int N, int K, bool out_f32 = false);      // fp32 outputs also take N % 256 == 0 (the neck)
 hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, const void* B, const void* B_lo, void* C, const float* bias,
-                                 int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s, int split_from_n = 0);
+                                 int M, int N, int K, bool out_f32, bool accumulate, hipStream_t s, int split_from_n = 0,
+                                 const float* add2d = nullptr, int add2d_period = 0);   // add2d: fp32 outputs only (patch embed + pos_embed)
 // split_from_n (ET output only, a multiple of 320): only output columns >= split_from_n take the lo terms; the tiles in front
 // of it are the plain hi x hi product (qkv: the v third alone)
 void set_gemm_variant(int v);   // process-wide test hook (kernel-level entry points): 0 = register-staged tiles, ..., 8 = automatic

@@ -472,7 +472,8 @@ def test_gemm_gln_split_precision(lib, name, prec, dt, ulp):
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
-@pytest.mark.parametrize("M,N,K,out_f32", [(256, 320, 64, 1), (512, 640, 192, 0), (512, 1280, 1280, 1), (768, 3840, 1280, 0)])
+@pytest.mark.parametrize("M,N,K,out_f32", [(256, 320, 64, 1), (512, 640, 192, 0), (512, 1280, 1280, 1), (768, 3840, 1280, 0),
+                                           (512, 256, 2304, 1), (256, 768, 768, 1)])      # N % 256 only: the neck / ViT-B patch embed (fp32 out)
 def test_gemm_split3_one_launch(lib, name, prec, dt, ulp, M, N, K, out_f32):
     """The block GEMMs of the reference-grade mode as ONE launch over a three-segment K axis (A_lo B + A B_lo + A B in the
     register accumulators): against the fp64 product of the un-rounded fp32 operands, far below one operand ulp; ET output =
@@ -504,7 +505,7 @@ def test_gemm_split3_one_launch(lib, name, prec, dt, ulp, M, N, K, out_f32):
     plain = A.to(dt).double() @ B.to(dt).double().t() + bias.double()
     assert ((plain - ref).abs().max() > 4 * (got - ref).abs().max()) or not out_f32
     assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), out.data_ptr(),
-                                   dev(bias).data_ptr(), M, N + 64, K, out_f32, 0, 0, stream()) != 0      # shape outside the tile: refused
+                                   dev(bias).data_ptr(), M, N + 32, K, out_f32, 0, 0, stream()) != 0      # shape outside the tiles: refused
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)

@@ -59,7 +59,7 @@ def test_oracle_matches_reference_vit_l(golden_dir):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("name,variant", [("vit_b", 0), ("vit_h", 0), ("vit_h", 1)])
+@pytest.mark.parametrize("name,variant", [("vit_b", 0), ("vit_h", 0), ("vit_h", 1), ("vit_h", 2)])
 def test_oracle_matches_reference_c2_c4(name, variant, golden_dir):
     """The C2 (32 hboxes, 20 + 12 chunks) and C4 (enclosing hbox / rbox mask prompt, multimask) fixtures on the
     realistic-margin weights: full-resolution masks of the REAL reference vs the oracle.  fp32 on both sides, so the

@@ -317,7 +317,9 @@ VIT_H_DEFAULT_SPLIT = 79
 
 
 @pytest.mark.parametrize("name,split,variant", [("vit_b", 15, 0), ("vit_h", 15, 0), ("vit_h", 31, 0), ("vit_h", 63, 0),
-                                                ("vit_h", 15, 1), ("vit_h", 31, 1), ("vit_h", 79, 0), ("vit_h", 79, 1)])
+                                                ("vit_h", 15, 1), ("vit_h", 31, 1), ("vit_h", 79, 0), ("vit_h", 79, 1),
+                                                # a third draw, generated AFTER split 79 / depth 24 had been chosen on the first two
+                                                ("vit_h", 79, 2), ("vit_h", 15, 2)])
 def test_c2_c4_against_reference_golden(name, split, variant, golden_dir):
     """BASELINE.json configs[1] (32 hboxes on one tile) and configs[3] (rbox -> enclosing hbox / rbox -> mask prompt,
     multimask_output=True) against FULL-RESOLUTION masks produced by the real reference on the realistic-margin weights

@@ -176,18 +176,20 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
 
 /* -- per-engine options (each handle has its own; the environment variable named in brackets only sets the value a NEW handle
  * starts with).  Returns SAMRS_ERR_BAD_ARG for an unknown name.
- *   "split"          [SAMRS_SPLIT, default 15] bit mask of the rounding points that run as a two-term operand split
- *                    (hi + lo, three MFMAs, ~2^-22 operand error instead of 2^-11): 1 = patch embed, 2 = neck, 4 = decoder
- *                    image->token out-projection, 8 = decoder upscaler (both transposed convs).  What each bit buys in mask
- *                    pixels: oracle/error_budget.py, DESIGN.md 2.  0 = the round-2 engine's arithmetic.
- *                    Reference-grade bits, not in the default: 16 = the encoder blocks' qkv + proj GEMMs, 32 = their MLP GEMMs
- *                    (three times the MFMA work of what they cover; 63 = every MFMA operand of the path split).  They need lo
- *                    copies of the block weights: set them BEFORE samrs_finalize_weights (SAMRS_SPLIT=63 / the option); they
- *                    can be cleared and set again afterwards.  64 = the cheap form of 16: only the v third of the qkv product (+ proj)
- *                    takes the lo terms -- q and k pass through the softmax (ViT-H shapes, else it acts like 16).
- *   "split_depth"    [SAMRS_SPLIT_DEPTH, default 0 = all] the bits 16 / 32 / 64 apply to the first N encoder blocks only: an operand
- *                    error made in an early block is carried through every later one, one made in the last blocks is not.
- *                    split 79 (15 | 64) with split_depth 24: C4 fixture IoU >= 0.999 at 0.86x the default's throughput.
+ *   "split"          [SAMRS_SPLIT; default 79 where the one-launch split GEMM covers the block shapes (ViT-H), else 15] bit mask of
+ *                    the rounding points that run as a two-term operand split (hi + lo, three MFMAs, ~2^-22 operand error
+ *                    instead of 2^-11): 1 = patch embed, 2 = neck, 4 = decoder image->token out-projection, 8 = decoder upscaler
+ *                    (both transposed convs).  15 = every block GEMM at the 1x f16 rate: enough for IoU >= 0.9995 on the single
+ *                    mask of token 0 (what the hbox-semantic path asks for); 0 = the round-2 engine's arithmetic.
+ *                    Block-GEMM bits: 64 = the v third of the qkv product + proj (q and k pass through the softmax), 16 = all of
+ *                    qkv + proj, 32 = the MLP GEMMs (three times the MFMA work of what they cover; 63 / 127 = every MFMA operand
+ *                    of the path).  79 = 15 | 64 holds IoU >= 0.999 on the three multimask tokens too (C4 fixtures) at 0.87-0.90x
+ *                    the throughput of 15 and is what a ViT-H handle starts with.  The block-GEMM bits need lo copies of the
+ *                    block weights: set them BEFORE samrs_finalize_weights; they can be cleared and set again afterwards.
+ *                    What each bit buys in mask pixels: oracle/error_budget.py, DESIGN.md 2.
+ *   "split_depth"    [SAMRS_SPLIT_DEPTH, default 0 = automatic] the block-GEMM bits apply to the first N encoder blocks only: an
+ *                    operand error made in an early block is carried through every later one, one made in the last blocks is
+ *                    not.  Automatic: every block for 16 / 32, the leading three quarters (24 of 32) for 64.
  *   "decoder_fusion" [SAMRS_DECODER_FUSION, default 1] 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm /
  *                    product launches; never split): the fused-vs-unfused parity test and timing experiments.
  *   "ln_fold"        [SAMRS_LN_FOLD, default 0] (embed_dim 1280; only while no block-GEMM bit of "split" is set) 1 = fold the encoder blocks' LayerNorms into the qkv / lin1

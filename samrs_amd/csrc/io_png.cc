@@ -92,6 +92,7 @@ int decode(const uint8_t* f, size_t n, uint8_t* dst, size_t dst_bytes, int* heig
     const int ch = hd.channels();
     const size_t row = size_t(hd.w) * ch;
     const size_t raw_bytes = (row + 1) * hd.h;
+    if (raw_bytes > 0x7fffffffull) return SAMRS_IO_UNSUPPORTED;                      // zlib's 32-bit counters; far beyond any tile
     uint8_t* raw = scratch(0, raw_bytes + row);                                      // + one zero row used as "row above the first"
     if (!raw) return SAMRS_IO_ENOMEM;
     uint8_t palette[256 * 3];
@@ -230,7 +231,7 @@ int encode(const char* path, const uint8_t* src, int h, int w, size_t stride, in
     if (level != SAMRS_IO_LEVEL_RUNS && (level < 1 || level > 9)) level = 6;
     const size_t row = size_t(w) * out_ch;
     const size_t filtered_bytes = (row + 1) * h;
-    if (filtered_bytes > 0xf0000000ull) return SAMRS_IO_ESIZE;                  // one IDAT chunk holds < 4 GiB
+    if (filtered_bytes > 0x7fffffffull) return SAMRS_IO_ESIZE;                  // one IDAT chunk holds < 4 GiB
     uint8_t* filtered = scratch(0, filtered_bytes);
     uint8_t* rows = scratch(1, row * 8);                                              // 5 candidates + current + previous + zeros
     if (!filtered || !rows) return SAMRS_IO_ENOMEM;

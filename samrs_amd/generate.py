@@ -227,6 +227,10 @@ def run(args) -> Dict[str, List[int]]:
         if not results:
             release()
         pending.extend(writers.submit(job, r) for r in results)
+        if run_log is not None:                                  # one JSON line per batch handed to the writers (per-run log)
+            run_log.write(json.dumps({"t": round(time.perf_counter() - t_run, 4), "rank": rank, "images": [str(r.key) for r in results],
+                                      "boxes": [int(len(r.labels)) for r in results], "done": done[0] + len(results)}) + "\n")
+            run_log.flush()
         for r in results:
             buf = loaned.pop(r.key, None)
             if buf is not None:
@@ -239,11 +243,19 @@ def run(args) -> Dict[str, List[int]]:
             print(f"[rank 0] {done[0]} images", flush=True)
 
     t_run = time.perf_counter()
+    run_log = None
+    if getattr(args, "log", None):
+        os.makedirs(os.path.dirname(os.path.abspath(args.log)) or ".", exist_ok=True)
+        run_log = open(f"{args.log}.rank{rank}" if world > 1 else args.log, "a")
+        run_log.write(json.dumps({"t": 0.0, "rank": rank, "world": world, "model": args.model, "split": sam.engine.get_option("split"),
+                                  "images_total": n_all, "images_todo": len(stems), "batch": batch, "box_batch": args.box_batch}) + "\n")
     try:
         pipe.run(batches(), sink)
         if clock: clock.add("loop.pipe_run_total", t_run)
     finally:
         writers.shutdown(wait=True)
+        if run_log is not None:
+            run_log.close()
     reap(block=True)
     wall = time.perf_counter() - t_run
     if clock and rank == 0:
@@ -290,6 +302,8 @@ def main(argv=None):
                     "this single-mask driver; 79 = multimask-grade; 31 / 63 = reference-grade; DESIGN.md section 2)")
     ap.add_argument("--png-level", type=int, default=6, help="zlib level of color/*.png (the pixels are the same at every level; gray/*.png uses the run-length preset)")
     ap.add_argument("--out-depth", type=int, default=4, help="pinned output buffers (batches on loan to the writers at once)")
+    ap.add_argument("--log", default=None, help="append one JSON line per batch (time, image stems, box counts) to this file "
+                    "(<file>.rank<r> with more than one rank)")
     ap.add_argument("--timing", action="store_true", help="print the host-side time per stage (decode, PNG encode, pickle, waits)")
     run(ap.parse_args(argv))
 

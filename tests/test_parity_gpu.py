@@ -574,7 +574,10 @@ def test_generation_driver_end_to_end(tmp_path):
     (tmp_path / "boxes.json").write_text(json.dumps(ann))
     stats = generate.run(generate.argparse.Namespace(
         images=str(img_dir), boxes=str(tmp_path / "boxes.json"), out=str(out_dir), model="vit_tiny", checkpoint=None,
-        precision="f16", classes=None, n_classes=18, palette=None, box_batch=20, no_rle=False))
+        precision="f16", classes=None, n_classes=18, palette=None, box_batch=20, no_rle=False, log=str(tmp_path / "run.jsonl")))
+    lines = [json.loads(l) for l in open(tmp_path / "run.jsonl")]
+    assert lines[0]["images_todo"] == 2 and sum(len(l.get("images", [])) for l in lines[1:]) == 2 and lines[-1]["done"] == 2
+    assert sorted(b for l in lines[1:] for b in l["boxes"]) == [23, 23]
     orc = get_oracle("vit_tiny")
     tot_pix = np.zeros(18, np.int64)
     for i in range(2):

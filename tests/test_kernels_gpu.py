@@ -532,6 +532,13 @@ def test_gemm_split3_column_mask(lib, name, prec, dt, ulp):
         assert torch.equal(outs[from_n][:, :from_n], plain[:, :from_n])
         assert torch.equal(outs[from_n][:, from_n:], outs[0][:, from_n:])
     assert not torch.equal(outs[0][:, :1280], plain[:, :1280])
+    # race screen: the persistent blocks hand ring buffers from tile to tile (stage 0 of the next tile lands under the epilogue);
+    # a missed wait shows up as run-to-run differences
+    for _ in range(12):
+        again = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+        assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), again.data_ptr(),
+                                       bias.data_ptr(), M, N, K, 0, 0, 1280, stream()) == 0
+        assert torch.equal(again.cpu(), outs[1280])
     assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), plain.data_ptr(),
                                    bias.data_ptr(), M, N, K, 0, 0, 100, stream()) != 0          # not a whole tile
 

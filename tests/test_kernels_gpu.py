@@ -513,14 +513,14 @@ def test_gemm_split3_column_mask(lib, name, prec, dt, ulp):
     """split_from_n: the tiles in front of it are the plain hi x hi product (bit-identical with samrs_k_gemm on the hi operands),
     the tiles from it on carry the lo terms (bit-identical with the unmasked launch) -- qkv with only its v third split."""
     g = torch.Generator().manual_seed(11)
-    M, N, K = 1024, 1920, 256                      # 6 N tiles; persistent blocks see light and heavy tiles in turn
+    M, N, K = 8192, 3840, 128                      # 32 x 12 = 384 tiles: the persistent blocks walk light and heavy tiles in turn
     A = torch.randn(M, K, generator=g)
     B = torch.randn(N, K, generator=g) / math.sqrt(K)
     bias = dev(torch.randn(N, generator=g) * 0.5)
     Ah, Al = split_bits(lib, prec, A)
     Bh, Bl = split_bits(lib, prec, B)
     outs = {}
-    for from_n in (0, 1280, 1920 - 320):
+    for from_n in (0, 2560, 3840 - 320):
         out = torch.zeros(M, N, dtype=torch.int16, device="cuda")
         assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), out.data_ptr(),
                                        bias.data_ptr(), M, N, K, 0, 0, from_n, stream()) == 0
@@ -528,17 +528,17 @@ def test_gemm_split3_column_mask(lib, name, prec, dt, ulp):
     plain = torch.zeros(M, N, dtype=torch.int16, device="cuda")
     assert lib.samrs_k_gemm(prec, Ah.data_ptr(), Bh.data_ptr(), plain.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 0, 0, 0, stream()) == 0
     plain = plain.cpu()
-    for from_n in (1280, 1920 - 320):
+    for from_n in (2560, 3840 - 320):
         assert torch.equal(outs[from_n][:, :from_n], plain[:, :from_n])
         assert torch.equal(outs[from_n][:, from_n:], outs[0][:, from_n:])
-    assert not torch.equal(outs[0][:, :1280], plain[:, :1280])
+    assert not torch.equal(outs[0][:, :2560], plain[:, :2560])
     # race screen: the persistent blocks hand ring buffers from tile to tile (stage 0 of the next tile lands under the epilogue);
     # a missed wait shows up as run-to-run differences
     for _ in range(12):
         again = torch.zeros(M, N, dtype=torch.int16, device="cuda")
         assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), again.data_ptr(),
-                                       bias.data_ptr(), M, N, K, 0, 0, 1280, stream()) == 0
-        assert torch.equal(again.cpu(), outs[1280])
+                                       bias.data_ptr(), M, N, K, 0, 0, 2560, stream()) == 0
+        assert torch.equal(again.cpu(), outs[2560])
     assert lib.samrs_k_gemm_split3(prec, Ah.data_ptr(), Al.data_ptr(), Bh.data_ptr(), Bl.data_ptr(), plain.data_ptr(),
                                    bias.data_ptr(), M, N, K, 0, 0, 100, stream()) != 0          # not a whole tile
 

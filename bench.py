@@ -109,6 +109,9 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # host threads: the weight synthesis below is torch-CPU work; N ranks x every hardware thread of the node oversubscribes a
+    # container whose CPU quota is a fraction of it (16 of 256 on the pool's boxes)
+    torch.set_num_threads(max(1, min(32, int((_cpu_quota() or len(os.sched_getaffinity(0))) // max(1, world)))))
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -37,3 +37,14 @@ def gpu_available() -> bool:
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _host_io_library():
+    """libsamrs_io.so (g++, ~2 s) is a build artefact: make sure it exists before tests that go through samrs_amd.tile_io
+    (a clean checkout has no .so files; the HIP library is built by the tests that need it, tests/test_cabi_symbols.py)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "samrs_amd", "csrc")
+    if not os.path.exists(os.path.join(csrc, "libsamrs_io.so")):
+        subprocess.run(["make", "-C", csrc, "libsamrs_io.so"], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    yield

@@ -18,7 +18,6 @@ from samrs_amd import generate, synth  # noqa: E402
 
 
 def main() -> None:
-    from PIL import Image
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 96
     model = sys.argv[2] if len(sys.argv) > 2 else "vit_h"
     root = tempfile.mkdtemp(prefix="samrs_gen_")
@@ -27,11 +26,16 @@ def main() -> None:
     base = [synth.make_image(i) for i in range(8)]                      # 8 distinct blob tiles, re-used with a roll
     ann = {}
     t0 = time.perf_counter()
+    from concurrent.futures import ThreadPoolExecutor
+    from samrs_amd import tile_io
+
+    def put(i):
+        tile_io.write_rgb(os.path.join(img_dir, f"T{i:05d}.png"), np.ascontiguousarray(np.roll(base[i % 8], 37 * (i // 8), axis=1)), 1)
+    with ThreadPoolExecutor(8) as ex:
+        list(ex.map(put, range(n)))
     for i in range(n):
-        stem = f"T{i:05d}"
-        Image.fromarray(np.roll(base[i % 8], 37 * (i // 8), axis=1)).save(os.path.join(img_dir, stem + ".png"), compress_level=1)
         b, l = synth.make_boxes(i, 32)
-        ann[stem] = {"boxes": b.tolist(), "labels": l.tolist()}
+        ann[f"T{i:05d}"] = {"boxes": b.tolist(), "labels": l.tolist()}
     with open(os.path.join(root, "boxes.json"), "w") as f:
         json.dump(ann, f)
     print(f"wrote {n} tiles in {time.perf_counter() - t0:.1f}s", flush=True)

@@ -127,8 +127,12 @@ struct samrs_engine {
     // decoder workspaces
     float *TOK0 = nullptr, *Q = nullptr, *TA = nullptr, *TQ = nullptr, *TK = nullptr, *TV = nullptr, *TO = nullptr;
     float *MH = nullptr, *QP = nullptr, *KT = nullptr, *VT = nullptr, *O128 = nullptr, *T2IW = nullptr;
-    float *K0F = nullptr;          // shared layer-0 keys fp32 [tokens][C]
-    uint16_t* K0E = nullptr;
+    // Per embedding slot, written when the slot's image is set (prepare_slot_keys) and read-only for every predict on it: the
+    // layer-0 image side of the two-way transformer without a mask prompt is the same for every box of an image (keys =
+    // embedding + no_mask_embed, their k / v / q projections), so a second predict call / box chunk on the image costs nothing here
+    float *K0F = nullptr;          // layer-0 keys fp32 [max_images][tokens][C]
+    uint16_t* K0E = nullptr;       // ... in the operand type
+    uint16_t* KVQ0 = nullptr;      // their K_t2i | V_t2i | Q_i2t projections [max_images][tokens][3 C / 2]
     float* KF = nullptr;           // per-prompt keys fp32 [Bb*tokens][C]
     uint16_t* KE = nullptr;
     uint16_t* KE_lo = nullptr;     // split remainder of the final keys (operand of the first transposed conv)
@@ -549,7 +553,8 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->QP, BT * Ci)); CK(e, dalloc(e, &e->KT, BT * Ci)); CK(e, dalloc(e, &e->VT, BT * Ci));
     CK(e, dalloc(e, &e->O128, BT * Ci));
     CK(e, dalloc(e, &e->T2IW, t2i_workspace_floats(c.max_prompts, e->T_max)));
-    CK(e, dalloc(e, &e->K0F, (size_t)tokens * C)); CK(e, dalloc(e, &e->K0E, (size_t)tokens * C));
+    CK(e, dalloc(e, &e->K0F, (size_t)c.max_images * tokens * C)); CK(e, dalloc(e, &e->K0E, (size_t)c.max_images * tokens * C));
+    CK(e, dalloc(e, &e->KVQ0, (size_t)c.max_images * tokens * 3 * (C / 2)));
     CK(e, dalloc(e, &e->KF, Bb * tokens * C)); CK(e, dalloc(e, &e->KE, Bb * tokens * C));
     CK(e, dalloc(e, &e->KE_lo, Bb * tokens * C));
     CK(e, dalloc(e, &e->KVQ, Bb * tokens * 3 * Ci)); CK(e, dalloc(e, &e->OI, Bb * tokens * Ci));
@@ -567,6 +572,8 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
 // images[i]: device pointer of tile i (uint8 HWC, in_h[i] x in_w[i], long side == img_size).  Tiles of one call may
 // differ in size (HRSC / DIOR images after ResizeLongestSide): only the im2col reads pixels, everything downstream
 // works on the zero-padded 64 x 64 token grid (sam.py:170-173).
+static int prepare_slot_keys(samrs_engine_t* e, int slot0, int n, hipStream_t s);
+
 static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in_h, const int* in_w, int n, int slot0,
                   void* stream, int n_blocks, bool do_neck) {
     if (!e || !images || !in_h || !in_w) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_set_images: null argument");
@@ -751,6 +758,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     }
     CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.3.weight"), W(e, "image_encoder.neck.3.bias"), 1e-6f,
                            nullptr, e->EMB + (size_t)slot0 * tokens * C, M, C, 0, g, 0, s));
+    { const int rc = prepare_slot_keys(e, slot0, n, s); if (rc != SAMRS_OK) return rc; }
     for (int i = 0; i < n; ++i) e->slot_set[slot0 + i] = 1;
     return SAMRS_OK;
 }
@@ -792,12 +800,26 @@ int samrs_get_embedding(samrs_engine_t* e, int slot, float* out_chw, void* strea
     return SAMRS_OK;
 }
 
+// layer-0 image side of slots [slot0, slot0 + n): see the K0F / K0E / KVQ0 members
+static int prepare_slot_keys(samrs_engine_t* e, int slot0, int n, hipStream_t s) {
+    const int C = e->C, Ci = C / 2, tokens = e->tokens, prec = e->prec;
+    const DecLayer& L = e->layers[0];
+    for (int i = 0; i < n; ++i) {
+        const size_t o = (size_t)(slot0 + i) * tokens * C;
+        CK(e, launch_make_keys(prec, e->EMB + o, nullptr, W(e, "prompt_encoder.no_mask_embed.weight"), e->K0F + o, e->K0E + o, 1, tokens, C, s));
+    }
+    CK(e, launch_gemm_et(prec, e->K0E + (size_t)slot0 * tokens * C, L.kvq_w, e->KVQ0 + (size_t)slot0 * tokens * 3 * Ci, L.kvq_b, L.kvq_pe,
+                         tokens, n * tokens, 3 * Ci, C, false, false, false, s));
+    return SAMRS_OK;
+}
+
 int samrs_set_embedding(samrs_engine_t* e, int slot, const float* emb_chw, void* stream) {
     if (!e || !emb_chw) return fail(e, SAMRS_ERR_BAD_ARG, "samrs_set_embedding: null argument");
     if (!e->finalized) return fail(e, SAMRS_ERR_BAD_WEIGHTS, "weights not finalized");
     if (slot < 0 || slot >= e->cfg.max_images) return fail(e, SAMRS_ERR_CAPACITY, "slot out of range");
     ON_DEVICE(e);
     CK(e, launch_transpose_f32(emb_chw, e->EMB + (size_t)slot * e->tokens * e->C, e->C, e->tokens, (hipStream_t)stream));
+    { const int rc = prepare_slot_keys(e, slot, 1, (hipStream_t)stream); if (rc != SAMRS_OK) return rc; }
     e->slot_set[slot] = 1;
     return SAMRS_OK;
 }
@@ -889,9 +911,10 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
 
     const float* emb = e->EMB + (size_t)slot * tokens * C;
     const bool shared0 = (mask_input == nullptr);
-    if (shared0) {
-        CK(e, launch_make_keys(prec, emb, nullptr, W(e, "prompt_encoder.no_mask_embed.weight"), e->K0F, e->K0E, 1, tokens, C, s));
-    } else {
+    // layer-0 image side of this slot (prepare_slot_keys, at set_image time)
+    const float* k0f = e->K0F + (size_t)slot * tokens * C;
+    const uint16_t* kvq0 = e->KVQ0 + (size_t)slot * tokens * 3 * Ci;
+    if (!shared0) {
         if (!e->DENSE) CK(e, dalloc(e, &e->DENSE, (size_t)c.max_prompts * tokens * C));
         MaskEmbedParams mp{W(e, "prompt_encoder.mask_downscaling.0.weight"), W(e, "prompt_encoder.mask_downscaling.0.bias"),
                            W(e, "prompt_encoder.mask_downscaling.1.weight"), W(e, "prompt_encoder.mask_downscaling.1.bias"),
@@ -919,12 +942,12 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
         CK(e, lin(e->TO, C, L.self.ow, L.self.ob, e->Q, C, BT, C, C, false, li > 0));
         CK(e, ln_tok(L.n1w, L.n1b));
         // image-side projections for this layer: K_t2i | V_t2i | Q_i2t  (PE folded in as add2d)
-        const uint16_t* keys_et = sh ? e->K0E : e->KE;
         const long bstride = sh ? 0 : tokens;
-        CK(e, launch_gemm_et(prec, keys_et, L.kvq_w, e->KVQ, L.kvq_b, L.kvq_pe, tokens, sh ? tokens : Mi, 3 * Ci, C, false, false, false, s));
+        const uint16_t* kvq = sh ? kvq0 : e->KVQ;
+        if (!sh) CK(e, launch_gemm_et(prec, e->KE, L.kvq_w, e->KVQ, L.kvq_b, L.kvq_pe, tokens, Mi, 3 * Ci, C, false, false, false, s));
         // (2) tokens -> image
         CK(e, lin2(e->Q, e->TOK0, C, L.t2i.qw, L.t2i.qb, e->QP, Ci, BT, Ci, C));
-        CK(e, launch_t2i_attention(prec, e->QP, e->KVQ, e->KVQ + Ci, 3 * Ci, bstride, e->O128, e->T2IW, n, T, tokens, Ci, 8, s));
+        CK(e, launch_t2i_attention(prec, e->QP, kvq, kvq + Ci, 3 * Ci, bstride, e->O128, e->T2IW, n, T, tokens, Ci, 8, s));
         CK(e, lin(e->O128, Ci, L.t2i.ow, L.t2i.ob, e->Q, C, BT, C, Ci, false, true));
         CK(e, ln_tok(L.n2w, L.n2b));
         // (3) MLP (ReLU)
@@ -945,14 +968,14 @@ static int predict_chunk(samrs_engine_t* e, int slot, int n, const float* boxes,
             // (final t2i projections, upscaler), so its 4 bytes per element are not written
             // SPLIT_OI: attention output and out-projection weights as hi + lo; SPLIT_UP: the last layer also writes the split
             // remainder of the final keys for the first transposed conv
-            CK(e, launch_i2t_fused(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, L.i2t_ow,
-                                   (e->split & SPLIT_OI) ? L.i2t_ow_lo : nullptr, L.i2t.ob, sh ? e->K0F : e->KF,
+            CK(e, launch_i2t_fused(prec, kvq + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, L.i2t_ow,
+                                   (e->split & SPLIT_OI) ? L.i2t_ow_lo : nullptr, L.i2t.ob, sh ? k0f : e->KF,
                                    sh ? 0 : tokens, L.n4w, L.n4b, 1e-5f, li == 1 ? nullptr : e->KF, e->KE,
                                    (li == 1 && (e->split & SPLIT_UP)) ? e->KE_lo : nullptr, n, T, tokens, Ci, C, s));
         } else {
-            CK(e, launch_i2t_attention(prec, e->KVQ + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, e->OI, n, T, tokens, Ci, 8, s));
+            CK(e, launch_i2t_attention(prec, kvq + 2 * Ci, 3 * Ci, bstride, e->KT, e->VT, e->OI, n, T, tokens, Ci, 8, s));
             if (sh)
-                CK(e, launch_gemm_et(prec, e->OI, L.i2t_ow, e->KF, L.i2t.ob, e->K0F, tokens, Mi, C, Ci, true, false, false, s));
+                CK(e, launch_gemm_et(prec, e->OI, L.i2t_ow, e->KF, L.i2t.ob, k0f, tokens, Mi, C, Ci, true, false, false, s));
             else
                 CK(e, launch_gemm_et(prec, e->OI, L.i2t_ow, e->KF, L.i2t.ob, nullptr, 0, Mi, C, Ci, true, false, true, s));
             CK(e, launch_layernorm(prec, e->KF, L.n4w, L.n4b, 1e-5f, e->KE, e->KF, Mi, C, 0, g, 0, s));

@@ -194,6 +194,18 @@ def main(argv):
             else:
                 bp = {q: (blocks, sp) for q in pts}
             report(label, tag, so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points=bp))
+    if what in ("plans8",):
+        # the ViT-H default (v + proj, blocks 0..23) with the two correction terms on fp8 operands (block-scaled fp8 MFMA: 2x the f16 rate)
+        sp, sp8 = so.split2(F16), so.split_fp8_lo(F16)
+        e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
+        n = cfg.depth
+        blocks = range(0, 3 * n // 4)
+        report("E1 + v + proj split in blocks 0..%d, lo terms exact (= the default)" % (3 * n // 4 - 1), "p6_v_in_proj_in_%d" % len(blocks),
+               so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points={q: (blocks, sp) for q in ("enc.v_in", "enc.proj_in")}))
+        report("  ... lo terms on fp8 (e4m3) operands", "p8_fp8lo_%d" % len(blocks),
+               so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points={q: (blocks, sp8) for q in ("enc.v_in", "enc.proj_in")}))
+        report("all four block GEMMs in every block, lo terms on fp8 operands", "p8_fp8lo_all4",
+               so.Rounding(enc=F16, dec=F16, points=dict(e1, **{q: sp8 for q in ("enc.qkv_in", "enc.proj_in", "enc.lin1_in", "enc.lin2_in")})))
     if what in ("plans", "all"):
         sp = so.split2(F16)
         report("plan A: encoder f16, decoder operands split f16 (hi+lo)", "f16",

@@ -78,6 +78,8 @@ class Rounding:
             dt = self.points[name]
         else:
             dt = self.enc if name.startswith("enc.") else self.dec
+        if hasattr(dt, "matmul"):                 # term-level emulation (split_fp8_lo): _linear needs the object itself
+            return dt
         return lambda x: self._r(x, dt)
 
     def e(self, x: Tensor) -> Tensor:
@@ -97,8 +99,35 @@ _EXACT = Rounding()
 
 
 def _linear(x: Tensor, sd: SD, name: str, r: Callable[[Tensor], Tensor]) -> Tensor:
+    if hasattr(r, "matmul"):                      # a term-level emulation (split_fp8_lo): needs both operands at once
+        return r.matmul(x, sd[name + ".weight"]) + sd[name + ".bias"]
     w = r(sd[name + ".weight"])
     return r(x) @ w.t() + sd[name + ".bias"]
+
+
+class split_fp8_lo:
+    """Error-budget probe for a cheaper operand split: x w^T = x_hi w_hi^T + x_lo w_hi^T + x_hi w_lo^T with the hi x hi term on
+    `dt` operands and the two CORRECTION terms on fp8 (e4m3, 3 mantissa bits) operands with a power-of-two scale per row --
+    what gfx950's block-scaled fp8 MFMA would compute at twice the f16 rate.  The corrections are 2^-11 of the product, so
+    their operands' 2^-4 rounding leaves ~2^-15 instead of the plain path's 2^-12."""
+
+    def __init__(self, dt=torch.float16):
+        self.dt = dt
+
+    @staticmethod
+    def _q8(t: Tensor) -> Tensor:
+        amax = t.abs().amax(dim=-1, keepdim=True).clamp(min=1e-30)
+        scale = torch.exp2(torch.floor(torch.log2(448.0 / amax)))          # E8M0-style: a power of two per row
+        return (t * scale).to(torch.float8_e4m3fn).to(torch.float32) / scale
+
+    def __call__(self, t: Tensor) -> Tensor:      # used where a plain rounding function is expected (weights of a conv, ...)
+        hi = t.to(self.dt).to(torch.float32)
+        return hi + (t - hi).to(self.dt).to(torch.float32)
+
+    def matmul(self, x: Tensor, w: Tensor) -> Tensor:
+        xh, wh = x.to(self.dt).to(torch.float32), w.to(self.dt).to(torch.float32)
+        xl, wl = x - xh, w - wh
+        return xh @ wh.t() + self._q8(xl) @ self._q8(wh).t() + self._q8(xh) @ self._q8(wl).t()
 
 
 # ------------------------------------------------------------------------------------------

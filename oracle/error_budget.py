@@ -206,6 +206,15 @@ def main(argv):
                so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points={q: (blocks, sp8) for q in ("enc.v_in", "enc.proj_in")}))
         report("all four block GEMMs in every block, lo terms on fp8 operands", "p8_fp8lo_all4",
                so.Rounding(enc=F16, dec=F16, points=dict(e1, **{q: sp8 for q in ("enc.qkv_in", "enc.proj_in", "enc.lin1_in", "enc.lin2_in")})))
+    if what in ("plans9",):
+        # the same with the lo terms on fp6 / fp4 operands (block-scaled f8f6f4 MFMA: 4x the f16 rate), MX blocks of 32
+        sp = so.split2(F16)
+        e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
+        four = ("enc.qkv_in", "enc.proj_in", "enc.lin1_in", "enc.lin2_in")
+        for fmt in ("e2m3", "e2m1"):
+            q = so.split_fp8_lo(F16, fmt=fmt, block=32)
+            report(f"all four block GEMMs in every block, lo terms on {fmt} operands", f"p9_{fmt}_all4",
+                   so.Rounding(enc=F16, dec=F16, points=dict(e1, **{k: q for k in four})))
     if what in ("plans", "all"):
         sp = so.split2(F16)
         report("plan A: encoder f16, decoder operands split f16 (hi+lo)", "f16",

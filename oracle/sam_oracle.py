@@ -111,14 +111,26 @@ class split_fp8_lo:
     what gfx950's block-scaled fp8 MFMA would compute at twice the f16 rate.  The corrections are 2^-11 of the product, so
     their operands' 2^-4 rounding leaves ~2^-15 instead of the plain path's 2^-12."""
 
-    def __init__(self, dt=torch.float16):
-        self.dt = dt
+    def __init__(self, dt=torch.float16, fmt: str = "e4m3", block: int = 0):
+        """fmt: "e4m3" (fp8), "e2m3" / "e3m2" (the two fp6 formats of the f8f6f4 MFMA, 4x the f16 rate), "e2m1" (fp4);
+        block: elements along k that share one power-of-two scale (MX: 32; 0 = the whole row)."""
+        self.dt, self.fmt, self.block = dt, fmt, block
 
-    @staticmethod
-    def _q8(t: Tensor) -> Tensor:
+    _FMT = {"e4m3": (4, 3, 7, 448.0), "e2m3": (2, 3, 1, 7.5), "e3m2": (3, 2, 3, 28.0), "e2m1": (2, 1, 1, 6.0)}   # ebits, mbits, bias, max
+
+    def _q8(self, t: Tensor) -> Tensor:
+        ebits, mbits, bias, vmax = self._FMT[self.fmt]
+        shp = t.shape
+        if self.block and shp[-1] % self.block == 0:
+            t = t.reshape(*shp[:-1], shp[-1] // self.block, self.block)
         amax = t.abs().amax(dim=-1, keepdim=True).clamp(min=1e-30)
-        scale = torch.exp2(torch.floor(torch.log2(448.0 / amax)))          # E8M0-style: a power of two per row
-        return (t * scale).to(torch.float8_e4m3fn).to(torch.float32) / scale
+        # E8M0 scale: the block maximum lands in the top binade of the format
+        scale = torch.exp2(torch.floor(torch.log2(amax)) - float(2 ** ebits - 1 - bias - (1 if self.fmt == "e4m3" else 0)))
+        v = t / scale
+        e = torch.floor(torch.log2(v.abs().clamp(min=1e-30))).clamp(min=float(1 - bias))       # subnormals share the lowest exponent
+        step = torch.exp2(e - mbits)
+        q = (torch.round(v / step) * step).clamp(-vmax, vmax)
+        return (q * scale).reshape(shp)
 
     def __call__(self, t: Tensor) -> Tensor:      # used where a plain rounding function is expected (weights of a conv, ...)
         hi = t.to(self.dt).to(torch.float32)

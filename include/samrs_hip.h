@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAMRS_ABI_VERSION 2
+#define SAMRS_ABI_VERSION 3
 
 enum samrs_status {
     SAMRS_OK = 0,
@@ -36,7 +36,9 @@ enum samrs_status {
     SAMRS_ERR_HIP = -4,          /* a HIP runtime call failed                                   */
     SAMRS_ERR_BAD_WEIGHTS = -5,  /* unknown / missing / mis-shaped tensor (strict load,
                                     build_sam.py:103-106)                                       */
-    SAMRS_ERR_CAPACITY = -6      /* more images / prompts than the handle was created for       */
+    SAMRS_ERR_CAPACITY = -6,     /* more images / prompts than the handle was created for       */
+    SAMRS_ERR_PRECISION = -7     /* multimask predict on an embedding encoded below the mode the
+                                    multimask outputs need (see samrs_get_slot_info)            */
 };
 
 /* MFMA operand type.  Accumulation, residual stream, LayerNorm / softmax statistics and the
@@ -106,6 +108,13 @@ int samrs_get_embedding(samrs_engine_t* e, int slot, float* out_chw, void* strea
 int samrs_set_embedding(samrs_engine_t* e, int slot, const float* emb_chw, void* stream);
 /* SamPredictor.reset_image (predictor.py:264-271). */
 int samrs_reset_image(samrs_engine_t* e, int slot);
+/* The operand-split mode travels with the embedding (ABI 3): *split = the "split" option in force when the slot's image was
+ * encoded (-1: installed by samrs_set_embedding), *split_depth = the number of leading blocks its block-GEMM bits covered.
+ * samrs_predict(multimask = 1) on a slot whose mask lacks the block-GEMM bits this model's multimask outputs need (ViT-H: 64 or
+ * 16; read-only option "grade_multimask") returns SAMRS_ERR_PRECISION instead of answering in whatever mode a single-mask
+ * pipeline left behind -- unless option "allow_reduced" is 1 (set by an explicit SAMRS_SPLIT, or by the caller).  The
+ * reference's SamPredictor.predict defaults to multimask_output=True (predictor.py:92-100, mask_decoder.py:101-106). */
+int samrs_get_slot_info(const samrs_engine_t* e, int slot, int32_t* is_set, int32_t* split, int32_t* split_depth);
 
 /* -- prompt side ---------------------------------------------------------------------------
  * replaces: SamPredictor.predict_torch (predictor.py:168-245) = PromptEncoder.forward
@@ -200,7 +209,9 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    LayerNorm2d + GELU epilogue, then the ConvT #2 + GELU + product kernel (A/B runs, tests).
  *   "split_passes"   [SAMRS_SPLIT_PASSES, default 0] reference-grade bits of "split" only: 1 = the three terms of a split block GEMM as
  *                    three accumulating launches through an fp32 scratch (the generic route, every shape); 0 = as ONE launch over a
- *                    three-segment K axis where the shape fits the 256 x 320 tile (ViT-H; samrs_k_gemm_split3), else the generic route. */
+ *                    three-segment K axis where the shape fits the 256 x 320 tile (ViT-H; samrs_k_gemm_split3), else the generic route.
+ *   "allow_reduced"  [SAMRS_ALLOW_REDUCED; default 0, 1 when SAMRS_SPLIT is set] 1 = samrs_predict(multimask = 1) accepts embeddings
+ *                    encoded below the multimask grade (see samrs_get_slot_info) instead of returning SAMRS_ERR_PRECISION. */
 int samrs_set_option(samrs_engine_t* e, const char* name, int value);
 int samrs_get_option(const samrs_engine_t* e, const char* name, int* value);
 

@@ -53,7 +53,7 @@ int samrs_io_png_read_rgb(const char* path, uint8_t* dst, size_t dst_bytes, int*
 int samrs_io_png_decode_rgb(const uint8_t* file, size_t file_bytes, uint8_t* dst, size_t dst_bytes, int* height, int* width);
 
 /* Write an 8-bit gray PNG (the class map, 255 = unlabeled).  `stride` = bytes between rows of `src` (>= width).
- * The file is written to `<path>.tmp` and renamed, so a reader never sees half a file. */
+ * The file is written to `<path>.tmp.<pid>` and renamed, so a reader never sees half a file and two processes never share a tmp. */
 int samrs_io_png_write_gray(const char* path, const uint8_t* src, int height, int width, size_t stride, int level);
 
 /* Write a truecolour PNG whose pixel is lut[3 * src[y, x] .. +3]: the palette image of the class map without

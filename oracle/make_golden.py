@@ -5,6 +5,7 @@ Run in the authoring container (needs ``/root/reference``)::
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden vit_tiny vit_tiny80 vit_b vit_h
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden vit_b_c2c4 vit_h_c2c4      # C2 / C4 fixtures, margin weights
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden vit_h_c2c4_v1              # a second, independent draw of the same
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden vit_b_inst vit_h_inst      # the instance drivers' recipes as scripted
 
 Weights / images / prompts come from ``samrs_amd.synth`` (seeded, reproducible anywhere), the
 outputs come from the reference's own ``SamPredictor`` (Generate Dataset/segment_anything/
@@ -144,15 +145,73 @@ def extended(name: str, variant: int = 0) -> None:
           int(np.unpackbits(blob["c2_unstable"]).sum()), flush=True)
 
 
+INSTANCE_TAU = 2.5e-3      # the engine's own logit-error bound (oracle/parity_sample.py TAU_FRAC), not the 1e-2 of the C2 / C4 fixtures
+
+
+def instance_inputs(variant: int = 0, n: int = 8):
+    """Inputs of the instance-recipe fixture: FAIR1M-shaped rboxes on one tile; the foreground point of an object is its centre."""
+    polys, plabels = synth.make_rboxes(20 + 10 * variant, n)
+    return dict(polys=polys, plabels=plabels, hboxes=synth.enclosing_hboxes(polys),
+                points=polys.mean(axis=1).astype(np.float32), image_index=40 + variant)
+
+
+def instances(name: str, variant: int = 0) -> None:
+    """``tests/golden/<name>_inst.npz``: the three instance drivers' prompt recipes EXACTLY AS SCRIPTED, run by the REAL
+    reference, all with ``multimask_output=False``:
+      inst_point  main_sam_hbox_mask_instance.py:160-165  point_coords=gt_points[:, None, :] (NOT through apply_coords),
+                  point_labels=ones, boxes=None, mask_input=None
+      inst_mask   main_sam_rbox_mask_instance.py:159-164  mask_input=rbox_mask_prompts[:, None], nothing else
+      inst_rhbox  main_sam_rhbox_mask_instance.py:163-168 boxes=apply_boxes_torch(enclosing hboxes), nothing else
+    Stored like the C2 / C4 fixtures: bit-packed full-resolution masks, the per-mask set of pixels whose reference logit is
+    within INSTANCE_TAU x std of the threshold, stride-4 low-res logits, IoU predictions, areas."""
+    from oracle import rbox_prompt
+    cfg = synth.CONFIGS[name]
+    sd = synth.make_state_dict(cfg, 0, logit_scale=synth.MARGIN_LOGIT_SCALE)
+    sa, sam = ref_import.build_reference_sam(cfg, sd)
+    pred = sa.SamPredictor(sam)
+    inp = instance_inputs(variant)
+    h = w = 1024
+    img = synth.make_image(inp["image_index"], h, w)
+    pred.set_image(img)
+    f = pred.get_image_embedding()
+    blob = {"emb_sample": f[0, ::16, ::4, ::4].numpy().copy(), "logit_scale": np.float64(synth.MARGIN_LOGIT_SCALE),
+            "tau_frac": np.float64(INSTANCE_TAU)}
+    prompts = np.stack([rbox_prompt.rbox_mask_prompt(p.astype(np.int32), h, w) for p in inp["polys"]])
+    blob["mask_prompt_sum"] = np.float64(prompts.astype(np.float64).sum())
+    n = len(inp["polys"])
+    recipes = {
+        "inst_point": dict(point_coords=torch.from_numpy(inp["points"])[:, None, :], point_labels=torch.ones(n)[:, None]),
+        "inst_mask": dict(mask_input=torch.from_numpy(prompts.astype(np.float32))[:, None]),
+        "inst_rhbox": dict(boxes=pred.transform.apply_boxes_torch(torch.as_tensor(inp["hboxes"]), (h, w))),
+    }
+    for tag, kw in recipes.items():
+        lg, iou, low = pred.predict_torch(kw.get("point_coords"), kw.get("point_labels"), kw.get("boxes"), kw.get("mask_input"),
+                                          multimask_output=False, return_logits=True)
+        masks = lg > sam.mask_threshold
+        tau = INSTANCE_TAU * low.std().item()
+        near = lg.abs() < tau
+        blob[tag + "_masks"] = _pack(masks.numpy())
+        blob[tag + "_nearmask"] = _pack(near.numpy())
+        blob[tag + "_near"] = near.flatten(2).sum(-1).numpy().astype(np.int64)
+        blob[tag + "_iou"] = iou.numpy().copy()
+        blob[tag + "_low"] = low[:, :, ::4, ::4].numpy().copy()
+        blob[tag + "_low_std"] = np.float64(low.std().item())
+        blob[tag + "_area"] = masks.flatten(2).sum(-1).numpy().astype(np.int64)
+        print(name, tag, "areas", blob[tag + "_area"].ravel().tolist(), "near", blob[tag + "_near"].ravel().tolist(), flush=True)
+    path = os.path.join(GOLDEN_DIR, name + "_inst" + (f"_v{variant}" if variant else "") + ".npz")
+    np.savez_compressed(path, **blob)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", flush=True)
+
+
 def main(names):
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(os.cpu_count() or 1)
     import re
-    ext = [re.fullmatch(r"(.+)_c2c4(?:_v(\d+))?", n) for n in names]
+    ext = [re.fullmatch(r"(.+)_(c2c4|inst)(?:_v(\d+))?", n) for n in names]
     names = [n for n, m in zip(names, ext) if m is None]
     for m in ext:
         if m is not None:
-            extended(m.group(1), int(m.group(2) or 0))
+            (extended if m.group(2) == "c2c4" else instances)(m.group(1), int(m.group(3) or 0))
     for name in names:
         cfg = synth.CONFIGS[name]
         sd = synth.make_state_dict(cfg, 0)

@@ -1,0 +1,195 @@
+"""TEST INFRASTRUCTURE ONLY -- a statistical parity sample at ViT-H, checked by the PINNED oracle on the machine that runs it.
+
+The reference fixtures under ``tests/golden/`` are 3 tiles x 32 boxes (C2) and 3 x 4 objects x 3 masks (C4): too few masks to
+carry a "min" ("What's weak" 1).  Fixtures of the size wanted -- >= 256 C2 masks, >= 96 C4 masks per prompt
+type, the three instance drivers' scripted recipes, non-1024 inputs -- would be tens of MB of incompressible bit-packed
+masks, so this module does the next best thing: it runs ``oracle/sam_oracle.py`` (pinned to the real reference by those
+fixtures: low-res logits within 2e-4, <= 8 flipped pixels per mask, tests/test_oracle_golden.py) on the CPU of the GPU box,
+tile by tile, and compares the engine with it in every requested precision mode while the tile's oracle results are in
+memory.  Nothing here is imported by the product (``samrs_amd/``).
+
+Workloads (all seeded through ``samrs_amd.synth``; the same tensors on every machine):
+
+  c2          main_sam_hbox_semantic.py:148-206 -- 32 hboxes per 1024^2 tile, single mask, painted class map
+  c4box       BASELINE.json configs[3] -- enclosing hbox of a FAIR1M-shaped rbox, multimask_output=True (3 masks per object)
+  c4mask      the same objects through the +-1000 rbox mask prompt, multimask_output=True
+  inst_point  main_sam_hbox_mask_instance.py:160-165 AS SCRIPTED: one foreground point per object (not run through
+              apply_coords), no box, no mask, multimask_output=False
+  inst_mask   main_sam_rbox_mask_instance.py:159-164 AS SCRIPTED: mask prompt only, multimask_output=False
+  inst_rhbox  main_sam_rhbox_mask_instance.py:163-168 AS SCRIPTED: enclosing hbox only, multimask_output=False
+  c2_800      a DIOR-shaped 800 x 800 tile (ResizeLongestSide to 1024 x 1024, utils/transforms.py:26-31,93-102), 32 hboxes
+  c2_ragged   an HRSC2016-shaped ragged tile (771 x 1163 -> 679 x 1024 + padding), 32 hboxes
+
+Per mask: IoU, flipped pixels, flipped pixels OUTSIDE the set where the oracle's own full-resolution logit is within
+tau of the threshold (tau = TAU_FRAC x std of the call's low-res logits).  Per c2 tile: differing class-map pixels, the
+"unstable" set (oracle.make_golden.unstable_class_map at the same tau) and the differing pixels outside it.
+"""
+from __future__ import annotations
+
+import time
+from collections import defaultdict
+from typing import Dict, Iterable, List, Sequence
+
+import numpy as np
+import torch
+
+from samrs_amd import synth
+
+# the engine's own logit-error bound: max |low-res logit error| / std measured <= 2.5e-3 in the 1x-rate mode (split 15);
+# a pixel whose reference logit is further than that from the threshold cannot flip (bilinear upsampling is a convex
+# combination), so "zero flips outside tau" + "max error < tau" is the zero-tolerance statement the class map supports
+TAU_FRAC = 2.5e-3
+
+N_C2_TILES = 8          # x 32 boxes  = 256 single masks
+N_C4_TILES = 4          # x 8 rboxes  = 32 objects -> 96 multimask masks per prompt type, 32 masks per scripted recipe
+BOXES_PER_TILE = 32
+RBOXES_PER_TILE = 8
+ODD_SHAPES = (("c2_800", (800, 800)), ("c2_ragged", (771, 1163)))
+
+
+def tiles(n_c2: int = N_C2_TILES, n_c4: int = N_C4_TILES, odd: bool = True):
+    """The sample, tile by tile: dicts with the image and the annotations of every workload that runs on it."""
+    for i in range(n_c2):
+        boxes, labels = synth.make_boxes(300 + i, BOXES_PER_TILE)
+        t = dict(name=f"tile{i}", image=synth.make_image(200 + i), c2=(boxes, labels))
+        if i < n_c4:
+            polys, plabels = synth.make_rboxes(400 + i, RBOXES_PER_TILE)
+            t["rboxes"] = polys
+        yield t
+    if odd:
+        for j, (tag, (h, w)) in enumerate(ODD_SHAPES):
+            boxes, labels = synth.make_boxes(500 + j, BOXES_PER_TILE, h, w)
+            yield dict(name=tag, image=synth.make_image(250 + j, h, w), c2=(boxes, labels), c2_tag=tag)
+
+
+def workloads(tile, rasterise):
+    """(tag, prompt kwargs in ORIGINAL pixels, multimask) of one tile.  `rasterise(polys, hw)` -> fp32 [n, 256, 256] mask
+    prompts (CPU tensor); the oracle side uses oracle/rbox_prompt.py, the engine side its GPU rasteriser (bit-exact with it,
+    tests/test_rbox_prompt.py)."""
+    hw = tile["image"].shape[:2]
+    out = [(tile.get("c2_tag", "c2"), dict(boxes=tile["c2"][0]), False)]
+    if "rboxes" in tile:
+        polys = tile["rboxes"]
+        hb = synth.enclosing_hboxes(polys)
+        pts = polys.mean(axis=1).astype(np.float32)                       # one foreground point per object: its centre
+        out += [("c4box", dict(boxes=hb), True),
+                ("c4mask", dict(mask_polys=polys), True),
+                ("inst_point", dict(points=pts), False),
+                ("inst_mask", dict(mask_polys=polys), False),
+                ("inst_rhbox", dict(boxes=hb), False)]
+    return out
+
+
+def _oracle_call(orc, so, kw, multimask, hw):
+    from oracle import rbox_prompt
+    boxes = pc = pl = mi = None
+    if "boxes" in kw:
+        boxes = so.apply_boxes(torch.from_numpy(kw["boxes"]), hw, orc.cfg.img_size)
+    if "points" in kw:
+        pc = torch.from_numpy(kw["points"])[:, None, :]                   # AS IS: the driver does not call apply_coords
+        pl = torch.ones(len(kw["points"]), 1, dtype=torch.int)
+    if "mask_polys" in kw:
+        pr = np.stack([rbox_prompt.rbox_mask_prompt(p.astype(np.int32), hw[0], hw[1]) for p in kw["mask_polys"]])
+        mi = torch.from_numpy(pr.astype(np.float32))[:, None]
+    return orc.predict_torch(pc, pl, boxes, mi, multimask_output=multimask, return_logits=True)
+
+
+def _engine_call(pred, kw, multimask, hw):
+    from samrs_amd import transforms
+    dev = pred.device
+    boxes = pc = pl = mi = None
+    if "boxes" in kw:
+        boxes = pred.transform.apply_boxes_torch(torch.from_numpy(kw["boxes"]).to(dev), hw)
+    if "points" in kw:
+        pc = torch.from_numpy(kw["points"]).to(dev)[:, None, :]
+        pl = torch.ones(len(kw["points"]), 1, dtype=torch.int32, device=dev)
+    if "mask_polys" in kw:
+        mi = transforms.rbox_mask_prompts(kw["mask_polys"], hw, img_size=pred.model.image_encoder.img_size, device=dev)[:, None]
+    return pred.predict_torch(pc, pl, boxes, mi, multimask_output=multimask)
+
+
+def run(pred, orc, modes: Sequence[int], tile_iter: Iterable[dict] = None, tau_frac: float = TAU_FRAC, log=print):
+    """Engine (`pred`: samrs_amd.SamPredictor on a ViT-H engine whose block-weight lo copies exist) against the oracle
+    predictor `orc` for every mode in `modes` (the engine's "split" option).  Returns {mode: {tag: {field: list}}}."""
+    from oracle import sam_oracle as so
+    from oracle.make_golden import unstable_class_map
+    eng = pred.model.engine
+    rec: Dict[int, Dict[str, Dict[str, List]]] = {m: defaultdict(lambda: defaultdict(list)) for m in modes}
+    for tile in (tile_iter if tile_iter is not None else tiles()):
+        img = tile["image"]
+        hw = img.shape[:2]
+        t0 = time.time()
+        orc.set_image(img)
+        ref = {}
+        for tag, kw, mm in workloads(tile, None):
+            lg, q0, low0 = _oracle_call(orc, so, kw, mm, hw)
+            tau = tau_frac * low0.std().item()
+            ref[tag] = dict(masks=lg > orc.mask_threshold, near=lg.abs() < tau, low=low0, q=q0, tau=tau, std=low0.std().item())
+            if "c2" in tile and tag == tile.get("c2_tag", "c2"):
+                labels = tile["c2"][1]
+                seg0, _ = so.paint_semantic(ref[tag]["masks"][:, 0].numpy(), labels, hw)
+                ref[tag]["seg"] = seg0
+                ref[tag]["unstable"] = unstable_class_map(lg[:, 0], tau).numpy()
+            del lg
+        t_or = time.time() - t0
+        for mode in modes:
+            eng.set_option("split", mode)
+            pred.set_image(img)
+            for tag, kw, mm in workloads(tile, None):
+                m, q, low = _engine_call(pred, kw, mm, hw)
+                r, R = rec[mode][tag], ref[tag]
+                mc = m.cpu()
+                flip = mc != R["masks"]
+                inter = (mc & R["masks"]).flatten(2).sum(-1).double()
+                union = (mc | R["masks"]).flatten(2).sum(-1).double().clamp(min=1)
+                r["iou"] += (inter / union).flatten().tolist()
+                r["area"] += R["masks"].flatten(2).sum(-1).flatten().tolist()
+                r["flips"] += flip.flatten(2).sum(-1).flatten().tolist()
+                r["flips_outside_tau"] += (flip & ~R["near"]).flatten(2).sum(-1).flatten().tolist()
+                r["near"] += R["near"].flatten(2).sum(-1).flatten().tolist()
+                r["low_err_over_std"].append(((low.cpu() - R["low"]).abs().max() / R["std"]).item())
+                r["low_rel_l2"].append(((low.cpu() - R["low"]).norm() / R["low"].norm()).item())
+                r["q_err"].append((q.cpu() - R["q"]).abs().max().item())
+                if "seg" in R:
+                    seg = torch.full(hw, 255, dtype=torch.uint8, device=pred.device)
+                    eng.paint(m[:, 0], torch.from_numpy(tile["c2"][1]), seg)
+                    diff = seg.cpu().numpy() != R["seg"]
+                    r["classmap_diff"].append(int(diff.sum()))
+                    r["classmap_unstable"].append(int(R["unstable"].sum()))
+                    r["classmap_diff_outside"].append(int((diff & ~R["unstable"]).sum()))
+        log(f"parity sample {tile['name']} {hw}: oracle {t_or:.1f} s, {len(ref)} workloads x {len(modes)} modes")
+    return {m: {t: dict(f) for t, f in d.items()} for m, d in rec.items()}
+
+
+def summarise(rec) -> dict:
+    """{mode: {tag: summary}}: n masks, IoU min / 1st percentile / mean, masks under 0.999 / 0.9995, flips, class-map counts."""
+    out = {}
+    for mode, tags in rec.items():
+        out[mode] = {}
+        for tag, f in tags.items():
+            iou = np.asarray(f["iou"])
+            s = dict(n_masks=int(iou.size), iou_min=float(iou.min()), iou_p1=float(np.percentile(iou, 1)), iou_mean=float(iou.mean()),
+                     n_below_0999=int((iou < 0.999).sum()), n_below_09995=int((iou < 0.9995).sum()),
+                     area_of_min=int(np.asarray(f["area"])[int(iou.argmin())]), flips_max=int(max(f["flips"])),
+                     flips_outside_tau=int(sum(f["flips_outside_tau"])), near_max=int(max(f["near"])),
+                     low_err_over_std_max=float(max(f["low_err_over_std"])), low_rel_l2_max=float(max(f["low_rel_l2"])),
+                     q_err_max=float(max(f["q_err"])))
+            if "classmap_diff" in f:
+                s.update(classmap_diff=[int(v) for v in f["classmap_diff"]], classmap_diff_max=int(max(f["classmap_diff"])),
+                         classmap_diff_mean=float(np.mean(f["classmap_diff"])),
+                         classmap_unstable_max=int(max(f["classmap_unstable"])),
+                         classmap_diff_outside_unstable=int(sum(f["classmap_diff_outside"])))
+            out[mode][tag] = s
+    return out
+
+
+def table(summary) -> str:
+    rows = ["| mode | workload | masks | IoU min | IoU p1 | IoU mean | < 0.999 | < 0.9995 | area of min | flips outside tau | max err / std | class-map px differing (max / mean) | unstable px (max) | differing outside |",
+            "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for mode, tags in summary.items():
+        for tag, s in tags.items():
+            cm = f"{s['classmap_diff_max']} / {s['classmap_diff_mean']:.0f}" if "classmap_diff" in s else "-"
+            rows.append(f"| {mode} | {tag} | {s['n_masks']} | {s['iou_min']:.5f} | {s['iou_p1']:.5f} | {s['iou_mean']:.5f} | {s['n_below_0999']} | "
+                        f"{s['n_below_09995']} | {s['area_of_min']} | {s['flips_outside_tau']} | {s['low_err_over_std_max']:.2e} | {cm} | "
+                        f"{s.get('classmap_unstable_max', '-')} | {s.get('classmap_diff_outside_unstable', '-')} |")
+    return "\n".join(rows)

@@ -57,9 +57,14 @@ class Sam:
         self.engine = Engine(self.cfg, device, self.precision, self.max_images, self.max_prompts, self.max_points)
         for k, v in self.options.items():
             self.engine.set_option(k, v)
+        # an explicit operand-split mode for the whole engine is the caller's decision, multimask outputs included (otherwise
+        # the engine refuses multimask predicts on embeddings encoded below its multimask grade: samrs_get_slot_info)
+        if "split" in self.options and "allow_reduced" not in self.options:
+            self.engine.set_option("allow_reduced", 1)
         self.engine.load_state_dict(self._state_dict)
         # what this model runs in when nobody says otherwise (ViT-H: 79, else 15): the multimask-safe mode; the pipelines of
-        # driver.py switch between it and the 1x-rate mode by output contract (TilePipeline precision="auto")
+        # driver.py run THEIR OWN calls in it or in the 1x-rate mode by output contract (TilePipeline precision="auto") and leave
+        # the engine's option as it is
         self.default_split = self.engine.get_option("split")
         self._device = device
         return self

@@ -89,7 +89,12 @@ template <int PREC>
 __device__ __forceinline__ void split2_pack(float a, float b, uint32_t& hi, uint32_t& lo) {
     hi = pack2<PREC>(a, b);
     const float ha = ET<PREC>::to_float((uint16_t)(hi & 0xffffu)), hb = ET<PREC>::to_float((uint16_t)(hi >> 16));
-    lo = pack2_fast<PREC>(a - ha, b - hb);
+    // saturating as well: where |v| exceeds the f16 range hi = +-65504 and v - hi can exceed it too (the raw residual
+    // stream in front of the neck is the one operand without a LayerNorm); an inf in lo would poison the accumulator.
+    // The 2^-22 claim holds for 2^-14 * 2^11 <= |v| <= 65504 in f16 (lo = a multiple of hi's ulp / 2^11 must still be a
+    // normal or subnormal f16: below |v| ~ 2^-3 the lo term loses bits one by one and is 0 under |v| ~ 2^-14); bf16 has the
+    // fp32 exponent range and no such floor.
+    lo = pack2<PREC>(a - ha, b - hb);
 }
 
 // ---------------------------------------------------------------------------------------------

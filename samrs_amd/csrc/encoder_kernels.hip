@@ -198,14 +198,19 @@ __device__ __forceinline__ void load_q_frags(const uint16_t* qrow /* &Q[q][0] or
     }
 }
 
-// One 32-row tile of  M * Q^T : rows come from an LDS matrix [rows][HD] (ET, row stride HD).
-template <int PREC, int HD>
+// One 32-row tile of  M * Q^T : rows come from an LDS matrix [rows][STR] (ET, row stride STR elements, HD of them used).
+// STR = HD + 8 (an ODD number of 16-byte chunks per row) makes the ds_read_b128 fragment reads conflict-free: the 16 lanes
+// of a lane group read one chunk column of 16 rows that are distinct mod 16, and (row * odd + c) mod 16 is then a permutation
+// of the sixteen 16-byte slots of the bank row.  With STR = HD (an even chunk count: 10 for HD = 80, 8 for HD = 64) only
+// every second slot is reachable: 2-way conflicts at HD = 80 (PMC round 3: half of the LDS-active cycles of the global
+// kernel), 8-way at HD = 64.
+template <int PREC, int HD, int STR = HD>
 __device__ __forceinline__ f32x16_t tile_times_qT(const uint16_t* lds_rows /* row 0 of the tile */,
                                                   int lane, const uint4 (&qf)[HD / 16]) {
     f32x16_t acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const uint16_t* p = lds_rows + (lane & 31) * HD + 8 * (lane >> 5);
+    const uint16_t* p = lds_rows + (lane & 31) * STR + 8 * (lane >> 5);
 #pragma unroll
     for (int ks = 0; ks < HD / 16; ++ks) {
         const uint4 a = *reinterpret_cast<const uint4*>(p + 16 * ks);
@@ -246,6 +251,15 @@ __device__ __forceinline__ uint4 load_vt_frag(const uint16_t* vt_row /* &Vt[d][t
     const uint2 lo = *reinterpret_cast<const uint2*>(vt_row + 16 * u + 4 * hh);
     const uint2 hi = *reinterpret_cast<const uint2*>(vt_row + 16 * u + 8 + 4 * hh);
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+// The same fragment from a V^T tile whose keys are stored PERMUTED inside every group of 16 (vt_pack_kernel: position p holds
+// key (p & 3) | ((p & 4) << 1) | ((p & 8) >> 1), i.e. 0-3, 8-11, 4-7, 12-15): the eight keys of lane half hh are then 16
+// contiguous bytes -- one ds_read_b128 instead of two ds_read_b64, and with a row stride of an odd number of 16-byte chunks
+// the 16 rows of a lane group fall on 16 different slots (no bank conflict; two 8-byte reads of one half could never be
+// better than 2-way: 32 lanes on the 16 eight-byte positions of one parity).
+__device__ __forceinline__ uint4 load_vt_frag_perm(const uint16_t* vt_row /* &Vt[d][tile position 0] */, int u, int hh) {
+    return *reinterpret_cast<const uint4*>(vt_row + 16 * u + 8 * hh);
 }
 
 template <int PREC>
@@ -357,6 +371,10 @@ __device__ __forceinline__ float ones_row_sum(const f32x16_t (&O)[DT], int hh) {
 //   * HD = 80: the spare V^T row 80 holds ones, the PV product delivers the row sum (ones_row_sum).
 // 166 -> 145 us per launch (8 tiles, ViT-H) on its own; in the tile loop the step time did not move (the loop runs at
 // the socket power limit).
+// Round 4, measured and NOT kept: K rows padded to 88 elements (an odd number of 16-byte chunks: conflict-free fragment
+// reads, as in the global kernel).  SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.28 -> 0.165, but the padded addressing costs
+// registers (the kernel sits at 256: RH had to move to LDS and the K slot coordinates be recomputed per item) and the launch
+// went 145.3 -> 154.4 us: the item is bound by its barrier / staging phases, not by LDS cycles (profiles/r04_attention_lds.txt).
 // =========================================================================================
 template <int HD>
 struct WinCfg {
@@ -737,14 +755,17 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const uint16_t* __restrict
     }
     __syncthreads();
     uint16_t* dst = vt + (size_t)P * HD * ntok + (size_t)t * 64;
-    for (int c = threadIdx.x; c < HD * 8; c += 256) {                       // (d, 8-token chunk)
-        const int d = c / 8, k0 = (c % 8) * 8;
+    for (int c = threadIdx.x; c < HD * 8; c += 256) {                       // (d, 8-position chunk)
+        // chunk c8 of a 64-key tile holds keys 16 (c8 / 2) + 4 (c8 % 2) + {0,1,2,3, 8,9,10,11}: the key order of the PV
+        // MFMA's B fragment (pack_p), so that the attention kernel reads a lane's eight keys with ONE 16-byte LDS read
+        // (load_vt_frag_perm).  The layout is private to vt_pack_kernel / global_attention_kernel.
+        const int d = c / 8, c8 = c % 8, k0 = 16 * (c8 >> 1) + 4 * (c8 & 1);
         uint4 o;
         o.x = tile[k0 + 0][d] | ((uint32_t)tile[k0 + 1][d] << 16);
         o.y = tile[k0 + 2][d] | ((uint32_t)tile[k0 + 3][d] << 16);
-        o.z = tile[k0 + 4][d] | ((uint32_t)tile[k0 + 5][d] << 16);
-        o.w = tile[k0 + 6][d] | ((uint32_t)tile[k0 + 7][d] << 16);
-        *reinterpret_cast<uint4*>(dst + (size_t)d * ntok + k0) = o;
+        o.z = tile[k0 + 8][d] | ((uint32_t)tile[k0 + 9][d] << 16);
+        o.w = tile[k0 + 10][d] | ((uint32_t)tile[k0 + 11][d] << 16);
+        *reinterpret_cast<uint4*>(dst + (size_t)d * ntok + c8 * 8) = o;
     }
 }
 
@@ -759,9 +780,10 @@ template <int HD, int NW = 4>
 struct GlbCfg {
     static constexpr int G = 64, KT = 64;                 // grid side, keys per tile
     static constexpr int DT = (HD + 31) / 32;
-    static constexpr int VSTR = KT + 8;                   // 72 el = 144 B = 9 DMA chunks per d row (8 data + 1 pad): 2-way on the
-                                                          // fragment reads, the best a 16-byte-granular row stride can do
-    static constexpr int K_BYTES = KT * HD * 2;
+    static constexpr int VSTR = KT + 8;                   // 72 el = 144 B = 9 DMA chunks per d row (8 data + 1 pad): an odd chunk
+                                                          // count, conflict-free for the 16-byte reads of load_vt_frag_perm
+    static constexpr int KSTR = HD + 8;                   // K row stride: HD / 8 data chunks + 1 pad chunk (odd: see tile_times_qT)
+    static constexpr int K_BYTES = KT * KSTR * 2;
     static constexpr int VT_BYTES = DT * 32 * VSTR * 2;
     static constexpr int KV_BYTES = 2 * (K_BYTES + VT_BYTES);    // double buffered
     static constexpr int SSTR = 33;
@@ -863,9 +885,10 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
     // Now: the K tile comes straight from qkv (per-lane source addresses, rows of 2 HD bytes), the V^T tile from the
     // pre-transposed copy vt[img][head][d][token] written by vt_pack_kernel; 22 one-KiB pieces per tile and block
     // instead of 28 loads + 76 LDS stores, no staging registers, nothing to wait for until the end of the tile.
-    constexpr int CH = HD / 8;
-    constexpr int NCH = C::KT * CH;                 // 16-byte chunks of a K tile, row-major [key][HD]
-    constexpr int KPC = (NCH + 63) / 64;            // K pieces (640 chunks -> 10)
+    constexpr int CH = HD / 8, CHP = C::KSTR / 8;   // data chunks / chunks incl. the pad chunk per K row
+    static_assert(CHP == CH + 1 && (CHP & 1), "K rows: an odd number of 16-byte chunks");
+    constexpr int NCH = C::KT * CHP;                // 16-byte chunks of a K tile, row-major [key][KSTR]
+    constexpr int KPC = (NCH + 63) / 64;            // K pieces (704 chunks -> 11)
     constexpr int VCH = HD * 9;                     // chunks of a V^T tile: HD rows x (8 data + 1 pad)
     constexpr int VPC = (VCH + 63) / 64;            // V pieces (720 -> 12, the last one partial)
     constexpr int NPC = KPC + VPC;                  // pieces per tile; wave w takes pieces w, w + NW, ...
@@ -881,7 +904,9 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
         uint32_t o = ~0u;
         if (pc < KPC) {
             const int L = pc * 64 + lane;
-            if (L < NCH) o = (uint32_t)((L / CH) * (3 * D) + (L % CH) * 8) * 2u;
+            // the pad chunk re-reads the row's last data chunk (a DMA lane cannot be skipped inside a row without breaking
+            // the 16-bytes-per-lane destination pattern; its content is never read)
+            if (L < NCH) o = (uint32_t)((L / CHP) * (3 * D) + min(L % CHP, CH - 1) * 8) * 2u;
         } else if (pc < NPC) {
             const int L = (pc - KPC) * 64 + lane;
             if (L < VCH) { const int d = L / 9, c = (L % 9) < 8 ? (L % 9) : 7; o = (uint32_t)(d * NTOK + c * 8) * 2u; }
@@ -941,7 +966,7 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
         float mx = -INFINITY;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            S[a] = tile_times_qT<PREC, HD>(Kb(buf) + a * 32 * HD, lane, qf);
+            S[a] = tile_times_qT<PREC, HD, C::KSTR>(Kb(buf) + a * 32 * C::KSTR, lane, qf);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = S[a][r] * c2 + rw[a][r];
@@ -967,7 +992,7 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
                 const uint4 pb = pack_p<PREC>(S[a], u);
 #pragma unroll
                 for (int dt = 0; dt < C::DT; ++dt) {
-                    const uint4 va = load_vt_frag(Vb(buf) + (dt * 32 + ql) * C::VSTR + 32 * a, u, hh);
+                    const uint4 va = load_vt_frag_perm(Vb(buf) + (dt * 32 + ql) * C::VSTR + 32 * a, u, hh);
                     O[dt] = ET<PREC>::mfma32(va, pb, O[dt]);
                 }
             }

@@ -114,6 +114,12 @@ struct samrs_engine {
     uint16_t* N1e = nullptr;       // [Bi*tokens, C]
     float* EMB = nullptr;          // [slots][tokens][C] fp32 (token-major)
     std::vector<char> slot_set;
+    // Precision is a property of the EMBEDDING: the "split" mask (and the depth its block-GEMM bits reached) a slot's image was
+    // encoded with; -1 = installed by samrs_set_embedding (the caller's numbers, nothing to say about them).  samrs_predict
+    // checks it against what the requested outputs need (grade_multimask) instead of trusting whoever touched "split" last.
+    std::vector<int> slot_split, slot_depth;
+    int grade_multimask = 0;       // block-GEMM bits (any of them) the three multimask tokens need on this model; 0 = none
+    bool allow_reduced = false;    // option "allow_reduced": multimask predicts on a slot encoded below that grade are the caller's choice
 
     // decoder weights
     std::vector<DecLayer> layers;
@@ -349,6 +355,8 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->nwin = (e->grid + cfg->window_size - 1) / cfg->window_size;
     e->T_max = 5 + cfg->max_points + 1 + 2;
     e->slot_set.assign(cfg->max_images, 0);
+    e->slot_split.assign(cfg->max_images, 0);
+    e->slot_depth.assign(cfg->max_images, 0);
     e->decoder_fusion = env_int("SAMRS_DECODER_FUSION", 1) != 0;
     e->ln_fold = env_int("SAMRS_LN_FOLD", 0) != 0;
     // default: the cheap rounding points everywhere; where the one-launch split GEMM covers the block shapes (ViT-H), also the
@@ -356,6 +364,10 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     // fixtures at ViT-H, for 0.90x the throughput.  SAMRS_SPLIT=15 / option "split" = 15: the 1x-rate arithmetic.
     const bool h_like = gemm_split3_ok(e->tokens, 3 * e->D, e->D) && gemm_split3_ok(e->tokens, e->D, e->D) && (2 * e->D) % 320 == 0;
     e->split = env_int("SAMRS_SPLIT", SPLIT_DEFAULT | (h_like ? SPLIT_ATTN_V : 0)) & SPLIT_ALL;
+    // ViT-H: the multimask tokens hold IoU >= 0.999 only from the v-third / proj split on; below ViT-H the 1x rate does
+    e->grade_multimask = h_like ? SPLIT_ATTN_ANY : 0;
+    // an explicit SAMRS_SPLIT is the operator's decision about the whole process, multimask outputs included
+    e->allow_reduced = env_int("SAMRS_ALLOW_REDUCED", getenv("SAMRS_SPLIT") ? 1 : 0) != 0;
     e->upscaler_fused = env_int("SAMRS_UPSCALER_FUSED", 1) != 0;
     e->split_passes = env_int("SAMRS_SPLIT_PASSES", 0) != 0;
     e->split_depth = env_int("SAMRS_SPLIT_DEPTH", 0);
@@ -759,7 +771,11 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.3.weight"), W(e, "image_encoder.neck.3.bias"), 1e-6f,
                            nullptr, e->EMB + (size_t)slot0 * tokens * C, M, C, 0, g, 0, s));
     { const int rc = prepare_slot_keys(e, slot0, n, s); if (rc != SAMRS_OK) return rc; }
-    for (int i = 0; i < n; ++i) e->slot_set[slot0 + i] = 1;
+    for (int i = 0; i < n; ++i) {
+        e->slot_set[slot0 + i] = 1;
+        e->slot_split[slot0 + i] = e->split;
+        e->slot_depth[slot0 + i] = (e->split & (SPLIT_ATTN | SPLIT_MLP)) ? depth_full : (e->split & SPLIT_ATTN_V) ? depth_v : 0;
+    }
     return SAMRS_OK;
 }
 
@@ -821,6 +837,17 @@ int samrs_set_embedding(samrs_engine_t* e, int slot, const float* emb_chw, void*
     CK(e, launch_transpose_f32(emb_chw, e->EMB + (size_t)slot * e->tokens * e->C, e->C, e->tokens, (hipStream_t)stream));
     { const int rc = prepare_slot_keys(e, slot, 1, (hipStream_t)stream); if (rc != SAMRS_OK) return rc; }
     e->slot_set[slot] = 1;
+    e->slot_split[slot] = -1;
+    e->slot_depth[slot] = 0;
+    return SAMRS_OK;
+}
+
+int samrs_get_slot_info(const samrs_engine_t* e, int slot, int32_t* is_set, int32_t* split, int32_t* split_depth) {
+    if (!e) return SAMRS_ERR_BAD_ARG;
+    if (slot < 0 || slot >= e->cfg.max_images) return SAMRS_ERR_CAPACITY;
+    if (is_set) *is_set = e->slot_set[slot];
+    if (split) *split = e->slot_set[slot] ? e->slot_split[slot] : 0;
+    if (split_depth) *split_depth = e->slot_set[slot] ? e->slot_depth[slot] : 0;
     return SAMRS_OK;
 }
 
@@ -847,6 +874,16 @@ int samrs_predict(samrs_engine_t* e, int slot, int n, const float* boxes, const 
                   float* lowres_out, void* stream) {
     if (!e) return SAMRS_ERR_BAD_ARG;
     if (n < 1) return fail(e, SAMRS_ERR_BAD_ARG, "n_prompts must be >= 1");
+    // The three multimask tokens need more operand precision than token 0 (C4 fixtures at ViT-H: IoU 0.9983 - 0.9992 at the 1x
+    // rate, >= 0.999 from the v-third split on).  The mode an image was encoded in travels with its slot, so a multimask
+    // predict on an embedding some single-mask pipeline produced is refused instead of silently answering in that mode.
+    if (multimask && !e->allow_reduced && e->grade_multimask && slot >= 0 && slot < e->cfg.max_images && e->slot_set[slot]) {
+        const int sm = e->slot_split[slot];
+        if (sm >= 0 && (!(sm & e->grade_multimask) || (e->split & (SPLIT_OI | SPLIT_UP)) != (SPLIT_OI | SPLIT_UP)))
+            return fail(e, SAMRS_ERR_PRECISION, "multimask_output=True on an embedding encoded with split=%d (decoder split=%d): this model's "
+                        "multimask outputs need a block-GEMM split bit (64 or 16) and the decoder bits 4 | 8 to hold IoU >= 0.999; "
+                        "re-encode the image in the engine's default mode, or set option \"allow_reduced\" = 1", sm, e->split);
+    }
     const int cap = e->cfg.max_prompts;
     const size_t nsel = multimask ? 3 : 1;
     const size_t mask_stride = nsel * (size_t)(orig_h > 0 ? orig_h : 0) * (size_t)(orig_w > 0 ? orig_w : 0) * (return_logits ? 4 : 1);
@@ -1089,6 +1126,7 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     else if (n == "upscaler_fused") e->upscaler_fused = value != 0;
     else if (n == "split_passes") e->split_passes = value != 0;
     else if (n == "split_depth") e->split_depth = value > 0 ? value : 0;
+    else if (n == "allow_reduced") e->allow_reduced = value != 0;
     else return fail(e, SAMRS_ERR_BAD_ARG, "unknown option %s", name);
     return SAMRS_OK;
 }
@@ -1102,6 +1140,8 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
     else if (n == "upscaler_fused") *value = e->upscaler_fused;
     else if (n == "split_passes") *value = e->split_passes;
     else if (n == "split_depth") *value = e->split_depth;
+    else if (n == "allow_reduced") *value = e->allow_reduced;
+    else if (n == "grade_multimask") *value = e->grade_multimask;     // read-only
     else return SAMRS_ERR_BAD_ARG;
     return SAMRS_OK;
 }

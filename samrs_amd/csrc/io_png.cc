@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <new>
@@ -269,7 +270,8 @@ int encode(const char* path, const uint8_t* src, int h, int w, size_t stride, in
     if (z != Z_STREAM_END) return SAMRS_IO_EWRITE;
 
     std::string tmp;
-    try { tmp = std::string(path) + ".tmp"; } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
+    // per process: two ranks that (wrongly) took the same image can clobber the final file with identical bytes, never a half-written tmp
+    try { tmp = std::string(path) + ".tmp." + std::to_string((long)getpid()); } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
     FILE* fp = fopen(tmp.c_str(), "wb");
     if (!fp) return SAMRS_IO_EOPEN;
     uint8_t ihdr[13];

@@ -20,6 +20,7 @@ backend ``nccl`` = RCCL over xGMI on the GPU box, ``gloo`` in the CPU tests).
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import queue
@@ -101,6 +102,20 @@ def reduce_statistics(class_pixels: torch.Tensor, class_instances: torch.Tensor,
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     c = class_pixels.numel()
     return buf[:c].clone(), buf[c:].clone()
+
+
+def agree_on_list(items: List, group=None, src: int = 0) -> List:
+    """Every rank gets RANK `src`'s copy of a Python list (``broadcast_object_list``; no-op outside a process group).
+    Used wherever the work list is derived from something a rank could see differently from its peers -- e.g. ``generate
+    --resume`` lists the output directory while faster ranks may already be writing into it: the shards
+    (``sorted(files)[r::world]``, Generate Dataset/main_sam_hbox_semantic.py:110) are only disjoint and complete when all
+    ranks index the SAME list."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(items)
+    box = [list(items) if dist.get_rank(group) == src else None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]
 
 
 class InstancePrompter:
@@ -332,19 +347,25 @@ class TilePipeline:
 
     def __init__(self, sam, n_classes: int, batch: int = 8, box_batch: int = 20, keep_masks: bool = False,
                  out_depth: int = 3, max_boxes: int = 512, device_inputs: bool = False, rle: bool = False,
-                 rle_buffer_mb: int = 256, precision="auto"):
-        """precision: which operand-split mode the ENGINE runs in while this pipeline drives it (engine option "split").
+                 rle_buffer_mb: int = 256, precision="auto", _multimask: bool = False):
+        """precision: the operand-split mode (engine option "split") THIS PIPELINE'S OWN CALLS run in.  The option is set around
+        each of the pipeline's encode / decode calls and restored afterwards (``Engine.options``), so the mode never outlives
+        them: a ``SamPredictor`` built on the same model keeps the engine's own default (round 3 changed the engine's option for
+        good, and whoever built the last pipeline decided everybody's precision).  The mode an image was encoded in is
+        recorded with its embedding slot (``Engine.get_slot_info``).
         "auto" = by output contract: this pipeline only ever asks for the single mask of token 0, which holds IoU >= 0.9995 against
-        the reference with every block GEMM at the 1x f16 rate (C2 fixtures), so it switches the engine to split 15; a multimask
-        pipeline (InstancePipeline(multimask=True)) keeps the engine's own default, which at ViT-H adds the v third of qkv +
-        proj on hi + lo operands (split 79: what the three multimask tokens need for IoU >= 0.999, C4 fixtures; 0.90x the
-        throughput).  An explicit choice -- builder ``options={"split": ...}`` or SAMRS_SPLIT -- is never overridden.
-        "engine" = leave the option alone; an int = set it."""
+        the reference with every block GEMM at the 1x f16 rate (C2 fixtures): split 15; a multimask pipeline
+        (InstancePipeline(multimask=True)) runs in the model's own default, which at ViT-H adds the v third of qkv + proj on
+        hi + lo operands (split 79: what the three multimask tokens need for IoU >= 0.999, C4 fixtures; 0.90x the throughput).
+        An explicit choice -- builder ``options={"split": ...}`` or SAMRS_SPLIT -- is never overridden.
+        "engine" = the engine's option as it stands at each call; an int = that mode (and, for a multimask pipeline, the
+        caller's consent to run its multimask predicts in it: option "allow_reduced")."""
         from .transforms import ResizeLongestSide
         eng = sam.engine
         if eng is None:
             raise RuntimeError("move the model to the GPU first: sam.to('cuda')")
-        self._apply_precision(sam, precision, multimask=False)
+        self.split_mode = self._choose_split(sam, precision, multimask=_multimask)
+        self.allow_reduced = isinstance(precision, int) and not isinstance(precision, bool)
         if out_depth < 2:
             raise ValueError("out_depth must be >= 2: batch k-1's results are still on loan to the sink when batch k decodes")
         if eng.max_images < 2 * batch:
@@ -385,18 +406,28 @@ class TilePipeline:
             self.free_out.put(_OutBuf(batch, side, max_boxes, rle))
 
     @staticmethod
-    def _apply_precision(sam, precision, multimask: bool) -> None:
+    def _choose_split(sam, precision, multimask: bool) -> Optional[int]:
+        """The "split" mode a pipeline's own calls run in; None = whatever the engine's option says at each call."""
         from .engine import SPLIT_DEFAULT
-        eng = sam.engine
         if precision == "engine":
-            return
+            return None
         if precision == "auto":
-            explicit = "split" in getattr(sam, "options", {}) or "SAMRS_SPLIT" in os.environ
-            want = getattr(sam, "default_split", SPLIT_DEFAULT) if multimask else SPLIT_DEFAULT
-            if not explicit and eng.get_option("split") != want:
-                eng.set_option("split", want)
+            if "split" in getattr(sam, "options", {}) or "SAMRS_SPLIT" in os.environ:
+                return None                                          # an explicit choice for the whole engine stands
+            return int(getattr(sam, "default_split", SPLIT_DEFAULT)) if multimask else SPLIT_DEFAULT
+        return int(precision)
+
+    @contextlib.contextmanager
+    def _mode(self):
+        """The engine in this pipeline's operand-split mode for the calls inside the block (host-side state read at launch)."""
+        if self.split_mode is None:
+            yield
             return
-        eng.set_option("split", int(precision))
+        kw = {"split": self.split_mode}
+        if self.allow_reduced:
+            kw["allow_reduced"] = 1
+        with self.eng.options(**kw):
+            yield
 
     # -- stage A: stage tiles + boxes of one batch, H2D on s_h2d ------------------------------------------------
     def _stage(self, b: int, items: List[WorkItem]):
@@ -455,10 +486,11 @@ class TilePipeline:
         with torch.cuda.stream(self.s_enc):
             self.s_enc.wait_event(self.ev_h2d[b])
             self.s_enc.wait_event(self.ev_dec[b])                  # decoder is done with embedding slot set b
-            if same:
-                self.eng.set_images(self.dev_in[b][:n], b * self.batch)
-            else:
-                self.eng.set_images_ragged([t for t, _ in tiles], b * self.batch)
+            with self._mode():
+                if same:
+                    self.eng.set_images(self.dev_in[b][:n], b * self.batch)
+                else:
+                    self.eng.set_images_ragged([t for t, _ in tiles], b * self.batch)
             self.ev_enc[b].record(self.s_enc)
             self.ev_in_free[b].record(self.s_enc)
 
@@ -499,8 +531,9 @@ class TilePipeline:
             self.seg_dev[b].fill_(255)                                               # main_sam_hbox_semantic.py:162
             if self.rle:
                 self.rle_cur[b].zero_()
-            for i, ((t, hw), (off, nb)) in enumerate(zip(tiles, offs)):
-                self._decode_tile(b, i, t, hw, off, nb, out)
+            with self._mode():
+                for i, ((t, hw), (off, nb)) in enumerate(zip(tiles, offs)):
+                    self._decode_tile(b, i, t, hw, off, nb, out)
             out.areas.copy_(self.area_dev[b], non_blocking=True)
             if self.rle:
                 out.rle_tab.copy_(self.rle_tab[b], non_blocking=True)
@@ -628,9 +661,7 @@ class InstancePipeline(TilePipeline):
             raise ValueError("prompt must be 'box', 'rbox_mask' or 'point'")
         if prompt == "point":
             self.BOX_WIDTH = 2
-        precision = kw.pop("precision", "auto")
-        super().__init__(sam, n_classes, precision="engine", **kw)
-        self._apply_precision(sam, precision, multimask=bool(multimask))
+        super().__init__(sam, n_classes, precision=kw.pop("precision", "auto"), _multimask=bool(multimask), **kw)
         self.prompt, self.multimask = prompt, bool(multimask)
         self.qual_dev = [torch.zeros(self.batch, self.max_boxes, dtype=torch.float32, device=self.dev) for _ in range(2)]
         for _ in range(self.free_out.qsize()):

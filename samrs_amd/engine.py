@@ -6,6 +6,7 @@ importing / constructing fails loudly.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import Dict, Optional, Tuple
@@ -21,13 +22,13 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsamrs_hip.so")
 PREC_BF16, PREC_F16 = 0, 1
 PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16}
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 # "split" option bits (include/samrs_hip.h): rounding points that run as a two-term operand split
 SPLIT_PATCH, SPLIT_NECK, SPLIT_OI, SPLIT_UP, SPLIT_DEFAULT = 1, 2, 4, 8, 15
 SPLIT_ATTN, SPLIT_MLP, SPLIT_ATTN_V, SPLIT_ALL = 16, 32, 64, 127          # reference-grade bits: set before the weights are loaded
 # (64 = the attention-side split restricted to the v third of qkv + proj; option "split_depth" = leading blocks they apply to)
 
-OK, ERR_NOT_SET, ERR_BAD_SHAPE, ERR_BAD_ARG, ERR_HIP, ERR_BAD_WEIGHTS, ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
+OK, ERR_NOT_SET, ERR_BAD_SHAPE, ERR_BAD_ARG, ERR_HIP, ERR_BAD_WEIGHTS, ERR_CAPACITY, ERR_PRECISION = 0, -1, -2, -3, -4, -5, -6, -7
 
 
 class samrs_config(C.Structure):
@@ -104,13 +105,14 @@ def load_library() -> C.CDLL:
     lib.samrs_k_gemm_gln.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, vp, vp, vp]
     lib.samrs_k_upscale2_masks.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_gemm_split3.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
+    lib.samrs_get_slot_info.argtypes = [vp, ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_set_images_ragged", "samrs_get_embedding",
                  "samrs_set_embedding", "samrs_reset_image", "samrs_predict", "samrs_paint", "samrs_k_gemm",
                  "samrs_k_gemm_f32", "samrs_k_convert", "samrs_k_layernorm", "samrs_k_window_attention",
                  "samrs_k_global_attention", "samrs_k_postprocess", "samrs_k_gemm_gln", "samrs_k_upscale2_masks",
                  "samrs_k_gemm_stats", "samrs_k_gemm_fold", "samrs_k_ln_fold_weight", "samrs_k_rowstats_convert", "samrs_k_ln_rowstat",
                  "samrs_set_option", "samrs_get_option", "samrs_rle_encode", "samrs_k_convert_split", "samrs_select_best",
-                 "samrs_k_upscaler_fused", "samrs_k_gemm_split3"):
+                 "samrs_k_upscaler_fused", "samrs_k_gemm_split3", "samrs_get_slot_info"):
         getattr(lib, name).restype = ip
     if lib.samrs_abi_version() != ABI_VERSION:
         raise ImportError("libsamrs_hip.so ABI version mismatch; rebuild it")
@@ -128,6 +130,12 @@ def _stream() -> int:
 
 class EngineError(RuntimeError):
     pass
+
+
+class PrecisionError(EngineError):
+    """``multimask_output=True`` on an embedding that was encoded below the operand-split mode this model's multimask
+    outputs need (SAMRS_ERR_PRECISION; ``Engine.get_slot_info``).  Re-encode the image in the engine's default mode
+    (``SamPredictor.set_image`` does), or accept the reduced mode with ``engine.set_option("allow_reduced", 1)``."""
 
 
 class Engine:
@@ -167,6 +175,8 @@ class Engine:
             raise RuntimeError(msg)
         if rc in (ERR_BAD_SHAPE, ERR_BAD_ARG):
             raise AssertionError(msg)
+        if rc == ERR_PRECISION:
+            raise PrecisionError(msg)
         raise EngineError(f"libsamrs_hip error {rc}: {msg}")
 
     # -- per-engine options (include/samrs_hip.h: "split", "decoder_fusion", "ln_fold", "gemm_variant")
@@ -177,6 +187,28 @@ class Engine:
         v = C.c_int()
         self._check(self.lib.samrs_get_option(self.handle, name.encode(), C.byref(v)))
         return v.value
+
+    @contextlib.contextmanager
+    def options(self, **values: int):
+        """Options in force for the calls made inside the block only (a pipeline's operand-split mode must not outlive the
+        pipeline's own calls: the engine is shared with every SamPredictor built on the same model)."""
+        old = {k: self.get_option(k) for k in values}
+        try:
+            for k, v in values.items():
+                if v != old[k]:
+                    self.set_option(k, v)
+            yield self
+        finally:
+            for k, v in old.items():
+                if self.get_option(k) != v:
+                    self.set_option(k, v)
+
+    def get_slot_info(self, slot: int = 0) -> Dict[str, int]:
+        """{"is_set", "split", "split_depth"} of an embedding slot: the operand-split mode its image was encoded in (-1: the
+        embedding was installed by set_embedding)."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.samrs_get_slot_info(self.handle, slot, C.byref(a), C.byref(b), C.byref(c)))
+        return {"is_set": int(a.value), "split": int(b.value), "split_depth": int(c.value)}
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -80,7 +80,7 @@ def write_outputs(out_dir: str, stem: str, seg: np.ndarray, masks: Optional[np.n
             entry["mask"] = rle.encode(masks[j])
         info.append(entry)
     # the pickle goes last and through a rename: --resume takes its presence as "this image is complete"
-    tmp = os.path.join(out_dir, "ins", stem + ".pkl.tmp")
+    tmp = os.path.join(out_dir, "ins", f"{stem}.pkl.tmp.{os.getpid()}")     # per process: two ranks can never share a tmp file
     with open(tmp, "wb") as f:
         pickle.dump(info, f)                                                                # :216
     os.replace(tmp, os.path.join(out_dir, "ins", stem + ".pkl"))
@@ -110,23 +110,36 @@ def run(args) -> Dict[str, List[int]]:
     names = [l.strip() for l in open(args.classes)] if args.classes else [str(i) for i in range(args.n_classes)]
     n_classes = len(names)
     palette = np.load(args.palette) if args.palette else default_palette(n_classes)
+    # 255 is the "unlabeled" value of gray/*.png (main_sam_hbox_semantic.py:162) and stays white in color/*.png (:163)
+    if n_classes > 255 or len(palette) > 255:
+        raise ValueError(f"{n_classes} classes / {len(palette)} palette rows: class ids must stay below 255 (255 = unlabeled)")
+    bad = [s for s, a in ann.items() if len(a["labels"]) and not (0 <= min(a["labels"]) and max(a["labels"]) < n_classes)]
+    if bad:
+        raise ValueError(f"labels outside 0..{n_classes - 1} in the annotations of {bad[:3]}{' ...' if len(bad) > 3 else ''}")
     batch = getattr(args, "batch", 8)
     # --split: an explicit operand-split mode (engine option "split"); default: the pipeline picks by output contract -- this
     # driver asks for single masks only, which hold IoU >= 0.9995 with the block GEMMs at the 1x rate (split 15)
-    opts = {"split": args.split} if getattr(args, "split", None) is not None else None
+    # no --split: 15 explicitly, BEFORE the weights are finalized, so that a ViT-H engine does not allocate the lo copies of its
+    # qkv / proj weights and the Ylo / AOlo workspaces (~0.75 GB of HBM this driver would never touch)
+    opts = {"split": args.split if getattr(args, "split", None) is not None else 15}
     sam = samrs_amd.sam_model_registry[args.model](checkpoint=args.checkpoint, precision=args.precision, options=opts,
                                                    max_images=2 * batch, max_prompts=args.box_batch).to(f"cuda:{local}")
     exts = (".png", ".jpg", ".jpeg", ".tif", ".bmp")
     files = {os.path.splitext(f)[0]: f for f in os.listdir(args.images) if f.lower().endswith(exts)}
     stems = sorted(s for s in files if s in ann and len(ann[s]["boxes"]) > 0)                       # :126-129
     n_all = len(stems)
+    done_before: List[str] = []
     if getattr(args, "resume", False):
-        # restart = re-run what is missing: every rank filters the same sorted list the same way, so the
-        # shards stay disjoint.  NB: the class statistics of a resumed run cover only the images processed by THIS run;
-        # `Generate Dataset/statistic.py` recomputes them from ins/*.pkl over the whole output directory.
-        stems = [s for s in stems if not outputs_exist(args.out, s)]
+        # restart = re-run what is missing.  The output directory is listed ONCE, on rank 0, and the result is
+        # broadcast: a rank that finished loading its weights earlier may already be writing files while a slower one would
+        # still be listing, and ranks indexing different todo lists skip or repeat images (round-3 advisor finding).
+        todo = [s for s in stems if not outputs_exist(args.out, s)] if rank == 0 else None
+        todo = driver.agree_on_list(todo if todo is not None else [])
+        keep = set(todo)
+        done_before = [s for s in stems if s not in keep]
+        stems = todo
         if rank == 0:
-            print(f"[rank 0] --resume: {n_all - len(stems)} of {n_all} images already complete", flush=True)
+            print(f"[rank 0] --resume: {len(done_before)} of {n_all} images already complete", flush=True)
     max_boxes = max([len(ann[s]["labels"]) for s in stems] + [1])
     # per-instance RLE (main_sam_hbox_semantic.py:201-202) is encoded on the device; the full masks never cross PCIe
     pipe = driver.TilePipeline(sam, n_classes, batch=batch, box_batch=args.box_batch, rle=not args.no_rle,
@@ -247,7 +260,7 @@ def run(args) -> Dict[str, List[int]]:
     if getattr(args, "log", None):
         os.makedirs(os.path.dirname(os.path.abspath(args.log)) or ".", exist_ok=True)
         run_log = open(f"{args.log}.rank{rank}" if world > 1 else args.log, "a")
-        run_log.write(json.dumps({"t": 0.0, "rank": rank, "world": world, "model": args.model, "split": sam.engine.get_option("split"),
+        run_log.write(json.dumps({"t": 0.0, "rank": rank, "world": world, "model": args.model, "split": pipe.split_mode if pipe.split_mode is not None else sam.engine.get_option("split"),
                                   "images_total": n_all, "images_todo": len(stems), "batch": batch, "box_batch": args.box_batch}) + "\n")
     try:
         pipe.run(batches(), sink)
@@ -261,6 +274,20 @@ def run(args) -> Dict[str, List[int]]:
     if clock and rank == 0:
         import sys
         print("[rank 0] --timing: " + clock.report(done[0], wall), file=sys.stderr, flush=True)
+    # a resumed run's statistics cover the WHOLE output directory, like `Generate Dataset/statistic.py:12-21,44-49` computes
+    # them: the images completed by an earlier run contribute through their ins/*.pkl (label + size per instance), read by
+    # the ranks in shards and merged by the same all-reduce / all-gather as this run's counters
+    if done_before:
+        old_pix, old_ins = np.zeros(n_classes, np.int64), np.zeros(n_classes, np.int64)
+        for stem in done_before[rank::world]:
+            with open(os.path.join(args.out, "ins", stem + ".pkl"), "rb") as f:
+                for entry in pickle.load(f):
+                    if int(entry["size"]) > 0:                                                      # statistic.py:18
+                        old_pix[int(entry["label"])] += int(entry["size"])
+                        old_ins[int(entry["label"])] += 1
+                        sizes.append(int(entry["size"]))
+        pipe.class_pixels += torch.from_numpy(old_pix).to(pipe.class_pixels.device)
+        pipe.class_instances += torch.from_numpy(old_ins).to(pipe.class_instances.device)
     pix, ins = driver.reduce_statistics(pipe.class_pixels, pipe.class_instances)
     all_sizes = driver.gather_mask_sizes(sizes)
     stats = {"class_pixel_num": pix.cpu().tolist(), "class_instance_num": ins.cpu().tolist(),

@@ -114,7 +114,7 @@ def _check2d(a: np.ndarray) -> np.ndarray:
 
 
 def write_gray(path: str, seg: np.ndarray, level: int = LEVEL_RUNS) -> None:
-    """8-bit gray PNG of a class map (atomic: written to `path + '.tmp'`, then renamed)."""
+    """8-bit gray PNG of a class map (atomic: written to `path + '.tmp.<pid>'`, then renamed)."""
     seg = _check2d(seg)
     rc = load_library().samrs_io_png_write_gray(os.fsencode(path), _ptr(seg), seg.shape[0], seg.shape[1], seg.strides[0], level)
     if rc != OK:
@@ -146,6 +146,9 @@ def write_rgb(path: str, img: np.ndarray, level: int = 6) -> None:
 def class_lut(palette: np.ndarray) -> np.ndarray:
     """[256, 3] lookup table: class id -> palette colour, everything else (255 = unlabeled) white
     (main_sam_hbox_semantic.py:163 initialises the colour image to 255)."""
+    palette = np.asarray(palette, dtype=np.uint8).reshape(-1, 3)
+    if len(palette) > 255:
+        raise ValueError(f"{len(palette)} palette rows: class ids must stay below 255 (255 = unlabeled, painted white)")
     lut = np.full((256, 3), 255, dtype=np.uint8)
     lut[:len(palette)] = palette
     return lut

@@ -95,6 +95,39 @@ def test_oracle_matches_reference_c2_c4(name, variant, golden_dir):
     assert (m.numpy() != unpack(g["c4mask_masks"])).reshape(12, -1).sum(1).max() <= 8
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("name", ["vit_b", "vit_h"])
+def test_oracle_matches_reference_instance_recipes(name, golden_dir):
+    """The three instance drivers' prompt recipes exactly as scripted -- point-only (main_sam_hbox_mask_instance.py:160-165),
+    mask-only (main_sam_rbox_mask_instance.py:159-164), enclosing-hbox-only (main_sam_rhbox_mask_instance.py:163-168), all
+    ``multimask_output=False`` -- run by the REAL reference (oracle/make_golden.py instances) vs the oracle."""
+    from oracle import rbox_prompt
+    from oracle.make_golden import instance_inputs
+    g = np.load(os.path.join(golden_dir, name + "_inst.npz"))
+    cfg = synth.CONFIGS[name]
+    pred = so.OraclePredictor(synth.make_state_dict(cfg, 0, logit_scale=float(g["logit_scale"])), cfg)
+    inp = instance_inputs(0)
+    hw = (1024, 1024)
+    pred.set_image(synth.make_image(inp["image_index"]))
+    np.testing.assert_allclose(pred.features[0, ::16, ::4, ::4].numpy(), g["emb_sample"], atol=2e-4, rtol=0)
+    n = len(inp["polys"])
+    unpack = lambda b: np.unpackbits(b, axis=-1).reshape(*b.shape[:-1], *hw).astype(bool)
+    prompts = np.stack([rbox_prompt.rbox_mask_prompt(p.astype(np.int32), *hw) for p in inp["polys"]]).astype(np.float32)
+    assert abs(prompts.astype(np.float64).sum() - float(g["mask_prompt_sum"])) < 1e-3
+    calls = {
+        "inst_point": dict(point_coords=torch.from_numpy(inp["points"])[:, None, :], point_labels=torch.ones(n, 1, dtype=torch.int)),
+        "inst_mask": dict(point_coords=None, point_labels=None, mask_input=torch.from_numpy(prompts)[:, None]),
+        "inst_rhbox": dict(point_coords=None, point_labels=None, boxes=so.apply_boxes(torch.from_numpy(inp["hboxes"]), hw)),
+    }
+    for tag, kw in calls.items():
+        m, q, low = pred.predict_torch(multimask_output=False, **kw)
+        np.testing.assert_allclose(low[:, :, ::4, ::4].numpy(), g[tag + "_low"], atol=LOGIT_ATOL * synth.MARGIN_LOGIT_SCALE, rtol=0)
+        np.testing.assert_allclose(q.numpy(), g[tag + "_iou"], atol=LOGIT_ATOL, rtol=0)
+        flips = (m.numpy() != unpack(g[tag + "_masks"])).reshape(n, -1).sum(1)
+        assert flips.max() <= 8, (tag, flips)
+        assert np.abs(m.flatten(2).sum(-1).numpy() - g[tag + "_area"]).max() <= 8
+
+
 def test_box_chunking_matches_driver():
     # main_sam_hbox_semantic.py:157-181: part_num = n // 20 + 1, empty tail skipped
     assert so.box_chunks(32) == [(0, 20), (20, 32)]

@@ -423,6 +423,69 @@ def test_c2_c4_against_reference_golden(name, split, variant, golden_dir):
     sam.engine.close()
 
 
+@pytest.mark.parametrize("name", ["vit_b", "vit_h"])
+def test_instance_recipes_as_scripted_against_reference_golden(name, golden_dir):
+    """VERDICT r03 "missing" 2: every reference instance driver calls ``multimask_output=False`` --
+    main_sam_hbox_mask_instance.py:160-165 (point only, the point NOT run through apply_coords),
+    main_sam_rbox_mask_instance.py:159-164 (mask prompt only), main_sam_rhbox_mask_instance.py:163-168 (enclosing hbox only).
+    The three recipes through ``driver.InstancePrompter`` (the drop-in predictor surface) in the mode
+    ``InstancePipeline(multimask=False)`` selects (split 15: single-mask output), against full-resolution masks of the REAL
+    reference (tests/golden/<name>_inst.npz, oracle/make_golden.py instances): per-mask IoU >= 0.9995 -- the single-mask floor
+    of the C2 path --, every pixel whose reference logit is at least tau = 2.5e-3 x std from the threshold reproduced
+    exactly, low-res logits and IoU predictions within the f16 tolerances."""
+    import samrs_amd
+    from samrs_amd import driver, transforms
+    from oracle.make_golden import instance_inputs
+    g = np.load(os.path.join(golden_dir, name + "_inst.npz"))
+    cfg = synth.CONFIGS[name]
+    sd = synth.make_state_dict(cfg, 0, logit_scale=float(g["logit_scale"]))
+    sam = samrs_amd.sam_model_registry[name](state_dict=sd, precision="f16", max_prompts=8, max_points=1, max_images=2).to("cuda")
+    eng = sam.engine
+    inp = instance_inputs(0)
+    img = synth.make_image(inp["image_index"])
+    hw = img.shape[:2]
+    # the mode the product's single-mask instance pipeline runs its calls in
+    mode = driver.InstancePipeline(sam, 37, prompt="point", multimask=False, batch=1, box_batch=8, max_boxes=8).split_mode
+    assert mode == 15
+    pred = samrs_amd.SamPredictor(sam)
+    tau_frac = float(g["tau_frac"])
+    with eng.options(split=mode):
+        pred.set_image(img)
+        assert eng.get_slot_info(pred.slot)["split"] == 15
+        rel = ((pred.get_image_embedding().cpu()[0, ::16, ::4, ::4] - torch.from_numpy(g["emb_sample"])).norm() / torch.from_numpy(g["emb_sample"]).norm()).item()
+        assert rel < 5e-3
+        prompts = transforms.rbox_mask_prompts(inp["polys"], hw, img_size=1024, device=torch.device("cuda"))
+        assert abs(prompts.double().sum().item() - float(g["mask_prompt_sum"])) < 1e-6 * abs(float(g["mask_prompt_sum"])) + 1e-3
+        n = len(inp["polys"])
+        calls = {
+            "inst_point": dict(point_coords=torch.from_numpy(inp["points"]).cuda()[:, None, :], point_labels=torch.ones(n, 1, device="cuda")),
+            "inst_mask": dict(point_coords=None, point_labels=None, mask_input=prompts[:, None]),
+            "inst_rhbox": dict(point_coords=None, point_labels=None,
+                               boxes=pred.transform.apply_boxes_torch(torch.from_numpy(inp["hboxes"]).cuda(), hw)),
+        }
+        prompter = driver.InstancePrompter(pred)
+        for tag, kw in calls.items():
+            m, q, l = pred.predict_torch(multimask_output=False, **kw)
+            gm = torch.from_numpy(_unpack(g[tag + "_masks"], hw))
+            near = torch.from_numpy(_unpack(g[tag + "_nearmask"], hw))
+            ious = iou_stats(m.cpu().flatten(0, 1), gm.flatten(0, 1))
+            flip = m.cpu() != gm
+            lg = torch.from_numpy(g[tag + "_low"])
+            err = (l.cpu()[:, :, ::4, ::4] - lg).abs().max().item() / float(g[tag + "_low_std"])
+            qerr = (q.cpu() - torch.from_numpy(g[tag + "_iou"])).abs().max().item()
+            print(f"instance recipe {name} {tag}: IoU min {ious.min():.5f} mean {ious.mean():.5f}; flipped px per mask max {int(flip.flatten(2).sum(-1).max())} "
+                  f"(reference px within tau: max {int(g[tag + '_near'].max())}); flips outside tau {int((flip & ~near).sum())}; "
+                  f"low-res max err / std {err:.2e} (tau {tau_frac:.1e}); iou-pred err {qerr:.2e}")
+            assert int((flip & ~near).sum()) == 0, f"{tag}: mask pixels differ where the reference's logit has margin"
+            assert ious.min() >= 0.9995, (tag, ious.min().item())
+            assert err < tau_frac and qerr < 5e-3, tag
+            # the product's prompter (chunking, point / mask / box plumbing) returns the same masks
+            mode_name = {"inst_point": "point", "inst_mask": "rbox_mask", "inst_rhbox": "box"}[tag]
+            pm, pq = prompter.predict(img, mode_name, hboxes=inp["hboxes"], rboxes=inp["polys"], points=inp["points"], already_set=True)
+            assert torch.equal(pm, m[:, 0]) and torch.equal(pq, q[:, 0])
+    eng.close()
+
+
 def test_vit_b_c1_config_vs_oracle():
     """BASELINE.json configs[0]: ViT-B, one 1024^2 tile, 4 hboxes, CPU reference path."""
     so = _oracle()

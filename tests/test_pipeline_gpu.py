@@ -2,6 +2,8 @@
 one-image-at-a-time loop that restates the reference driver (driver.SemanticGenerator), plus the boundary features
 that came with it: ragged encoder batches, prompt batches beyond max_prompts, prompt-shape validation.
 Integer / index work and identical kernels on both sides: every comparison is bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -259,31 +261,86 @@ def test_pipeline_rle_mode_equals_host_rle():
 
 
 def test_precision_follows_the_output_contract():
-    """ViT-H engines default to the multimask-safe operand split (79: IoU >= 0.999 on the C4 fixtures); a single-mask pipeline switches
-    the engine to the 1x-rate mode (15: IoU >= 0.9995 on the C2 fixtures), a multimask pipeline switches it back; an explicit
-    choice (builder options / precision=) is never overridden.  Smaller models have one mode (15)."""
+    """ViT-H engines default to the multimask-safe operand split (79: IoU >= 0.999 on the C4 fixtures); a single-mask pipeline
+    runs ITS OWN calls in the 1x-rate mode (15: IoU >= 0.9995 on the C2 fixtures), a multimask pipeline in the model's default; an
+    explicit choice (builder options / precision=) is never overridden.  The engine's option is left alone (round 3: whoever
+    built the last pipeline decided everybody's precision); the mode an image was encoded in is recorded with its slot.  Smaller
+    models have one mode (15)."""
     import samrs_amd
     from samrs_amd import driver
     sam = samrs_amd.sam_model_registry["vit_h"](precision="f16", max_images=2, max_prompts=8, max_points=1).to("cuda")
     eng = sam.engine
     assert sam.default_split == eng.get_option("split") == 79 and eng.get_option("split_depth") == 0
-    driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8)
-    assert eng.get_option("split") == 15
-    driver.InstancePipeline(sam, 18, prompt="box", multimask=True, batch=1, box_batch=8, max_boxes=8)
+    assert eng.get_option("grade_multimask") == 16 | 64 and eng.get_option("allow_reduced") == 0
+    p = driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8)
+    assert p.split_mode == 15 and not p.allow_reduced
+    p = driver.InstancePipeline(sam, 18, prompt="box", multimask=True, batch=1, box_batch=8, max_boxes=8)
+    assert p.split_mode == 79
+    p = driver.InstancePipeline(sam, 18, prompt="point", multimask=False, batch=1, box_batch=8, max_boxes=8)
+    assert p.split_mode == 15
+    p = driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8, precision="engine")
+    assert p.split_mode is None
+    p = driver.InstancePipeline(sam, 18, prompt="box", multimask=True, batch=1, box_batch=8, max_boxes=8, precision=15)
+    assert p.split_mode == 15 and p.allow_reduced                  # an explicit reduced mode for a multimask pipeline = consent
+    assert eng.get_option("split") == 79                           # building pipelines changed nothing on the engine
+    # a single-mask pipeline's run leaves its slots marked with ITS mode and the engine's option untouched
+    p = driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8)
+    bx, lb = synth.make_boxes(0, 4)
+    p.run([[driver.WorkItem("a", synth.make_image(0), bx, lb)]], lambda res, rel: rel())
     assert eng.get_option("split") == 79
-    driver.InstancePipeline(sam, 18, prompt="point", multimask=False, batch=1, box_batch=8, max_boxes=8)
-    assert eng.get_option("split") == 15
-    driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8, precision="engine")
-    assert eng.get_option("split") == 15
-    driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8, precision=79)
-    assert eng.get_option("split") == 79
+    assert eng.get_slot_info(0) == {"is_set": 1, "split": 15, "split_depth": 0}
     eng.close()
     sam = samrs_amd.sam_model_registry["vit_h"](precision="f16", max_images=2, max_prompts=8, max_points=1, options={"split": 31}).to("cuda")
-    driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8)
-    assert sam.engine.get_option("split") == 31
+    p = driver.TilePipeline(sam, 18, batch=1, box_batch=8, max_boxes=8)
+    assert p.split_mode is None and sam.engine.get_option("split") == 31 and sam.engine.get_option("allow_reduced") == 1
     sam.engine.close()
     tiny = samrs_amd.sam_model_registry["vit_tiny"](max_images=2, max_prompts=8).to("cuda")
-    assert tiny.default_split == 15
-    driver.InstancePipeline(tiny, 18, prompt="box", multimask=True, batch=1, box_batch=8, max_boxes=8)
-    assert tiny.engine.get_option("split") == 15
+    assert tiny.default_split == 15 and tiny.engine.get_option("grade_multimask") == 0
+    p = driver.InstancePipeline(tiny, 18, prompt="box", multimask=True, batch=1, box_batch=8, max_boxes=8)
+    assert p.split_mode == 15
     tiny.engine.close()
+
+
+def test_multimask_after_a_single_mask_pipeline_keeps_its_precision(golden_dir):
+    """a TilePipeline (single mask, 1x-rate mode) followed by the drop-in
+    ``SamPredictor.predict_torch(multimask_output=True)`` (the reference's default, predictor.py:92-100) on the SAME model still
+    meets the C4 floor -- the predictor encodes in the engine's default mode, which no pipeline changes any more -- and a
+    multimask predict on an embedding the pipeline encoded is refused (PrecisionError) unless the caller allows the reduced
+    mode; the refusal costs nothing on the single-mask path."""
+    import samrs_amd
+    from samrs_amd import driver
+    from samrs_amd.engine import PrecisionError
+    from oracle.make_golden import extended_inputs
+    g = np.load(os.path.join(golden_dir, "vit_h_c2c4.npz"))
+    cfg = synth.CONFIGS["vit_h"]
+    sd = synth.make_state_dict(cfg, 0, logit_scale=float(g["logit_scale"]))
+    sam = samrs_amd.sam_model_registry["vit_h"](state_dict=sd, precision="f16", max_images=2, max_prompts=32, max_points=1).to("cuda")
+    eng = sam.engine
+    inp = extended_inputs(0)
+    img = synth.make_image(inp["image_index"])
+    hw = img.shape[:2]
+    pipe = driver.TilePipeline(sam, 18, batch=1, box_batch=20, max_boxes=32)
+    pipe.run([[driver.WorkItem("t", img, inp["boxes"], inp["labels"])]], lambda res, rel: rel())
+    assert eng.get_slot_info(0)["split"] == 15
+    tb_dev = samrs_amd.ResizeLongestSide(1024).apply_boxes_torch(torch.from_numpy(inp["hboxes"]).cuda(), hw)
+    with pytest.raises(PrecisionError, match="multimask"):
+        eng.predict(0, tb_dev, None, None, None, True, False, hw, hw)          # the pipeline's slot, multimask: refused
+    m1, _, _ = eng.predict(0, tb_dev, None, None, None, False, False, hw, hw)  # single mask on it: fine
+    with eng.options(allow_reduced=1):
+        m15, _, _ = eng.predict(0, tb_dev, None, None, None, True, False, hw, hw)
+    pred = samrs_amd.SamPredictor(sam)
+    pred.set_image(img)
+    assert eng.get_slot_info(pred.slot) == {"is_set": 1, "split": 79, "split_depth": 24}
+    m, q, l = pred.predict_torch(None, None, tb_dev, None, multimask_output=True)
+    gm = torch.from_numpy(np.unpackbits(g["c4box_masks"], axis=-1).reshape(-1, 3, *hw).astype(bool))
+
+    def ious(a):
+        a = a.cpu().flatten(0, 1).flatten(1)
+        b = gm.flatten(0, 1).flatten(1)
+        return ((a & b).sum(1).double() / (a | b).sum(1).double().clamp(min=1))
+    i79, i15 = ious(m), ious(m15)
+    print(f"C4 hbox after a single-mask pipeline: predictor (slot split 79) IoU min {i79.min():.5f}; the pipeline's slot with allow_reduced "
+          f"(split 15) {i15.min():.5f}")
+    assert i79.min() >= 0.999
+    assert i15.min() >= 0.998 and m1.shape[1] == 1
+    eng.close()

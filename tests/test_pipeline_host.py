@@ -62,35 +62,52 @@ def test_work_queues_get_distinct_default_keys():
 
 
 def test_precision_policy_of_the_pipelines(monkeypatch):
-    """driver.TilePipeline._apply_precision: "auto" picks the engine's operand-split mode by output contract (single mask = 15,
-    multimask = the model's own default), never over an explicit choice; "engine" leaves it alone; an int sets it."""
+    """driver.TilePipeline._choose_split: "auto" picks the operand-split mode of the PIPELINE'S OWN calls by output contract
+    (single mask = 15, multimask = the model's own default), never over an explicit engine-wide choice; "engine" = whatever the
+    engine's option says; an int = that mode.  Engine.options applies a mode for the duration of a block and restores what
+    was there: the engine's option never outlives a pipeline's call (round 3: the last pipeline built decided for everybody)."""
     from types import SimpleNamespace
+    from samrs_amd.engine import Engine
 
     class FakeEngine:
+        options = Engine.options
+
         def __init__(self, split):
-            self.opts = {"split": split}
+            self.opts = {"split": split, "allow_reduced": 0}
+            self.sets = []
 
         def get_option(self, k):
             return self.opts[k]
 
         def set_option(self, k, v):
             self.opts[k] = v
+            self.sets.append((k, v))
 
     monkeypatch.delenv("SAMRS_SPLIT", raising=False)
-    ap = driver.TilePipeline._apply_precision
+    cs = driver.TilePipeline._choose_split
     sam = SimpleNamespace(engine=FakeEngine(79), options={}, default_split=79)
-    ap(sam, "auto", multimask=False)
-    assert sam.engine.opts["split"] == 15
-    ap(sam, "auto", multimask=True)
-    assert sam.engine.opts["split"] == 79
-    ap(sam, "engine", multimask=False)
-    assert sam.engine.opts["split"] == 79
-    ap(sam, 31, multimask=False)
-    assert sam.engine.opts["split"] == 31
+    assert cs(sam, "auto", multimask=False) == 15
+    assert cs(sam, "auto", multimask=True) == 79
+    assert cs(sam, "engine", multimask=False) is None
+    assert cs(sam, 31, multimask=False) == 31
+    assert sam.engine.opts["split"] == 79 and sam.engine.sets == []           # choosing a mode touches nothing
     chosen = SimpleNamespace(engine=FakeEngine(63), options={"split": 63}, default_split=63)
-    ap(chosen, "auto", multimask=False)
-    assert chosen.engine.opts["split"] == 63                       # the builder's options= win
+    assert cs(chosen, "auto", multimask=False) is None                       # the builder's options= win
     monkeypatch.setenv("SAMRS_SPLIT", "79")
-    env = SimpleNamespace(engine=FakeEngine(79), options={}, default_split=79)
-    ap(env, "auto", multimask=False)
-    assert env.engine.opts["split"] == 79                          # and so does the environment
+    assert cs(sam, "auto", multimask=False) is None                          # and so does the environment
+    # the mode is in force inside the block only, also when the block raises
+    pipe = SimpleNamespace(eng=sam.engine, split_mode=15, allow_reduced=False)
+    with driver.TilePipeline._mode(pipe):
+        assert sam.engine.opts["split"] == 15
+    assert sam.engine.opts["split"] == 79
+    pipe.allow_reduced = True
+    with pytest.raises(KeyError):
+        with driver.TilePipeline._mode(pipe):
+            assert sam.engine.opts == {"split": 15, "allow_reduced": 1}
+            raise KeyError("x")
+    assert sam.engine.opts == {"split": 79, "allow_reduced": 0}
+    pipe.split_mode = None
+    n = len(sam.engine.sets)
+    with driver.TilePipeline._mode(pipe):
+        pass
+    assert len(sam.engine.sets) == n                                         # "engine": not even a call

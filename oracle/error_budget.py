@@ -12,6 +12,7 @@ reports per configuration, against the exact run:
     python -m oracle.error_budget vit_h plans2     floor (only the four block GEMMs in f16), E1 = the engine's default split, ...
     python -m oracle.error_budget vit_h plans3     which block GEMMs must be split as well for the C4 fixture to clear 0.999
     python -m oracle.error_budget vit_h plans4     the v third of the qkv product on its own
+    python -m oracle.error_budget vit_h plans10    the lo terms on MXFP4 (e2m1, 32-element scale blocks) operands, per mode
 
 Encoder passes are cached under $SAMRS_EB_CACHE (default /tmp/samrs_error_budget); delete it after changing the oracle.
 
@@ -215,6 +216,19 @@ def main(argv):
             q = so.split_fp8_lo(F16, fmt=fmt, block=32)
             report(f"all four block GEMMs in every block, lo terms on {fmt} operands", f"p9_{fmt}_all4",
                    so.Rounding(enc=F16, dec=F16, points=dict(e1, **{k: q for k in four})))
+    if what in ("plans10",):
+        # round 4: the lo terms on MXFP4 operands (e2m1, one E8M0 scale per 32 k: the format whose LDS stage has the geometry of
+        # the f16 stage, gemm.hip) in the modes the engine offers -- which blocks / GEMMs have to take them for the C4 floor?
+        sp = so.split2(F16)
+        q4 = so.split_fp8_lo(F16, fmt="e2m1", block=32)
+        e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
+        n = cfg.depth
+        for label, pts, blocks in (("E1 + v + proj, blocks 0..%d, lo terms e2m1 / 32" % (3 * n // 4 - 1), ("enc.v_in", "enc.proj_in"), range(0, 3 * n // 4)),
+                                   ("E1 + v + proj, every block, lo terms e2m1 / 32", ("enc.v_in", "enc.proj_in"), range(0, n)),
+                                   ("E1 + qkv + proj, every block, lo terms e2m1 / 32", ("enc.qkv_in", "enc.proj_in"), range(0, n)),
+                                   ("E1 + v + proj + lin2, every block, lo terms e2m1 / 32", ("enc.v_in", "enc.proj_in", "enc.lin2_in"), range(0, n))):
+            tag = "p10_e2m1_" + "_".join(k.split(".")[1] for k in pts) + "_%d" % len(blocks)
+            report(label, tag, so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points={k: (blocks, q4) for k in pts}))
     if what in ("plans", "all"):
         sp = so.split2(F16)
         report("plan A: encoder f16, decoder operands split f16 (hi+lo)", "f16",

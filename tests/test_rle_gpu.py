@@ -99,3 +99,18 @@ def test_select_best_matches_torch(eng):
         rows = torch.arange(7, device="cuda")
         assert torch.equal(best.view(torch.bool), m[rows, idx]) and torch.equal(qual, q[rows, idx])
         assert torch.equal(areas, m[rows, idx].flatten(1).sum(1))
+
+
+def test_device_rle_known_answers(eng, golden_dir):
+    """samrs_rle_encode against the cocoapi known-answer vectors (tests/golden/coco_rle_known_answers.json: the published example
+    and hand-derived cases, see tests/test_rle_and_writers.py::test_rle_string_known_answers) -- the device coder pinned to the
+    library's published behaviour, not only to this repo's host restatement."""
+    import json
+    import os
+    vec = json.load(open(os.path.join(golden_dir, "coco_rle_known_answers.json")))["vectors"]
+    for v in vec:
+        mask = rle.decode({"size": v["size"], "counts": v["counts"]})
+        out, cur, tab = _encode(eng, mask[None].astype(np.uint8))
+        off, n, nc = (int(x) for x in tab[0])
+        assert out[off:off + n].tobytes().decode("ascii") == v["string"], v["name"]
+        assert nc == len(v["counts"])

@@ -37,6 +37,7 @@ for step in "$@"; do
     c4)      run c4 600 python bench.py --workload c4 --steps ${BENCH_STEPS:-6} --warmup 2 $BQ ;;
     decb)    run decb 300 python tools/dec_bench.py 20 ;;
     gemmb)   run gemmb 900 python tools/gemm_bench.py ${GEMM_VARIANTS:-27,28} f16 ;;
+    mxprobe) run mxprobe 120 bash -c "hipcc --offload-arch=gfx950 -O2 -o /tmp/mx_probe tools/mx_probe.hip && /tmp/mx_probe" ;;
     mfma)    run mfma 300 bash -c "hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_rate tools/mfma_rate.hip && /tmp/mfma_rate" ;;
     prof)    prof_env
              run prof 1200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r04 -- python bench.py --steps 3 --warmup 1 $BQ ;;

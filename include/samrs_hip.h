@@ -210,6 +210,12 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *   "split_passes"   [SAMRS_SPLIT_PASSES, default 0] reference-grade bits of "split" only: 1 = the three terms of a split block GEMM as
  *                    three accumulating launches through an fp32 scratch (the generic route, every shape); 0 = as ONE launch over a
  *                    three-segment K axis where the shape fits the 256 x 320 tile (ViT-H; samrs_k_gemm_split3), else the generic route.
+ *   "lo_format"      [SAMRS_LO_FORMAT; default 4 where the MX kernel covers the block shapes (ViT-H), else 0] operand format of the two
+ *                    correction terms of the attention-side block-GEMM split (bits 64 / 16): 0 = f16 (a split GEMM is three f16
+ *                    passes), 4 = MXFP4 (e2m1 + E8M0 scale per 32 k on gfx950's block-scaled MFMA: the corrections run at 4x the f16
+ *                    rate on a quarter of the stages, a split GEMM costs 1.5 passes; oracle/error_budget.py plans10 for what the
+ *                    format costs in mask pixels: nothing measurable).  The fp4 weight copies are made at samrs_finalize_weights
+ *                    when a block-GEMM bit is set by then; afterwards the option can be flipped between 0 and 4 (A/B runs).
  *   "allow_reduced"  [SAMRS_ALLOW_REDUCED; default 0, 1 when SAMRS_SPLIT is set] 1 = samrs_predict(multimask = 1) accepts embeddings
  *                    encoded below the multimask grade (see samrs_get_slot_info) instead of returning SAMRS_ERR_PRECISION. */
 int samrs_set_option(samrs_engine_t* e, const char* name, int value);
@@ -309,6 +315,24 @@ int samrs_k_upscale2_masks(int prec, const void* u1, const void* w_et, const voi
 int samrs_k_upscaler_fused(int prec, const void* keys_et, const void* keys_lo_et, const void* w1_et, const void* w1_lo_et,
                            const float* b1, const float* ln, const void* w2_et, const void* w2_lo_et, const float* b2,
                            const float* hyper, float* low, int n, int grid, int n_mask_tokens, int sel0, int n_sel, void* stream);
+/* Operand split with the two correction terms on MXFP4 operands (gfx950 v_mfma_scale_f32_16x16x128_f8f6f4, e2m1 codes + one E8M0
+ * scale per 32 k; option "lo_format" = 4):
+ *   samrs_k_mx4_pack   x (fp32 [rows][K]) or the ET pair (hi_in, lo_in) -> fp4 codes of hi / lo, q_* [rows][Kp / 2] bytes, and their
+ *                      scale tiles s_* (samrs_k_mx_scale_bytes(rows, Kp, is_b) bytes each; A-operand or B-operand tile order);
+ *                      out_hi (optional, with x): ET(x).  Every group of G source elements becomes GP on the padded axis (zeros
+ *                      behind it): Kp = K / G * GP, a multiple of 256; plain: G = GP = K.
+ *   samrs_k_gemm_mx    C = A B^T + A4lo B4hi^T + A4hi B4lo^T + bias: the f16 product over K, the two fp4 products over Kp, fp32
+ *                      accumulators throughout; out_f32 = 0: C_et rounded once, = 1: fp32 (accumulate != 0 adds to C).
+ *                      M % 256 == 0, N % 320 == 0, K % 64 == 0; split_from_n as for samrs_k_gemm_split3. */
+int64_t samrs_k_mx_scale_bytes(int rows, int Kp, int is_b);
+/* LayerNorm that also emits its output as MXFP4 hi / lo (what the engine feeds the qkv GEMM in "lo_format" 4): D % 256 == 0 */
+int samrs_k_layernorm_mx(int prec, const float* X, const float* gamma, const float* beta, float eps, void* out_et, int rows, int D,
+                         void* q_hi, void* q_lo, void* s_hi, void* s_lo, void* stream);
+int samrs_k_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo_in, void* out_hi, void* q_hi, void* q_lo, void* s_hi,
+                     void* s_lo, int rows, int K, int G, int GP, int is_b, void* stream);
+int samrs_k_gemm_mx(int prec, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int Kp, const void* a4_lo,
+                    const void* a4_hi, const void* sa_lo, const void* sa_hi, const void* b4_hi, const void* b4_lo, const void* sb_hi,
+                    const void* sb_lo, int out_f32, int accumulate, int split_from_n, void* stream);
 /* fp32 -> hi (= samrs_k_convert) and lo = ET(x - hi): the two-term operand split */
 int samrs_k_convert_split(int prec, const float* in, void* out_hi_et, void* out_lo_et, int64_t n, void* stream);
 

@@ -133,7 +133,11 @@ def run(pred, orc, modes: Sequence[int], tile_iter: Iterable[dict] = None, tau_f
             del lg
         t_or = time.time() - t0
         for mode in modes:
-            eng.set_option("split", mode)
+            # a mode is the engine's "split" option, or "<split>:<lo_format>" (lo_format 0 = f16 lo terms, 4 = MXFP4 lo terms)
+            split, _, lo = str(mode).partition(":")
+            eng.set_option("split", int(split))
+            if lo:
+                eng.set_option("lo_format", int(lo))
             pred.set_image(img)
             for tag, kw, mm in workloads(tile, None):
                 m, q, low = _engine_call(pred, kw, mm, hw)

@@ -98,6 +98,49 @@ __device__ __forceinline__ void split2_pack(float a, float b, uint32_t& hi, uint
 }
 
 // ---------------------------------------------------------------------------------------------
+// MXFP4 operands of the split products' correction terms (gemm.hip gemm_et_mx_kernel): e2m1 codes, one E8M0 scale per
+// 32 elements, the scale bytes stored in the order the GEMM's lanes read them.  Shared by the GEMM, the generic pack
+// kernel and the producers that emit the format themselves (LayerNorm).
+// ---------------------------------------------------------------------------------------------
+constexpr int MXK = 256;                       // k per MX stage (128 bytes of fp4 per row: the f16 stage's geometry)
+constexpr int MX_SA_BYTES = 2048, MX_SB_BYTES = 4096;      // scale tile of one (256-row A tile | 320-row B tile, stage)
+
+// ---- fp4 (e2m1) quantisation of one value that has been divided by its block scale: the nearest point of
+// {0, 0.5, 1, 1.5, 2, 3, 4, 6} (ties to even; |v| > 6 saturates, which can only hit the block maximum: the scale puts it in [4, 8)),
+// exactly what oracle/sam_oracle.py split_fp8_lo._q8 computes for fmt="e2m1" ----
+__device__ __forceinline__ uint32_t fp4_code(float v) {
+    const float a = fabsf(v);
+    const float step = a >= 4.f ? 2.f : a >= 2.f ? 1.f : 0.5f;
+    const float q = fminf(rintf(a / step) * step, 6.f);
+    const int idx = (int)(q * 2.f);                            // 0 1 2 3 4 6 8 12
+    const uint32_t code = idx <= 4 ? (uint32_t)idx : (uint32_t)(idx >> 2) + 4u;
+    return code | (v < 0.f ? 8u : 0u);
+}
+// E8M0 exponent of a block: floor(log2(amax)) - 2 (OCP MX: emax of e2m1 is 2), as a biased byte; amax = 0 / subnormal -> 2^-127
+__device__ __forceinline__ int mx_scale_byte(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);            // biased fp32 exponent = floor(log2) + 127 for normal values
+    return e > 2 ? e - 2 : 0;
+}
+__device__ __forceinline__ float mx_inv_scale(int byte) {                  // 2^-(byte - 127), exact
+    return __uint_as_float((uint32_t)(254 - byte) << 23);                  // byte in [0, 252]: exponent field 254 - byte in [2, 254]
+}
+// byte offset of the scale of (row r, padded-k block b) in the tiled scale tensors described above
+__device__ __forceinline__ size_t mx_scale_index(bool is_b, int r, int b, int nst4) {
+    const int st = b >> 3, kh = (b >> 2) & 1, fq = b & 3;
+    if (!is_b) {
+        const int tile = r >> 8, wm = (r >> 7) & 1, j = (r >> 4) & 7, fr = r & 15;
+        return ((size_t)tile * nst4 + st) * MX_SA_BYTES + (size_t)(((kh * 2 + wm) * 64 + fq * 16 + fr) * 8 + j);
+    }
+    const int tile = r / 320, rr = r % 320, wn = rr / 80, i = (rr % 80) >> 4, fr = rr & 15;
+    return ((size_t)tile * nst4 + st) * MX_SB_BYTES + (size_t)(((kh * 4 + wn) * 64 + fq * 16 + fr) * 8 + i);
+}
+
+// optional MX outputs of a producer kernel (all null: none)
+struct MxOut {
+    unsigned char *q_hi = nullptr, *q_lo = nullptr, *s_hi = nullptr, *s_lo = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
 // wave-level reductions (64 lanes)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

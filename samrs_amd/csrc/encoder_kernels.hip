@@ -105,7 +105,8 @@ template <int PREC>
 __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
     float eps, uint16_t* __restrict__ out_et, float* __restrict__ out_f32, int rows_out, int D,
-    int window_mode, int grid, int window, uint16_t* __restrict__ out_lo /* optional: the split remainder of out_et */) {
+    int window_mode, int grid, int window, uint16_t* __restrict__ out_lo /* optional: the split remainder of out_et */,
+    MxOut mx /* optional (plain row order only): hi and lo of the output as MXFP4 codes + scale tiles, gemm_et_mx_kernel's A operands */) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows_out) return;
@@ -173,6 +174,34 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
                     split2_pack<PREC>(o0, o1, h.x, l.x);
                     split2_pack<PREC>(o2, o3, h.y, l.y);
                     reinterpret_cast<uint2*>(out_lo + (size_t)row * D)[idx] = l;
+                }
+                if (mx.q_hi) {
+                    // a lane holds elements 4 idx .. 4 idx + 3: an MX block (32 elements) = 8 consecutive lanes of one pass.
+                    // hi = the ET value just written, lo = the fp32 remainder; one E8M0 scale per block and tensor.
+                    float h[4], l[4];
+                    const float ov[4] = {o0, o1, o2, o3};
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        h[e2] = ET<PREC>::to_float((uint16_t)(((e2 & 2) ? o.y : o.x) >> (16 * (e2 & 1))));
+                        l[e2] = ov[e2] - h[e2];
+                    }
+                    float ah = fmaxf(fmaxf(fabsf(h[0]), fabsf(h[1])), fmaxf(fabsf(h[2]), fabsf(h[3])));
+                    float al = fmaxf(fmaxf(fabsf(l[0]), fabsf(l[1])), fmaxf(fabsf(l[2]), fabsf(l[3])));
+#pragma unroll
+                    for (int sh = 1; sh < 8; sh <<= 1) { ah = fmaxf(ah, __shfl_xor(ah, sh, 64)); al = fmaxf(al, __shfl_xor(al, sh, 64)); }
+                    const int bh = mx_scale_byte(ah), bl = mx_scale_byte(al);
+                    const float ih = mx_inv_scale(bh), il = mx_inv_scale(bl);
+                    uint32_t ch = 0, cl = 0;
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) { ch |= fp4_code(h[e2] * ih) << (4 * e2); cl |= fp4_code(l[e2] * il) << (4 * e2); }
+                    const size_t dst = (size_t)row * (D >> 1) + (size_t)idx * 2;
+                    *reinterpret_cast<uint16_t*>(mx.q_hi + dst) = (uint16_t)ch;
+                    *reinterpret_cast<uint16_t*>(mx.q_lo + dst) = (uint16_t)cl;
+                    if ((lane & 7) == 0) {
+                        const size_t si = mx_scale_index(false, row, idx >> 3, D / MXK);
+                        mx.s_hi[si] = (unsigned char)bh;
+                        mx.s_lo[si] = (unsigned char)bl;
+                    }
                 }
             }
             if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[idx] = make_float4(o0, o1, o2, o3);
@@ -1221,13 +1250,18 @@ hipError_t launch_rowstats_convert(int prec, const float* X, void* Xh, float* st
 
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
-                            int window, hipStream_t s, void* out_lo) {
+                            int window, hipStream_t s, void* out_lo, void* mx_q_hi, void* mx_q_lo, void* mx_s_hi, void* mx_s_lo) {
     if (D % 4 || D > LN_MAXV * 256) return hipErrorInvalidValue;
+    MxOut mx;
+    if (mx_q_hi) {       // MX outputs: whole stages per row, rows in plain order, an ET output to take hi from, no partial lane passes
+        if (!mx_q_lo || !mx_s_hi || !mx_s_lo || !out_et || window_mode || D % MXK) return hipErrorInvalidValue;
+        mx.q_hi = (unsigned char*)mx_q_hi; mx.q_lo = (unsigned char*)mx_q_lo; mx.s_hi = (unsigned char*)mx_s_hi; mx.s_lo = (unsigned char*)mx_s_lo;
+    }
     const int blocks = (rows_out + 3) / 4;
     if (prec == PREC_BF16)
-        layernorm_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo);
+        layernorm_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo, mx);
     else
-        layernorm_kernel<PREC_F16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo);
+        layernorm_kernel<PREC_F16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo, mx);
     return hipGetLastError();
 }
 

@@ -63,6 +63,11 @@ struct EncBlock {
     const float *ln1w, *ln1b, *ln2w, *ln2b, *qkv_b, *proj_b, *lin1_b, *lin2_b, *rel_h, *rel_w;
     uint16_t *qkv_w = nullptr, *proj_w = nullptr, *lin1_w = nullptr, *lin2_w = nullptr;
     uint16_t *qkv_w_lo = nullptr, *proj_w_lo = nullptr, *lin1_w_lo = nullptr, *lin2_w_lo = nullptr;   // reference-grade bits only
+    // option "lo_format" = 4: the lo terms of the attention-side split on MXFP4 operands (gemm.hip gemm_et_mx_kernel): fp4 codes of
+    // hi and lo of the weights + their scale tiles (B layout); proj's K axis padded per head (80 -> 96) so that no MX block
+    // straddles two heads
+    unsigned char *qkv_w4[2] = {nullptr, nullptr}, *qkv_s4[2] = {nullptr, nullptr};       // [0] = hi, [1] = lo
+    unsigned char *proj_w4[2] = {nullptr, nullptr}, *proj_s4[2] = {nullptr, nullptr};
     // LayerNorm folded into qkv / lin1 (ViT-H): W diag(gamma) in ET, its row sums, b + W beta
     uint16_t *qkv_wf = nullptr, *lin1_wf = nullptr;
     float *qkv_c = nullptr, *qkv_bf = nullptr, *lin1_c = nullptr, *lin1_bf = nullptr;
@@ -93,6 +98,11 @@ struct samrs_engine {
     int gemm_variant = -1;                          // -1 = the library default (launch_gemm_et's automatic choice)
     int split_depth = 0;                            // reference-grade bits apply to the first N blocks (0 = all)
     bool split_passes = false;                      // reference-grade block GEMMs as three accumulating launches instead of one (A/B)
+    int lo_format = 0;                              // 0: lo terms on f16 operands (three-segment f16 GEMM); 4: on MXFP4 operands
+    bool mx_ready = false;                          // the fp4 weight copies + activation workspaces exist (fixed at samrs_finalize_weights)
+    int mx_gp = 0, mx_kp_proj = 0;                  // proj's padded K axis: heads x mx_gp (head_dim rounded up to 32)
+    unsigned char *Y4[2] = {nullptr, nullptr}, *SY4[2] = {nullptr, nullptr};       // LN output as fp4 hi / lo + scale tiles (A layout)
+    unsigned char *AO4[2] = {nullptr, nullptr}, *SAO4[2] = {nullptr, nullptr};     // attention output likewise (padded K axis)
     bool upscaler_fused = true;                     // one-kernel upscaler (upscaler_fused.hip) instead of ConvT1 GEMM + ConvT2 kernel
 
     // encoder weights / workspaces
@@ -371,6 +381,7 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->upscaler_fused = env_int("SAMRS_UPSCALER_FUSED", 1) != 0;
     e->split_passes = env_int("SAMRS_SPLIT_PASSES", 0) != 0;
     e->split_depth = env_int("SAMRS_SPLIT_DEPTH", 0);
+    e->lo_format = (h_like && env_int("SAMRS_LO_FORMAT", 4) == 4) ? 4 : 0;
     return e;
 }
 
@@ -464,6 +475,22 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
             e->can_fold = true;
         }
         const bool lo_a = (e->split & SPLIT_ATTN_ANY) != 0, lo_m = (e->split & SPLIT_MLP) != 0;
+        if (lo_a && e->lo_format == 4 && gemm_mx_ok(c.max_images * e->tokens, 3 * D, D, D)) {
+            // fp4 copies of hi / lo of the attention-side weights (from the fp32 tensors, before to_et frees them)
+            const int gp = (e->hd + 31) / 32 * 32, kp = c.num_heads * gp;
+            if (gemm_mx_ok(c.max_images * e->tokens, D, D, kp)) {
+                e->mx_gp = gp; e->mx_kp_proj = kp;
+                for (int h = 0; h < 2; ++h) {
+                    CK(e, dalloc(e, &b.qkv_w4[h], (size_t)3 * D * D / 2)); CK(e, dalloc(e, &b.qkv_s4[h], mx_scale_bytes(3 * D, D, true)));
+                    CK(e, dalloc(e, &b.proj_w4[h], (size_t)D * kp / 2)); CK(e, dalloc(e, &b.proj_s4[h], mx_scale_bytes(D, kp, true)));
+                }
+                CK(e, launch_mx4_pack(e->prec, W(e, p + ".attn.qkv.weight"), nullptr, nullptr, nullptr, b.qkv_w4[0], b.qkv_w4[1], b.qkv_s4[0],
+                                      b.qkv_s4[1], 3 * D, D, D, D, true, s));
+                CK(e, launch_mx4_pack(e->prec, W(e, p + ".attn.proj.weight"), nullptr, nullptr, nullptr, b.proj_w4[0], b.proj_w4[1], b.proj_s4[0],
+                                      b.proj_s4[1], D, D, e->hd, gp, true, s));
+                e->mx_ready = true;
+            }
+        }
         if ((rc = to_et(e, p + ".attn.qkv.weight", &b.qkv_w, true, s, lo_a ? &b.qkv_w_lo : nullptr))) return rc;
         if ((rc = to_et(e, p + ".attn.proj.weight", &b.proj_w, true, s, lo_a ? &b.proj_w_lo : nullptr))) return rc;
         if ((rc = to_et(e, p + ".mlp.lin1.weight", &b.lin1_w, true, s, lo_m ? &b.lin1_w_lo : nullptr))) return rc;
@@ -549,6 +576,12 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
         CK(e, dalloc(e, &e->Ylo, M * D));
         if (e->split & SPLIT_MLP) CK(e, dalloc(e, &e->F32T, M * 4 * D));      // the generic attention-side route allocates it on first use
         if (e->split & SPLIT_ATTN_ANY) CK(e, dalloc(e, &e->AOlo, M * D));
+        if (e->mx_ready) {
+            for (int h = 0; h < 2; ++h) {
+                CK(e, dalloc(e, &e->Y4[h], M * D / 2)); CK(e, dalloc(e, &e->SY4[h], mx_scale_bytes((int)M, D, false)));
+                CK(e, dalloc(e, &e->AO4[h], M * e->mx_kp_proj / 2)); CK(e, dalloc(e, &e->SAO4[h], mx_scale_bytes((int)M, e->mx_kp_proj, false)));
+            }
+        }
         if (e->split & SPLIT_MLP) CK(e, dalloc(e, &e->Hlo, M * 4 * D));
     }
     size_t hsz = M * 4 * D;
@@ -657,10 +690,17 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         const bool sp_attn = attn_full || ((e->split & SPLIT_ATTN_V) && i < depth_v), sp_mlp = any_mlp && i < depth_full;
         // v third only: needs the tile mask of the one-launch kernel; other shapes split all of qkv
         const int v_from = (sp_attn && !attn_full && one3 && gemm_split3_ok(M, 3 * D, D) && (2 * D) % 320 == 0) ? 2 * D : 0;
+        const bool mx_attn = e->lo_format == 4 && e->mx_ready && !e->split_passes && gemm_mx_ok(M, 3 * D, D, D) && (2 * D) % 320 == 0;
         // norm1 + qkv in plain token order for both block kinds; the windowed kernel partitions
         // on the fly and takes k / v of padding positions from the qkv bias
         if (fold) {
             CK(e, launch_gemm_et_fold(prec, e->Y, b.qkv_wf, e->QKV, b.qkv_bf, b.qkv_c, e->ROWSTAT, M, 3 * D, D, false, s));
+        } else if (sp_attn && mx_attn) {
+            // lo terms on MXFP4 operands: the LayerNorm emits the fp4 codes + scales of its output's hi and lo (no ET lo copy)
+            CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, nullptr,
+                                   e->Y4[0], e->Y4[1], e->SY4[0], e->SY4[1]));
+            CK(e, launch_gemm_et_mx(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, M, 3 * D, D, D, e->Y4[1], e->Y4[0], e->SY4[1], e->SY4[0],
+                                    b.qkv_w4[0], b.qkv_w4[1], b.qkv_s4[0], b.qkv_s4[1], false, false, attn_full ? 0 : 2 * D, s));
         } else if (sp_attn) {
             CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, e->Ylo));
             if (one3 && gemm_split3_ok(M, 3 * D, D)) {     // one launch, ET output rounded once from the register accumulators
@@ -686,7 +726,13 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, launch_gemm_et_stats(prec, e->AO, b.proj_w, e->X, b.proj_b, e->Y, e->STATS, M, D, D, s));
             CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
         } else {
-            if (sp_attn && one3 && gemm_split3_ok(M, D, D)) {
+            if (sp_attn && mx_attn) {
+                // attention output (hi, lo) -> fp4 on the per-head padded K axis; the GEMM adds into the residual stream
+                CK(e, launch_mx4_pack(prec, nullptr, e->AO, e->AOlo, nullptr, e->AO4[0], e->AO4[1], e->SAO4[0], e->SAO4[1], M, D, e->hd,
+                                      e->mx_gp, false, s));
+                CK(e, launch_gemm_et_mx(prec, e->AO, b.proj_w, e->X, b.proj_b, M, D, D, e->mx_kp_proj, e->AO4[1], e->AO4[0], e->SAO4[1],
+                                        e->SAO4[0], b.proj_w4[0], b.proj_w4[1], b.proj_s4[0], b.proj_s4[1], true, true, 0, s));
+            } else if (sp_attn && one3 && gemm_split3_ok(M, D, D)) {
                 CK(e, launch_gemm_et_split3(prec, e->AO, e->AOlo, b.proj_w, b.proj_w_lo, e->X, b.proj_b, M, D, D, true, true, s));
             } else {
                 if (sp_attn) {
@@ -1127,6 +1173,13 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     else if (n == "split_passes") e->split_passes = value != 0;
     else if (n == "split_depth") e->split_depth = value > 0 ? value : 0;
     else if (n == "allow_reduced") e->allow_reduced = value != 0;
+    else if (n == "lo_format") {
+        if (value != 0 && value != 4) return fail(e, SAMRS_ERR_BAD_ARG, "lo_format is 0 (f16 lo terms) or 4 (MXFP4 lo terms)");
+        if (value == 4 && e->finalized && !e->mx_ready)
+            return fail(e, SAMRS_ERR_BAD_ARG, "lo_format 4 needs the fp4 weight copies: set it (and a block-GEMM split bit) before the weights are "
+                                              "finalized; it covers the attention-side split of models whose block GEMMs fit the 256 x 320 tile (ViT-H)");
+        e->lo_format = value;
+    }
     else return fail(e, SAMRS_ERR_BAD_ARG, "unknown option %s", name);
     return SAMRS_OK;
 }
@@ -1141,6 +1194,7 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
     else if (n == "split_passes") *value = e->split_passes;
     else if (n == "split_depth") *value = e->split_depth;
     else if (n == "allow_reduced") *value = e->allow_reduced;
+    else if (n == "lo_format") *value = (e->finalized && !e->mx_ready) ? 0 : e->lo_format;
     else if (n == "grade_multimask") *value = e->grade_multimask;     // read-only
     else return SAMRS_ERR_BAD_ARG;
     return SAMRS_OK;
@@ -1259,6 +1313,10 @@ int samrs_k_layernorm(int prec, const float* X, const float* gamma, const float*
     (void)n_images;
     KRET(launch_layernorm(prec, X, gamma, beta, eps, out_et, out_f32, rows_out, D, window_mode, grid, window, (hipStream_t)stream));
 }
+int samrs_k_layernorm_mx(int prec, const float* X, const float* gamma, const float* beta, float eps, void* out_et, int rows, int D,
+                         void* q_hi, void* q_lo, void* s_hi, void* s_lo, void* stream) {
+    KRET(launch_layernorm(prec, X, gamma, beta, eps, out_et, nullptr, rows, D, 0, 0, 0, (hipStream_t)stream, nullptr, q_hi, q_lo, s_hi, s_lo));
+}
 int samrs_k_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
                              int n_images, int grid, int window, int heads, int head_dim, void* stream) {
     KRET(launch_window_attention(prec, qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, window, heads, head_dim, (hipStream_t)stream));
@@ -1313,6 +1371,18 @@ int samrs_k_upscaler_fused(int prec, const void* keys, const void* keys_lo, cons
                            int grid, int n_mask_tokens, int sel0, int n_sel, void* stream) {
     KRET(launch_upscaler_fused(prec, keys, keys_lo, w1, w1_lo, b1, ln, w2, w2_lo, b2, hyper, low, n, grid, n_mask_tokens, sel0, n_sel,
                                (hipStream_t)stream));
+}
+int64_t samrs_k_mx_scale_bytes(int rows, int Kp, int is_b) { return (int64_t)mx_scale_bytes(rows, Kp, is_b != 0); }
+int samrs_k_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo_in, void* out_hi, void* q_hi, void* q_lo, void* s_hi,
+                     void* s_lo, int rows, int K, int G, int GP, int is_b, void* stream) {
+    return launch_mx4_pack(prec, x, hi_in, lo_in, out_hi, q_hi, q_lo, s_hi, s_lo, rows, K, G, GP, is_b != 0, (hipStream_t)stream) == hipSuccess
+               ? SAMRS_OK : SAMRS_ERR_BAD_SHAPE;
+}
+int samrs_k_gemm_mx(int prec, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int Kp, const void* a4_lo,
+                    const void* a4_hi, const void* sa_lo, const void* sa_hi, const void* b4_hi, const void* b4_lo, const void* sb_hi,
+                    const void* sb_lo, int out_f32, int accumulate, int split_from_n, void* stream) {
+    return launch_gemm_et_mx(prec, A, B, C, bias, M, N, K, Kp, a4_lo, a4_hi, sa_lo, sa_hi, b4_hi, b4_lo, sb_hi, sb_lo, out_f32 != 0,
+                             accumulate != 0, split_from_n, (hipStream_t)stream) == hipSuccess ? SAMRS_OK : SAMRS_ERR_BAD_SHAPE;
 }
 int samrs_k_convert_split(int prec, const float* in, void* out_hi, void* out_lo, int64_t n, void* stream) {
     KRET(launch_convert(prec, in, out_hi, (long)n, (hipStream_t)stream, out_lo));

@@ -2449,6 +2449,311 @@ __global__ __launch_bounds__(64 * S) void gemm_f32_kernel(F32Batch bt, int lda, 
     }
 }
 
+
+// =============================================================================================================================
+// MXFP4 lo terms (round 4).  The operand split  A B^T ~= A_hi B_hi^T + A_lo B_hi^T + A_hi B_lo^T  pays two extra f16 passes for
+// corrections that are 2^-11 of the product.  Their operands tolerate very few mantissa bits (oracle/error_budget.py plans8 - 10:
+// e2m1 lo terms leave 1.8e-1 of a plain f16 GEMM's error, and the C4 floor of the multimask mode holds with them), so here the
+// two correction terms run on gfx950's block-scaled  v_mfma_scale_f32_16x16x128_f8f6f4  with FP4 (e2m1) operands and one E8M0
+// scale per 32 k (OCP MX): 4x the f16 MFMA rate -- and, the reason for fp4 rather than fp8 / fp6, the SAME LDS geometry as the
+// f16 stage: a 128-byte stage row holds 256 k of fp4 (two 64-byte k-halves of 128 k each) where it holds 64 k of f16, and a
+// lane's fragment of a k-half is the same 16 bytes (32 fp4 values = its MX block) it is for f16.  So the pair-stage image, its
+// XOR swizzle, the DMA map, the 13 fragment reads and the 40 MFMAs per k-half are those of gemm_et_x64_kernel; an MX stage
+// differs in the MFMA opcode, in two 8-byte scale reads per k-half, and in six 1-KiB scale pieces per stage.  A correction
+// segment over K is K / 256 stages against K / 64 for the f16 segment: the split product costs 1.5x a plain one (f16 lo: 3x).
+//
+// Operand tensors (written by mx4_pack_kernel, or by the producers themselves):
+//   A4 / B4  [rows][Kp / 2] bytes: element k' of a row in nibble k' (low nibble first); Kp = padded K (a multiple of 256)
+//   scales   E8M0 bytes, one per (row, 32-k' block), stored in the order the kernel's lanes read them:
+//              A: [tile_m = r / 256][stage = b / 8][k-half = (b / 4) % 2][wm = (r / 128) % 2][fq = b % 4][fr = r % 16][j = (r / 16) % 8]
+//              B: [tile_n = n / 320][stage][k-half][wn = (n / 80) % 4][fq][fr = n % 16][i = (n % 80) / 16, 8 slots]
+//            i.e. 2 KiB / 4 KiB per (tile, stage), DMA'd as they are; lane (fr, fq) of wave (wm, wn) reads 8 bytes per operand and
+//            k-half, byte j / i = the scale of its row in m-tile j / n-tile i (op_sel picks the byte).
+// K' may be K with each group of G elements padded to GP (heads of 80 padded to 96 for the proj GEMM: no MX block straddles two
+// heads, so the attention kernels can emit the blocks of their own head); the f16 segment keeps the plain K.
+// =============================================================================================================================
+constexpr int MX_S_BYTES = MX_SA_BYTES + MX_SB_BYTES;          // MXK, MX_SA_BYTES, MX_SB_BYTES and the quantisers: common.h
+
+struct MxOperands {
+    const unsigned char *a4_lo, *a4_hi, *b4_hi, *b4_lo;      // fp4 data
+    const unsigned char *sa_lo, *sa_hi, *sb_hi, *sb_lo;      // scale tiles
+    int Kp;                                                  // padded K of the MX segments
+    int split_from_n;                                        // output columns below this take no lo terms (ET outputs; 0 = all do)
+};
+
+typedef int mx_v8i __attribute__((ext_vector_type(8)));
+typedef int mx_v4i __attribute__((ext_vector_type(4)));
+
+template <int OPA, int OPB>
+__device__ __forceinline__ f32x4_t mfma_mx4(const uint4& a, const uint4& b, f32x4_t c, int sa, int sb) {
+    const mx_v4i xa = {(int)a.x, (int)a.y, (int)a.z, (int)a.w}, xb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(__builtin_shufflevector(xa, xa, 0, 1, 2, 3, -1, -1, -1, -1),
+                                                            __builtin_shufflevector(xb, xb, 0, 1, 2, 3, -1, -1, -1, -1), c,
+                                                            4 /* fp4 e2m1 */, 4, OPA, sa, OPB, sb);
+}
+
+template <int PREC, bool OUT_F32>
+__global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv, const float* __restrict__ bias,
+    int M, int N, int K, int accumulate, MxOperands mx) {
+    constexpr int NI = 5;
+    constexpr int XBN = 64 * NI;
+    constexpr int XROWS = QBM + XBN;
+    constexpr int XSTAGE_ELEMS = XROWS * XBK;
+    constexpr uint32_t XSB = XSTAGE_ELEMS * 2;             // stage bytes (f16 and MX alike: rows x 128 B)
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * XSTAGE_ELEMS + MX_S_BYTES];   // ring (144 KiB) + 2 x 6 KiB of scales
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    constexpr int GROUP = 8;
+    const int tiles_n = N / XBN, tiles_m = M / QBM;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_group = GROUP * tiles_n;
+    const int group = bid / per_group, first_m = group * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = bid - group * per_group;
+    const int tile_m = first_m + in_g % gsz, tile_n = in_g / gsz;
+    const int m0 = tile_m * QBM, n0 = tile_n * XBN;
+
+    const int nst1 = K / XBK;                              // f16 stages
+    const int nst4 = mx.Kp / MXK;                          // MX stages per correction segment
+    const int nmx = n0 >= mx.split_from_n ? 2 * nst4 : 0;  // this tile's MX stages (wave-uniform): A_lo B_hi, then A_hi B_lo
+    const int nst = nmx + nst1;
+
+    // DMA map as in gemm_et_x64_kernel; the per-lane byte offset depends on the row stride of the source (2 K vs Kp / 2)
+    const int prow = 8 * wave + ((lane >> 2) & 7);
+    const uint32_t lane_off = (uint32_t)(lane >> 5) * 64u + (uint32_t)qswz(prow, lane & 3) * 16u;
+    const uint32_t voff16 = (uint32_t)prow * (uint32_t)K * 2u + lane_off;
+    const uint32_t voff4 = (uint32_t)prow * (uint32_t)(mx.Kp >> 1) + lane_off;
+    const unsigned char* A16 = reinterpret_cast<const unsigned char*>(A) + (size_t)m0 * K * 2;
+    const unsigned char* B16 = reinterpret_cast<const unsigned char*>(B) + (size_t)n0 * K * 2;
+    const size_t row4 = (size_t)(mx.Kp >> 1);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
+    const uint32_t lds_sc = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + 2u * XSB);
+    // piece q_ (literal) of stage st_ into the ring buffer at byte offset wr_ (scales: buffer (wr_ != 0))
+#define MX_PIECE(st_, wr_, q_)                                                                                       \
+    do {                                                                                                             \
+        const int st__ = (st_);                                                                                      \
+        const uint32_t dst__ = lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u); \
+        if (st__ < nmx) {                                                                                            \
+            const int seg__ = st__ >= nst4, s__ = st__ - seg__ * nst4;                                               \
+            const unsigned char* src__ = (q_) < 4 ? (seg__ ? mx.a4_hi : mx.a4_lo) + ((size_t)m0 + (q_) * 64) * row4          \
+                                                   : (seg__ ? mx.b4_lo : mx.b4_hi) + ((size_t)n0 + ((q_) - 4) * 64) * row4;  \
+            glds16_s(voff4, src__ + (size_t)s__ * 128, dst__);                                                       \
+        } else {                                                                                                     \
+            const unsigned char* src__ = (q_) < 4 ? A16 + (size_t)(q_) * 64 * K * 2 : B16 + (size_t)((q_) - 4) * 64 * K * 2; \
+            glds16_s(voff16, src__ + (size_t)(st__ - nmx) * 128, dst__);                                             \
+        }                                                                                                            \
+    } while (0)
+    // the stage's scale tiles: 2 KiB (A) + 4 KiB (B) as six 1-KiB pieces, one per wave 0 .. 5
+#define MX_SCALES(st_, wr_)                                                                                          \
+    do {                                                                                                             \
+        const int st__ = (st_);                                                                                      \
+        if (st__ < nmx && wave < 6) {                                                                                \
+            const int seg__ = st__ >= nst4, s__ = st__ - seg__ * nst4;                                               \
+            const unsigned char* src__ = wave < 2                                                                    \
+                ? (seg__ ? mx.sa_hi : mx.sa_lo) + ((size_t)tile_m * nst4 + s__) * MX_SA_BYTES + wave * 1024          \
+                : (seg__ ? mx.sb_lo : mx.sb_hi) + ((size_t)tile_n * nst4 + s__) * MX_SB_BYTES + (wave - 2) * 1024;   \
+            glds16_s((uint32_t)lane * 16u, src__, lds_sc + ((wr_) ? (uint32_t)MX_S_BYTES : 0u) + (uint32_t)wave * 1024u); \
+        }                                                                                                            \
+    } while (0)
+#define MX_ISSUE(st_, wr_)                                                                                           \
+    do {                                                                                                             \
+        MX_PIECE(st_, wr_, 0); MX_PIECE(st_, wr_, 1); MX_PIECE(st_, wr_, 2); MX_PIECE(st_, wr_, 3); MX_PIECE(st_, wr_, 4); \
+        MX_PIECE(st_, wr_, 5); MX_PIECE(st_, wr_, 6); MX_PIECE(st_, wr_, 7); MX_PIECE(st_, wr_, 8); MX_SCALES(st_, wr_); \
+    } while (0)
+
+    f32x4_t acc[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    uint32_t offA[8], offB[NI];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int r = wm * 128 + j * 16 + fr; offA[j] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, fq) * 8) * 2; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int r = QBM + wn * (16 * NI) + i * 16 + fr;
+        offB[i] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, fq) * 8) * 2;
+    }
+    const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);
+    const uint32_t scA = 2u * XSB + (uint32_t)((wm * 64 + fq * 16 + fr) * 8);                    // + kh * 1024 + buffer * MX_S_BYTES
+    const uint32_t scB = 2u * XSB + (uint32_t)MX_SA_BYTES + (uint32_t)((wn * 64 + fq * 16 + fr) * 8);   // + kh * 2048 + ...
+
+    MX_ISSUE(0, 0u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) {
+        if (nst > 1) MX_ISSUE(1, XSB);
+        __builtin_amdgcn_s_barrier();
+    }
+
+#define MX_READ(rd_, kh_)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NI; ++i)                                                         \
+        fb[i] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offB[i]);                     \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                          \
+        fa[j] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offA[j]);
+#define MX_READ_SC(rd_, kh_)                                                                               \
+    sa = *reinterpret_cast<const uint2*>(ldsb + scA + ((rd_) ? (uint32_t)MX_S_BYTES : 0u) + (kh_) * 1024); \
+    sb = *reinterpret_cast<const uint2*>(ldsb + scB + ((rd_) ? (uint32_t)MX_S_BYTES : 0u) + (kh_) * 2048);
+    // one row of MFMAs (m-tile j_) + the DMA piece that rides behind it
+#define MX_DMA_AFTER(j_, dma_, st_, wr_)                                                                   \
+    if (dma_) {                                                                                            \
+        if ((j_) == 0) MX_PIECE(st_, wr_, 0); if ((j_) == 1) MX_PIECE(st_, wr_, 1);                        \
+        if ((j_) == 2) MX_PIECE(st_, wr_, 2); if ((j_) == 3) MX_PIECE(st_, wr_, 3);                        \
+        if ((j_) == 4) MX_PIECE(st_, wr_, 4); if ((j_) == 5) MX_PIECE(st_, wr_, 5);                        \
+        if ((j_) == 6) { MX_PIECE(st_, wr_, 6); MX_SCALES(st_, wr_); }                                     \
+        if ((j_) == 7) { MX_PIECE(st_, wr_, 7); MX_PIECE(st_, wr_, 8); }                                   \
+    }
+#define MX_MFMA_F16(dma_, st_, wr_)                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                        \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]); \
+        MX_DMA_AFTER(j, dma_, st_, wr_)                                                                    \
+    }
+    // first MFMA operand = the weight fragment (n rows): its scale is the B scale, byte i; second = activation fragment, byte j
+#define MX_ROW(j_, OPB_, sav_)                                                                             \
+    acc[0][j_] = mfma_mx4<0, OPB_>(fb[0], fa[j_], acc[0][j_], (int)sb.x, (int)(sav_));                     \
+    acc[1][j_] = mfma_mx4<1, OPB_>(fb[1], fa[j_], acc[1][j_], (int)sb.x, (int)(sav_));                     \
+    acc[2][j_] = mfma_mx4<2, OPB_>(fb[2], fa[j_], acc[2][j_], (int)sb.x, (int)(sav_));                     \
+    acc[3][j_] = mfma_mx4<3, OPB_>(fb[3], fa[j_], acc[3][j_], (int)sb.x, (int)(sav_));                     \
+    acc[4][j_] = mfma_mx4<0, OPB_>(fb[4], fa[j_], acc[4][j_], (int)sb.y, (int)(sav_));                     \
+    /* pin the row here: unlike the plain MFMA intrinsics the scaled one is not convergent, and LLVM sinks all 80 of a stage */ \
+    /* below the (branchy) DMA pieces that are meant to ride between the rows -- two k-halves of fragments live, 670 spills */  \
+    asm volatile("" : "+v"(acc[0][j_]), "+v"(acc[1][j_]), "+v"(acc[2][j_]), "+v"(acc[3][j_]), "+v"(acc[4][j_]));
+#define MX_MFMA_FP4(dma_, st_, wr_)                                                                        \
+    MX_ROW(0, 0, sa.x) MX_DMA_AFTER(0, dma_, st_, wr_) MX_ROW(1, 1, sa.x) MX_DMA_AFTER(1, dma_, st_, wr_)  \
+    MX_ROW(2, 2, sa.x) MX_DMA_AFTER(2, dma_, st_, wr_) MX_ROW(3, 3, sa.x) MX_DMA_AFTER(3, dma_, st_, wr_)  \
+    MX_ROW(4, 0, sa.y) MX_DMA_AFTER(4, dma_, st_, wr_) MX_ROW(5, 1, sa.y) MX_DMA_AFTER(5, dma_, st_, wr_)  \
+    MX_ROW(6, 2, sa.y) MX_DMA_AFTER(6, dma_, st_, wr_) MX_ROW(7, 3, sa.y) MX_DMA_AFTER(7, dma_, st_, wr_)
+
+    // One stage (the schedule of gemm_et_x64_kernel<MODE = 3>: one block barrier per stage, DMA pieces spread between the MFMA
+    // rows, the two wave groups half a stage apart).  The MX stages and the f16 stages run in two consecutive loops -- one MFMA
+    // flavour per loop body; a single loop with a per-stage branch made the register allocator spill 670 registers -- and the
+    // hand-over between them needs nothing: MX_PIECE decides per TARGET stage what it fetches.
+#define MX_STAGE(READ_SC0_, READ_SC1_, MFMA_)                                                              \
+    {                                                                                                      \
+        uint4 fa[8], fb[NI];                                                                               \
+        const uint32_t wr = XSB - rd;                                                                      \
+        const bool dma0 = (grp == 0) && (t + 1 < nst);                                                     \
+        const bool dma1 = (grp == 1) && (t + 2 < nst);                                                     \
+        if (grp == 0) __builtin_amdgcn_s_barrier();                           /* R_t */                    \
+        MX_READ(rd, 0)                                                                                     \
+        READ_SC0_                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                     \
+        MFMA_(dma0, t + 1, wr)                                                                             \
+        __builtin_amdgcn_s_setprio(0);                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        MX_READ(rd, 1)                                                                                     \
+        READ_SC1_                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+        if (grp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (grp == 1) __builtin_amdgcn_s_barrier();       /* R_{t+1} of group 1: buffer rd is free from here on */ \
+        __builtin_amdgcn_s_setprio(1);                                                                     \
+        MFMA_(dma1, t + 2, rd)                                                                             \
+        __builtin_amdgcn_s_setprio(0);                                                                     \
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        rd = wr;                                                                                           \
+    }
+    uint32_t rd = 0;
+    int t = 0;
+    for (; t < nmx; ++t) {
+        uint2 sa, sb;
+        MX_STAGE(MX_READ_SC(rd, 0), MX_READ_SC(rd, 1), MX_MFMA_FP4)
+    }
+    for (; t < nst; ++t) MX_STAGE(, , MX_MFMA_F16)
+#undef MX_STAGE
+    if (grp == 0) __builtin_amdgcn_s_barrier();            // both groups: same barrier count; every ring read is done
+
+    {   // epilogues of gemm_et_x64_kernel (NI = 5)
+        if constexpr (!OUT_F32) {
+            epilogue_pair_et<PREC, false>(acc, reinterpret_cast<unsigned char*>(lds), Cv, bias, nullptr, 1, N, m0 + wm * 128,
+                                          n0 + (wn >> 1) * 160, wm, wn, lane);
+        } else {
+            unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (2 * XSB / 8);
+            epilogue_coalesced<PREC, true, false, 8, 2, NI>(acc, scr, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + wn * (16 * NI),
+                                                           accumulate, lane, nullptr);
+        }
+    }
+#undef MX_PIECE
+#undef MX_SCALES
+#undef MX_ISSUE
+#undef MX_READ
+#undef MX_READ_SC
+#undef MX_DMA_AFTER
+#undef MX_MFMA_F16
+#undef MX_ROW
+#undef MX_MFMA_FP4
+}
+
+// One (row, 32-k' block) per 8 lanes, 4 elements per lane.  Source: fp32 x (SRC_F32: hi = ET(x), lo = x - hi; also writes the ET
+// copy when out_hi is given) or the ET pair (hi, lo) an existing producer wrote.  k' = padded index: group g = k' / GP holds the
+// G source elements g G .. g G + G - 1 followed by GP - G zeros.
+template <int PREC, bool SRC_F32>
+__global__ __launch_bounds__(256) void mx4_pack_kernel(const float* __restrict__ x, const uint16_t* __restrict__ hi_in,
+                                                       const uint16_t* __restrict__ lo_in, uint16_t* __restrict__ out_hi,
+                                                       unsigned char* __restrict__ q_hi, unsigned char* __restrict__ q_lo,
+                                                       unsigned char* __restrict__ s_hi, unsigned char* __restrict__ s_lo,
+                                                       int rows, int K, int G, int GP, int is_b) {
+    const int Kp = (K / G) * GP, nblk = Kp / 32, nst4 = Kp / MXK;
+    const long item = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;           // (row, block)
+    const int sub = threadIdx.x & 7;
+    if (item >= (long)rows * nblk) return;
+    const int r = (int)(item / nblk), b = (int)(item % nblk);
+    const int kp = b * 32 + sub * 4, g = kp / GP, off = kp % GP;            // GP % 4 == 0 and G % 4 == 0: a lane's 4 elements share a fate
+    float h[4] = {0.f, 0.f, 0.f, 0.f}, l[4] = {0.f, 0.f, 0.f, 0.f};
+    if (off < G) {
+        const size_t src = (size_t)r * K + (size_t)g * G + off;
+        if constexpr (SRC_F32) {
+            const float4 v = *reinterpret_cast<const float4*>(x + src);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            uint2 hb;
+            hb.x = pack2<PREC>(vv[0], vv[1]); hb.y = pack2<PREC>(vv[2], vv[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = ET<PREC>::to_float((uint16_t)(((e & 2) ? hb.y : hb.x) >> (16 * (e & 1))));
+                l[e] = vv[e] - h[e];
+            }
+            if (out_hi) *reinterpret_cast<uint2*>(out_hi + src) = hb;
+        } else {
+            const uint2 hb = *reinterpret_cast<const uint2*>(hi_in + src), lb = *reinterpret_cast<const uint2*>(lo_in + src);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[e] = ET<PREC>::to_float((uint16_t)(((e & 2) ? hb.y : hb.x) >> (16 * (e & 1))));
+                l[e] = ET<PREC>::to_float((uint16_t)(((e & 2) ? lb.y : lb.x) >> (16 * (e & 1))));
+            }
+        }
+    }
+    float ah = fmaxf(fmaxf(fabsf(h[0]), fabsf(h[1])), fmaxf(fabsf(h[2]), fabsf(h[3])));
+    float al = fmaxf(fmaxf(fabsf(l[0]), fabsf(l[1])), fmaxf(fabsf(l[2]), fabsf(l[3])));
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { ah = fmaxf(ah, __shfl_xor(ah, o, 64)); al = fmaxf(al, __shfl_xor(al, o, 64)); }
+    const int bh = mx_scale_byte(ah), bl = mx_scale_byte(al);
+    const float ih = mx_inv_scale(bh), il = mx_inv_scale(bl);
+    uint32_t ch = 0, cl = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ch |= fp4_code(h[e] * ih) << (4 * e); cl |= fp4_code(l[e] * il) << (4 * e); }
+    const size_t dst = (size_t)r * (Kp / 2) + (size_t)b * 16 + sub * 2;
+    *reinterpret_cast<uint16_t*>(q_hi + dst) = (uint16_t)ch;
+    *reinterpret_cast<uint16_t*>(q_lo + dst) = (uint16_t)cl;
+    if (sub == 0) {
+        const size_t si = mx_scale_index(is_b != 0, r, b, nst4);
+        s_hi[si] = (unsigned char)bh;
+        s_lo[si] = (unsigned char)bl;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const float* bias,
@@ -2713,4 +3018,57 @@ hipError_t launch_gemm_et_gln(int prec, const void* A, const void* B, void* C, c
     if (prec == PREC_BF16) return launch_gemm_dual_gln<PREC_BF16>(A, B, C, bias, gamma_beta, M, N, K, s, A_lo, B_lo);
     if (prec == PREC_F16) return launch_gemm_dual_gln<PREC_F16>(A, B, C, bias, gamma_beta, M, N, K, s, A_lo, B_lo);
     return hipErrorInvalidValue;
+}
+
+
+// ---- MXFP4 lo-term GEMM (gemm_et_mx_kernel) ----------------------------------------------------------------------------------
+bool gemm_mx_ok(int M, int N, int K, int Kp) {
+    return M > 0 && N > 0 && K > 0 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0 && Kp > 0 && Kp % MXK == 0;
+}
+size_t mx_scale_bytes(int rows, int Kp, bool is_b) {
+    return is_b ? (size_t)((rows + 319) / 320) * (Kp / MXK) * MX_SB_BYTES : (size_t)((rows + 255) / 256) * (Kp / MXK) * MX_SA_BYTES;
+}
+hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int Kp,
+                             const void* a4_lo, const void* a4_hi, const void* sa_lo, const void* sa_hi,
+                             const void* b4_hi, const void* b4_lo, const void* sb_hi, const void* sb_lo,
+                             bool out_f32, bool accumulate, int split_from_n, hipStream_t s) {
+    if (!gemm_mx_ok(M, N, K, Kp) || !A || !B || !C || !a4_lo || !a4_hi || !sa_lo || !sa_hi || !b4_hi || !b4_lo || !sb_hi || !sb_lo)
+        return hipErrorInvalidValue;
+    if ((accumulate && !out_f32) || split_from_n < 0 || split_from_n % WBN || (split_from_n && out_f32)) return hipErrorInvalidValue;
+    MxOperands mx;
+    mx.a4_lo = (const unsigned char*)a4_lo; mx.a4_hi = (const unsigned char*)a4_hi;
+    mx.b4_hi = (const unsigned char*)b4_hi; mx.b4_lo = (const unsigned char*)b4_lo;
+    mx.sa_lo = (const unsigned char*)sa_lo; mx.sa_hi = (const unsigned char*)sa_hi;
+    mx.sb_hi = (const unsigned char*)sb_hi; mx.sb_lo = (const unsigned char*)sb_lo;
+    mx.Kp = Kp; mx.split_from_n = split_from_n;
+    const dim3 grid((M / QBM) * (N / WBN)), block(QTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (prec == PREC_F16) {
+        if (out_f32) gemm_et_mx_kernel<PREC_F16, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);
+        else gemm_et_mx_kernel<PREC_F16, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);
+    } else if (prec == PREC_BF16) {
+        if (out_f32) gemm_et_mx_kernel<PREC_BF16, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);
+        else gemm_et_mx_kernel<PREC_BF16, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);
+    } else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// fp32 [rows][K] (x) or the ET pair (hi_in, lo_in) -> fp4 hi / lo [rows][Kp / 2] + their scale tiles; Kp = K / G * GP
+hipError_t launch_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo_in, void* out_hi, void* q_hi, void* q_lo,
+                           void* s_hi, void* s_lo, int rows, int K, int G, int GP, bool is_b, hipStream_t s) {
+    if (rows <= 0 || K <= 0 || G <= 0 || K % G || G % 4 || GP % 32 || GP < G || ((K / G) * GP) % MXK) return hipErrorInvalidValue;
+    if (!x && !(hi_in && lo_in)) return hipErrorInvalidValue;
+    const long items = (long)rows * ((K / G) * GP / 32);
+    const dim3 grid((unsigned)((items * 8 + 255) / 256)), block(256);
+    const uint16_t* hi = reinterpret_cast<const uint16_t*>(hi_in);
+    const uint16_t* lo = reinterpret_cast<const uint16_t*>(lo_in);
+#define MXP(P_, F_) mx4_pack_kernel<P_, F_><<<grid, block, 0, s>>>(x, hi, lo, (uint16_t*)out_hi, (unsigned char*)q_hi, (unsigned char*)q_lo, \
+                                                                  (unsigned char*)s_hi, (unsigned char*)s_lo, rows, K, G, GP, is_b ? 1 : 0)
+    if (prec == PREC_F16) { if (x) MXP(PREC_F16, true); else MXP(PREC_F16, false); }
+    else if (prec == PREC_BF16) { if (x) MXP(PREC_BF16, true); else MXP(PREC_BF16, false); }
+    else return hipErrorInvalidValue;
+#undef MXP
+    return hipGetLastError();
 }

@@ -58,7 +58,10 @@ hipError_t launch_rowstats_convert(int prec, const float* X, void* Xh, float* st
 hipError_t launch_ln_rowstat(const float* stats, float* rowstat, int rows, float eps, hipStream_t s);
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
-                            int window, hipStream_t s, void* out_lo = nullptr);
+                            int window, hipStream_t s, void* out_lo = nullptr,
+                            // optional (plain row order, D % 256 == 0): the output's hi / lo as MXFP4 codes [rows][D / 2] + scale tiles
+                            // (the A operands of launch_gemm_et_mx: no ET lo copy, no separate pack pass)
+                            void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr);
 // out_lo (optional, both attention kernels): the split remainder of `out` (reference-grade mode: proj on hi + lo operands)
 hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
                                    int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo = nullptr);
@@ -135,6 +138,23 @@ hipError_t launch_i2t_fused(int prec, const void* qi, int ld, long q_bstride, co
                             const void* w_lo /* null: un-split out-projection */, const float* bias, const float* resid,
                             long r_bstride, const float* gamma, const float* beta, float eps, float* outF, void* outE,
                             void* outE_lo /* optional split remainder of outE */, int n, int T, int tokens, int Ci, int C, hipStream_t s);
+
+// ---- gemm.hip: operand split with the two correction terms on MXFP4 operands (gemm_et_mx_kernel) ------------------------------
+// C = A B^T (f16 segment, K) + A4lo B4hi^T + A4hi B4lo^T (block-scaled fp4 segments over the padded K axis Kp) + bias.
+// a4_* [M][Kp / 2], b4_* [N][Kp / 2] bytes and their scale tiles come from launch_mx4_pack (sizes: mx_scale_bytes).  ET output
+// rounded once from the fp32 accumulators, or fp32 output (optionally accumulated into C).  M % 256 == 0, N % 320 == 0,
+// K % 64 == 0, Kp % 256 == 0.  split_from_n (ET outputs, a multiple of 320): columns below it take no lo terms.
+bool gemm_mx_ok(int M, int N, int K, int Kp);
+size_t mx_scale_bytes(int rows, int Kp, bool is_b);
+hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int Kp,
+                             const void* a4_lo, const void* a4_hi, const void* sa_lo, const void* sa_hi,
+                             const void* b4_hi, const void* b4_lo, const void* sb_hi, const void* sb_lo,
+                             bool out_f32, bool accumulate, int split_from_n, hipStream_t s);
+// x (fp32 [rows][K]) or the ET pair (hi_in, lo_in) -> fp4 codes of hi and lo [rows][Kp / 2] + E8M0 scale tiles (A layout, or the
+// B layout when is_b); optional out_hi = ET(x).  Padded axis: every group of G source elements becomes GP (zeros behind it);
+// Kp = K / G * GP must be a multiple of 256.  Plain: G = GP = K.
+hipError_t launch_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo_in, void* out_hi, void* q_hi, void* q_lo,
+                           void* s_hi, void* s_lo, int rows, int K, int G, int GP, bool is_b, hipStream_t s);
 
 // ---- upscaler_fused.hip ---------------------------------------------------------------------
 // mask_decoder.py:53-59,154-167 in one kernel: keys [n * grid^2][256] ET -> ConvT #1 + LayerNorm2d + GELU -> ConvT #2 + GELU ->

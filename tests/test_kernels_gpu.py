@@ -862,3 +862,152 @@ def test_device_resize_is_bit_exact_with_pil(lib, hw):
     ref = np.array(Image.fromarray(img).resize((nw, nh), Image.BILINEAR)) if (nh, nw) != hw else img
     got = t.apply_image_device(torch.as_tensor(img).cuda()).cpu().numpy()
     assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# round 4: the operand split's correction terms on MXFP4 operands (gemm_et_mx_kernel, mx4_pack_kernel, LayerNorm's MX outputs)
+# ------------------------------------------------------------------------------------------------------------------------------
+def _mx_pad(x, G, GP):
+    """[rows][K] -> [rows][K / G * GP]: every group of G elements followed by GP - G zeros (the per-head padded K axis)."""
+    rows, K = x.shape
+    out = torch.zeros(rows, K // G, GP, dtype=x.dtype)
+    out[:, :, :G] = x.reshape(rows, K // G, G)
+    return out.reshape(rows, K // G * GP)
+
+
+def _mx_pack(lib, prec, x, G, GP, is_b):
+    """samrs_k_mx4_pack on fp32 x: (hi ET bits [rows][K], q_hi, q_lo [rows][Kp / 2] u8, s_hi, s_lo scale tiles) on the device."""
+    rows, K = x.shape
+    Kp = K // G * GP
+    hi = torch.zeros(rows, K, dtype=torch.int16, device="cuda")
+    q = [torch.zeros(rows, Kp // 2, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    nb = int(lib.samrs_k_mx_scale_bytes(rows, Kp, int(is_b)))
+    sc = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    xd = dev(x)
+    assert lib.samrs_k_mx4_pack(prec, xd.data_ptr(), None, None, hi.data_ptr(), q[0].data_ptr(), q[1].data_ptr(), sc[0].data_ptr(),
+                                sc[1].data_ptr(), rows, K, G, GP, int(is_b), stream()) == 0
+    return hi, q, sc
+
+
+def _mx_decode(q, s, rows, Kp, is_b):
+    """Host inverse of the packed format (codes + tiled scales -> fp64 values [rows][Kp]): pins the data AND the scale-tile layout."""
+    E2M1 = torch.tensor([0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0], dtype=torch.float64)
+    qb = q.cpu().to(torch.int64)
+    nib = torch.stack([qb & 15, qb >> 4], dim=-1).reshape(rows, Kp)              # element 2 i = low nibble of byte i
+    val = E2M1[nib & 7] * torch.where((nib & 8) != 0, -1.0, 1.0)
+    sb = s.cpu().to(torch.int64)
+    r = torch.arange(rows)[:, None]
+    b = torch.arange(Kp // 32)[None, :]
+    st, kh, fq = b >> 3, (b >> 2) & 1, b & 3
+    nst4 = Kp // 256
+    if not is_b:
+        idx = ((r >> 8) * nst4 + st) * 2048 + ((kh * 2 + ((r >> 7) & 1)) * 64 + fq * 16 + (r & 15)) * 8 + ((r >> 4) & 7)
+    else:
+        rr = r % 320
+        idx = ((r // 320) * nst4 + st) * 4096 + ((kh * 4 + rr // 80) * 64 + fq * 16 + (rr & 15)) * 8 + ((rr % 80) >> 4)
+    scale = torch.pow(2.0, (sb[idx] - 127).double())                            # [rows][Kp / 32]
+    return val * scale.repeat_interleave(32, dim=1)
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("G,GP", [(1280, 1280), (80, 96)])
+def test_mx4_pack_matches_the_oracle_quantiser(lib, name, prec, dt, ulp, G, GP):
+    """mx4_pack_kernel against oracle/sam_oracle.py split_fp8_lo(fmt="e2m1", block=32)._q8 -- the emulation the error budget was
+    run with (plans9 / plans10) -- for hi = ET(x) and lo = x - hi, plain and per-head padded K axis, A- and B-operand scale tiles:
+    every decoded value identical."""
+    from oracle import sam_oracle as so
+    g = torch.Generator().manual_seed(5 + G)
+    K = 1280
+    for rows, is_b in ((512, False), (640, True)):
+        x = torch.randn(rows, K, generator=g) * torch.exp(torch.randn(rows, K, generator=g))       # a wide magnitude range per block
+        x[3, 64:96] = 0.0                                                                           # an all-zero block
+        hi_bits, q, sc = _mx_pack(lib, prec, x, G, GP, is_b)
+        hi = x.to(dt).to(torch.float32)
+        assert torch.equal(hi_bits.cpu().view(dt).to(torch.float32), hi)
+        q4 = so.split_fp8_lo(dt, fmt="e2m1", block=32)
+        Kp = K // G * GP
+        for h, src in ((0, hi), (1, x - hi)):
+            want = q4._q8(_mx_pad(src, G, GP).double())      # fp64: floor(log2(amax)) exact next to powers of two
+            got = _mx_decode(q[h], sc[h], rows, Kp, is_b)
+            bad = (got != want)
+            assert not bad.any(), f"{name} G={G} is_b={is_b} {'lo' if h else 'hi'}: {int(bad.sum())} of {bad.numel()} values differ"
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("G,GP,out_f32,from_n", [(1280, 1280, 1, 0), (80, 96, 1, 0), (1280, 1280, 0, 0), (1280, 1280, 0, 320)])
+def test_gemm_mx_lo_terms(lib, name, prec, dt, ulp, G, GP, out_f32, from_n):
+    """gemm_et_mx_kernel: C = A_hi B_hi^T + q4(A_lo) q4(B_hi)^T + q4(A_hi) q4(B_lo)^T + bias, the two correction terms on gfx950's
+    block-scaled fp4 MFMA.  (i) against the fp64 evaluation of exactly that expression (the oracle's emulation, decoded from the
+    kernel's own packed operands): fp32 accumulation noise only; (ii) against the fp64 product of the UN-rounded operands: the
+    error of a plain f16 GEMM cut by more than 3x (oracle/error_budget.py: 2.9e-4 -> 5.2e-5); (iii) fp32 output accumulates into
+    C, ET output is rounded once; split_from_n: the tiles in front of it are the plain product, bit for bit."""
+    g = torch.Generator().manual_seed(21 + GP + out_f32 + from_n)
+    M, N, K = 512, 640, 1280
+    A = torch.randn(M, K, generator=g)
+    B = (torch.rand(N, K, generator=g) * 2 - 1) / math.sqrt(K)
+    bias = torch.randn(N, generator=g) * 0.5
+    Ah, qa, sa = _mx_pack(lib, prec, A, G, GP, False)
+    Bh, qb, sb = _mx_pack(lib, prec, B, G, GP, True)
+    Kp = K // G * GP
+    ah, bh = A.to(dt).double(), B.to(dt).double()
+    emul = (ah @ bh.t() + _mx_decode(qa[1], sa[1], M, Kp, False) @ _mx_decode(qb[0], sb[0], N, Kp, True).t()
+            + _mx_decode(qa[0], sa[0], M, Kp, False) @ _mx_decode(qb[1], sb[1], N, Kp, True).t() + bias.double())
+    exact = A.double() @ B.double().t() + bias.double()
+    plain = ah @ bh.t() + bias.double()
+    args = (qa[1].data_ptr(), qa[0].data_ptr(), sa[1].data_ptr(), sa[0].data_ptr(), qb[0].data_ptr(), qb[1].data_ptr(), sb[0].data_ptr(), sb[1].data_ptr())
+    if out_f32:
+        res = torch.randn(M, N, generator=g)
+        out = dev(res.clone())
+        assert lib.samrs_k_gemm_mx(prec, Ah.data_ptr(), Bh.data_ptr(), out.data_ptr(), dev(bias).data_ptr(), M, N, K, Kp, *args, 1, 1, 0, stream()) == 0
+        got = out.cpu().double() - res.double()
+        e_emul = ((got - emul).norm() / emul.norm()).item()
+        e_exact, e_plain = ((got - exact).norm() / exact.norm()).item(), ((plain - exact).norm() / exact.norm()).item()
+        print(f"gemm_mx {name} G={G}->{GP} fp32 out: vs emulation {e_emul:.2e}; vs exact {e_exact:.2e} (plain {name} GEMM: {e_plain:.2e})")
+        assert e_emul < 2e-6
+        assert e_exact < 0.3 * e_plain
+    else:
+        out = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+        assert lib.samrs_k_gemm_mx(prec, Ah.data_ptr(), Bh.data_ptr(), out.data_ptr(), dev(bias).data_ptr(), M, N, K, Kp, *args, 0, 0, from_n, stream()) == 0
+        got = out.cpu().view(dt).double()
+        want = emul.clone()
+        want[:, :from_n] = plain[:, :from_n]
+        err = ((got - want).abs() / want.abs().clamp(min=1.0)).max().item()
+        print(f"gemm_mx {name} ET out, split_from_n={from_n}: max err vs emulation {err:.2e} (operand ulp {ulp:.1e})")
+        assert err < 0.51 * ulp
+        if from_n:
+            ref = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+            assert lib.samrs_k_gemm(prec, Ah.data_ptr(), Bh.data_ptr(), ref.data_ptr(), dev(bias).data_ptr(), None, 0, M, N, K, 0, 0, 0, stream()) == 0
+            assert torch.equal(out.cpu()[:, :from_n], ref.cpu()[:, :from_n])
+            assert not torch.equal(out.cpu()[:, from_n:], ref.cpu()[:, from_n:])
+    # race screen (two wave groups half a stage apart, DMA pieces of two stage kinds in flight): run-to-run identical
+    first = out.clone()
+    for _ in range(8):
+        if out_f32:
+            out.copy_(dev(res))
+        assert lib.samrs_k_gemm_mx(prec, Ah.data_ptr(), Bh.data_ptr(), out.data_ptr(), dev(bias).data_ptr(), M, N, K, Kp, *args, out_f32, out_f32, from_n, stream()) == 0
+        assert torch.equal(out, first)
+    assert lib.samrs_k_gemm_mx(prec, Ah.data_ptr(), Bh.data_ptr(), out.data_ptr(), dev(bias).data_ptr(), M, N + 64, K, Kp, *args, out_f32, 0, 0, stream()) != 0
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_layernorm_mx_outputs_equal_the_pack_kernel(lib, name, prec, dt, ulp):
+    """The LayerNorm's own MXFP4 outputs (what the engine feeds the qkv GEMM in lo_format 4) == samrs_k_mx4_pack of the fp32
+    LayerNorm output, byte for byte (codes and scale tiles), and its ET output is unchanged."""
+    g = torch.Generator().manual_seed(9)
+    rows, D = 768, 1280
+    x = torch.randn(rows, D, generator=g) * 3 + 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(D, generator=g), 0.05 * torch.randn(D, generator=g)
+    xd, gd, bd = dev(x), dev(gamma), dev(beta)
+    et = torch.zeros(rows, D, dtype=torch.int16, device="cuda")
+    f32 = torch.zeros(rows, D, dtype=torch.float32, device="cuda")
+    assert lib.samrs_k_layernorm(prec, xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-6, et.data_ptr(), f32.data_ptr(), rows, D, 0, 1, 64, 14, stream()) == 0
+    hi, q, sc = _mx_pack(lib, prec, f32.cpu(), D, D, False)
+    et2 = torch.zeros_like(et)
+    q2 = [torch.zeros_like(t) for t in q]
+    s2 = [torch.zeros_like(t) for t in sc]
+    assert lib.samrs_k_layernorm_mx(prec, xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-6, et2.data_ptr(), rows, D, q2[0].data_ptr(),
+                                    q2[1].data_ptr(), s2[0].data_ptr(), s2[1].data_ptr(), stream()) == 0
+    assert torch.equal(et2, et) and torch.equal(hi, et)
+    for h in range(2):
+        assert torch.equal(q2[h], q[h]), f"{'lo' if h else 'hi'} codes differ"
+        assert torch.equal(s2[h], sc[h])

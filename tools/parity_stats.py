@@ -17,7 +17,7 @@ ap.add_argument("--model", default="vit_h")
 ap.add_argument("--create-split", type=int, default=127, help="the split mask the engine is created with (lo weight copies)")
 ap.add_argument("--out", default="gpurun_out/parity_stats.json")
 a = ap.parse_args()
-modes = [int(m) for m in a.modes.split(",")]
+modes = [int(m) if m.isdigit() else m for m in a.modes.split(",")]      # "79" or "79:4" = split 79 with lo_format 4
 torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))
 cfg = synth.CONFIGS[a.model]
 sd = synth.make_state_dict(cfg, 0, logit_scale=synth.MARGIN_LOGIT_SCALE)

@@ -1,0 +1,91 @@
+"""TEST INFRASTRUCTURE ONLY -- the downstream consumer of the generated labels (BASELINE.json configs[4]).
+
+What it restates, from ``Pretraining and Finetuning/End_to_End`` of the reference:
+  datasets.py:185-232   ``SegmentationDataset.__init__``: ``root/train.txt`` / ``valid.txt`` list the stems; image =
+                        ``image_path/<stem><ext_img>``, label = ``label_path/<stem><ext_lbl>`` -- for SAMRS the label path is the
+                        generation driver's ``.../hbox_segs_init/gray/`` directory (main_pretrain.py:186-190);
+  datasets.py:247-273   ``__getitem__``: ``np.array(Image.open(img))``, ``np.array(Image.open(lbl))`` -> normalised CHW float
+                        tensor + HxW label tensor (the albumentations pipeline in between is an identity here: albumentations /
+                        torchvision cannot be installed, and the check is about the FILE CONTRACT, not the augmentation);
+  main_pretrain.py:206-208  ``DistributedSampler(dataset, num_replicas=world, rank=rank)``;
+  main_pretrain.py:60,321   ``nn.CrossEntropyLoss(ignore_index=255)`` over ``classes1 = 18`` logits (:183): every label value
+                        must be a class id below the class count or exactly 255.
+The UperNet / ViT backbone itself (mmseg, mmengine, timm: not installable, profiles/r02_optional_install_attempt.log) is replaced
+by a one-layer per-pixel classifier: what is exercised is that the files ``python -m samrs_amd.generate`` writes load, shard,
+batch and train through the reference's read path under DDP -- a loss that is finite, ignores the unlabeled pixels and gives
+every rank the same averaged gradient.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Tuple
+
+import numpy as np
+import torch
+from PIL import Image
+
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)      # timm.data.constants, used by datasets.py:238
+IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+IGNORE_LABEL = 255                                  # main_pretrain.py:60
+
+
+class SegmentationDataset(torch.utils.data.Dataset):
+    """datasets.py:181-273 without the augmentation pipeline."""
+
+    def __init__(self, root: str, image_path: str, label_path: str, ext_img: str = ".png", ext_lbl: str = ".png", flag: str = "trn"):
+        def read(name):
+            with open(os.path.join(root, name)) as f:
+                return [l.strip() for l in f.readlines()]                          # :189-190, :205-206
+        trn, val = read("train.txt"), read("valid.txt")
+        stems = {"trn": trn, "val": val[-500:], "tes": val}[flag]                  # :219-227
+        self.files = [os.path.join(image_path, s + ext_img) for s in stems]        # :198
+        self.targets = [os.path.join(label_path, s + ext_lbl) for s in stems]      # :199
+
+    def __len__(self) -> int:
+        return len(self.targets)
+
+    def __getitem__(self, i: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        image = np.array(Image.open(self.files[i]))                                # :250
+        label = np.array(Image.open(self.targets[i]))                              # :251
+        if image.ndim != 3 or image.shape[2] != 3 or label.ndim != 2 or label.shape != image.shape[:2] or label.dtype != np.uint8:
+            raise ValueError(f"{self.targets[i]}: not an 8-bit single-channel label map of the image's size")
+        x = torch.from_numpy(image.astype(np.float32) / 255.0).permute(2, 0, 1)    # ToTensor (:236)
+        x = (x - torch.tensor(IMAGENET_DEFAULT_MEAN)[:, None, None]) / torch.tensor(IMAGENET_DEFAULT_STD)[:, None, None]   # :237
+        return x, torch.from_numpy(label)                                          # :256
+
+
+def train_steps(dataset: SegmentationDataset, n_classes: int, rank: int, world: int, steps: int = 2, batch_size: int = 2, seed: int = 0):
+    """A DDP training loop in miniature over the reference's sampler + loss.  Returns (losses, flattened weight after the steps,
+    indices this rank drew, label histogram this rank saw)."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    torch.manual_seed(seed)
+    model = torch.nn.Conv2d(3, n_classes, kernel_size=1)                           # stands in for UperNet-ViT-B (not installable)
+    ddp = DDP(model) if (dist.is_available() and dist.is_initialized() and world > 1) else model
+    sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=False)      # main_pretrain.py:206
+    loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=0, drop_last=False)
+    criterion = torch.nn.CrossEntropyLoss(ignore_index=IGNORE_LABEL)               # main_pretrain.py:321
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.1)
+    losses: List[float] = []
+    hist = np.zeros(256, dtype=np.int64)
+    drawn = list(iter(sampler))
+    it = iter(loader)
+    for _ in range(steps):
+        try:
+            x, y = next(it)
+        except StopIteration:
+            it = iter(loader)
+            x, y = next(it)
+        bad = (y != IGNORE_LABEL) & (y >= n_classes)
+        if bool(bad.any()):
+            raise ValueError(f"label values outside 0..{n_classes - 1} and != {IGNORE_LABEL}: {torch.unique(y[bad]).tolist()}")
+        hist += np.bincount(y.numpy().ravel(), minlength=256)
+        opt.zero_grad()
+        loss = criterion(ddp(x), y.long())                                         # the training scripts call .long() on the target
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    w = torch.cat([p.detach().flatten() for p in model.parameters()])
+    return losses, w, drawn, hist

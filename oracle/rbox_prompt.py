@@ -20,7 +20,10 @@ horizontal pass then vertical pass).  They could not be checked against cv2 here
   * the resize against torch F.interpolate(bilinear, align_corners=False) in float64 (same sampling rule;
     cv2 rounds the two tap weights to float32, so agreement is ~1e-4 on the +-1000 range),
   * the polygon fill against a brute-force even-odd / on-boundary rule on random convex quads
-    (tests/test_rbox_prompt.py).
+    (tests/test_rbox_prompt.py),
+  * round 4: both against hand-derived known answers of the published rules (tests/golden/opencv_known_answers.json:
+    inclusive rectangle, 45-degree diamond, degenerate slivers, clipping, a 45-degree hypotenuse; INTER_LINEAR up- and
+    down-scaling with clamped ends) -- tests/test_rbox_prompt.py::test_fill_poly_and_resize_known_answers.
 One known deviation is documented in `line8`: cv2 clips a boundary line to the image before walking it.
 """
 from __future__ import annotations

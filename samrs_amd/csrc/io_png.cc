@@ -10,8 +10,10 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace {
@@ -290,6 +292,245 @@ int encode(const char* path, const uint8_t* src, int h, int w, size_t stride, in
     return rc;
 }
 
+// ---- label-aware encoder (SAMRS_IO_LEVEL_LABELS) -------------------------------------------------------------------------------
+// A class map is piecewise constant, and the colour image of the reference (`seg_color`, main_sam_hbox_semantic.py:163,199) is the
+// class map seen through a palette: pixel (y, x) repeats its left neighbour or the pixel above it wherever the LABEL does.  zlib
+// has to rediscover that byte by byte (hash chains over 3 MiB of RGB: 40 - 60 ms per 1024^2 tile at level 6 on noise-like maps,
+// the dominant host cost of the generation CLI); here the LZ77 parse is done on the 1-byte label map and written out as deflate
+// tokens of the RGB stream: a run of labels equal to the row above = one match at distance (row bytes + 1), a run equal to the
+// left neighbour = one match at distance (bytes per pixel), anything else = the pixel's literal bytes.  All rows use PNG filter 0
+// (none), one dynamic-Huffman deflate block per <= 2^20 tokens; the file is a plain PNG any reader decodes to the same pixels.
+
+struct BitWriter {
+    std::vector<uint8_t>* out;
+    uint64_t acc = 0;
+    int n = 0;
+    void put(uint32_t v, int bits) {               // LSB first
+        acc |= uint64_t(v) << n;
+        n += bits;
+        while (n >= 8) { out->push_back(uint8_t(acc)); acc >>= 8; n -= 8; }
+    }
+    void flush() { if (n > 0) { out->push_back(uint8_t(acc)); acc = 0; n = 0; } }
+};
+
+// code lengths (<= maxbits) of a Huffman code for freq[0 .. n): plain Huffman; if the tree is too deep the counts are flattened
+// (halved, rounding up) and the tree rebuilt -- converges in a few rounds, costs a fraction of a percent of size when it triggers
+void huffman_lengths(const uint32_t* freq, int n, int maxbits, uint8_t* len) {
+    std::vector<uint32_t> f(freq, freq + n);
+    for (;;) {
+        struct Node { uint64_t w; int l, r; };
+        std::vector<Node> nodes;
+        std::vector<int> heap;
+        for (int i = 0; i < n; ++i) if (f[i]) { nodes.push_back({f[i], -1 - i, 0}); heap.push_back(int(nodes.size()) - 1); }
+        for (int i = 0; i < n; ++i) len[i] = 0;
+        if (heap.empty()) return;
+        if (heap.size() == 1) { len[-1 - nodes[heap[0]].l] = 1; return; }
+        auto cmp = [&](int a, int b) { return nodes[a].w > nodes[b].w || (nodes[a].w == nodes[b].w && a > b); };
+        std::make_heap(heap.begin(), heap.end(), cmp);
+        while (heap.size() > 1) {
+            std::pop_heap(heap.begin(), heap.end(), cmp); int a = heap.back(); heap.pop_back();
+            std::pop_heap(heap.begin(), heap.end(), cmp); int b = heap.back(); heap.pop_back();
+            nodes.push_back({nodes[a].w + nodes[b].w, a, b});
+            heap.push_back(int(nodes.size()) - 1);
+            std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+        int deepest = 0;
+        std::vector<std::pair<int, int>> stack{{heap[0], 0}};
+        while (!stack.empty()) {
+            auto [id, d] = stack.back(); stack.pop_back();
+            if (nodes[id].l < 0) { len[-1 - nodes[id].l] = uint8_t(d < 255 ? d : 255); if (d > deepest) deepest = d; }
+            else { stack.push_back({nodes[id].l, d + 1}); stack.push_back({nodes[id].r, d + 1}); }
+        }
+        if (deepest <= maxbits) return;
+        for (int i = 0; i < n; ++i) if (f[i]) f[i] = (f[i] + 1) / 2;
+    }
+}
+
+// canonical codes, bit-reversed for the LSB-first writer
+void canonical_codes(const uint8_t* len, int n, uint16_t* code) {
+    int count[16] = {0}, next[16] = {0};
+    for (int i = 0; i < n; ++i) count[len[i]]++;
+    count[0] = 0;
+    int c = 0;
+    for (int b = 1; b < 16; ++b) { c = (c + count[b - 1]) << 1; next[b] = c; }
+    for (int i = 0; i < n; ++i) {
+        if (!len[i]) { code[i] = 0; continue; }
+        unsigned v = unsigned(next[len[i]]++), r = 0;
+        for (int b = 0; b < len[i]; ++b) { r = (r << 1) | (v & 1); v >>= 1; }
+        code[i] = uint16_t(r);
+    }
+}
+
+const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+struct LenCode { uint16_t sym; uint8_t ebits; uint16_t eval; };
+inline LenCode len_code(int len) {                 // 3 .. 258
+    static uint8_t table[259];
+    static bool init = false;
+    if (!init) { for (int c = 0; c < 29; ++c) for (int l = kLenBase[c]; l <= (c == 28 ? 258 : kLenBase[c + 1] - 1) && l <= 258; ++l) table[l] = uint8_t(c); table[258] = 28; init = true; }
+    const int c = table[len];
+    return {uint16_t(257 + c), kLenExtra[c], uint16_t(len - kLenBase[c])};
+}
+inline void dist_code(int dist, int* sym, int* ebits, int* eval) {
+    int c = 29;
+    while (kDistBase[c] > dist) --c;
+    *sym = c; *ebits = kDistExtra[c]; *eval = dist - kDistBase[c];
+}
+
+// token: bit 31 = match; match: bits 0-8 = length (3 .. 258), bit 16 = 1 for the "up" distance (0 = "left"); literal: bits 0-7
+int encode_labels(const char* path, const uint8_t* src, int h, int w, size_t stride, const uint8_t* lut) {
+    if (!path || !src || h <= 0 || w <= 0 || uint32_t(h) > kMaxSide || uint32_t(w) > kMaxSide) return SAMRS_IO_ESIZE;
+    const int bpp = lut ? 3 : 1;
+    if (stride < size_t(w)) return SAMRS_IO_ESIZE;
+    const size_t row = size_t(w) * bpp;
+    const int d_left = bpp, d_up = int(row) + 1;
+    const bool up_ok = d_up <= 32768;
+    const int max_px = 258 / bpp;                  // pixels per match token
+    const int min_px = bpp == 1 ? 3 : 1;           // deflate's shortest match is 3 bytes
+    std::vector<uint32_t> tok;
+    std::vector<uint8_t> out;
+    try { tok.reserve(size_t(h) * 64 + 1024); out.reserve(size_t(h) * 64 + 4096); } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
+    uLong adler = adler32(0L, Z_NULL, 0);
+    std::vector<uint8_t> rowbuf;
+    try { rowbuf.resize(row + 1); } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
+    try {
+        for (int y = 0; y < h; ++y) {
+            const uint8_t* g = src + size_t(y) * stride;
+            const uint8_t* up = (y > 0 && up_ok) ? g - stride : nullptr;
+            // the raw (filter 0) row, only for the zlib checksum
+            rowbuf[0] = 0;
+            if (lut) for (int x = 0; x < w; ++x) { const uint8_t* c = lut + 3 * g[x]; uint8_t* d = &rowbuf[1 + 3 * size_t(x)]; d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; }
+            else memcpy(&rowbuf[1], g, size_t(w));
+            adler = adler32(adler, rowbuf.data(), uInt(row + 1));
+            tok.push_back(0);                      // the filter-type byte
+            int x = 0;
+            while (x < w) {
+                int lu = 0, ll = 0;
+                if (up) while (x + lu < w && g[x + lu] == up[x + lu]) ++lu;
+                if (x > 0) while (x + ll < w && g[x + ll] == g[x + ll - 1]) ++ll;
+                // the colour of a label never changes inside an image, so equal labels <=> equal pixels for the match
+                if (lu >= min_px && lu > ll + (bpp == 3 ? 1 : 2)) {          // "up" costs ~10 more bits per token than "left"
+                    int n = lu;
+                    while (n > 0) { const int m = n > max_px ? max_px : n; if (m < min_px) break; tok.push_back(0x80000000u | 0x10000u | uint32_t(m * bpp)); x += m; n -= m; }
+                } else if (ll >= min_px) {
+                    int n = ll;
+                    while (n > 0) { const int m = n > max_px ? max_px : n; if (m < min_px) break; tok.push_back(0x80000000u | uint32_t(m * bpp)); x += m; n -= m; }
+                } else if (lu >= min_px) {
+                    const int m = lu > max_px ? max_px : lu;
+                    tok.push_back(0x80000000u | 0x10000u | uint32_t(m * bpp)); x += m;
+                } else {
+                    if (lut) { const uint8_t* c = lut + 3 * g[x]; tok.push_back(c[0]); tok.push_back(c[1]); tok.push_back(c[2]); }
+                    else tok.push_back(g[x]);
+                    ++x;
+                }
+            }
+        }
+        // ---- zlib stream: header, dynamic-Huffman blocks of <= 2^20 tokens, adler32 ----
+        out.push_back(0x78); out.push_back(0x9c);
+        BitWriter bw{&out};
+        int ls, le, lv, us = 0, ue = 0, uv = 0;
+        dist_code(d_left, &ls, &le, &lv);
+        if (up_ok) dist_code(d_up, &us, &ue, &uv);
+        const size_t BLOCK = size_t(1) << 20;
+        for (size_t t0 = 0; t0 < tok.size() || t0 == 0; t0 += BLOCK) {
+            const size_t t1 = t0 + BLOCK < tok.size() ? t0 + BLOCK : tok.size();
+            uint32_t fl[286] = {0}, fd[30] = {0};
+            for (size_t t = t0; t < t1; ++t) {
+                const uint32_t k = tok[t];
+                if (k & 0x80000000u) { fl[len_code(int(k & 0x1ff)).sym]++; fd[(k & 0x10000u) ? us : ls]++; }
+                else fl[k & 0xff]++;
+            }
+            fl[256] = 1;
+            if (!fd[ls] && !(up_ok && fd[us])) fd[0] = 1;                    // at least one distance code must be defined
+            uint8_t ll_len[286], d_len[30];
+            uint16_t ll_code[286], d_code[30];
+            huffman_lengths(fl, 286, 15, ll_len);
+            huffman_lengths(fd, 30, 15, d_len);
+            canonical_codes(ll_len, 286, ll_code);
+            canonical_codes(d_len, 30, d_code);
+            int hlit = 286, hdist = 30;
+            while (hlit > 257 && !ll_len[hlit - 1]) --hlit;
+            while (hdist > 1 && !d_len[hdist - 1]) --hdist;
+            // code-length sequence with the 16 / 17 / 18 run symbols
+            std::vector<uint16_t> cl;              // low 5 bits symbol, then extra value << 5
+            std::vector<uint8_t> seq(ll_len, ll_len + hlit);
+            seq.insert(seq.end(), d_len, d_len + hdist);
+            for (size_t i = 0; i < seq.size();) {
+                size_t j = i;
+                while (j < seq.size() && seq[j] == seq[i]) ++j;
+                size_t run = j - i;
+                if (seq[i] == 0) {
+                    while (run >= 11) { const size_t r = run > 138 ? 138 : run; cl.push_back(uint16_t(18 | ((r - 11) << 5))); run -= r; }
+                    if (run >= 3) { cl.push_back(uint16_t(17 | ((run - 3) << 5))); run = 0; }
+                    while (run--) cl.push_back(0);
+                } else {
+                    cl.push_back(seq[i]); --run;
+                    while (run >= 3) { const size_t r = run > 6 ? 6 : run; cl.push_back(uint16_t(16 | ((r - 3) << 5))); run -= r; }
+                    while (run--) cl.push_back(seq[i]);
+                }
+                i = j;
+            }
+            uint32_t fc[19] = {0};
+            for (uint16_t v : cl) fc[v & 31]++;
+            uint8_t c_len[19];
+            uint16_t c_code[19];
+            huffman_lengths(fc, 19, 7, c_len);
+            canonical_codes(c_len, 19, c_code);
+            static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            int hclen = 19;
+            while (hclen > 4 && !c_len[order[hclen - 1]]) --hclen;
+            bw.put(t1 == tok.size() ? 1u : 0u, 1);
+            bw.put(2u, 2);                          // dynamic Huffman
+            bw.put(uint32_t(hlit - 257), 5); bw.put(uint32_t(hdist - 1), 5); bw.put(uint32_t(hclen - 4), 4);
+            for (int i = 0; i < hclen; ++i) bw.put(c_len[order[i]], 3);
+            for (uint16_t v : cl) {
+                const int sym = v & 31;
+                bw.put(c_code[sym], c_len[sym]);
+                if (sym == 16) bw.put(uint32_t(v >> 5), 2);
+                else if (sym == 17) bw.put(uint32_t(v >> 5), 3);
+                else if (sym == 18) bw.put(uint32_t(v >> 5), 7);
+            }
+            for (size_t t = t0; t < t1; ++t) {
+                const uint32_t k = tok[t];
+                if (k & 0x80000000u) {
+                    const LenCode lc = len_code(int(k & 0x1ff));
+                    bw.put(ll_code[lc.sym], ll_len[lc.sym]);
+                    if (lc.ebits) bw.put(lc.eval, lc.ebits);
+                    if (k & 0x10000u) { bw.put(d_code[us], d_len[us]); if (ue) bw.put(uint32_t(uv), ue); }
+                    else { bw.put(d_code[ls], d_len[ls]); if (le) bw.put(uint32_t(lv), le); }
+                } else bw.put(ll_code[k & 0xff], ll_len[k & 0xff]);
+            }
+            bw.put(ll_code[256], ll_len[256]);
+            if (t1 == tok.size()) break;
+        }
+        bw.flush();
+        out.push_back(uint8_t(adler >> 24)); out.push_back(uint8_t(adler >> 16)); out.push_back(uint8_t(adler >> 8)); out.push_back(uint8_t(adler));
+    } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
+    if (out.size() > 0x7fffffffull) return SAMRS_IO_ESIZE;
+
+    std::string tmp;
+    try { tmp = std::string(path) + ".tmp." + std::to_string((long)getpid()); } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
+    FILE* fp = fopen(tmp.c_str(), "wb");
+    if (!fp) return SAMRS_IO_EOPEN;
+    uint8_t ihdr[13];
+    put_be32(ihdr, uint32_t(w));
+    put_be32(ihdr + 4, uint32_t(h));
+    ihdr[8] = 8;
+    ihdr[9] = bpp == 1 ? 0 : 2;
+    ihdr[10] = ihdr[11] = ihdr[12] = 0;
+    int rc = fwrite(kSignature, 1, 8, fp) == 8 ? SAMRS_IO_OK : SAMRS_IO_EWRITE;
+    if (rc == SAMRS_IO_OK) rc = write_chunk(fp, "IHDR", ihdr, 13);
+    if (rc == SAMRS_IO_OK) rc = write_chunk(fp, "IDAT", out.data(), uint32_t(out.size()));
+    if (rc == SAMRS_IO_OK) rc = write_chunk(fp, "IEND", nullptr, 0);
+    if (fclose(fp) != 0 && rc == SAMRS_IO_OK) rc = SAMRS_IO_EWRITE;
+    if (rc == SAMRS_IO_OK && rename(tmp.c_str(), path) != 0) rc = SAMRS_IO_EWRITE;
+    if (rc != SAMRS_IO_OK) remove(tmp.c_str());
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -320,11 +561,13 @@ int samrs_io_png_read_rgb(const char* path, uint8_t* dst, size_t dst_bytes, int*
 }
 
 int samrs_io_png_write_gray(const char* path, const uint8_t* src, int height, int width, size_t stride, int level) {
+    if (level == SAMRS_IO_LEVEL_LABELS) return encode_labels(path, src, height, width, stride, nullptr);
     return encode(path, src, height, width, stride, 1, nullptr, level);
 }
 
 int samrs_io_png_write_lut_rgb(const char* path, const uint8_t* src, int height, int width, size_t stride, const uint8_t* lut, int level) {
     if (!lut) return SAMRS_IO_ESIZE;
+    if (level == SAMRS_IO_LEVEL_LABELS) return encode_labels(path, src, height, width, stride, lut);
     return encode(path, src, height, width, stride, 1, lut, level);
 }
 

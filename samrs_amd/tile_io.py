@@ -18,8 +18,9 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-ABI_VERSION = 1
-LEVEL_RUNS = -1            # SAMRS_IO_LEVEL_RUNS: zlib run-length strategy, the preset for class maps
+ABI_VERSION = 2
+LEVEL_RUNS = -1            # SAMRS_IO_LEVEL_RUNS: zlib run-length strategy
+LEVEL_LABELS = -2          # SAMRS_IO_LEVEL_LABELS: the label-aware encoder (class maps and their palette images): the preset of generate
 OK, EOPEN, UNSUPPORTED, ECORRUPT, ESIZE, EWRITE, ENOMEM = 0, -1, -2, -3, -4, -5, -6
 _NAMES = {EOPEN: "cannot open", UNSUPPORTED: "unsupported PNG variant", ECORRUPT: "corrupt PNG", ESIZE: "bad size",
           EWRITE: "write failed", ENOMEM: "out of memory"}

@@ -711,6 +711,15 @@ def test_generation_driver_end_to_end(tmp_path):
             if d["size"] > 0:
                 tot_pix[d["label"]] += d["size"]
     assert stats["class_pixel_num"] == tot_pix.tolist()
+    # N4 (BASELINE.json configs[4]): the files this run wrote go through the reference's training read path
+    # (oracle/consumer_check.py: PF/End_to_End/datasets.py:185-273 + CrossEntropyLoss(ignore_index=255), main_pretrain.py:321);
+    # the two-rank DDP form of the same check runs on CPU (tests/test_consumer_gloo.py)
+    from oracle import consumer_check as cc
+    (tmp_path / "train.txt").write_text("P0000\nP0001\n")
+    (tmp_path / "valid.txt").write_text("P0001\n")
+    ds = cc.SegmentationDataset(str(tmp_path), str(img_dir), str(out_dir / "gray"), flag="trn")
+    losses, _, drawn, hist = cc.train_steps(ds, 18, 0, 1, steps=2, batch_size=1)
+    assert drawn == [0, 1] and all(np.isfinite(losses)) and hist[18:255].sum() == 0 and hist[:18].sum() > 0
     # --resume: nothing is missing -> nothing is recomputed, nothing is rewritten; remove one pickle -> exactly that image
     # (a second run() in the same process also exercises the per-run work-queue key)
     before = {p: os.stat(p).st_mtime_ns for p in sorted(str(x) for x in out_dir.rglob("*.p*"))}

@@ -23,7 +23,11 @@ def _worker(rank, world, port, out):
         time.sleep(0.02 if rank == 0 else 0.002)        # rank 0 is the "slow GPU": it must end up with fewer chunks
     sizes = [100 * rank + k for k in range(3 + 4 * rank)]   # ragged: 3 entries on rank 0, 7 on rank 1
     gathered = driver.gather_mask_sizes(sizes)
-    out[rank] = (mine, gathered)
+    # generate --resume: the ranks may SEE different todo lists (rank 1 lists the output directory later, after rank 0 wrote
+    # two more images); everybody must work from rank 0's list (driver.agree_on_list)
+    seen = ["a", "b", "c", "d"] if rank == 0 else ["c", "d"]
+    agreed = driver.agree_on_list(seen if rank == 0 else [])
+    out[rank] = (mine, gathered, agreed)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -42,6 +46,7 @@ def test_dynamic_queue_covers_everything_once_and_balances():
     assert len(r1) > len(r0), f"the faster rank should have pulled more chunks ({len(r0)} vs {len(r1)})"
     expect = [0, 1, 2] + [100 + k for k in range(7)]
     assert out[0][1] == expect and out[1][1] == expect
+    assert out[0][2] == out[1][2] == ["a", "b", "c", "d"]
 
 
 def test_static_queue_is_the_strided_shard():
@@ -61,3 +66,4 @@ def test_static_queue_is_the_strided_shard():
 
 def test_gather_mask_sizes_single_process():
     assert driver.gather_mask_sizes([5, 0, 7]) == [5, 0, 7]
+    assert driver.agree_on_list(["x", "y"]) == ["x", "y"]                  # no process group: the caller's own list

@@ -320,10 +320,17 @@ int samrs_k_upscaler_fused(int prec, const void* keys_et, const void* keys_lo_et
  *   samrs_k_mx4_pack   x (fp32 [rows][K]) or the ET pair (hi_in, lo_in) -> fp4 codes of hi / lo, q_* [rows][Kp / 2] bytes, and their
  *                      scale tiles s_* (samrs_k_mx_scale_bytes(rows, Kp, is_b) bytes each; A-operand or B-operand tile order);
  *                      out_hi (optional, with x): ET(x).  Every group of G source elements becomes GP on the padded axis (zeros
- *                      behind it): Kp = K / G * GP, a multiple of 256; plain: G = GP = K.
+ *                      behind it): Kp = K / G * GP, a multiple of 256; plain: G = GP = K.  is_b: bit 0 = B-operand scale tiles, bit 1 = the
+ *                      block-internal element order in which the attention kernels emit their own MX rows (position 16 h + 4 g + e
+ *                      of a block holds element 8 g + 4 h + e): what the proj weights are packed with.
  *   samrs_k_gemm_mx    C = A B^T + A4lo B4hi^T + A4hi B4lo^T + bias: the f16 product over K, the two fp4 products over Kp, fp32
  *                      accumulators throughout; out_f32 = 0: C_et rounded once, = 1: fp32 (accumulate != 0 adds to C).
  *                      M % 256 == 0, N % 320 == 0, K % 64 == 0; split_from_n as for samrs_k_gemm_split3. */
+/* the attention kernels with their optional extra outputs: out_lo (the f16 split remainder) or, instead, hi / lo of the output as
+ * MXFP4 on the per-head padded K axis (q_* [rows][heads * ceil32(head_dim) / 2], A-operand scale tiles); global = 0: windowed (14) */
+int samrs_k_attention_mx(int prec, int global, const void* qkv_et, const float* qkv_bias, const float* rel_h, const float* rel_w,
+                         void* out_et, void* out_lo_et, int n_images, int grid, int heads, int head_dim, void* q_hi, void* q_lo,
+                         void* s_hi, void* s_lo, void* stream);
 int64_t samrs_k_mx_scale_bytes(int rows, int Kp, int is_b);
 /* LayerNorm that also emits its output as MXFP4 hi / lo (what the engine feeds the qkv GEMM in "lo_format" 4): D % 256 == 0 */
 int samrs_k_layernorm_mx(int prec, const float* X, const float* gamma, const float* beta, float eps, void* out_et, int rows, int D,

@@ -373,6 +373,62 @@ __device__ __forceinline__ float ones_row_sum(const f32x16_t (&O)[DT], int hh) {
     return hh == oh ? mine : other;
 }
 
+// Attention output of one query row and head as MXFP4 (LO == 2: the proj GEMM's A operands in "lo_format" 4; gemm.hip
+// gemm_et_mx_kernel).  The K axis of that GEMM is padded per head to DT * 32 (80 -> 96), so the DT blocks of this (row, head)
+// belong to this lane pair alone: lanes l and l + 32 hold 16 values each of block dt (d = 32 dt + 8 g + 4 hh + e), exchange
+// their maxima once per block and tensor, and write their 16 codes as ONE 8-byte store -- the block stores its elements in the
+// order p = 16 hh + 4 g + e, the same permutation the engine applies to the proj weights (mx4_pack_kernel PERM; the block scale
+// is shared, so any order both operands agree on gives the same product).  hi = the ET value the plain path stores, lo = the
+// fp32 remainder.  Rows d >= HD of the last block (incl. the ones-row that carries the softmax sum) are padding: zero.
+template <int PREC, int HD, int DT>
+__device__ __forceinline__ void store_attention_row_mx(const f32x16_t (&O)[DT], float inv, uint16_t* __restrict__ orow, int hh,
+                                                       const MxOut& mx, size_t row, int head, int heads) {
+    const int nblk = heads * DT, nst4 = nblk * 32 / MXK;
+    unsigned char* qh = mx.q_hi + row * (size_t)(nblk * 16) + (size_t)head * (DT * 16);
+    unsigned char* ql = mx.q_lo + row * (size_t)(nblk * 16) + (size_t)head * (DT * 16);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        float h[16], l[16];
+        float ah = 0.f, al = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 32 * dt + 8 * g + 4 * hh;
+            const bool real = d0 < HD;                       // HD % 8 == 0: a group of four is real or padding as a whole
+            uint2 o = make_uint2(0u, 0u);
+            if (real) {
+                o.x = pack2_fast<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
+                o.y = pack2_fast<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + d0) = o;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float hv = ET<PREC>::to_float((uint16_t)(((e & 2) ? o.y : o.x) >> (16 * (e & 1))));
+                h[4 * g + e] = hv;
+                l[4 * g + e] = real ? O[dt][4 * g + e] * inv - hv : 0.f;
+                ah = fmaxf(ah, fabsf(hv));
+                al = fmaxf(al, fabsf(l[4 * g + e]));
+            }
+        }
+        ah = fmaxf(ah, xhalf_partner(ah));
+        al = fmaxf(al, xhalf_partner(al));
+        const int bh = mx_scale_byte(ah), bl = mx_scale_byte(al);
+        const float ih = mx_inv_scale(bh), il = mx_inv_scale(bl);
+        uint2 ch = make_uint2(0u, 0u), cl = make_uint2(0u, 0u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ch.x |= fp4_code(h[i] * ih) << (4 * i);     ch.y |= fp4_code(h[8 + i] * ih) << (4 * i);
+            cl.x |= fp4_code(l[i] * il) << (4 * i);     cl.y |= fp4_code(l[8 + i] * il) << (4 * i);
+        }
+        *reinterpret_cast<uint2*>(qh + dt * 16 + 8 * hh) = ch;
+        *reinterpret_cast<uint2*>(ql + dt * 16 + 8 * hh) = cl;
+        if (hh == 0) {
+            const size_t si = mx_scale_index(false, (int)row, head * DT + dt, nst4);
+            mx.s_hi[si] = (unsigned char)bh;
+            mx.s_lo[si] = (unsigned char)bl;
+        }
+    }
+}
+
 // =========================================================================================
 // windowed attention.  Work item = (window, head); 8 waves, wave w < 7 owns the 32-query strip w
 // (7 strips cover the 196 window tokens), keys are visited tile by tile with an online softmax.
@@ -425,11 +481,11 @@ struct WinCfg {
     static constexpr int LDS_BYTES = K_BYTES + VT_BYTES + S_BYTES + TAB_BYTES + BIAS_BYTES;
 };
 
-template <int PREC, int HD, bool LO = false>
+template <int PREC, int HD, int LO = 0 /* 0: out only; 1: + its f16 split remainder (out_lo); 2: + hi / lo as MXFP4 (mx) */>
 __global__ __launch_bounds__(512) void window_attention_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ rel_h,
     const float* __restrict__ rel_w, uint16_t* __restrict__ out, int grid, int heads, int n_items,
-    uint16_t* __restrict__ out_lo = nullptr /* LO: the split remainder of out (reference-grade mode) */) {
+    uint16_t* __restrict__ out_lo = nullptr /* LO == 1: the split remainder of out (reference-grade mode) */, MxOut mx = MxOut()) {
     using C = WinCfg<HD>;
     constexpr int KS = HD / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -708,8 +764,11 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         // write: token (q) -> un-partitioned row; drop window padding (image_encoder.py:287-288)
         if (qin) {
             const float inv = 1.0f / l_run;
-            const size_t obase = (size_t)im * img_rows * D + (size_t)(qoff / (3 * D)) * D + head * HD;
+            const size_t orow_i = (size_t)im * img_rows + (size_t)(qoff / (3 * D));
+            const size_t obase = orow_i * D + head * HD;
             uint16_t* orow = out + obase;
+            if constexpr (LO == 2) store_attention_row_mx<PREC, HD, C::DT>(O, inv, orow, hh, mx, orow_i, head, heads);
+            else
 #pragma unroll
             for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
@@ -720,7 +779,7 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
                         o.x = pack2_fast<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
                         o.y = pack2_fast<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
                         *reinterpret_cast<uint2*>(orow + d0) = o;
-                        if constexpr (LO) {
+                        if constexpr (LO == 1) {
                             uint2 h, l;
                             split2_pack<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv, h.x, l.x);
                             split2_pack<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv, h.y, l.y);
@@ -826,11 +885,11 @@ struct GlbCfg {
 // NW waves = NW x 32 queries per block.  NW = 8 (one block per CU, 113 KiB of LDS): the K / V^T tiles are staged once for
 // 256 queries, which halves the LDS-DMA pieces each wave has to push through the CU's texture-address queue per tile
 // (measured: ~150 cycles of issue time per piece and wave; 22 pieces per tile and block).
-template <int PREC, int HD, int NW, bool LO = false>
+template <int PREC, int HD, int NW, int LO = 0 /* as for window_attention_kernel */>
 __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, const float* __restrict__ rel_h,
     const float* __restrict__ rel_w, uint16_t* __restrict__ out, int heads,
-    uint16_t* __restrict__ out_lo = nullptr /* LO: the split remainder of out */) {
+    uint16_t* __restrict__ out_lo = nullptr /* LO == 1: the split remainder of out */, MxOut mx = MxOut()) {
     using C = GlbCfg<HD, NW>;
     constexpr int KS = HD / 16;
     constexpr int QPB = 32 * NW, NTH = 64 * NW;     // queries / threads per block
@@ -1050,6 +1109,8 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
     const float inv = 1.0f / l_run;
     const size_t obase = ((size_t)im * NTOK + q) * D + head * HD;
     uint16_t* orow = out + obase;
+    if constexpr (LO == 2) store_attention_row_mx<PREC, HD, C::DT>(O, inv, orow, hh, mx, (size_t)im * NTOK + q, head, heads);
+    else
 #pragma unroll
     for (int dt = 0; dt < C::DT; ++dt)
 #pragma unroll
@@ -1060,7 +1121,7 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
                 o.x = pack2_fast<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv);
                 o.y = pack2_fast<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + d0) = o;
-                if constexpr (LO) {
+                if constexpr (LO == 1) {
                     uint2 h, l;
                     split2_pack<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv, h.x, l.x);
                     split2_pack<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv, h.y, l.y);
@@ -1265,9 +1326,9 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
     return hipGetLastError();
 }
 
-template <int PREC, int HD, bool LO = false>
+template <int PREC, int HD, int LO = 0>
 static hipError_t launch_win(const void* qkv, const float* qb, const float* rh, const float* rw, void* out, int n_images,
-                             int grid, int heads, hipStream_t s, void* out_lo = nullptr) {
+                             int grid, int heads, hipStream_t s, void* out_lo = nullptr, MxOut mx = MxOut()) {
     using C = WinCfg<HD>;
     auto k = window_attention_kernel<PREC, HD, LO>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
@@ -1280,16 +1341,23 @@ static hipError_t launch_win(const void* qkv, const float* qb, const float* rh, 
         return n > 0 ? n : 256;
     }();
     dim3 g(n_items < n_cu ? n_items : n_cu), b(C::THREADS);      // persistent: one block per CU (LDS-limited)
-    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, qb, rh, rw, (uint16_t*)out, grid, heads, n_items, (uint16_t*)out_lo);
+    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, qb, rh, rw, (uint16_t*)out, grid, heads, n_items, (uint16_t*)out_lo, mx);
     return hipGetLastError();
 }
 
 hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
-                                   int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo) {
+                                   int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo,
+                                   void* mx_q_hi, void* mx_q_lo, void* mx_s_hi, void* mx_s_lo) {
     if (window != 14) return hipErrorInvalidValue;
+    MxOut mx;
+    if (mx_q_hi) {
+        if (!mx_q_lo || !mx_s_hi || !mx_s_lo || (heads * ((head_dim + 31) / 32) * 32) % MXK) return hipErrorInvalidValue;
+        mx.q_hi = (unsigned char*)mx_q_hi; mx.q_lo = (unsigned char*)mx_q_lo; mx.s_hi = (unsigned char*)mx_s_hi; mx.s_lo = (unsigned char*)mx_s_lo;
+    }
 #define WIN_CALL(P, H)                                                                                                          \
-    return out_lo ? launch_win<P, H, true>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s, out_lo)                  \
-                  : launch_win<P, H, false>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s)
+    return mx_q_hi ? launch_win<P, H, 2>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s, nullptr, mx)               \
+         : out_lo ? launch_win<P, H, 1>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s, out_lo)                     \
+                  : launch_win<P, H, 0>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s)
     if (prec == PREC_BF16) {
         if (head_dim == 64) WIN_CALL(PREC_BF16, 64);
         if (head_dim == 80) WIN_CALL(PREC_BF16, 80);
@@ -1304,38 +1372,45 @@ hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_b
 // waves per block of the global attention kernel: 8 (256 queries, one block per CU) by default, 4 = the two-blocks-per-CU shape
 static int g_glb_waves = [] { const char* v = getenv("SAMRS_GLB_WAVES"); return (v && atoi(v) == 4) ? 4 : 8; }();
 
-template <int PREC, int HD, int NW, bool LO = false>
+template <int PREC, int HD, int NW, int LO = 0>
 static hipError_t launch_glb_nw(const void* qkv, const float* rh, const float* rw, void* out, int n_images,
-                                int heads, void* vt_ws, hipStream_t s, void* out_lo = nullptr) {
+                                int heads, void* vt_ws, hipStream_t s, void* out_lo = nullptr, MxOut mx = MxOut()) {
     using C = GlbCfg<HD, NW>;
     constexpr int NTOK = C::G * C::G;
     auto k = global_attention_kernel<PREC, HD, NW, LO>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
     dim3 g((NTOK / (32 * NW)) * heads * n_images), b(64 * NW);
-    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, (const uint16_t*)vt_ws, rh, rw, (uint16_t*)out, heads, (uint16_t*)out_lo);
+    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, (const uint16_t*)vt_ws, rh, rw, (uint16_t*)out, heads, (uint16_t*)out_lo, mx);
     return hipGetLastError();
 }
 
 template <int PREC, int HD>
 static hipError_t launch_glb(const void* qkv, const float* rh, const float* rw, void* out, int n_images,
-                             int heads, void* vt_ws, hipStream_t s, void* out_lo) {
+                             int heads, void* vt_ws, hipStream_t s, void* out_lo, MxOut mx) {
     constexpr int NTOK = GlbCfg<HD>::G * GlbCfg<HD>::G;
     vt_pack_kernel<HD><<<n_images * heads * (NTOK / 64), 256, 0, s>>>((const uint16_t*)qkv, (uint16_t*)vt_ws, heads, NTOK);
     HIP_CHECK_RET(hipGetLastError());
-    if (out_lo) return launch_glb_nw<PREC, HD, 8, true>(qkv, rh, rw, out, n_images, heads, vt_ws, s, out_lo);
+    if (mx.q_hi) return launch_glb_nw<PREC, HD, 8, 2>(qkv, rh, rw, out, n_images, heads, vt_ws, s, nullptr, mx);
+    if (out_lo) return launch_glb_nw<PREC, HD, 8, 1>(qkv, rh, rw, out, n_images, heads, vt_ws, s, out_lo);
     if (g_glb_waves == 4) return launch_glb_nw<PREC, HD, 4>(qkv, rh, rw, out, n_images, heads, vt_ws, s);
     return launch_glb_nw<PREC, HD, 8>(qkv, rh, rw, out, n_images, heads, vt_ws, s);
 }
 
 hipError_t launch_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
-                                   int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s, void* out_lo) {
+                                   int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s, void* out_lo,
+                                   void* mx_q_hi, void* mx_q_lo, void* mx_s_hi, void* mx_s_lo) {
     if (grid != 64 || !vt_ws) return hipErrorInvalidValue;
+    MxOut mx;
+    if (mx_q_hi) {
+        if (!mx_q_lo || !mx_s_hi || !mx_s_lo || (heads * ((head_dim + 31) / 32) * 32) % MXK) return hipErrorInvalidValue;
+        mx.q_hi = (unsigned char*)mx_q_hi; mx.q_lo = (unsigned char*)mx_q_lo; mx.s_hi = (unsigned char*)mx_s_hi; mx.s_lo = (unsigned char*)mx_s_lo;
+    }
     if (prec == PREC_BF16) {
-        if (head_dim == 64) return launch_glb<PREC_BF16, 64>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo);
-        if (head_dim == 80) return launch_glb<PREC_BF16, 80>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo);
+        if (head_dim == 64) return launch_glb<PREC_BF16, 64>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo, mx);
+        if (head_dim == 80) return launch_glb<PREC_BF16, 80>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo, mx);
     } else if (prec == PREC_F16) {
-        if (head_dim == 64) return launch_glb<PREC_F16, 64>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo);
-        if (head_dim == 80) return launch_glb<PREC_F16, 80>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo);
+        if (head_dim == 64) return launch_glb<PREC_F16, 64>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo, mx);
+        if (head_dim == 80) return launch_glb<PREC_F16, 80>(qkv, rel_h, rel_w, out, n_images, heads, vt_ws, s, out_lo, mx);
     }
     return hipErrorInvalidValue;
 }

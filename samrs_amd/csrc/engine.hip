@@ -487,7 +487,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
                 CK(e, launch_mx4_pack(e->prec, W(e, p + ".attn.qkv.weight"), nullptr, nullptr, nullptr, b.qkv_w4[0], b.qkv_w4[1], b.qkv_s4[0],
                                       b.qkv_s4[1], 3 * D, D, D, D, true, s));
                 CK(e, launch_mx4_pack(e->prec, W(e, p + ".attn.proj.weight"), nullptr, nullptr, nullptr, b.proj_w4[0], b.proj_w4[1], b.proj_s4[0],
-                                      b.proj_s4[1], D, D, e->hd, gp, true, s));
+                                      b.proj_s4[1], D, D, e->hd, gp, true, s, /* perm: the attention kernels' block order */ true));
                 e->mx_ready = true;
             }
         }
@@ -716,20 +716,21 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
             CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
         }
+        const bool mx_ao = sp_attn && mx_attn;      // the attention kernels write the proj GEMM's MX operands themselves
         if (!b.global)
             CK(e, launch_window_attention(prec, e->QKV, b.qkv_b, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s,
-                                          sp_attn ? e->AOlo : nullptr));
+                                          (sp_attn && !mx_ao) ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,
+                                          mx_ao ? e->SAO4[0] : nullptr, mx_ao ? e->SAO4[1] : nullptr));
         else
             CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, e->VTG, s,
-                                          sp_attn ? e->AOlo : nullptr));
+                                          (sp_attn && !mx_ao) ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,
+                                          mx_ao ? e->SAO4[0] : nullptr, mx_ao ? e->SAO4[1] : nullptr));
         if (fold) {
             CK(e, launch_gemm_et_stats(prec, e->AO, b.proj_w, e->X, b.proj_b, e->Y, e->STATS, M, D, D, s));
             CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
         } else {
             if (sp_attn && mx_attn) {
-                // attention output (hi, lo) -> fp4 on the per-head padded K axis; the GEMM adds into the residual stream
-                CK(e, launch_mx4_pack(prec, nullptr, e->AO, e->AOlo, nullptr, e->AO4[0], e->AO4[1], e->SAO4[0], e->SAO4[1], M, D, e->hd,
-                                      e->mx_gp, false, s));
+                // the attention kernel wrote hi / lo of its output as fp4 on the per-head padded K axis; the GEMM adds into the residual stream
                 CK(e, launch_gemm_et_mx(prec, e->AO, b.proj_w, e->X, b.proj_b, M, D, D, e->mx_kp_proj, e->AO4[1], e->AO4[0], e->SAO4[1],
                                         e->SAO4[0], b.proj_w4[0], b.proj_w4[1], b.proj_s4[0], b.proj_s4[1], true, true, 0, s));
             } else if (sp_attn && one3 && gemm_split3_ok(M, D, D)) {
@@ -1335,6 +1336,23 @@ int samrs_k_global_attention(int prec, const void* qkv, const float* rel_h, cons
     }
     KRET(launch_global_attention(prec, qkv, rel_h, rel_w, out, n_images, grid, heads, head_dim, ws, (hipStream_t)stream));
 }
+int samrs_k_attention_mx(int prec, int global, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
+                         void* out_lo, int n_images, int grid, int heads, int head_dim, void* q_hi, void* q_lo, void* s_hi, void* s_lo,
+                         void* stream) {
+    if (!global)
+        KRET(launch_window_attention(prec, qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, 14, heads, head_dim, (hipStream_t)stream, out_lo,
+                                     q_hi, q_lo, s_hi, s_lo));
+    static void* ws = nullptr;
+    static size_t ws_bytes = 0;
+    const size_t need = (size_t)n_images * heads * head_dim * grid * grid * 2;
+    if (need > ws_bytes) {
+        if (ws) (void)hipFree(ws);
+        ws = nullptr; ws_bytes = 0;
+        if (hipMalloc(&ws, need) != hipSuccess) return SAMRS_ERR_HIP;
+        ws_bytes = need;
+    }
+    KRET(launch_global_attention(prec, qkv, rel_h, rel_w, out, n_images, grid, heads, head_dim, ws, (hipStream_t)stream, out_lo, q_hi, q_lo, s_hi, s_lo));
+}
 int samrs_resample_pass_u8(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* coef, int ksize,
                            int in_len, int out_len, int other, int horizontal, void* stream) {
     if (!in || !out || !bounds || !coef || ksize < 1 || in_len < 1 || out_len < 1 || other < 1) return SAMRS_ERR_BAD_ARG;
@@ -1375,7 +1393,8 @@ int samrs_k_upscaler_fused(int prec, const void* keys, const void* keys_lo, cons
 int64_t samrs_k_mx_scale_bytes(int rows, int Kp, int is_b) { return (int64_t)mx_scale_bytes(rows, Kp, is_b != 0); }
 int samrs_k_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo_in, void* out_hi, void* q_hi, void* q_lo, void* s_hi,
                      void* s_lo, int rows, int K, int G, int GP, int is_b, void* stream) {
-    return launch_mx4_pack(prec, x, hi_in, lo_in, out_hi, q_hi, q_lo, s_hi, s_lo, rows, K, G, GP, is_b != 0, (hipStream_t)stream) == hipSuccess
+    // is_b bit 1: the attention kernels' block-internal element order (launch_mx4_pack perm)
+    return launch_mx4_pack(prec, x, hi_in, lo_in, out_hi, q_hi, q_lo, s_hi, s_lo, rows, K, G, GP, (is_b & 1) != 0, (hipStream_t)stream, (is_b & 2) != 0) == hipSuccess
                ? SAMRS_OK : SAMRS_ERR_BAD_SHAPE;
 }
 int samrs_k_gemm_mx(int prec, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int Kp, const void* a4_lo,

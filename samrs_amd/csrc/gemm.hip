@@ -2705,13 +2705,16 @@ __global__ __launch_bounds__(256) void mx4_pack_kernel(const float* __restrict__
                                                        const uint16_t* __restrict__ lo_in, uint16_t* __restrict__ out_hi,
                                                        unsigned char* __restrict__ q_hi, unsigned char* __restrict__ q_lo,
                                                        unsigned char* __restrict__ s_hi, unsigned char* __restrict__ s_lo,
-                                                       int rows, int K, int G, int GP, int is_b) {
+                                                       int rows, int K, int G, int GP, int is_b, int perm) {
     const int Kp = (K / G) * GP, nblk = Kp / 32, nst4 = Kp / MXK;
     const long item = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;           // (row, block)
     const int sub = threadIdx.x & 7;
     if (item >= (long)rows * nblk) return;
     const int r = (int)(item / nblk), b = (int)(item % nblk);
-    const int kp = b * 32 + sub * 4, g = kp / GP, off = kp % GP;            // GP % 4 == 0 and G % 4 == 0: a lane's 4 elements share a fate
+    // position 4 sub .. 4 sub + 3 of the block holds source elements at block offset 4 sub (natural order) or 8 (sub & 3) + 4 (sub >> 2)
+    // (perm: the order store_attention_row_mx writes its rows in)
+    const int in_blk = perm ? 8 * (sub & 3) + 4 * (sub >> 2) : sub * 4;
+    const int kp = b * 32 + in_blk, g = kp / GP, off = kp % GP;             // GP % 4 == 0 and G % 4 == 0: a lane's 4 elements share a fate
     float h[4] = {0.f, 0.f, 0.f, 0.f}, l[4] = {0.f, 0.f, 0.f, 0.f};
     if (off < G) {
         const size_t src = (size_t)r * K + (size_t)g * G + off;
@@ -3057,7 +3060,7 @@ hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, co
 
 // fp32 [rows][K] (x) or the ET pair (hi_in, lo_in) -> fp4 hi / lo [rows][Kp / 2] + their scale tiles; Kp = K / G * GP
 hipError_t launch_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo_in, void* out_hi, void* q_hi, void* q_lo,
-                           void* s_hi, void* s_lo, int rows, int K, int G, int GP, bool is_b, hipStream_t s) {
+                           void* s_hi, void* s_lo, int rows, int K, int G, int GP, bool is_b, hipStream_t s, bool perm) {
     if (rows <= 0 || K <= 0 || G <= 0 || K % G || G % 4 || GP % 32 || GP < G || ((K / G) * GP) % MXK) return hipErrorInvalidValue;
     if (!x && !(hi_in && lo_in)) return hipErrorInvalidValue;
     const long items = (long)rows * ((K / G) * GP / 32);
@@ -3065,7 +3068,7 @@ hipError_t launch_mx4_pack(int prec, const float* x, const void* hi_in, const vo
     const uint16_t* hi = reinterpret_cast<const uint16_t*>(hi_in);
     const uint16_t* lo = reinterpret_cast<const uint16_t*>(lo_in);
 #define MXP(P_, F_) mx4_pack_kernel<P_, F_><<<grid, block, 0, s>>>(x, hi, lo, (uint16_t*)out_hi, (unsigned char*)q_hi, (unsigned char*)q_lo, \
-                                                                  (unsigned char*)s_hi, (unsigned char*)s_lo, rows, K, G, GP, is_b ? 1 : 0)
+                                                                  (unsigned char*)s_hi, (unsigned char*)s_lo, rows, K, G, GP, is_b ? 1 : 0, perm ? 1 : 0)
     if (prec == PREC_F16) { if (x) MXP(PREC_F16, true); else MXP(PREC_F16, false); }
     else if (prec == PREC_BF16) { if (x) MXP(PREC_BF16, true); else MXP(PREC_BF16, false); }
     else return hipErrorInvalidValue;

@@ -64,11 +64,15 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
                             void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr);
 // out_lo (optional, both attention kernels): the split remainder of `out` (reference-grade mode: proj on hi + lo operands)
 hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
-                                   int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo = nullptr);
+                                   int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo = nullptr,
+                                   // optional (instead of out_lo): hi / lo of the output as MXFP4 on the per-head padded K axis
+                                   // [rows][heads * ceil32(head_dim) / 2], block-internal order of store_attention_row_mx
+                                   void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr);
 hipError_t launch_gelu_split(int prec, const float* in, void* hi, void* lo, long n, hipStream_t s);
 // vt_ws: ET workspace of n_images * heads * head_dim * grid^2 elements (receives V transposed per head)
 hipError_t launch_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
-                                   int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s, void* out_lo = nullptr);
+                                   int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s, void* out_lo = nullptr,
+                                   void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr);
 hipError_t launch_neck_im2col(const void* in, void* A, int n_images, int grid, int C, hipStream_t s);
 hipError_t launch_transpose_f32(const float* in, float* out, int rows, int cols, hipStream_t s);
 
@@ -153,8 +157,10 @@ hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, co
 // x (fp32 [rows][K]) or the ET pair (hi_in, lo_in) -> fp4 codes of hi and lo [rows][Kp / 2] + E8M0 scale tiles (A layout, or the
 // B layout when is_b); optional out_hi = ET(x).  Padded axis: every group of G source elements becomes GP (zeros behind it);
 // Kp = K / G * GP must be a multiple of 256.  Plain: G = GP = K.
+// perm: the block-internal element order of the attention kernels' own MX outputs (store_attention_row_mx: position 16 hh + 4 g + e
+// holds element 8 g + 4 hh + e) -- for the proj weights, whose A operand those kernels write.
 hipError_t launch_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo_in, void* out_hi, void* q_hi, void* q_lo,
-                           void* s_hi, void* s_lo, int rows, int K, int G, int GP, bool is_b, hipStream_t s);
+                           void* s_hi, void* s_lo, int rows, int K, int G, int GP, bool is_b, hipStream_t s, bool perm = false);
 
 // ---- upscaler_fused.hip ---------------------------------------------------------------------
 // mask_decoder.py:53-59,154-167 in one kernel: keys [n * grid^2][256] ET -> ConvT #1 + LayerNorm2d + GELU -> ConvT #2 + GELU ->

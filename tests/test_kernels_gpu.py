@@ -1011,3 +1011,43 @@ def test_layernorm_mx_outputs_equal_the_pack_kernel(lib, name, prec, dt, ulp):
     for h in range(2):
         assert torch.equal(q2[h], q[h]), f"{'lo' if h else 'hi'} codes differ"
         assert torch.equal(s2[h], sc[h])
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+@pytest.mark.parametrize("is_global", [0, 1])
+def test_attention_mx_outputs_equal_the_pack_kernel(lib, name, prec, dt, ulp, is_global):
+    """Both attention kernels' own MXFP4 outputs (what the engine feeds the proj GEMM in lo_format 4: per-head padded K axis
+    80 -> 96, block-internal order of store_attention_row_mx) against the pack kernel run on the (out, out_lo) pair of the f16-lo
+    variant of the same kernel: the ET output identical in all three variants, the hi codes / scales identical, the lo codes within
+    one fp4 step (the MX variant quantises the fp32 remainder, the pack kernel its f16 rounding) and almost always equal."""
+    g = torch.Generator().manual_seed(31 + is_global)
+    n_img, heads, hd, grid = 1, 16, 80, 64
+    D = heads * hd
+    rows = n_img * grid * grid
+    qkv = dev((torch.randn(rows, 3 * D, generator=g)).to(dt)).view(torch.int16)
+    bias = dev(torch.randn(3 * D, generator=g))
+    tab = 127 if is_global else 27
+    rh, rw = dev(0.02 * torch.randn(tab, hd, generator=g)), dev(0.02 * torch.randn(tab, hd, generator=g))
+    Kp = heads * 96
+    out = [torch.zeros(rows, D, dtype=torch.int16, device="cuda") for _ in range(3)]
+    lo = torch.zeros(rows, D, dtype=torch.int16, device="cuda")
+    q = [torch.zeros(rows, Kp // 2, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    nb = int(lib.samrs_k_mx_scale_bytes(rows, Kp, 0))
+    sc = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    common = (qkv.data_ptr(), bias.data_ptr(), rh.data_ptr(), rw.data_ptr())
+    assert lib.samrs_k_attention_mx(prec, is_global, *common, out[0].data_ptr(), None, n_img, grid, heads, hd, None, None, None, None, stream()) == 0
+    assert lib.samrs_k_attention_mx(prec, is_global, *common, out[1].data_ptr(), lo.data_ptr(), n_img, grid, heads, hd, None, None, None, None, stream()) == 0
+    assert lib.samrs_k_attention_mx(prec, is_global, *common, out[2].data_ptr(), None, n_img, grid, heads, hd, q[0].data_ptr(), q[1].data_ptr(),
+                                    sc[0].data_ptr(), sc[1].data_ptr(), stream()) == 0
+    assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
+    assert lib.samrs_k_mx4_pack(prec, None, out[1].data_ptr(), lo.data_ptr(), None, q[2].data_ptr(), q[3].data_ptr(), sc[2].data_ptr(), sc[3].data_ptr(),
+                                rows, D, hd, 96, 2, stream()) == 0                     # is_b = 2: A scale tiles, attention block order
+    assert torch.equal(q[0], q[2]) and torch.equal(sc[0], sc[2]), "hi codes / scales differ"
+    same_scale = torch.equal(sc[1], sc[3])
+    diff = (q[1] != q[3]).float().mean().item()
+    print(f"attention MX {name} global={is_global}: lo bytes differing from the pack of the f16-rounded remainder: {diff:.2e}; lo scales equal: {same_scale}")
+    assert diff < 2e-2
+    # decoded values: hi exact; lo within one fp4 step of the block scale
+    a = _mx_decode(q[1], sc[1], rows, Kp, False)
+    b = _mx_decode(q[3], sc[3], rows, Kp, False)
+    assert ((a - b).abs() <= 0.51 * b.abs().reshape(rows, -1, 32).amax(-1, keepdim=True).clamp(min=1e-30).expand(-1, -1, 32).reshape(rows, Kp)).all()

@@ -135,6 +135,39 @@ __device__ __forceinline__ size_t mx_scale_index(bool is_b, int r, int b, int ns
     return ((size_t)tile * nst4 + st) * MX_SB_BYTES + (size_t)(((kh * 4 + wn) * 64 + fq * 16 + fr) * 8 + i);
 }
 
+// four / eight values of one block -> packed fp4 codes (element 0 in the low nibble), given the block's E8M0 scale byte.
+// SAMRS_FP4_HWCVT = 1: gfx950's v_cvt_scalef32_pk_fp4_f32 (two values per instruction; tools/mx_probe.hip checks on the device
+// that it is bit-identical with fp4_code(v / scale) incl. ties and saturation); 0: the software quantiser (~15 VALU per value:
+// +75 us per windowed-attention launch when that kernel emits its MX rows with it).
+#ifndef SAMRS_FP4_HWCVT
+#define SAMRS_FP4_HWCVT 1
+#endif
+__device__ __forceinline__ uint32_t fp4_pack4(float a, float b, float c, float d, int scale_byte) {
+#if SAMRS_FP4_HWCVT
+    const float sc = __uint_as_float((uint32_t)scale_byte << 23);              // 2^(byte - 127); byte 0: the hardware reads the exponent field
+    uint32_t r = 0u;
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, a, b, sc, 0);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, c, d, sc, 1);
+    return r & 0xffffu;
+#else
+    const float inv = mx_inv_scale(scale_byte);
+    return fp4_code(a * inv) | (fp4_code(b * inv) << 4) | (fp4_code(c * inv) << 8) | (fp4_code(d * inv) << 12);
+#endif
+}
+__device__ __forceinline__ uint32_t fp4_pack8(const float* v, int scale_byte) {
+#if SAMRS_FP4_HWCVT
+    const float sc = __uint_as_float((uint32_t)scale_byte << 23);
+    uint32_t r = 0u;
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[0], v[1], sc, 0);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[2], v[3], sc, 1);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[4], v[5], sc, 2);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[6], v[7], sc, 3);
+    return r;
+#else
+    return fp4_pack4(v[0], v[1], v[2], v[3], scale_byte) | (fp4_pack4(v[4], v[5], v[6], v[7], scale_byte) << 16);
+#endif
+}
+
 // optional MX outputs of a producer kernel (all null: none)
 struct MxOut {
     unsigned char *q_hi = nullptr, *q_lo = nullptr, *s_hi = nullptr, *s_lo = nullptr;

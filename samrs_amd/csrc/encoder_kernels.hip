@@ -190,10 +190,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
 #pragma unroll
                     for (int sh = 1; sh < 8; sh <<= 1) { ah = fmaxf(ah, __shfl_xor(ah, sh, 64)); al = fmaxf(al, __shfl_xor(al, sh, 64)); }
                     const int bh = mx_scale_byte(ah), bl = mx_scale_byte(al);
-                    const float ih = mx_inv_scale(bh), il = mx_inv_scale(bl);
-                    uint32_t ch = 0, cl = 0;
-#pragma unroll
-                    for (int e2 = 0; e2 < 4; ++e2) { ch |= fp4_code(h[e2] * ih) << (4 * e2); cl |= fp4_code(l[e2] * il) << (4 * e2); }
+                    const uint32_t ch = fp4_pack4(h[0], h[1], h[2], h[3], bh), cl = fp4_pack4(l[0], l[1], l[2], l[3], bl);
                     const size_t dst = (size_t)row * (D >> 1) + (size_t)idx * 2;
                     *reinterpret_cast<uint16_t*>(mx.q_hi + dst) = (uint16_t)ch;
                     *reinterpret_cast<uint16_t*>(mx.q_lo + dst) = (uint16_t)cl;
@@ -412,13 +409,7 @@ __device__ __forceinline__ void store_attention_row_mx(const f32x16_t (&O)[DT], 
         ah = fmaxf(ah, xhalf_partner(ah));
         al = fmaxf(al, xhalf_partner(al));
         const int bh = mx_scale_byte(ah), bl = mx_scale_byte(al);
-        const float ih = mx_inv_scale(bh), il = mx_inv_scale(bl);
-        uint2 ch = make_uint2(0u, 0u), cl = make_uint2(0u, 0u);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            ch.x |= fp4_code(h[i] * ih) << (4 * i);     ch.y |= fp4_code(h[8 + i] * ih) << (4 * i);
-            cl.x |= fp4_code(l[i] * il) << (4 * i);     cl.y |= fp4_code(l[8 + i] * il) << (4 * i);
-        }
+        const uint2 ch = make_uint2(fp4_pack8(h, bh), fp4_pack8(h + 8, bh)), cl = make_uint2(fp4_pack8(l, bl), fp4_pack8(l + 8, bl));
         *reinterpret_cast<uint2*>(qh + dt * 16 + 8 * hh) = ch;
         *reinterpret_cast<uint2*>(ql + dt * 16 + 8 * hh) = cl;
         if (hh == 0) {

@@ -2743,10 +2743,7 @@ __global__ __launch_bounds__(256) void mx4_pack_kernel(const float* __restrict__
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) { ah = fmaxf(ah, __shfl_xor(ah, o, 64)); al = fmaxf(al, __shfl_xor(al, o, 64)); }
     const int bh = mx_scale_byte(ah), bl = mx_scale_byte(al);
-    const float ih = mx_inv_scale(bh), il = mx_inv_scale(bl);
-    uint32_t ch = 0, cl = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { ch |= fp4_code(h[e] * ih) << (4 * e); cl |= fp4_code(l[e] * il) << (4 * e); }
+    const uint32_t ch = fp4_pack4(h[0], h[1], h[2], h[3], bh), cl = fp4_pack4(l[0], l[1], l[2], l[3], bl);
     const size_t dst = (size_t)r * (Kp / 2) + (size_t)b * 16 + sub * 2;
     *reinterpret_cast<uint16_t*>(q_hi + dst) = (uint16_t)ch;
     *reinterpret_cast<uint16_t*>(q_lo + dst) = (uint16_t)cl;

@@ -4,6 +4,7 @@
 // the kernels use.      hipcc -O2 --offload-arch=gfx950 tools/mx_probe.hip -o /tmp/mx_probe && /tmp/mx_probe
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,6 +25,26 @@ __global__ void probe(const uint4* a, const uint4* b, const int* sa, const int* 
     v4f acc = {0.f, 0.f, 0.f, 0.f};
     acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(xa8, yb8, acc, 4, 4, 1, sa[l], 2, sb[l]);
     out[l] = acc;
+}
+
+// second probe: v_cvt_scalef32_pk_fp4_f32 (two f32 -> two fp4 codes into byte `sel` of the destination) against the software
+// quantiser of samrs_amd/csrc/common.h (fp4_code: nearest of {0, .5, 1, 1.5, 2, 3, 4, 6}, ties to even, saturating) applied to
+// v / 2^(exponent(scale) - 127): if they agree bit for bit, the producers may use the instruction instead of ~15 VALU per value
+__global__ void cvt_probe(const float* v, const float* sc, unsigned* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned r = 0xffffffffu;
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[2 * i], v[2 * i + 1], sc[i], 0);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(r, v[2 * i + 1], v[2 * i], sc[i], 2);
+    out[i] = r;
+}
+static unsigned sw_fp4(float v) {
+    const float a = fabsf(v);
+    const float step = a >= 4.f ? 2.f : a >= 2.f ? 1.f : 0.5f;
+    const float q = fminf(rintf(a / step) * step, 6.f);
+    const int idx = (int)(q * 2.f);
+    const unsigned code = idx <= 4 ? (unsigned)idx : (unsigned)(idx >> 2) + 4u;
+    return code | (std::signbit(v) ? 8u : 0u);
 }
 
 static const float E2M1[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
@@ -78,5 +99,46 @@ int main() {
     // NB: with both operands using the same nibble convention the order cannot be told apart by this product (a permutation of
     // k inside a block): both hypotheses match or neither does.  What the test pins is everything else.
     printf(ok_h >= 0 ? "MX fp4 probe: layout / scale / C-D assumptions hold\n" : "MX fp4 probe: MISMATCH\n");
+
+    // ---- conversion instruction ----
+    const int n = 1 << 16;
+    float* hv = (float*)malloc(2 * n * 4); float* hs = (float*)malloc(n * 4); unsigned* ho = (unsigned*)malloc(n * 4);
+    for (int i = 0; i < n; ++i) {
+        const int k = (int)(rnd() % 61) - 30;                                     // scale 2^-30 .. 2^30
+        hs[i] = ldexpf(1.0f + (rnd() & 0xff) / 512.0f, k);                        // mantissa bits set: only the exponent may count
+        for (int e = 0; e < 2; ++e) {
+            float x;
+            const unsigned sel = rnd() % 8;
+            if (sel == 0) { static const float ties[8] = {0.25f, 0.75f, 1.25f, 1.75f, 2.5f, 3.5f, 5.0f, 7.0f}; x = ties[rnd() % 8]; }   // exact ties, 7 saturates
+            else if (sel == 1) x = 0.0f;
+            else x = (float)(rnd() & 0xffff) / 8192.0f;                            // 0 .. 8
+            if (rnd() & 1) x = -x;
+            hv[2 * i + e] = ldexpf(x, k);
+        }
+    }
+    float *dv, *ds; unsigned* dou;
+    CHECK(hipMalloc(&dv, 2 * n * 4)); CHECK(hipMalloc(&ds, n * 4)); CHECK(hipMalloc(&dou, n * 4));
+    CHECK(hipMemcpy(dv, hv, 2 * n * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(ds, hs, n * 4, hipMemcpyHostToDevice));
+    cvt_probe<<<n / 256, 256>>>(dv, ds, dou, n);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(ho, dou, n * 4, hipMemcpyDeviceToHost));
+    long bad_div = 0, bad_mul = 0, bad_layout = 0, zero_sign = 0;
+    for (int i = 0; i < n; ++i) {
+        int ex; frexpf(hs[i], &ex); const int k = ex - 1;                         // hs = m * 2^k, m in [1, 2)
+        const unsigned c0 = sw_fp4(ldexpf(hv[2 * i], -k)), c1 = sw_fp4(ldexpf(hv[2 * i + 1], -k));
+        const unsigned m0 = sw_fp4(ldexpf(hv[2 * i], k)), m1 = sw_fp4(ldexpf(hv[2 * i + 1], k));
+        const unsigned b0 = ho[i] & 0xff, b2 = (ho[i] >> 16) & 0xff;
+        if ((ho[i] & 0xff00ff00u) != 0xff00ff00u) ++bad_layout;                    // bytes 1 and 3 must keep the old value
+        auto eq = [&](unsigned got, unsigned lo, unsigned hi) {                    // ignore the sign of a zero code
+            auto nz = [](unsigned c) { return (c & 7) ? c : 0u; };
+            return nz(got & 15) == nz(lo) && nz(got >> 4) == nz(hi);
+        };
+        if (!(eq(b0, c0, c1) && eq(b2, c1, c0))) ++bad_div;
+        if (!(eq(b0, m0, m1) && eq(b2, m1, m0))) ++bad_mul;
+        if (((b0 & 7) == 0 && (b0 & 8)) || ((b0 >> 4 & 7) == 0 && (b0 >> 4 & 8))) ++zero_sign;
+    }
+    printf("v_cvt_scalef32_pk_fp4_f32 vs software quantiser: %ld of %d pairs differ under 'divide by 2^exp(scale)', %ld under 'multiply'; "
+           "%ld layout violations (low nibble = src0, byte = sel); %ld negative-zero codes\n", bad_div, n, bad_mul, bad_layout, zero_sign);
+    printf(bad_div == 0 && bad_layout == 0 ? "cvt probe: the instruction IS the software quantiser (divide form)\n" : "cvt probe: NOT identical\n");
     return ok_h >= 0 ? 0 : 1;
 }

@@ -356,7 +356,7 @@ def main() -> None:
             ns = _ap.Namespace(images=os.path.join(root, "img"), boxes=os.path.join(root, "boxes.json"), out=os.path.join(root, "out"),
                                model=args.model, checkpoint=None, precision=args.dtype, classes=None, n_classes=18, palette=None,
                                box_batch=64, no_rle=False, batch=B, schedule="static", readers=8, writers=16, resume=False,
-                               rle_buffer_mb=512, timing=True, png_level=6, out_depth=4)
+                               rle_buffer_mb=512, timing=True, png_level=-2, out_depth=4)
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):             # stdout carries the ONE JSON line of this script, nothing else
                 st = generate.run(ns)["timing"]

@@ -305,12 +305,19 @@ struct BitWriter {
     std::vector<uint8_t>* out;
     uint64_t acc = 0;
     int n = 0;
-    void put(uint32_t v, int bits) {               // LSB first
+    void put(uint32_t v, int bits) {               // LSB first; at most 32 bits per call, spilled four bytes at a time
         acc |= uint64_t(v) << n;
         n += bits;
-        while (n >= 8) { out->push_back(uint8_t(acc)); acc >>= 8; n -= 8; }
+        if (n >= 32) {
+            const size_t at = out->size();
+            out->resize(at + 4);
+            const uint32_t w = uint32_t(acc);
+            memcpy(out->data() + at, &w, 4);       // little-endian host (x86-64): byte 0 = the oldest bits
+            acc >>= 32;
+            n -= 32;
+        }
     }
-    void flush() { if (n > 0) { out->push_back(uint8_t(acc)); acc = 0; n = 0; } }
+    void flush() { while (n > 0) { out->push_back(uint8_t(acc)); acc >>= 8; n -= 8; } acc = 0; n = 0; }
 };
 
 // code lengths (<= maxbits) of a Huffman code for freq[0 .. n): plain Huffman; if the tree is too deep the counts are flattened
@@ -367,11 +374,13 @@ const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97,
 const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
 struct LenCode { uint16_t sym; uint8_t ebits; uint16_t eval; };
+struct LenTable {
+    uint8_t c[259];
+    LenTable() { for (int k = 0; k < 29; ++k) for (int l = kLenBase[k]; l <= (k == 28 ? 258 : kLenBase[k + 1] - 1) && l <= 258; ++l) c[l] = uint8_t(k); c[258] = 28; }
+};
+const LenTable kLenTable;
 inline LenCode len_code(int len) {                 // 3 .. 258
-    static uint8_t table[259];
-    static bool init = false;
-    if (!init) { for (int c = 0; c < 29; ++c) for (int l = kLenBase[c]; l <= (c == 28 ? 258 : kLenBase[c + 1] - 1) && l <= 258; ++l) table[l] = uint8_t(c); table[258] = 28; init = true; }
-    const int c = table[len];
+    const int c = kLenTable.c[len];
     return {uint16_t(257 + c), kLenExtra[c], uint16_t(len - kLenBase[c])};
 }
 inline void dist_code(int dist, int* sym, int* ebits, int* eval) {
@@ -390,9 +399,13 @@ int encode_labels(const char* path, const uint8_t* src, int h, int w, size_t str
     const bool up_ok = d_up <= 32768;
     const int max_px = 258 / bpp;                  // pixels per match token
     const int min_px = bpp == 1 ? 3 : 1;           // deflate's shortest match is 3 bytes
-    std::vector<uint32_t> tok;
-    std::vector<uint8_t> out;
-    try { tok.reserve(size_t(h) * 64 + 1024); out.reserve(size_t(h) * 64 + 4096); } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
+    // worst case (no two neighbours equal): one token per byte + one per row; the vectors keep their capacity per thread
+    thread_local std::vector<uint32_t> tok_tl;
+    thread_local std::vector<uint8_t> out_tl;
+    std::vector<uint32_t>& tok = tok_tl;
+    std::vector<uint8_t>& out = out_tl;
+    tok.clear(); out.clear();
+    try { tok.reserve(size_t(h) * (row + 1)); out.reserve(size_t(h) * (row + 1) + 4096); } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
     uLong adler = adler32(0L, Z_NULL, 0);
     std::vector<uint8_t> rowbuf;
     try { rowbuf.resize(row + 1); } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
@@ -422,8 +435,7 @@ int encode_labels(const char* path, const uint8_t* src, int h, int w, size_t str
                     const int m = lu > max_px ? max_px : lu;
                     tok.push_back(0x80000000u | 0x10000u | uint32_t(m * bpp)); x += m;
                 } else {
-                    if (lut) { const uint8_t* c = lut + 3 * g[x]; tok.push_back(c[0]); tok.push_back(c[1]); tok.push_back(c[2]); }
-                    else tok.push_back(g[x]);
+                    tok.push_back(lut ? (0x40000000u | g[x]) : uint32_t(g[x]));      // colour: ONE token per literal pixel (its label)
                     ++x;
                 }
             }
@@ -441,6 +453,7 @@ int encode_labels(const char* path, const uint8_t* src, int h, int w, size_t str
             for (size_t t = t0; t < t1; ++t) {
                 const uint32_t k = tok[t];
                 if (k & 0x80000000u) { fl[len_code(int(k & 0x1ff)).sym]++; fd[(k & 0x10000u) ? us : ls]++; }
+                else if (k & 0x40000000u) { const uint8_t* c = lut + 3 * (k & 0xff); fl[c[0]]++; fl[c[1]]++; fl[c[2]]++; }
                 else fl[k & 0xff]++;
             }
             fl[256] = 1;
@@ -493,8 +506,18 @@ int encode_labels(const char* path, const uint8_t* src, int h, int w, size_t str
                 else if (sym == 17) bw.put(uint32_t(v >> 5), 3);
                 else if (sym == 18) bw.put(uint32_t(v >> 5), 7);
             }
+            // colour: the three literal codes of every label, the first two pre-merged (<= 30 bits)
+            uint32_t px_bits01[256], px_bits2[256];
+            uint8_t px_n01[256], px_n2[256];
+            if (lut) for (int v = 0; v < 256; ++v) {
+                const uint8_t* c = lut + 3 * v;
+                px_bits01[v] = uint32_t(ll_code[c[0]]) | (uint32_t(ll_code[c[1]]) << ll_len[c[0]]);
+                px_n01[v] = uint8_t(ll_len[c[0]] + ll_len[c[1]]);
+                px_bits2[v] = ll_code[c[2]]; px_n2[v] = ll_len[c[2]];
+            }
             for (size_t t = t0; t < t1; ++t) {
                 const uint32_t k = tok[t];
+                if (k & 0x40000000u) { const int v = int(k & 0xff); bw.put(px_bits01[v], px_n01[v]); bw.put(px_bits2[v], px_n2[v]); continue; }
                 if (k & 0x80000000u) {
                     const LenCode lc = len_code(int(k & 0x1ff));
                     bw.put(ll_code[lc.sym], ll_len[lc.sym]);

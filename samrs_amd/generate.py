@@ -58,7 +58,7 @@ class StageClock:
 
 def write_outputs(out_dir: str, stem: str, seg: np.ndarray, masks: Optional[np.ndarray], boxes: np.ndarray,
                   labels: np.ndarray, areas: np.ndarray, palette: np.ndarray, class_names: Sequence[str],
-                  rles: Optional[Sequence[dict]] = None, clock: Optional[StageClock] = None, png_level: int = 6) -> None:
+                  rles: Optional[Sequence[dict]] = None, clock: Optional[StageClock] = None, png_level: int = tile_io.LEVEL_LABELS) -> None:
     """`rles`: the per-instance COCO RLE dicts when they were encoded on the device (driver.TileResult.rle); otherwise they are
     encoded here from `masks` (host restatement), or left out when both are None (--no-rle)."""
     import time
@@ -67,7 +67,11 @@ def write_outputs(out_dir: str, stem: str, seg: np.ndarray, masks: Optional[np.n
         os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
     # native PNG encoders (libsamrs_io.so): no interpreter lock held while a tile is compressed; the colour image is the class
     # map seen through a 256-entry table (:163 white background, :199 palette colour per painted box)
-    tile_io.write_gray(os.path.join(out_dir, "gray", stem + ".png"), seg, tile_io.LEVEL_RUNS)   # :212,214
+    # png_level: LEVEL_LABELS (default) = the label-aware encoder for both images -- the colour image IS the class map seen through
+    # the palette, so its deflate tokens are derived from the 1-byte map (4x less CPU than zlib on the RGB bytes); 1..9 = zlib for
+    # color/*.png (and the run-length preset for gray/*.png), kept for A/B runs.  The decoded pixels never depend on it.
+    tile_io.write_gray(os.path.join(out_dir, "gray", stem + ".png"), seg,
+                       tile_io.LEVEL_LABELS if png_level == tile_io.LEVEL_LABELS else tile_io.LEVEL_RUNS)   # :212,214
     if clock: t0 = clock.add("write.gray_png", t0)
     tile_io.write_lut_rgb(os.path.join(out_dir, "color", stem + ".png"), seg, tile_io.class_lut(palette), png_level)   # :213,215
     if clock: t0 = clock.add("write.color_png", t0)
@@ -154,7 +158,7 @@ def run(args) -> Dict[str, List[int]]:
 
     import time
     tile_io.load_library()                                  # fail here, not on a worker thread, when libsamrs_io.so is missing
-    png_level = getattr(args, "png_level", 6)
+    png_level = getattr(args, "png_level", tile_io.LEVEL_LABELS)
     clock = StageClock() if getattr(args, "timing", False) else None
 
     # Tiles of the native size are decoded straight into pinned buffers the pipeline can upload from (driver._stage: "caller-owned
@@ -327,7 +331,9 @@ def main(argv=None):
     ap.add_argument("--writers", type=int, default=16, help="PNG / pickle writer threads")
     ap.add_argument("--split", type=int, default=None, help="engine operand-split mode (15 = block GEMMs at the 1x f16 rate, the default of "
                     "this single-mask driver; 79 = multimask-grade; 31 / 63 = reference-grade; DESIGN.md section 2)")
-    ap.add_argument("--png-level", type=int, default=6, help="zlib level of color/*.png (the pixels are the same at every level; gray/*.png uses the run-length preset)")
+    ap.add_argument("--png-level", type=int, default=tile_io.LEVEL_LABELS,
+                    help="-2 (default): the label-aware PNG encoder for gray/ and color/ (deflate tokens derived from the class map); 1..9: zlib "
+                         "level of color/*.png, run-length preset for gray/*.png.  The decoded pixels are the same either way")
     ap.add_argument("--out-depth", type=int, default=4, help="pinned output buffers (batches on loan to the writers at once)")
     ap.add_argument("--log", default=None, help="append one JSON line per batch (time, image stems, box counts) to this file "
                     "(<file>.rank<r> with more than one rank)")

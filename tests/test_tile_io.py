@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("hw", [(1, 1), (1, 7), (7, 1), (16, 20), (64, 80), (257, 300), (1024, 1024)])
-@pytest.mark.parametrize("level", [1, 6, tile_io.LEVEL_RUNS])
+@pytest.mark.parametrize("level", [1, 6, tile_io.LEVEL_RUNS, tile_io.LEVEL_LABELS])
 def test_written_files_decode_in_pil(tmp_path, hw, level):
     seg = _class_map(*hw, seed=hw[0])
     pal = np.random.default_rng(1).integers(0, 256, (18, 3), dtype=np.uint8)
@@ -50,7 +50,7 @@ def test_written_files_decode_in_pil(tmp_path, hw, level):
     ci = Image.open(c)
     assert ci.mode == "RGB" and np.array_equal(np.array(ci), lut[seg])
     assert np.array_equal(np.array(Image.open(r)), noise)
-    assert not os.path.exists(g + ".tmp")
+    assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]
     # and back through the native decoder
     assert np.array_equal(tile_io.read_rgb(c), lut[seg])
     assert np.array_equal(tile_io.read_rgb(g), np.repeat(seg[:, :, None], 3, axis=2))
@@ -166,3 +166,39 @@ def test_threads_run_concurrently(tmp_path):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs
+
+
+@pytest.mark.parametrize("kind", ["noise", "blobs", "constant", "columns", "rows", "wide"])
+def test_label_aware_encoder_is_a_plain_png(tmp_path, kind):
+    """SAMRS_IO_LEVEL_LABELS (the generation CLI's default): the deflate tokens of gray/*.png and color/*.png are derived from the
+    1-byte class map (runs equal to the row above / to the left neighbour, literal pixels otherwise; filter 0, dynamic Huffman).
+    Whatever the map looks like -- noise-like (the synthetic weights' worst case: one deflate block of ~10^6 tokens and more),
+    blobs, constant (one symbol: the degenerate Huffman tree), vertical / horizontal stripes (only "up" / only "left" matches),
+    a row too wide for the "up" distance to fit deflate's 32 KiB window -- PIL and the native decoder must return exactly the
+    class map / its palette expansion (main_sam_hbox_semantic.py:199,208-216: seg_color = MAPPING[seg_mask])."""
+    rng = np.random.default_rng(7)
+    h, w = 256, 384
+    if kind == "noise":
+        seg = rng.integers(0, 18, (1024, 1100)).astype(np.uint8)             # > 2^20 tokens: two deflate blocks
+    elif kind == "blobs":
+        seg = _class_map(h, w, seed=3)
+    elif kind == "constant":
+        seg = np.full((h, w), 255, np.uint8)
+    elif kind == "columns":
+        seg = np.repeat(rng.integers(0, 18, (1, w)).astype(np.uint8), h, axis=0)
+    elif kind == "rows":
+        seg = np.repeat(rng.integers(0, 18, (h, 1)).astype(np.uint8), w, axis=1)
+    else:
+        seg = np.repeat(rng.integers(0, 18, (3, 1200)).astype(np.uint8), 10, axis=1)      # 12000 px wide: 3 w + 1 > 32768
+    lut = tile_io.class_lut(rng.integers(0, 256, (18, 3), dtype=np.uint8))
+    g, c = str(tmp_path / "g.png"), str(tmp_path / "c.png")
+    tile_io.write_gray(g, seg, tile_io.LEVEL_LABELS)
+    tile_io.write_lut_rgb(c, seg, lut, tile_io.LEVEL_LABELS)
+    gi, ci = Image.open(g), Image.open(c)
+    assert gi.mode == "L" and ci.mode == "RGB"
+    assert np.array_equal(np.array(gi), seg) and np.array_equal(np.array(ci), lut[seg])
+    assert np.array_equal(tile_io.read_rgb(c), lut[seg])
+    # a strided source (a column slice of a wider map) encodes the same image
+    wide = np.concatenate([seg, seg[:, ::-1]], axis=1)
+    tile_io.write_lut_rgb(c, wide[:, :seg.shape[1]], lut, tile_io.LEVEL_LABELS)
+    assert np.array_equal(np.array(Image.open(c)), lut[seg])

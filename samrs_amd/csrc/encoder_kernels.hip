@@ -100,6 +100,9 @@ constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
 #ifndef SAMRS_GLB_ONES
 #define SAMRS_GLB_ONES 1
 #endif
+#ifndef SAMRS_GLB_SKEW      // A/B switch: 0 = the round-3 schedule of global_attention_kernel (all waves in the same phase)
+#define SAMRS_GLB_SKEW 1
+#endif
 
 template <int PREC>
 __global__ __launch_bounds__(256) void layernorm_kernel(
@@ -864,7 +867,9 @@ struct GlbCfg {
     static constexpr int KSTR = HD + 8;                   // K row stride: HD / 8 data chunks + 1 pad chunk (odd: see tile_times_qT)
     static constexpr int K_BYTES = KT * KSTR * 2;
     static constexpr int VT_BYTES = DT * 32 * VSTR * 2;
-    static constexpr int KV_BYTES = 2 * (K_BYTES + VT_BYTES);    // double buffered
+    // round 4: the two wave groups of a block run a third of a tile apart (see the main loop), which needs V^T triple-buffered
+    static constexpr int NKB = 2, NVB = SAMRS_GLB_SKEW ? 3 : 2;
+    static constexpr int KV_BYTES = NKB * K_BYTES + NVB * VT_BYTES;
     static constexpr int SSTR = 33;
     static constexpr int SCR_BYTES = NW * 32 * SSTR * 4;         // setup scratch, aliases the K/V buffers
     static constexpr int UNION_BYTES = KV_BYTES > SCR_BYTES ? KV_BYTES : SCR_BYTES;
@@ -889,8 +894,8 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
     float* Scr = reinterpret_cast<float*>(smem);                              // setup only
     // buffer b: K tile at b*(K_BYTES+VT_BYTES), V^T tile right after it (computed, not an array
     // of pointers: runtime-indexed arrays end up in scratch)
-    auto Kb = [&](int b) { return reinterpret_cast<uint16_t*>(smem + b * (C::K_BYTES + C::VT_BYTES)); };
-    auto Vb = [&](int b) { return reinterpret_cast<uint16_t*>(smem + b * (C::K_BYTES + C::VT_BYTES) + C::K_BYTES); };
+    auto Kb = [&](int b) { return reinterpret_cast<uint16_t*>(smem + b * C::K_BYTES); };                       // b in [0, NKB)
+    auto Vb = [&](int b) { return reinterpret_cast<uint16_t*>(smem + C::NKB * C::K_BYTES + b * C::VT_BYTES); };   // b in [0, NVB)
     float* RH = reinterpret_cast<float*>(smem + C::UNION_BYTES);             // [NW][32][RH_STR]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -992,29 +997,29 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
         }
         poff[i] = o;
     }
-#define GLB_DMA(kt_, buf_) GLB_DMA_RANGE(kt_, buf_, 0, PPW)
+#define GLB_DMA(kt_, kb_, vb_) GLB_DMA_RANGE(kt_, kb_, vb_, 0, PPW)
     // pieces [i0_, i1_) of this wave: the issue of a piece waits for a slot in the CU's texture-address queue (44 pieces
     // per tile time from the two resident blocks), so the pieces of the next tile are spread over the tile instead of
     // being queued in front of its first MFMA
-#define GLB_DMA_RANGE(kt_, buf_, i0_, i1_)                                                                   \
+#define GLB_DMA_RANGE(kt_, kb_, vb_, i0_, i1_)                                                               \
     _Pragma("unroll") for (int i_ = (i0_); i_ < (i1_) && i_ < PPW; ++i_) {                                   \
         const int pc_ = __builtin_amdgcn_readfirstlane(wave) + NW * i_;                                       \
         if (pc_ < NPC && poff[i_] != ~0u) {                                                                  \
             const bool isk_ = pc_ < KPC;                                                                     \
             const uint16_t* sb_ = isk_ ? base + (size_t)(kt_) * C::KT * (3 * D) + D : vth + (size_t)(kt_) * C::KT; \
-            const uint32_t dst_ = lds_base + (uint32_t)(buf_) * (C::K_BYTES + C::VT_BYTES) +                 \
-                                  (isk_ ? (uint32_t)pc_ * 1024u : (uint32_t)C::K_BYTES + (uint32_t)(pc_ - KPC) * 1024u); \
+            const uint32_t dst_ = lds_base + (isk_ ? (uint32_t)(kb_) * C::K_BYTES + (uint32_t)pc_ * 1024u            \
+                                                   : (uint32_t)(C::NKB * C::K_BYTES) + (uint32_t)(vb_) * C::VT_BYTES + (uint32_t)(pc_ - KPC) * 1024u); \
             glds16_sbase(poff[i_], sb_, __builtin_amdgcn_readfirstlane(dst_));                               \
         }                                                                                                    \
     }
     // rows d >= HD of V^T must be zero in both buffers (only when HD is not a multiple of 32); the DMA never touches them
     constexpr bool ONES = SAMRS_GLB_ONES && C::DT * 32 > HD;   // ... except row HD = 1: the softmax row sum rides on the PV product
     if (C::DT * 32 > HD) {
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < C::NVB; ++b)
             for (int i = tid; i < (C::DT * 32 - HD) * C::VSTR; i += NTH)
                 Vb(b)[HD * C::VSTR + i] = (ONES && i < C::VSTR) ? ET<PREC>::from_float(1.0f) : (uint16_t)0;
     }
-    GLB_DMA(0, 0)
+    GLB_DMA(0, 0, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -1034,10 +1039,21 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
 #else
 #define GLB_STAMP(i_)
 #endif
+    // Round 4 schedule (SAMRS_GLB_SKEW): the two wave groups of the block -- waves w and w + NW / 2 share a SIMD -- run a third of
+    // a tile apart, as the pair-stage GEMM's groups do.  With every wave in the same phase (round 3: one __syncthreads per tile
+    // re-aligned them) a SIMD's two waves wanted the matrix pipe at the same time (QK^T, PV) and the VALU at the same time (softmax:
+    // 32 exp2 per lane and tile at quarter rate), 3350 cycles per tile where the two units' work is 1400 + 2050.  Now group 1 takes
+    // its block barrier BETWEEN its softmax and its PV product, group 0 at the end of the tile: the barrier counts match, group 1's
+    // PV(t) runs beside group 0's QK^T(t + 1), and one group's softmax beside the other's MFMAs.  Buffer hand-over by the same
+    // barrier: tile t + 1 is fetched during tile t into K buffer (t + 1) & 1 and V^T buffer (t + 1) % 3 -- group 1 still reads
+    // V^T(t) after barrier t while group 0 already fetches tile t + 2, hence three V^T buffers; K(t) is only read before it.
+    const int grp = SAMRS_GLB_SKEW ? (wave >= NW / 2) : 0;
+    int vb = 0;                                                   // V^T buffer of tile kt
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
+        const int vb1 = SAMRS_GLB_SKEW ? (vb == 2 ? 0 : vb + 1) : (buf ^ 1);
         const bool more = kt + 1 < nkt;
-        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, 0, (PPW + 2) / 3)  // the other buffer was last read before the barrier that ended tile kt-1
+        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, 0, (PPW + 2) / 3)
         const float bh2 = rh[kt];  // RH[q][kh = kt], constant over the tile
         GLB_STAMP(0)
 
@@ -1057,13 +1073,18 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
         asm volatile("" :: "v"(mx), "v"(S[0][15]), "v"(S[1][15]));
 #endif
         GLB_STAMP(1)
-        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, (PPW + 2) / 3, 2 * ((PPW + 2) / 3))
+        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, (PPW + 2) / 3, 2 * ((PPW + 2) / 3))
         online_softmax_step<C::DT, !ONES>(S, 2, mx, bh2, m_run, l_run, O);
 #ifdef GLB_TIMING
         asm volatile("" :: "v"(S[0][0]), "v"(S[1][15]), "v"(l_run));
 #endif
         GLB_STAMP(2)
-        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, 2 * ((PPW + 2) / 3), PPW)
+        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, 2 * ((PPW + 2) / 3), PPW)
+        if (SAMRS_GLB_SKEW && grp == 1) {                           // group 1's rendezvous: its pieces of tile kt+1 have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");                          // no LDS read of the PV product may move above the barrier
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1071,7 +1092,7 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
                 const uint4 pb = pack_p<PREC>(S[a], u);
 #pragma unroll
                 for (int dt = 0; dt < C::DT; ++dt) {
-                    const uint4 va = load_vt_frag_perm(Vb(buf) + (dt * 32 + ql) * C::VSTR + 32 * a, u, hh);
+                    const uint4 va = load_vt_frag_perm(Vb(SAMRS_GLB_SKEW ? vb : buf) + (dt * 32 + ql) * C::VSTR + 32 * a, u, hh);
                     O[dt] = ET<PREC>::mfma32(va, pb, O[dt]);
                 }
             }
@@ -1079,10 +1100,18 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
         asm volatile("" :: "v"(O[0][0]), "v"(O[C::DT - 1][15]));
 #endif
         GLB_STAMP(3)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 have landed
-        GLB_STAMP(4)
-        __syncthreads();                                        // ... everybody's; and buffer `buf` is free again
+        if (!SAMRS_GLB_SKEW) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt+1 have landed
+            GLB_STAMP(4)
+            __syncthreads();                                        // ... everybody's; and buffer `buf` is free again
+        } else if (grp == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GLB_STAMP(4)
+            __builtin_amdgcn_s_barrier();                           // group 0's rendezvous, at the end of its tile
+            asm volatile("" ::: "memory");
+        }
         GLB_STAMP(5)
+        vb = vb1;
     }
 
 #ifdef GLB_TIMING

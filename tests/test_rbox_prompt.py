@@ -72,7 +72,7 @@ def test_hip_rbox_prompts_on_the_known_answer_polygons():
     for j, p in enumerate(polys):
         want = rp.rbox_mask_prompt(p.astype(np.int32), 1024, 1024).astype(np.float32)
         assert np.array_equal(got[j], want), k["fill_poly"][j]["name"]
-        assert (got[j] > 0).any() and (got[j] < 0).any()
+        assert (got[j] < 0).any()             # (a one-pixel sliver can vanish in the 4:1 bilinear reduction to 256 x 256: no > 0 assertion)
 
 
 def test_line8_closed_form_matches_walk():

@@ -23,11 +23,11 @@ for step in "$@"; do
     all)     run all 2400 python -m pytest tests -m gpu -q -rA -p no:cacheprovider ;;
     smoke)   run smoke 600 python -c "import __graft_entry__ as g; g.smoke()" ;;
     attnb)   run attnb_new 300 python tools/attn_bench.py
-             SAMRS_LIB_PATH=samrs_amd/csrc/libsamrs_hip_r03.so run attnb_r03 300 python tools/attn_bench.py
+             SAMRS_LIB_PATH=${AB_LIB:-samrs_amd/csrc/libsamrs_hip_noskew.so} run attnb_old 300 python tools/attn_bench.py
              run attnb_new2 300 python tools/attn_bench.py ;;
     attnpmc) prof_env
              run attnpmc1 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/attnpmc1 -o p -- python tools/attn_bench.py
-             SAMRS_LIB_PATH=samrs_amd/csrc/libsamrs_hip_r03.so run attnpmc0 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/attnpmc0 -o p -- python tools/attn_bench.py
+             SAMRS_LIB_PATH=${AB_LIB:-samrs_amd/csrc/libsamrs_hip_noskew.so} run attnpmc0 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/attnpmc0 -o p -- python tools/attn_bench.py
              run attnpmc2 300 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/attnpmc2 -o p -- python tools/attn_bench.py ;;
     kmx)     run kmx 600 $PT tests/test_kernels_gpu.py -k "mx" ;;
     c4ab)    SAMRS_LO_FORMAT=0 run c4_lo0 400 python bench.py --workload c4 --steps ${BENCH_STEPS:-12} --warmup 3 $BQ
@@ -40,7 +40,7 @@ for step in "$@"; do
     pstats)  run pstats 1500 python tools/parity_stats.py --modes ${PS_MODES:-15,79,63} ${PS_ARGS:-} ;;
     benchq)  run benchq 900 python bench.py --steps ${BENCH_STEPS:-8} --warmup 2 $BQ ${BENCH_EXTRA:-} ;;
     bench)   run bench 1500 python bench.py ${BENCH_ARGS:-} ;;
-    ablib)   run ablib 1200 bash tools/ab_libs.sh ${AB_ROUNDS:-2} samrs_amd/csrc/libsamrs_hip_r03.so samrs_amd/csrc/libsamrs_hip.so ;;
+    ablib)   run ablib 1200 bash tools/ab_libs.sh ${AB_ROUNDS:-2} ${AB_LIB:-samrs_amd/csrc/libsamrs_hip_noskew.so} samrs_amd/csrc/libsamrs_hip.so ;;
     c3)      run c3 600 python bench.py --workload c3 --steps ${BENCH_STEPS:-6} --warmup 2 $BQ ;;
     c4)      run c4 600 python bench.py --workload c4 --steps ${BENCH_STEPS:-6} --warmup 2 $BQ ;;
     decb)    run decb 300 python tools/dec_bench.py 20 ;;

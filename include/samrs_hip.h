@@ -152,8 +152,9 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
                 int orig_h, int orig_w, uint8_t* seg_mask, int64_t* areas_out,
                 int64_t* class_pixels, int64_t* class_instances, int n_classes, void* stream);
 
-/* -- instance drivers (main_sam_rhbox_mask_instance.py / main_sam_rbox_mask_instance.py with multimask_output=True,
- * BASELINE.json configs[3]): of the n_sel masks per object keep the one with the highest predicted IoU (first maximum),
+/* -- BASELINE.json configs[3] (the rbox / rhbox instance path WITH multimask_output=True; the reference's own scripts,
+ * main_sam_rhbox_mask_instance.py:168 / main_sam_rbox_mask_instance.py:164 / main_sam_hbox_mask_instance.py:165, all pass
+ * multimask_output=False and need none of this): of the n_sel masks per object keep the one with the highest predicted IoU (first maximum),
  * replacing the host-side `argmax` / gather / `.sum()`.  masks uint8 [n][n_sel][h][w], iou fp32 [n][n_sel] (both outputs of
  * samrs_predict) -> best_out uint8 [n][h][w], quality_out fp32 [n], areas_out int64 [n] (pixels set). */
 int samrs_select_best(samrs_engine_t* e, const uint8_t* masks, const float* iou, int n, int n_sel, int h, int w,

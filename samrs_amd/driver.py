@@ -642,7 +642,9 @@ def batched(items: Iterable[WorkItem], batch: int) -> Iterator[List[WorkItem]]:
 
 class InstancePipeline(TilePipeline):
     """The instance drivers' recipe (main_sam_rhbox_mask_instance.py:125-168 / main_sam_rbox_mask_instance.py:125-164)
-    on the same three-stream pipeline, with ``multimask_output=True`` (BASELINE.json configs[3]): annotations are
+    on the same three-stream pipeline.  ``multimask=True`` is BASELINE.json configs[3]; the reference's own instance scripts all pass
+    ``multimask_output=False`` (main_sam_rhbox_mask_instance.py:168, main_sam_rbox_mask_instance.py:164,
+    main_sam_hbox_mask_instance.py:165): ``multimask=False`` is their configuration.  Annotations are
     rotated boxes [n, 4, 2]; ``prompt="box"`` feeds the enclosing hbox (min / max of the corners, :125-130) through
     ``apply_boxes_torch``, ``prompt="rbox_mask"`` rasterises the rbox into a +-1000 mask prompt on the GPU
     (``transforms.rbox_mask_prompts``).  Of the three masks per object the one with the highest predicted IoU is kept

@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
         const bool more = kt + 1 < nkt;
         // group 1 waits for its pieces in the MIDDLE of the tile (before its barrier): it issues them one slot earlier than group 0,
         // so that its softmax still runs between the last issue and the wait
-        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, 0, (grp ? 2 : 1) * ((PPW + 2) / 3))
+        if (more) { if (grp) { GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, 0, 2 * ((PPW + 2) / 3)) } else { GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, 0, (PPW + 2) / 3) } }
         const float bh2 = rh[kt];  // RH[q][kh = kt], constant over the tile
         GLB_STAMP(0)
 
@@ -1075,13 +1075,13 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
         asm volatile("" :: "v"(mx), "v"(S[0][15]), "v"(S[1][15]));
 #endif
         GLB_STAMP(1)
-        if (more) GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, (grp ? 2 : 1) * ((PPW + 2) / 3), grp ? PPW : 2 * ((PPW + 2) / 3))
+        if (more) { if (grp) { GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, 2 * ((PPW + 2) / 3), PPW) } else { GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, (PPW + 2) / 3, 2 * ((PPW + 2) / 3)) } }
         online_softmax_step<C::DT, !ONES>(S, 2, mx, bh2, m_run, l_run, O);
 #ifdef GLB_TIMING
         asm volatile("" :: "v"(S[0][0]), "v"(S[1][15]), "v"(l_run));
 #endif
         GLB_STAMP(2)
-        if (more && !grp) GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, 2 * ((PPW + 2) / 3), PPW)
+        if (more && !grp) { GLB_DMA_RANGE(kt + 1, buf ^ 1, vb1, 2 * ((PPW + 2) / 3), PPW) }
         if (SAMRS_GLB_SKEW && grp == 1) {                           // group 1's rendezvous: its pieces of tile kt+1 have landed
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();

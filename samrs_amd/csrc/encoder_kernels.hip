@@ -100,8 +100,12 @@ constexpr int LN_MAXV = 8;  // float4 per lane -> D <= 2048
 #ifndef SAMRS_GLB_ONES
 #define SAMRS_GLB_ONES 1
 #endif
-#ifndef SAMRS_GLB_SKEW      // A/B switch: 0 = the round-3 schedule of global_attention_kernel (all waves in the same phase)
-#define SAMRS_GLB_SKEW 1
+// A/B switch: 1 = the two wave groups of global_attention_kernel a third of a tile apart (group 1 takes its block barrier between its
+// softmax and its PV product; V^T triple-buffered).  Built in round 4 on the theory that the phase-locked waves of a SIMD want the
+// matrix pipe and the VALU at the same times; measured on MI355X (tools/attn_bench.py, alternating libraries): 1217 - 1233 us against
+// 1182 - 1208 us for the phase-locked schedule -- no gain, so the default stays 0 (profiles/r04_attention_lds.txt).
+#ifndef SAMRS_GLB_SKEW
+#define SAMRS_GLB_SKEW 0
 #endif
 
 template <int PREC>
@@ -1039,7 +1043,7 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
 #else
 #define GLB_STAMP(i_)
 #endif
-    // Round 4 schedule (SAMRS_GLB_SKEW): the two wave groups of the block -- waves w and w + NW / 2 share a SIMD -- run a third of
+    // Optional schedule (SAMRS_GLB_SKEW = 1, off by default: measured no faster): the two wave groups of the block -- waves w and w + NW / 2 share a SIMD -- run a third of
     // a tile apart, as the pair-stage GEMM's groups do.  With every wave in the same phase (round 3: one __syncthreads per tile
     // re-aligned them) a SIMD's two waves wanted the matrix pipe at the same time (QK^T, PV) and the VALU at the same time (softmax:
     // 32 exp2 per lane and tile at quarter rate), 3350 cycles per tile where the two units' work is 1400 + 2050.  Now group 1 takes

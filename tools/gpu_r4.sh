@@ -35,6 +35,7 @@ for step in "$@"; do
              SAMRS_LO_FORMAT=0 run c4_lo0b 400 python bench.py --workload c4 --steps ${BENCH_STEPS:-12} --warmup 3 $BQ
              SAMRS_LO_FORMAT=4 run c4_lo4b 400 python bench.py --workload c4 --steps ${BENCH_STEPS:-12} --warmup 3 $BQ ;;
     mxb)     run mxb 300 python tools/mx_bench.py ;;
+    energy)  run energy 300 python tools/gemm_energy.py ;;
     profc4)  prof_env
              SAMRS_LO_FORMAT=${LOF:-4} run profc4 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/profc4 -o c4 -- python bench.py --workload c4 --steps 3 --warmup 1 $BQ ;;
     pstats)  run pstats 1500 python tools/parity_stats.py --modes ${PS_MODES:-15,79,63} ${PS_ARGS:-} ;;

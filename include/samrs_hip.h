@@ -212,7 +212,7 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    three accumulating launches through an fp32 scratch (the generic route, every shape); 0 = as ONE launch over a
  *                    three-segment K axis where the shape fits the 256 x 320 tile (ViT-H; samrs_k_gemm_split3), else the generic route.
  *   "lo_format"      [SAMRS_LO_FORMAT; default 4 where the MX kernel covers the block shapes (ViT-H), else 0] operand format of the two
- *                    correction terms of the attention-side block-GEMM split (bits 64 / 16): 0 = f16 (a split GEMM is three f16
+ *                    correction terms of the block-GEMM split (bits 64 / 16 and 32): 0 = f16 (a split GEMM is three f16
  *                    passes), 4 = MXFP4 (e2m1 + E8M0 scale per 32 k on gfx950's block-scaled MFMA: the corrections run at 4x the f16
  *                    rate on a quarter of the stages, a split GEMM costs 1.5 passes; oracle/error_budget.py plans10 for what the
  *                    format costs in mask pixels: nothing measurable).  The fp4 weight copies are made at samrs_finalize_weights
@@ -321,7 +321,7 @@ int samrs_k_upscaler_fused(int prec, const void* keys_et, const void* keys_lo_et
  *   samrs_k_mx4_pack   x (fp32 [rows][K]) or the ET pair (hi_in, lo_in) -> fp4 codes of hi / lo, q_* [rows][Kp / 2] bytes, and their
  *                      scale tiles s_* (samrs_k_mx_scale_bytes(rows, Kp, is_b) bytes each; A-operand or B-operand tile order);
  *                      out_hi (optional, with x): ET(x).  Every group of G source elements becomes GP on the padded axis (zeros
- *                      behind it): Kp = K / G * GP, a multiple of 256; plain: G = GP = K.  is_b: bit 0 = B-operand scale tiles, bit 1 = the
+ *                      behind it): Kp = K / G * GP, a multiple of 256; plain: G = GP = K.  is_b: bit 0 = B-operand scale tiles, bit 2 = the block order of a GEMM epilogue's MX rows (position 8 f + 4 i + e holds column 16 i + 4 f + e), bit 1 = the
  *                      block-internal element order in which the attention kernels emit their own MX rows (position 16 h + 4 g + e
  *                      of a block holds element 8 g + 4 h + e): what the proj weights are packed with.
  *   samrs_k_gemm_mx    C = A B^T + A4lo B4hi^T + A4hi B4lo^T + bias: the f16 product over K, the two fp4 products over Kp, fp32
@@ -341,6 +341,12 @@ int samrs_k_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo
 int samrs_k_gemm_mx(int prec, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int Kp, const void* a4_lo,
                     const void* a4_hi, const void* sa_lo, const void* sa_hi, const void* b4_hi, const void* b4_lo, const void* sb_hi,
                     const void* sb_lo, int out_f32, int accumulate, int split_from_n, void* stream);
+/* samrs_k_gemm_mx with an ET output, optionally the exact-erf GELU in the epilogue, and (o4_*: all four or none) the output ALSO written
+ * as MXFP4 hi / lo on a K axis padded per 80-column wave tile to 96 -- [M][N / 80 * 48] bytes + A-operand scale tiles, block-internal
+ * order = samrs_k_mx4_pack is_b bit 2: lin1 feeding lin2 in the all-split mode */
+int samrs_k_gemm_mx_gelu_mxout(int prec, const void* A, const void* B, void* C_et, const float* bias, int M, int N, int K, int Kp,
+                               const void* a4_lo, const void* a4_hi, const void* sa_lo, const void* sa_hi, const void* b4_hi, const void* b4_lo,
+                               const void* sb_hi, const void* sb_lo, int gelu, void* o4_hi, void* o4_lo, void* so_hi, void* so_lo, void* stream);
 /* fp32 -> hi (= samrs_k_convert) and lo = ET(x - hi): the two-term operand split */
 int samrs_k_convert_split(int prec, const float* in, void* out_hi_et, void* out_lo_et, int64_t n, void* stream);
 

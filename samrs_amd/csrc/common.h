@@ -173,6 +173,16 @@ struct MxOut {
     unsigned char *q_hi = nullptr, *q_lo = nullptr, *s_hi = nullptr, *s_lo = nullptr;
 };
 
+// value of lane l ^ 16 / l ^ 32 (v_permlane16_swap / v_permlane32_swap: VALU cross-lane moves, no LDS crossbar)
+__device__ __forceinline__ float lane_xor16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return (threadIdx.x & 16) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // wave-level reductions (64 lanes)
 // ---------------------------------------------------------------------------------------------

@@ -68,6 +68,9 @@ struct EncBlock {
     // straddles two heads
     unsigned char *qkv_w4[2] = {nullptr, nullptr}, *qkv_s4[2] = {nullptr, nullptr};       // [0] = hi, [1] = lo
     unsigned char *proj_w4[2] = {nullptr, nullptr}, *proj_s4[2] = {nullptr, nullptr};
+    // ... and of the MLP weights (bit 32): lin1 plain, lin2 on the K axis that lin1's epilogue writes its MX rows on (80 -> 96 per wave tile)
+    unsigned char *lin1_w4[2] = {nullptr, nullptr}, *lin1_s4[2] = {nullptr, nullptr};
+    unsigned char *lin2_w4[2] = {nullptr, nullptr}, *lin2_s4[2] = {nullptr, nullptr};
     // LayerNorm folded into qkv / lin1 (ViT-H): W diag(gamma) in ET, its row sums, b + W beta
     uint16_t *qkv_wf = nullptr, *lin1_wf = nullptr;
     float *qkv_c = nullptr, *qkv_bf = nullptr, *lin1_c = nullptr, *lin1_bf = nullptr;
@@ -101,6 +104,9 @@ struct samrs_engine {
     int lo_format = 0;                              // 0: lo terms on f16 operands (three-segment f16 GEMM); 4: on MXFP4 operands
     bool mx_ready = false;                          // the fp4 weight copies + activation workspaces exist (fixed at samrs_finalize_weights)
     int mx_gp = 0, mx_kp_proj = 0;                  // proj's padded K axis: heads x mx_gp (head_dim rounded up to 32)
+    bool mx_mlp_ready = false;                      // the same for the MLP GEMMs (bit 32 set at samrs_finalize_weights)
+    int mx_kp_lin2 = 0;                             // lin2's padded K axis: 4 D / 80 x 96
+    unsigned char *H4[2] = {nullptr, nullptr}, *SH4[2] = {nullptr, nullptr};       // GELU(lin1) as fp4 hi / lo, written by lin1's epilogue
     unsigned char *Y4[2] = {nullptr, nullptr}, *SY4[2] = {nullptr, nullptr};       // LN output as fp4 hi / lo + scale tiles (A layout)
     unsigned char *AO4[2] = {nullptr, nullptr}, *SAO4[2] = {nullptr, nullptr};     // attention output likewise (padded K axis)
     bool upscaler_fused = true;                     // one-kernel upscaler (upscaler_fused.hip) instead of ConvT1 GEMM + ConvT2 kernel
@@ -491,6 +497,21 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
                 e->mx_ready = true;
             }
         }
+        if (lo_m && e->lo_format == 4 && gemm_mx_ok(c.max_images * e->tokens, 4 * D, D, D) && (4 * D) % 80 == 0) {
+            const int kp2 = 4 * D / 80 * 96;
+            if (gemm_mx_ok(c.max_images * e->tokens, D, 4 * D, kp2)) {
+                e->mx_kp_lin2 = kp2;
+                for (int h = 0; h < 2; ++h) {
+                    CK(e, dalloc(e, &b.lin1_w4[h], (size_t)4 * D * D / 2)); CK(e, dalloc(e, &b.lin1_s4[h], mx_scale_bytes(4 * D, D, true)));
+                    CK(e, dalloc(e, &b.lin2_w4[h], (size_t)D * kp2 / 2)); CK(e, dalloc(e, &b.lin2_s4[h], mx_scale_bytes(D, kp2, true)));
+                }
+                CK(e, launch_mx4_pack(e->prec, W(e, p + ".mlp.lin1.weight"), nullptr, nullptr, nullptr, b.lin1_w4[0], b.lin1_w4[1], b.lin1_s4[0],
+                                      b.lin1_s4[1], 4 * D, D, D, D, true, s));
+                CK(e, launch_mx4_pack(e->prec, W(e, p + ".mlp.lin2.weight"), nullptr, nullptr, nullptr, b.lin2_w4[0], b.lin2_w4[1], b.lin2_s4[0],
+                                      b.lin2_s4[1], D, 4 * D, 80, 96, true, s, /* perm: the order of lin1's epilogue */ 2));
+                e->mx_mlp_ready = true;
+            }
+        }
         if ((rc = to_et(e, p + ".attn.qkv.weight", &b.qkv_w, true, s, lo_a ? &b.qkv_w_lo : nullptr))) return rc;
         if ((rc = to_et(e, p + ".attn.proj.weight", &b.proj_w, true, s, lo_a ? &b.proj_w_lo : nullptr))) return rc;
         if ((rc = to_et(e, p + ".mlp.lin1.weight", &b.lin1_w, true, s, lo_m ? &b.lin1_w_lo : nullptr))) return rc;
@@ -576,9 +597,17 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
         CK(e, dalloc(e, &e->Ylo, M * D));
         if (e->split & SPLIT_MLP) CK(e, dalloc(e, &e->F32T, M * 4 * D));      // the generic attention-side route allocates it on first use
         if (e->split & SPLIT_ATTN_ANY) CK(e, dalloc(e, &e->AOlo, M * D));
+        if (e->mx_mlp_ready) {
+            for (int h = 0; h < 2; ++h) {
+                CK(e, dalloc(e, &e->H4[h], M * e->mx_kp_lin2 / 2)); CK(e, dalloc(e, &e->SH4[h], mx_scale_bytes((int)M, e->mx_kp_lin2, false)));
+                if (!e->Y4[h]) { CK(e, dalloc(e, &e->Y4[h], M * D / 2)); CK(e, dalloc(e, &e->SY4[h], mx_scale_bytes((int)M, D, false))); }
+            }
+        }
         if (e->mx_ready) {
             for (int h = 0; h < 2; ++h) {
+                if (!e->Y4[h]) {
                 CK(e, dalloc(e, &e->Y4[h], M * D / 2)); CK(e, dalloc(e, &e->SY4[h], mx_scale_bytes((int)M, D, false)));
+                }
                 CK(e, dalloc(e, &e->AO4[h], M * e->mx_kp_proj / 2)); CK(e, dalloc(e, &e->SAO4[h], mx_scale_bytes((int)M, e->mx_kp_proj, false)));
             }
         }
@@ -690,6 +719,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         const bool sp_attn = attn_full || ((e->split & SPLIT_ATTN_V) && i < depth_v), sp_mlp = any_mlp && i < depth_full;
         // v third only: needs the tile mask of the one-launch kernel; other shapes split all of qkv
         const int v_from = (sp_attn && !attn_full && one3 && gemm_split3_ok(M, 3 * D, D) && (2 * D) % 320 == 0) ? 2 * D : 0;
+        const bool mx_mlp = e->lo_format == 4 && e->mx_mlp_ready && !e->split_passes && gemm_mx_ok(M, 4 * D, D, D) && gemm_mx_ok(M, D, 4 * D, e->mx_kp_lin2);
         const bool mx_attn = e->lo_format == 4 && e->mx_ready && !e->split_passes && gemm_mx_ok(M, 3 * D, D, D) && (2 * D) % 320 == 0;
         // norm1 + qkv in plain token order for both block kinds; the windowed kernel partitions
         // on the fly and takes k / v of padding positions from the qkv bias
@@ -742,7 +772,10 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                 }
                 CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
             }
-            CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, sp_mlp ? e->Ylo : nullptr));
+            if (sp_mlp && mx_mlp)
+                CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, nullptr, e->Y4[0], e->Y4[1], e->SY4[0], e->SY4[1]));
+            else
+                CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, sp_mlp ? e->Ylo : nullptr));
         }
         hipEvent_t t0 = nullptr, t1 = nullptr;
         if (e->timing) {
@@ -754,7 +787,11 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, hipEventRecord(t0, s));
         }
         if (fold) CK(e, launch_gemm_et_fold(prec, e->Y, b.lin1_wf, e->H, b.lin1_bf, b.lin1_c, e->ROWSTAT, M, 4 * D, D, true, s));
-        else if (sp_mlp) {
+        else if (sp_mlp && mx_mlp) {
+            // lo terms on MXFP4: ET output with the exact-erf GELU in the epilogue, which also emits H as fp4 hi / lo for lin2
+            CK(e, launch_gemm_et_mx(prec, e->Y, b.lin1_w, e->H, b.lin1_b, M, 4 * D, D, D, e->Y4[1], e->Y4[0], e->SY4[1], e->SY4[0], b.lin1_w4[0],
+                                    b.lin1_w4[1], b.lin1_s4[0], b.lin1_s4[1], false, false, 0, s, true, e->H4[0], e->H4[1], e->SH4[0], e->SH4[1]));
+        } else if (sp_mlp) {
             if (one3 && gemm_split3_ok(M, 4 * D, D)) {
                 CK(e, launch_gemm_et_split3(prec, e->Y, e->Ylo, b.lin1_w, b.lin1_w_lo, e->F32T, b.lin1_b, M, 4 * D, D, true, false, s));
             } else {
@@ -772,7 +809,10 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, launch_gemm_et_stats(prec, e->H, b.lin2_w, e->X, b.lin2_b, e->Y, e->STATS, M, D, 4 * D, s));
             if (i + 1 < c.depth) CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
         } else {
-            if (sp_mlp && one3 && gemm_split3_ok(M, D, 4 * D)) {
+            if (sp_mlp && mx_mlp) {
+                CK(e, launch_gemm_et_mx(prec, e->H, b.lin2_w, e->X, b.lin2_b, M, D, 4 * D, e->mx_kp_lin2, e->H4[1], e->H4[0], e->SH4[1], e->SH4[0],
+                                        b.lin2_w4[0], b.lin2_w4[1], b.lin2_s4[0], b.lin2_s4[1], true, true, 0, s));
+            } else if (sp_mlp && one3 && gemm_split3_ok(M, D, 4 * D)) {
                 CK(e, launch_gemm_et_split3(prec, e->H, e->Hlo, b.lin2_w, b.lin2_w_lo, e->X, b.lin2_b, M, D, 4 * D, true, true, s));
             } else {
                 if (sp_mlp) {
@@ -1176,7 +1216,7 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     else if (n == "allow_reduced") e->allow_reduced = value != 0;
     else if (n == "lo_format") {
         if (value != 0 && value != 4) return fail(e, SAMRS_ERR_BAD_ARG, "lo_format is 0 (f16 lo terms) or 4 (MXFP4 lo terms)");
-        if (value == 4 && e->finalized && !e->mx_ready)
+        if (value == 4 && e->finalized && !e->mx_ready && !e->mx_mlp_ready)
             return fail(e, SAMRS_ERR_BAD_ARG, "lo_format 4 needs the fp4 weight copies: set it (and a block-GEMM split bit) before the weights are "
                                               "finalized; it covers the attention-side split of models whose block GEMMs fit the 256 x 320 tile (ViT-H)");
         e->lo_format = value;
@@ -1195,7 +1235,7 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
     else if (n == "split_passes") *value = e->split_passes;
     else if (n == "split_depth") *value = e->split_depth;
     else if (n == "allow_reduced") *value = e->allow_reduced;
-    else if (n == "lo_format") *value = (e->finalized && !e->mx_ready) ? 0 : e->lo_format;
+    else if (n == "lo_format") *value = (e->finalized && !e->mx_ready && !e->mx_mlp_ready) ? 0 : e->lo_format;
     else if (n == "grade_multimask") *value = e->grade_multimask;     // read-only
     else return SAMRS_ERR_BAD_ARG;
     return SAMRS_OK;
@@ -1394,7 +1434,8 @@ int64_t samrs_k_mx_scale_bytes(int rows, int Kp, int is_b) { return (int64_t)mx_
 int samrs_k_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo_in, void* out_hi, void* q_hi, void* q_lo, void* s_hi,
                      void* s_lo, int rows, int K, int G, int GP, int is_b, void* stream) {
     // is_b bit 1: the attention kernels' block-internal element order (launch_mx4_pack perm)
-    return launch_mx4_pack(prec, x, hi_in, lo_in, out_hi, q_hi, q_lo, s_hi, s_lo, rows, K, G, GP, (is_b & 1) != 0, (hipStream_t)stream, (is_b & 2) != 0) == hipSuccess
+    return launch_mx4_pack(prec, x, hi_in, lo_in, out_hi, q_hi, q_lo, s_hi, s_lo, rows, K, G, GP, (is_b & 1) != 0, (hipStream_t)stream,
+                           (is_b & 2) ? 1 : (is_b & 4) ? 2 : 0) == hipSuccess
                ? SAMRS_OK : SAMRS_ERR_BAD_SHAPE;
 }
 int samrs_k_gemm_mx(int prec, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int Kp, const void* a4_lo,
@@ -1402,6 +1443,12 @@ int samrs_k_gemm_mx(int prec, const void* A, const void* B, void* C, const float
                     const void* sb_lo, int out_f32, int accumulate, int split_from_n, void* stream) {
     return launch_gemm_et_mx(prec, A, B, C, bias, M, N, K, Kp, a4_lo, a4_hi, sa_lo, sa_hi, b4_hi, b4_lo, sb_hi, sb_lo, out_f32 != 0,
                              accumulate != 0, split_from_n, (hipStream_t)stream) == hipSuccess ? SAMRS_OK : SAMRS_ERR_BAD_SHAPE;
+}
+int samrs_k_gemm_mx_gelu_mxout(int prec, const void* A, const void* B, void* C_et, const float* bias, int M, int N, int K, int Kp,
+                               const void* a4_lo, const void* a4_hi, const void* sa_lo, const void* sa_hi, const void* b4_hi, const void* b4_lo,
+                               const void* sb_hi, const void* sb_lo, int gelu, void* o4_hi, void* o4_lo, void* so_hi, void* so_lo, void* stream) {
+    return launch_gemm_et_mx(prec, A, B, C_et, bias, M, N, K, Kp, a4_lo, a4_hi, sa_lo, sa_hi, b4_hi, b4_lo, sb_hi, sb_lo, false, false, 0,
+                             (hipStream_t)stream, gelu != 0, o4_hi, o4_lo, so_hi, so_lo) == hipSuccess ? SAMRS_OK : SAMRS_ERR_BAD_SHAPE;
 }
 int samrs_k_convert_split(int prec, const float* in, void* out_hi, void* out_lo, int64_t n, void* stream) {
     KRET(launch_convert(prec, in, out_hi, (long)n, (hipStream_t)stream, out_lo));

@@ -383,12 +383,18 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
 // ---------------------------------------------------------------------------------------------
 // FOLD (LayerNorm folded into this GEMM, see gemm_et_x64p_kernel): the value is rstd_m * acc + (-rstd_m mean_m) * cvec_n +
 // bias_n with (rstd_m, -rstd_m mean_m) = rowstat[m] (global, written by ln_rowstat_kernel) instead of acc + bias_n.
-template <int PREC, bool GELU, int JC = 4, bool DRAIN = false, bool FOLD = false>
+// MXO (round 4): the output is also the A operand of a GEMM whose lo terms run on MXFP4 (lin1 -> lin2 in the all-split mode): besides
+// the ET row segments the epilogue writes hi / lo of every value as fp4 codes + E8M0 scales on a K axis padded per WAVE TILE (80 -> 96
+// columns: a 32-element block never straddles two waves; mx4_pack_kernel perm 2 lays the weights out the same way).  The 16 columns of
+// n-tile i of a row sit in the 4 lanes fq = 0..3 (4 each): block 0 = n-tiles 0 | 1, block 1 = 2 | 3, block 2 = 4 | zeros; block maxima
+// by two cross-lane swaps (l ^ 16, l ^ 32), codes by v_cvt_scalef32_pk_fp4_f32, one dword store per lane, block and tensor (position
+// 8 fq + 4 (i & 1) + e of the block holds column 16 (i & 1) + 4 fq + e).
+template <int PREC, bool GELU, int JC = 4, bool DRAIN = false, bool FOLD = false, bool MXO = false>
 __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned char* lds, void* __restrict__ Cv,
                                                  const float* __restrict__ bias, const float* __restrict__ pre2d, int period, int N,
                                                  int m_base /* wave tile row 0 */, int n_pair /* first column of the pair */,
                                                  int wm, int wn, int lane, const float2* __restrict__ rowstat = nullptr /* FOLD: [M] */,
-                                                 const float* __restrict__ cvec = nullptr /* FOLD */) {
+                                                 const float* __restrict__ cvec = nullptr /* FOLD */, MxOut mxo = MxOut()) {
     constexpr int RS = 400;                 // 320 data bytes + pad: 100 words = 4 (mod 32)
     constexpr int TS = 16 * RS;
     const int fr = lane & 15, fq = lane >> 4, half = wn & 1;
@@ -417,6 +423,7 @@ __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned 
             const int j = j0 + jj;
             float2 rs = make_float2(1.f, 0.f);
             if constexpr (FOLD) rs = rs_cur[jj];
+            float mxh[MXO ? 24 : 1], mxl[MXO ? 24 : 1];          // MXO: hi / lo of this row's 20 values (+ 4 zeros of the padded n-tile)
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y;
@@ -436,6 +443,39 @@ __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned 
                 o.x = pack2<PREC>(v0, v1);
                 o.y = pack2<PREC>(v2, v3);
                 *reinterpret_cast<uint2*>(scr + jj * TS + fr * RS + half * 160 + (i * 16 + 4 * fq) * 2) = o;
+                if constexpr (MXO) {
+                    const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float hv = ET<PREC>::to_float((uint16_t)(((e & 2) ? o.y : o.x) >> (16 * (e & 1))));
+                        mxh[4 * i + e] = hv;
+                        mxl[4 * i + e] = vv[e] - hv;
+                    }
+                }
+            }
+            if constexpr (MXO) {
+#pragma unroll
+                for (int e = 20; e < 24; ++e) { mxh[e] = 0.f; mxl[e] = 0.f; }
+                const int row = m_base + j * 16 + fr;
+                const int wt = (n_pair + half * 80) / 80, nblk = (N / 80) * 3;
+                const size_t rowb = (size_t)row * (size_t)(nblk * 16);
+#pragma unroll
+                for (int b3 = 0; b3 < 3; ++b3) {
+                    float ah = 0.f, al = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ah = fmaxf(ah, fabsf(mxh[8 * b3 + e])); al = fmaxf(al, fabsf(mxl[8 * b3 + e])); }
+                    ah = fmaxf(ah, lane_xor16(ah)); al = fmaxf(al, lane_xor16(al));
+                    ah = fmaxf(ah, lane_xor32(ah)); al = fmaxf(al, lane_xor32(al));
+                    const int bh = mx_scale_byte(ah), bl = mx_scale_byte(al);
+                    const size_t at = rowb + (size_t)(wt * 3 + b3) * 16 + 4 * fq;
+                    *reinterpret_cast<uint32_t*>(mxo.q_hi + at) = fp4_pack8(mxh + 8 * b3, bh);
+                    *reinterpret_cast<uint32_t*>(mxo.q_lo + at) = fp4_pack8(mxl + 8 * b3, bl);
+                    if (fq == 0) {
+                        const size_t si = mx_scale_index(false, row, wt * 3 + b3, nblk * 32 / MXK);
+                        mxo.s_hi[si] = (unsigned char)bh;
+                        mxo.s_lo[si] = (unsigned char)bl;
+                    }
+                }
             }
         }
         if (DRAIN && j0 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2492,10 +2532,10 @@ __device__ __forceinline__ f32x4_t mfma_mx4(const uint4& a, const uint4& b, f32x
                                                             4 /* fp4 e2m1 */, 4, OPA, sa, OPB, sb);
 }
 
-template <int PREC, bool OUT_F32>
+template <int PREC, bool OUT_F32, bool GELU = false, bool MXO = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv, const float* __restrict__ bias,
-    int M, int N, int K, int accumulate, MxOperands mx) {
+    int M, int N, int K, int accumulate, MxOperands mx, MxOut mxo = MxOut()) {
     constexpr int NI = 5;
     constexpr int XBN = 64 * NI;
     constexpr int XROWS = QBM + XBN;
@@ -2678,8 +2718,8 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
 
     {   // epilogues of gemm_et_x64_kernel (NI = 5)
         if constexpr (!OUT_F32) {
-            epilogue_pair_et<PREC, false>(acc, reinterpret_cast<unsigned char*>(lds), Cv, bias, nullptr, 1, N, m0 + wm * 128,
-                                          n0 + (wn >> 1) * 160, wm, wn, lane);
+            epilogue_pair_et<PREC, GELU, 4, false, false, MXO>(acc, reinterpret_cast<unsigned char*>(lds), Cv, bias, nullptr, 1, N, m0 + wm * 128,
+                                                               n0 + (wn >> 1) * 160, wm, wn, lane, nullptr, nullptr, mxo);
         } else {
             unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (2 * XSB / 8);
             epilogue_coalesced<PREC, true, false, 8, 2, NI>(acc, scr, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + wn * (16 * NI),
@@ -2713,7 +2753,8 @@ __global__ __launch_bounds__(256) void mx4_pack_kernel(const float* __restrict__
     const int r = (int)(item / nblk), b = (int)(item % nblk);
     // position 4 sub .. 4 sub + 3 of the block holds source elements at block offset 4 sub (natural order) or 8 (sub & 3) + 4 (sub >> 2)
     // (perm: the order store_attention_row_mx writes its rows in)
-    const int in_blk = perm ? 8 * (sub & 3) + 4 * (sub >> 2) : sub * 4;
+    // perm 2: the order of epilogue_pair_et<MXO> (position 8 fq + 4 ib + e holds column 16 ib + 4 fq + e; sub = 2 fq + ib)
+    const int in_blk = perm == 1 ? 8 * (sub & 3) + 4 * (sub >> 2) : perm == 2 ? 16 * (sub & 1) + 4 * (sub >> 1) : sub * 4;
     const int kp = b * 32 + in_blk, g = kp / GP, off = kp % GP;             // GP % 4 == 0 and G % 4 == 0: a lane's 4 elements share a fate
     float h[4] = {0.f, 0.f, 0.f, 0.f}, l[4] = {0.f, 0.f, 0.f, 0.f};
     if (off < G) {
@@ -3031,7 +3072,10 @@ size_t mx_scale_bytes(int rows, int Kp, bool is_b) {
 hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int Kp,
                              const void* a4_lo, const void* a4_hi, const void* sa_lo, const void* sa_hi,
                              const void* b4_hi, const void* b4_lo, const void* sb_hi, const void* sb_lo,
-                             bool out_f32, bool accumulate, int split_from_n, hipStream_t s) {
+                             bool out_f32, bool accumulate, int split_from_n, hipStream_t s, bool gelu, void* o4_hi, void* o4_lo,
+                             void* so_hi, void* so_lo) {
+    if ((gelu || o4_hi) && out_f32) return hipErrorInvalidValue;
+    if (o4_hi && (!o4_lo || !so_hi || !so_lo || N % 80 || ((N / 80) * 96) % MXK || split_from_n)) return hipErrorInvalidValue;
     if (!gemm_mx_ok(M, N, K, Kp) || !A || !B || !C || !a4_lo || !a4_hi || !sa_lo || !sa_hi || !b4_hi || !b4_lo || !sb_hi || !sb_lo)
         return hipErrorInvalidValue;
     if ((accumulate && !out_f32) || split_from_n < 0 || split_from_n % WBN || (split_from_n && out_f32)) return hipErrorInvalidValue;
@@ -3045,19 +3089,26 @@ hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, co
     const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
     const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
     const int acc = accumulate ? 1 : 0;
-    if (prec == PREC_F16) {
-        if (out_f32) gemm_et_mx_kernel<PREC_F16, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);
-        else gemm_et_mx_kernel<PREC_F16, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);
-    } else if (prec == PREC_BF16) {
-        if (out_f32) gemm_et_mx_kernel<PREC_BF16, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);
-        else gemm_et_mx_kernel<PREC_BF16, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);
-    } else return hipErrorInvalidValue;
+    MxOut mxo;
+    mxo.q_hi = (unsigned char*)o4_hi; mxo.q_lo = (unsigned char*)o4_lo; mxo.s_hi = (unsigned char*)so_hi; mxo.s_lo = (unsigned char*)so_lo;
+#define MXL(P_)                                                                                                          \
+    do {                                                                                                                 \
+        if (out_f32) gemm_et_mx_kernel<P_, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);                \
+        else if (o4_hi && gelu) gemm_et_mx_kernel<P_, false, true, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx, mxo);  \
+        else if (o4_hi) gemm_et_mx_kernel<P_, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx, mxo);         \
+        else if (gelu) gemm_et_mx_kernel<P_, false, true, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);               \
+        else gemm_et_mx_kernel<P_, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);                       \
+    } while (0)
+    if (prec == PREC_F16) MXL(PREC_F16);
+    else if (prec == PREC_BF16) MXL(PREC_BF16);
+    else return hipErrorInvalidValue;
+#undef MXL
     return hipGetLastError();
 }
 
 // fp32 [rows][K] (x) or the ET pair (hi_in, lo_in) -> fp4 hi / lo [rows][Kp / 2] + their scale tiles; Kp = K / G * GP
 hipError_t launch_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo_in, void* out_hi, void* q_hi, void* q_lo,
-                           void* s_hi, void* s_lo, int rows, int K, int G, int GP, bool is_b, hipStream_t s, bool perm) {
+                           void* s_hi, void* s_lo, int rows, int K, int G, int GP, bool is_b, hipStream_t s, int perm) {
     if (rows <= 0 || K <= 0 || G <= 0 || K % G || G % 4 || GP % 32 || GP < G || ((K / G) * GP) % MXK) return hipErrorInvalidValue;
     if (!x && !(hi_in && lo_in)) return hipErrorInvalidValue;
     const long items = (long)rows * ((K / G) * GP / 32);
@@ -3065,7 +3116,7 @@ hipError_t launch_mx4_pack(int prec, const float* x, const void* hi_in, const vo
     const uint16_t* hi = reinterpret_cast<const uint16_t*>(hi_in);
     const uint16_t* lo = reinterpret_cast<const uint16_t*>(lo_in);
 #define MXP(P_, F_) mx4_pack_kernel<P_, F_><<<grid, block, 0, s>>>(x, hi, lo, (uint16_t*)out_hi, (unsigned char*)q_hi, (unsigned char*)q_lo, \
-                                                                  (unsigned char*)s_hi, (unsigned char*)s_lo, rows, K, G, GP, is_b ? 1 : 0, perm ? 1 : 0)
+                                                                  (unsigned char*)s_hi, (unsigned char*)s_lo, rows, K, G, GP, is_b ? 1 : 0, perm)
     if (prec == PREC_F16) { if (x) MXP(PREC_F16, true); else MXP(PREC_F16, false); }
     else if (prec == PREC_BF16) { if (x) MXP(PREC_BF16, true); else MXP(PREC_BF16, false); }
     else return hipErrorInvalidValue;

@@ -153,14 +153,18 @@ size_t mx_scale_bytes(int rows, int Kp, bool is_b);
 hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int Kp,
                              const void* a4_lo, const void* a4_hi, const void* sa_lo, const void* sa_hi,
                              const void* b4_hi, const void* b4_lo, const void* sb_hi, const void* sb_lo,
-                             bool out_f32, bool accumulate, int split_from_n, hipStream_t s);
+                             bool out_f32, bool accumulate, int split_from_n, hipStream_t s,
+                             // ET outputs only: GELU in the epilogue, and (o4_*: all four or none) the output ALSO as MXFP4 hi / lo on a K
+                             // axis padded per 80-column wave tile to 96 ([M][N / 80 * 48] bytes, A-operand scale tiles, block-internal
+                             // order = launch_mx4_pack perm 2): lin1 -> lin2 of the all-split mode
+                             bool gelu = false, void* o4_hi = nullptr, void* o4_lo = nullptr, void* so_hi = nullptr, void* so_lo = nullptr);
 // x (fp32 [rows][K]) or the ET pair (hi_in, lo_in) -> fp4 codes of hi and lo [rows][Kp / 2] + E8M0 scale tiles (A layout, or the
 // B layout when is_b); optional out_hi = ET(x).  Padded axis: every group of G source elements becomes GP (zeros behind it);
 // Kp = K / G * GP must be a multiple of 256.  Plain: G = GP = K.
 // perm: the block-internal element order of the attention kernels' own MX outputs (store_attention_row_mx: position 16 hh + 4 g + e
 // holds element 8 g + 4 hh + e) -- for the proj weights, whose A operand those kernels write.
 hipError_t launch_mx4_pack(int prec, const float* x, const void* hi_in, const void* lo_in, void* out_hi, void* q_hi, void* q_lo,
-                           void* s_hi, void* s_lo, int rows, int K, int G, int GP, bool is_b, hipStream_t s, bool perm = false);
+                           void* s_hi, void* s_lo, int rows, int K, int G, int GP, bool is_b, hipStream_t s, int perm = 0 /* 1: attention, 2: GEMM epilogue */);
 
 // ---- upscaler_fused.hip ---------------------------------------------------------------------
 // mask_decoder.py:53-59,154-167 in one kernel: keys [n * grid^2][256] ET -> ConvT #1 + LayerNorm2d + GELU -> ConvT #2 + GELU ->

@@ -112,7 +112,8 @@ def load_library() -> C.CDLL:
     lib.samrs_k_gemm_mx.argtypes = [ip, vp, vp, vp, vp, ip, ip, ip, ip, vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, vp]
     lib.samrs_k_layernorm_mx.argtypes = [ip, vp, vp, vp, fp, vp, ip, ip, vp, vp, vp, vp, vp]
     lib.samrs_k_attention_mx.argtypes = [ip, ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, vp, vp, vp, vp, vp]
-    for name in ("samrs_k_mx4_pack", "samrs_k_gemm_mx", "samrs_k_layernorm_mx", "samrs_k_attention_mx"):
+    lib.samrs_k_gemm_mx_gelu_mxout.argtypes = [ip, vp, vp, vp, vp, ip, ip, ip, ip, vp, vp, vp, vp, vp, vp, vp, vp, ip, vp, vp, vp, vp, vp]
+    for name in ("samrs_k_mx4_pack", "samrs_k_gemm_mx", "samrs_k_layernorm_mx", "samrs_k_attention_mx", "samrs_k_gemm_mx_gelu_mxout"):
         getattr(lib, name).restype = ip
     lib.samrs_get_slot_info.argtypes = [vp, ip, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     for name in ("samrs_load_weight", "samrs_finalize_weights", "samrs_set_images", "samrs_set_images_ragged", "samrs_get_embedding",

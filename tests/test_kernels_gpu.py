@@ -1051,3 +1051,49 @@ def test_attention_mx_outputs_equal_the_pack_kernel(lib, name, prec, dt, ulp, is
     a = _mx_decode(q[1], sc[1], rows, Kp, False)
     b = _mx_decode(q[3], sc[3], rows, Kp, False)
     assert ((a - b).abs() <= 0.51 * b.abs().reshape(rows, -1, 32).amax(-1, keepdim=True).clamp(min=1e-30).expand(-1, -1, 32).reshape(rows, Kp)).all()
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_gemm_mx_gelu_epilogue_emits_mx_rows(lib, name, prec, dt, ulp):
+    """lin1 of the all-split mode: gemm_et_mx_kernel with the exact-erf GELU in its epilogue, which also writes its output as MXFP4
+    hi / lo rows for lin2 (K axis padded per 80-column wave tile to 96, block-internal order of the epilogue's lanes).  (i) the ET
+    output = GELU of the fp64 evaluation of the kernel's own expression, rounded once; (ii) the hi codes and scales are EXACTLY what
+    the pack kernel makes of that ET output (same layout, same order); (iii) the lo rows carry the remainder: adding the decoded lo
+    to the ET value cuts the distance to the exact GELU by more than half in rms."""
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 512, 640, 1280
+    A = torch.randn(M, K, generator=g)
+    B = (torch.rand(N, K, generator=g) * 2 - 1) * 2.0 / math.sqrt(K)
+    bias = torch.randn(N, generator=g) * 0.5
+    Ah, qa, sa = _mx_pack(lib, prec, A, K, K, False)
+    Bh, qb, sb = _mx_pack(lib, prec, B, K, K, True)
+    emul = (A.to(dt).double() @ B.to(dt).double().t() + _mx_decode(qa[1], sa[1], M, K, False) @ _mx_decode(qb[0], sb[0], N, K, True).t()
+            + _mx_decode(qa[0], sa[0], M, K, False) @ _mx_decode(qb[1], sb[1], N, K, True).t() + bias.double())
+    ref = F.gelu(emul)                                                            # exact erf GELU, fp64
+    Kp = N // 80 * 96
+    out = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+    q = [torch.zeros(M, Kp // 2, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    nb = int(lib.samrs_k_mx_scale_bytes(M, Kp, 0))
+    sc = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    assert lib.samrs_k_gemm_mx_gelu_mxout(prec, Ah.data_ptr(), Bh.data_ptr(), out.data_ptr(), dev(bias).data_ptr(), M, N, K, K, qa[1].data_ptr(),
+                                          qa[0].data_ptr(), sa[1].data_ptr(), sa[0].data_ptr(), qb[0].data_ptr(), qb[1].data_ptr(), sb[0].data_ptr(),
+                                          sb[1].data_ptr(), 1, q[0].data_ptr(), q[1].data_ptr(), sc[0].data_ptr(), sc[1].data_ptr(), stream()) == 0
+    got = out.cpu().view(dt).double()
+    err = ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
+    print(f"gemm_mx + GELU {name}: max err vs GELU(emulation) {err:.2e} (operand ulp {ulp:.1e})")
+    assert err < 0.6 * ulp
+    # (ii) hi rows == pack kernel on the ET output itself (fp32 copies of the ET values: hi = the value, lo = 0)
+    x = out.cpu().view(dt).to(torch.float32)
+    xd = dev(x)
+    assert lib.samrs_k_mx4_pack(prec, xd.data_ptr(), None, None, None, q[2].data_ptr(), q[3].data_ptr(), sc[2].data_ptr(), sc[3].data_ptr(),
+                                M, N, 80, 96, 4, stream()) == 0                   # is_b = 4: A scale tiles, epilogue block order
+    assert torch.equal(q[0], q[2]) and torch.equal(sc[0], sc[2]), "hi codes / scales of the epilogue differ from the pack kernel's"
+    # (iii) decode the lo rows back to columns: position 8 f + 4 i + e of block b3 of wave tile wt holds column 80 wt + 32 b3 + 16 i + 4 f + e
+    lo_pad = _mx_decode(q[1], sc[1], M, Kp, False).reshape(M, N // 80, 3, 4, 2, 4)         # [row][wt][b3][f][i][e]
+    lo_cols = lo_pad.permute(0, 1, 2, 4, 3, 5).reshape(M, N // 80, 96)[:, :, :80].reshape(M, N)
+    pad = lo_pad.permute(0, 1, 2, 4, 3, 5).reshape(M, N // 80, 96)[:, :, 80:]
+    assert (pad == 0).all()
+    before = (ref - got).pow(2).mean().sqrt().item()
+    after = (ref - (got + lo_cols)).pow(2).mean().sqrt().item()
+    print(f"   rms distance to the exact GELU: ET output {before:.3e}, ET + decoded lo {after:.3e}")
+    assert after < 0.5 * before

@@ -258,7 +258,7 @@ def test_split_block_gemms_one_launch_equals_three_passes():
         assert eng.get_option("split_passes") == passes
         pred.set_image(img)
         emb[passes] = pred.get_image_embedding().float().cpu()
-    eng.set_option("lo_format", 4)                          # round 4: qkv / proj lo terms on the block-scaled fp4 MFMA (MLP still f16 lo)
+    eng.set_option("lo_format", 4)                          # round 4: the lo terms of all four block GEMMs on the block-scaled fp4 MFMA
     pred.set_image(img)
     emb["mx"] = pred.get_image_embedding().float().cpu()
     eng.set_option("split", 15)
@@ -270,7 +270,7 @@ def test_split_block_gemms_one_launch_equals_three_passes():
     d_plain = ((plain - emb[1]).norm() / emb[1].norm()).item()
     print(f"one launch vs three passes: rel L2 {d:.2e}; MXFP4 lo terms vs exact lo terms: {d_mx:.2e}; default split vs reference-grade: {d_plain:.2e}")
     assert d < 2e-5 and d < 0.1 * d_plain
-    assert d_mx < 0.35 * d_plain            # the fp4 corrections keep most of what the split buys (error budget plans9: 5.2e-5 of 2.9e-4 per GEMM)
+    assert d_mx < 0.5 * d_plain             # the fp4 corrections (now of ALL four block GEMMs) keep most of what the split buys (error budget plans9)
 
 
 @pytest.mark.parametrize("name", ["vit_tiny", "vit_tiny80", "vit_b", "vit_l", "vit_h"])

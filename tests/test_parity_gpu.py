@@ -408,7 +408,9 @@ def test_c2_c4_against_reference_golden(name, split, variant, golden_dir):
     # round 2 (no operand split): 849 / 896 pixels at ViT-B / ViT-H; with the split rounding points the error budget
     # predicts 394 / 476 (oracle/error_budget.py plans2, row E1)
     # (error budget at ViT-H: 307 with the qkv + proj GEMMs split as well, 89 with every block GEMM split)
-    assert diff.sum() <= {0: 1000, 15: 620, 31: 420, 63: 160, 79: 480}[split], int(diff.sum())
+    # round 4: the lo terms of the block-GEMM splits run on MXFP4 operands by default (lo_format 4): error budget plans9 / plans10 predict
+    # 148 pixels for split 63 (90 with exact lo terms), unchanged counts for 79 / 31
+    assert diff.sum() <= {0: 1000, 15: 620, 31: 420, 63: 200, 79: 480}[split], int(diff.sum())
     # ---- C4: enclosing hbox prompt, multimask ----
     # measured at ViT-H: 0.99874 / 0.99877 (split 15), 0.99911 / 0.99927 (31), 0.99974 / 0.99984 (63); the error budget
     # predicted 0.99886 / 0.99881, 0.99919 / 0.99928, 0.99976 / 0.99984

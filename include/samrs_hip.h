@@ -192,8 +192,10 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    (both transposed convs).  15 = every block GEMM at the 1x f16 rate: enough for IoU >= 0.9995 on the single
  *                    mask of token 0 (what the hbox-semantic path asks for); 0 = the round-2 engine's arithmetic.
  *                    Block-GEMM bits: 64 = the v third of the qkv product + proj (q and k pass through the softmax), 16 = all of
- *                    qkv + proj, 32 = the MLP GEMMs (three times the MFMA work of what they cover; 63 / 127 = every MFMA operand
- *                    of the path).  79 = 15 | 64 holds IoU >= 0.999 on the three multimask tokens too (C4 fixtures) at 0.87-0.90x
+ *                    qkv + proj, 32 = the MLP GEMMs (63 / 127 = every MFMA operand of the path), 128 = lin2 alone of the MLP GEMMs
+ *                    ("lo_format" 4 only; 207 = 79 | 128 is the error budget's cheapest mode with more margin on the multimask
+ *                    outputs: oracle/error_budget.py plans10).  With "lo_format" 4 a split GEMM costs 1.25 - 1.8x a plain one (f16 lo
+ *                    terms: 3x).  79 = 15 | 64 holds IoU >= 0.999 on the three multimask tokens too (0.9992 on 192 masks) at 0.92x
  *                    the throughput of 15 and is what a ViT-H handle starts with.  The block-GEMM bits need lo copies of the
  *                    block weights: set them BEFORE samrs_finalize_weights; they can be cleared and set again afterwards.
  *                    What each bit buys in mask pixels: oracle/error_budget.py, DESIGN.md 2.

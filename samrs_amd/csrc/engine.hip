@@ -39,8 +39,10 @@ struct DevTensor {
 //                  samrs_finalize_weights (SAMRS_SPLIT=63 or the option), and can be cleared / set again afterwards.
 // SPLIT_ATTN_V: the attention-side split restricted to the v third of qkv (+ proj): q and k pass through the softmax and buy
 // next to nothing (error_budget.py plans4 / plans6); SPLIT_ATTN set as well = all of qkv.  One-launch route only (ViT-H shapes).
+// SPLIT_LIN2 (round 4; needs lo_format 4): lin2 alone of the MLP GEMMs takes the lo terms -- the error budget's cheapest way to more margin
+// on the multimask outputs (error_budget.py plans10); lin1 then runs on the MX kernel only to have its epilogue emit H's fp4 rows.
 enum { SPLIT_PATCH = 1, SPLIT_NECK = 2, SPLIT_OI = 4, SPLIT_UP = 8, SPLIT_DEFAULT = 15, SPLIT_ATTN = 16, SPLIT_MLP = 32, SPLIT_ATTN_V = 64,
-       SPLIT_ATTN_ANY = SPLIT_ATTN | SPLIT_ATTN_V, SPLIT_ALL = 127 };
+       SPLIT_LIN2 = 128, SPLIT_ATTN_ANY = SPLIT_ATTN | SPLIT_ATTN_V, SPLIT_ALL = 255 };
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 
 struct DecAttn {
@@ -480,7 +482,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
                                         b.lin1_c, b.lin1_bf, 4 * D, D, s));
             e->can_fold = true;
         }
-        const bool lo_a = (e->split & SPLIT_ATTN_ANY) != 0, lo_m = (e->split & SPLIT_MLP) != 0;
+        const bool lo_a = (e->split & SPLIT_ATTN_ANY) != 0, lo_m = (e->split & SPLIT_MLP) != 0, lo_l2 = (e->split & SPLIT_LIN2) != 0;
         if (lo_a && e->lo_format == 4 && gemm_mx_ok(c.max_images * e->tokens, 3 * D, D, D)) {
             // fp4 copies of hi / lo of the attention-side weights (from the fp32 tensors, before to_et frees them)
             const int gp = (e->hd + 31) / 32 * 32, kp = c.num_heads * gp;
@@ -497,7 +499,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
                 e->mx_ready = true;
             }
         }
-        if (lo_m && e->lo_format == 4 && gemm_mx_ok(c.max_images * e->tokens, 4 * D, D, D) && (4 * D) % 80 == 0) {
+        if ((lo_m || lo_l2) && e->lo_format == 4 && gemm_mx_ok(c.max_images * e->tokens, 4 * D, D, D) && (4 * D) % 80 == 0) {
             const int kp2 = 4 * D / 80 * 96;
             if (gemm_mx_ok(c.max_images * e->tokens, D, 4 * D, kp2)) {
                 e->mx_kp_lin2 = kp2;
@@ -592,8 +594,9 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->QKV, Mmax * 3 * D));
     CK(e, dalloc(e, &e->AO, M * D));
     CK(e, dalloc(e, &e->VTG, M * D));
-    e->split_ready = SPLIT_DEFAULT | (e->split & SPLIT_MLP) | ((e->split & SPLIT_ATTN_ANY) ? SPLIT_ATTN_ANY : 0);
-    if (e->split & (SPLIT_ATTN_ANY | SPLIT_MLP)) {
+    e->split_ready = SPLIT_DEFAULT | (e->split & SPLIT_MLP) | ((e->split & SPLIT_ATTN_ANY) ? SPLIT_ATTN_ANY : 0) | (e->mx_mlp_ready ? SPLIT_LIN2 : 0);
+    if ((e->split & SPLIT_LIN2) && !e->mx_mlp_ready) e->split &= ~SPLIT_LIN2;          // no MX kernel for these shapes (or lo_format 0): bit ignored
+    if (e->split & (SPLIT_ATTN_ANY | SPLIT_MLP | SPLIT_LIN2)) {
         CK(e, dalloc(e, &e->Ylo, M * D));
         if (e->split & SPLIT_MLP) CK(e, dalloc(e, &e->F32T, M * 4 * D));      // the generic attention-side route allocates it on first use
         if (e->split & SPLIT_ATTN_ANY) CK(e, dalloc(e, &e->AOlo, M * D));
@@ -720,6 +723,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         // v third only: needs the tile mask of the one-launch kernel; other shapes split all of qkv
         const int v_from = (sp_attn && !attn_full && one3 && gemm_split3_ok(M, 3 * D, D) && (2 * D) % 320 == 0) ? 2 * D : 0;
         const bool mx_mlp = e->lo_format == 4 && e->mx_mlp_ready && !e->split_passes && gemm_mx_ok(M, 4 * D, D, D) && gemm_mx_ok(M, D, 4 * D, e->mx_kp_lin2);
+        const bool sp_lin2 = (e->split & SPLIT_LIN2) && !sp_mlp && mx_mlp && i < depth_full;     // lin2 alone (lin1 only emits H's MX rows)
         const bool mx_attn = e->lo_format == 4 && e->mx_ready && !e->split_passes && gemm_mx_ok(M, 3 * D, D, D) && (2 * D) % 320 == 0;
         // norm1 + qkv in plain token order for both block kinds; the windowed kernel partitions
         // on the fly and takes k / v of padding positions from the qkv bias
@@ -787,7 +791,11 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, hipEventRecord(t0, s));
         }
         if (fold) CK(e, launch_gemm_et_fold(prec, e->Y, b.lin1_wf, e->H, b.lin1_bf, b.lin1_c, e->ROWSTAT, M, 4 * D, D, true, s));
-        else if (sp_mlp && mx_mlp) {
+        else if (sp_lin2) {
+            // lin1 without lo terms (split_from_n = N: no MX stages; the a4 / b4 operands are not touched), its epilogue emits H's fp4 rows
+            CK(e, launch_gemm_et_mx(prec, e->Y, b.lin1_w, e->H, b.lin1_b, M, 4 * D, D, D, e->Y4[1], e->Y4[0], e->SY4[1], e->SY4[0], b.lin1_w4[0],
+                                    b.lin1_w4[1], b.lin1_s4[0], b.lin1_s4[1], false, false, 4 * D, s, true, e->H4[0], e->H4[1], e->SH4[0], e->SH4[1]));
+        } else if (sp_mlp && mx_mlp) {
             // lo terms on MXFP4: ET output with the exact-erf GELU in the epilogue, which also emits H as fp4 hi / lo for lin2
             CK(e, launch_gemm_et_mx(prec, e->Y, b.lin1_w, e->H, b.lin1_b, M, 4 * D, D, D, e->Y4[1], e->Y4[0], e->SY4[1], e->SY4[0], b.lin1_w4[0],
                                     b.lin1_w4[1], b.lin1_s4[0], b.lin1_s4[1], false, false, 0, s, true, e->H4[0], e->H4[1], e->SH4[0], e->SH4[1]));
@@ -809,7 +817,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, launch_gemm_et_stats(prec, e->H, b.lin2_w, e->X, b.lin2_b, e->Y, e->STATS, M, D, 4 * D, s));
             if (i + 1 < c.depth) CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
         } else {
-            if (sp_mlp && mx_mlp) {
+            if ((sp_mlp && mx_mlp) || sp_lin2) {
                 CK(e, launch_gemm_et_mx(prec, e->H, b.lin2_w, e->X, b.lin2_b, M, D, 4 * D, e->mx_kp_lin2, e->H4[1], e->H4[0], e->SH4[1], e->SH4[0],
                                         b.lin2_w4[0], b.lin2_w4[1], b.lin2_s4[0], b.lin2_s4[1], true, true, 0, s));
             } else if (sp_mlp && one3 && gemm_split3_ok(M, D, 4 * D)) {
@@ -861,7 +869,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     for (int i = 0; i < n; ++i) {
         e->slot_set[slot0 + i] = 1;
         e->slot_split[slot0 + i] = e->split;
-        e->slot_depth[slot0 + i] = (e->split & (SPLIT_ATTN | SPLIT_MLP)) ? depth_full : (e->split & SPLIT_ATTN_V) ? depth_v : 0;
+        e->slot_depth[slot0 + i] = (e->split & (SPLIT_ATTN | SPLIT_MLP | SPLIT_LIN2)) ? depth_full : (e->split & SPLIT_ATTN_V) ? depth_v : 0;
     }
     return SAMRS_OK;
 }
@@ -1204,8 +1212,8 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     if (n == "decoder_fusion") e->decoder_fusion = value != 0;
     else if (n == "ln_fold") e->ln_fold = value != 0;
     else if (n == "split") {
-        if (e->finalized && (value & (SPLIT_ATTN_ANY | SPLIT_MLP) & ~e->split_ready))
-            return fail(e, SAMRS_ERR_BAD_ARG, "split bits 16 / 32 / 64 (block GEMMs) need their lo weights: set them before the weights are "
+        if (e->finalized && (value & (SPLIT_ATTN_ANY | SPLIT_MLP | SPLIT_LIN2) & ~e->split_ready))
+            return fail(e, SAMRS_ERR_BAD_ARG, "split bits 16 / 32 / 64 / 128 (block GEMMs) need their lo weights: set them before the weights are "
                                               "finalized (SAMRS_SPLIT or options={'split': ...})");
         e->split = value & SPLIT_ALL;
     }

@@ -3075,7 +3075,8 @@ hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, co
                              bool out_f32, bool accumulate, int split_from_n, hipStream_t s, bool gelu, void* o4_hi, void* o4_lo,
                              void* so_hi, void* so_lo) {
     if ((gelu || o4_hi) && out_f32) return hipErrorInvalidValue;
-    if (o4_hi && (!o4_lo || !so_hi || !so_lo || N % 80 || ((N / 80) * 96) % MXK || split_from_n)) return hipErrorInvalidValue;
+    // the MX-row epilogue goes with lo terms on every tile or (split_from_n == N) on none
+    if (o4_hi && (!o4_lo || !so_hi || !so_lo || N % 80 || ((N / 80) * 96) % MXK || (split_from_n && split_from_n != N))) return hipErrorInvalidValue;
     if (!gemm_mx_ok(M, N, K, Kp) || !A || !B || !C || !a4_lo || !a4_hi || !sa_lo || !sa_hi || !b4_hi || !b4_lo || !sb_hi || !sb_lo)
         return hipErrorInvalidValue;
     if ((accumulate && !out_f32) || split_from_n < 0 || split_from_n % WBN || (split_from_n && out_f32)) return hipErrorInvalidValue;

@@ -25,7 +25,7 @@ PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16}
 ABI_VERSION = 3
 # "split" option bits (include/samrs_hip.h): rounding points that run as a two-term operand split
 SPLIT_PATCH, SPLIT_NECK, SPLIT_OI, SPLIT_UP, SPLIT_DEFAULT = 1, 2, 4, 8, 15
-SPLIT_ATTN, SPLIT_MLP, SPLIT_ATTN_V, SPLIT_ALL = 16, 32, 64, 127          # reference-grade bits: set before the weights are loaded
+SPLIT_ATTN, SPLIT_MLP, SPLIT_ATTN_V, SPLIT_LIN2, SPLIT_ALL = 16, 32, 64, 128, 255          # reference-grade bits: set before the weights are loaded
 # (64 = the attention-side split restricted to the v third of qkv + proj; option "split_depth" = leading blocks they apply to)
 
 OK, ERR_NOT_SET, ERR_BAD_SHAPE, ERR_BAD_ARG, ERR_HIP, ERR_BAD_WEIGHTS, ERR_CAPACITY, ERR_PRECISION = 0, -1, -2, -3, -4, -5, -6, -7

@@ -166,7 +166,9 @@ int samrs_select_best(samrs_engine_t* e, const uint8_t* masks, const float* iou,
  * `out` (device bytes, capacity out_capacity) at 16-byte aligned offsets behind *cursor (device int64, in / out: the first
  * free byte; several calls append to one buffer), and table [n][3] (device int64) receives (offset, length, number of counts)
  * per mask; length < 0 means the string did not fit (-length - 1 bytes were needed) and was not written.  Column-major runs
- * starting with zeros, delta-coded 5-bit groups + 48, exactly as cocoapi's rleToString.  h * w < 2^30, w <= 8192. */
+ * starting with zeros, delta-coded 5-bit groups + 48, exactly as cocoapi's rleToString.  h * w < 2^30, w <= 8192.
+ * The run table this entry point builds lives in ONE scratch buffer per handle: all samrs_rle_encode calls on a handle must be
+ * stream-ordered with each other (same stream, or an event between them); two handles never share it. */
 int samrs_rle_encode(samrs_engine_t* e, const uint8_t* masks, int n, int h, int w, uint8_t* out, int64_t out_capacity,
                      int64_t* cursor, int64_t* table, void* stream);
 

@@ -327,7 +327,9 @@ VIT_H_DEFAULT_SPLIT = 79
 @pytest.mark.parametrize("name,split,variant", [("vit_b", 15, 0), ("vit_h", 15, 0), ("vit_h", 31, 0), ("vit_h", 63, 0),
                                                 ("vit_h", 15, 1), ("vit_h", 31, 1), ("vit_h", 79, 0), ("vit_h", 79, 1),
                                                 # a third draw, generated AFTER split 79 / depth 24 had been chosen on the first two
-                                                ("vit_h", 79, 2), ("vit_h", 15, 2)])
+                                                ("vit_h", 79, 2), ("vit_h", 15, 2),
+                                                # 207 = 79 | 128: the default + lin2 of every block with MXFP4 lo terms (the "margin" mode)
+                                                ("vit_h", 207, 0), ("vit_h", 207, 1), ("vit_h", 207, 2)])
 def test_c2_c4_against_reference_golden(name, split, variant, golden_dir):
     """BASELINE.json configs[1] (32 hboxes on one tile) and configs[3] (rbox -> enclosing hbox / rbox -> mask prompt,
     multimask_output=True) against FULL-RESOLUTION masks produced by the real reference on the realistic-margin weights
@@ -410,7 +412,8 @@ def test_c2_c4_against_reference_golden(name, split, variant, golden_dir):
     # (error budget at ViT-H: 307 with the qkv + proj GEMMs split as well, 89 with every block GEMM split)
     # round 4: the lo terms of the block-GEMM splits run on MXFP4 operands by default (lo_format 4): error budget plans9 / plans10 predict
     # 148 pixels for split 63 (90 with exact lo terms), unchanged counts for 79 / 31
-    assert diff.sum() <= {0: 1000, 15: 620, 31: 420, 63: 200, 79: 480}[split], int(diff.sum())
+    # split 207 (79 + lin2 alone): statistical sample 312 px max against 392 for split 79 (profiles/r04_parity_stats.md)
+    assert diff.sum() <= {0: 1000, 15: 620, 31: 420, 63: 200, 79: 480, 207: 400}[split], int(diff.sum())
     # ---- C4: enclosing hbox prompt, multimask ----
     # measured at ViT-H: 0.99874 / 0.99877 (split 15), 0.99911 / 0.99927 (31), 0.99974 / 0.99984 (63); the error budget
     # predicted 0.99886 / 0.99881, 0.99919 / 0.99928, 0.99976 / 0.99984
@@ -418,7 +421,8 @@ def test_c2_c4_against_reference_golden(name, split, variant, golden_dir):
     # the C4 minimum is set by one small mask and moves by +-5e-4 between draws, so the default's floor is 0.998
     # split 79 (v + proj, 24 leading blocks; error budget plans6: 0.99911 / 0.99926; measured 0.99920 / 0.99928 and, second draw,
     # 0.99951 / 0.99914, at +6.7 ms per step instead of +21.6 for split 31): the ViT-H default holds the north star's 0.999 on C4
-    c4_floor = 0.999 if (name == "vit_b" or split >= 31) else 0.998
+    # split 207: 0.99936 / 0.99942 over 96 + 96 sampled masks (margin 3.6e-4): the three fixture draws are asked for 0.9991
+    c4_floor = 0.9991 if split == 207 else 0.999 if (name == "vit_b" or split >= 31) else 0.998
     tb = pred.transform.apply_boxes_torch(torch.from_numpy(inp["hboxes"]).cuda(), hw)
     m, q, l = pred.predict_torch(None, None, tb, None, multimask_output=True)
     assert m.shape[1] == 3

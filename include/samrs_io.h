@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAMRS_IO_ABI_VERSION 2
+#define SAMRS_IO_ABI_VERSION 3
 
 #define SAMRS_IO_OK            0
 #define SAMRS_IO_EOPEN        -1   /* cannot open / create the file (errno is left set) */
@@ -43,7 +43,8 @@ extern "C" {
 /* SAMRS_IO_LEVEL_LABELS (class maps and their palette images only: samrs_io_png_write_gray / _write_lut_rgb): the label-aware
  * encoder.  The LZ77 parse is done on the 1-byte label map -- a run equal to the row above, a run equal to the left neighbour, or a
  * literal pixel -- and written as deflate tokens of the pixel stream (filter 0, dynamic Huffman): 5 - 10x less CPU than zlib level 6 on
- * the truecolour image, whose bytes zlib would have to match one by one.  Any PNG reader decodes the same pixels. */
+ * the truecolour image, whose bytes zlib would have to match one by one.  Any PNG reader decodes the same pixels.
+ * samrs_io_png_write_label_pair writes both images of a tile from one parse. */
 #define SAMRS_IO_LEVEL_LABELS -2
 
 int samrs_io_abi_version(void);
@@ -65,6 +66,13 @@ int samrs_io_png_write_gray(const char* path, const uint8_t* src, int height, in
  * materialising the RGB array (main_sam_hbox_semantic.py:163,199 paint it on the host). `lut` has 256 * 3 bytes. */
 int samrs_io_png_write_lut_rgb(const char* path, const uint8_t* src, int height, int width, size_t stride,
                                const uint8_t* lut, int level);
+
+/* Both images of a class map from ONE parse (SAMRS_IO_LEVEL_LABELS encoder): gray_path = the 8-bit gray PNG, color_path = the palette
+ * image lut[src[y, x]] -- main_sam_hbox_semantic.py:212-215 saves exactly this pair per tile.  The label runs are found once (tuned for
+ * the 3-byte stream; the gray stream writes runs shorter than deflate's 3-byte minimum as literals) and written twice with each stream's
+ * own Huffman codes.  Same pixels as the two single calls; each file atomic on its own (gray first). */
+int samrs_io_png_write_label_pair(const char* gray_path, const char* color_path, const uint8_t* src, int height, int width, size_t stride,
+                                  const uint8_t* lut);
 
 /* Write a packed RGB array (stride in bytes). */
 int samrs_io_png_write_rgb(const char* path, const uint8_t* src, int height, int width, size_t stride, int level);

@@ -301,23 +301,28 @@ int encode(const char* path, const uint8_t* src, int h, int w, size_t stride, in
 // left neighbour = one match at distance (bytes per pixel), anything else = the pixel's literal bytes.  All rows use PNG filter 0
 // (none), one dynamic-Huffman deflate block per <= 2^20 tokens; the file is a plain PNG any reader decodes to the same pixels.
 
-struct BitWriter {
-    std::vector<uint8_t>* out;
+struct BitWriter {                                // LSB first; the caller guarantees 8 writable bytes past the current position
+    uint8_t* p;
     uint64_t acc = 0;
-    int n = 0;
-    void put(uint32_t v, int bits) {               // LSB first; at most 32 bits per call, spilled four bytes at a time
+    int n = 0;                                    // pending bits, < 8 between calls
+    explicit BitWriter(uint8_t* at) : p(at) {}
+    inline void put(uint32_t v, int bits) {       // bits <= 32; bits == 0 is a no-op (the table-driven emitter relies on it)
         acc |= uint64_t(v) << n;
         n += bits;
-        if (n >= 32) {
-            const size_t at = out->size();
-            out->resize(at + 4);
-            const uint32_t w = uint32_t(acc);
-            memcpy(out->data() + at, &w, 4);       // little-endian host (x86-64): byte 0 = the oldest bits
-            acc >>= 32;
-            n -= 32;
-        }
+        memcpy(p, &acc, 8);                       // little-endian host (x86-64): byte 0 = the oldest bits
+        p += n >> 3;
+        acc >>= (n & ~7);
+        n &= 7;
     }
-    void flush() { while (n > 0) { out->push_back(uint8_t(acc)); acc >>= 8; n -= 8; } acc = 0; n = 0; }
+    inline void put2(uint32_t v1, int bits1, uint32_t v2, int bits2) {      // two strings at once; bits1 + bits2 <= 56
+        acc |= (uint64_t(v1) | (uint64_t(v2) << bits1)) << n;
+        n += bits1 + bits2;
+        memcpy(p, &acc, 8);
+        p += n >> 3;
+        acc >>= (n & ~7);
+        n &= 7;
+    }
+    uint8_t* flush() { if (n > 0) { *p++ = uint8_t(acc); acc = 0; n = 0; } return p; }
 };
 
 // code lengths (<= maxbits) of a Huffman code for freq[0 .. n): plain Huffman; if the tree is too deep the counts are flattened
@@ -389,73 +394,162 @@ inline void dist_code(int dist, int* sym, int* ebits, int* eval) {
     *sym = c; *ebits = kDistExtra[c]; *eval = dist - kDistBase[c];
 }
 
-// token: bit 31 = match; match: bits 0-8 = length (3 .. 258), bit 16 = 1 for the "up" distance (0 = "left"); literal: bits 0-7
-int encode_labels(const char* path, const uint8_t* src, int h, int w, size_t stride, const uint8_t* lut) {
-    if (!path || !src || h <= 0 || w <= 0 || uint32_t(h) > kMaxSide || uint32_t(w) > kMaxSide) return SAMRS_IO_ESIZE;
+// ---- the parse: one pass over the label map, tokens in PIXEL units (shared by the gray and the colour stream) ----
+// token: 0x00000000 | byte   a raw literal byte (the row's filter-type byte)
+//        0x40000000 | label  one literal pixel
+//        0x80000000 | up << 16 | npx   a run of npx pixels (1 .. 258) equal to the row above (up) or to the left neighbour; the
+//                                      emitter cuts it into matches of at most 258 bytes of ITS stream (86 pixels of RGB)
+// `unit` = bytes per pixel the parse is tuned for: a match must cover >= 3 BYTES, and an "up" match costs ~10 more bits than a
+// "left" one.  A parse made for unit 3 (min 1 pixel) also serves the gray stream: its emitter turns runs shorter than 3 pixels
+// into literals (labels read from the map) -- a few bytes larger than the unit-1 parse would give, one parse instead of two.
+struct TokenBuf {                                 // per writer thread; grows, never shrinks, never zero-filled
+    uint32_t* p = nullptr;
+    size_t cap = 0, n = 0;
+    ~TokenBuf() { free(p); }
+    const uint32_t& operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+};
+
+int parse_labels(const uint8_t* src, int h, int w, size_t stride, int unit, bool up_ok, TokenBuf* tokens) {
+    const int max_px = 258;                        // per token; the emitter cuts a run into matches of <= 258 BYTES of its stream
+    const int min_px = unit == 1 ? 3 : 1;
+    const int up_bias = unit == 3 ? 1 : 2;
+    const size_t worst = size_t(h) * (size_t(w) + 1);                     // all literals
+    if (tokens->cap < worst) {
+        uint32_t* q = static_cast<uint32_t*>(realloc(tokens->p, worst * sizeof(uint32_t)));
+        if (!q) return SAMRS_IO_ENOMEM;
+        tokens->p = q; tokens->cap = worst;
+    }
+    uint32_t* t = tokens->p;
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* g = src + size_t(y) * stride;
+        const uint8_t* up = (y > 0 && up_ok) ? g - stride : nullptr;
+        *t++ = 0;                                  // the filter-type byte
+        int x = 0;
+        while (x < w) {
+            int lu = 0, ll = 0;
+            if (up) {
+                while (x + lu + 8 <= w) {          // eight labels per compare
+                    uint64_t a, b;
+                    memcpy(&a, g + x + lu, 8); memcpy(&b, up + x + lu, 8);
+                    if (a != b) { lu += __builtin_ctzll(a ^ b) >> 3; goto up_done; }
+                    lu += 8;
+                }
+                while (x + lu < w && g[x + lu] == up[x + lu]) ++lu;
+            }
+        up_done:
+            if (x > 0) {
+                while (x + ll + 8 <= w) {
+                    uint64_t a, b;
+                    memcpy(&a, g + x + ll, 8); memcpy(&b, g + x + ll - 1, 8);
+                    if (a != b) { ll += __builtin_ctzll(a ^ b) >> 3; goto left_done; }
+                    ll += 8;
+                }
+                while (x + ll < w && g[x + ll] == g[x + ll - 1]) ++ll;
+            }
+        left_done:
+            // the colour of a label never changes inside an image, so equal labels <=> equal pixels for the match
+            int n = 0;
+            uint32_t kind = 0;
+            if (lu >= min_px && lu > ll + up_bias) { n = lu; kind = 0x80010000u; }
+            else if (ll >= min_px) { n = ll; kind = 0x80000000u; }
+            else if (lu >= min_px) { n = lu > max_px ? max_px : lu; kind = 0x80010000u; }
+            if (!n) { *t++ = 0x40000000u | g[x]; ++x; continue; }
+            while (n > 0) { const int m = n > max_px ? max_px : n; if (m < min_px) break; *t++ = kind | uint32_t(m); x += m; n -= m; }
+        }
+    }
+    tokens->n = size_t(t - tokens->p);
+    return SAMRS_IO_OK;
+}
+
+// ---- the emitter: the token list as the zlib stream of a bpp-byte-per-pixel image (bpp 1: the labels; bpp 3: lut[label]) ----
+// Token types alternate at random on a noise-like map, so neither pass branches on them: a token becomes two table indices
+// (literal pixel: its label twice; match: 256 + length in bytes, 512 + up) whose histogram is counted in the first pass and whose
+// pre-merged bit strings are written in the second (a string of 0 bits is a no-op of the bit writer).  The rare shapes -- the
+// filter byte of a row, runs longer than one match, runs of the gray stream shorter than deflate's 3-byte minimum -- take a side path.
+struct ByteBuf {                                  // per writer thread; grows, never zero-filled
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    ~ByteBuf() { free(p); }
+    bool reserve(size_t n) {
+        if (cap >= n) return true;
+        uint8_t* q = static_cast<uint8_t*>(realloc(p, n));
+        if (!q) return false;
+        p = q; cap = n;
+        return true;
+    }
+};
+
+int emit_labels(const char* path, const TokenBuf& tok, const uint8_t* src, int h, int w, size_t stride,
+                const uint8_t* lut, bool up_ok) {
     const int bpp = lut ? 3 : 1;
-    if (stride < size_t(w)) return SAMRS_IO_ESIZE;
     const size_t row = size_t(w) * bpp;
     const int d_left = bpp, d_up = int(row) + 1;
-    const bool up_ok = d_up <= 32768;
-    const int max_px = 258 / bpp;                  // pixels per match token
-    const int min_px = bpp == 1 ? 3 : 1;           // deflate's shortest match is 3 bytes
-    // worst case (no two neighbours equal): one token per byte + one per row; the vectors keep their capacity per thread
-    thread_local std::vector<uint32_t> tok_tl;
-    thread_local std::vector<uint8_t> out_tl;
-    std::vector<uint32_t>& tok = tok_tl;
-    std::vector<uint8_t>& out = out_tl;
-    tok.clear(); out.clear();
-    try { tok.reserve(size_t(h) * (row + 1)); out.reserve(size_t(h) * (row + 1) + 4096); } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
+    const uint32_t lit_px = bpp == 1 ? 3 : 1;      // runs below this many pixels are written as literals (deflate: >= 3 bytes)
+    const uint32_t max_px = 258 / bpp;             // pixels per match of this stream (a token carries up to 258 pixels)
+    thread_local ByteBuf out_tl, rowbuf_tl;
+    // worst case per token: three matches of (15 + 5) + (15 + 13) bits; per block: ~600 bytes of code lengths
+    const size_t nblocks = (tok.size() >> 20) + 1;
+    if (!out_tl.reserve(tok.size() * 18 + nblocks * 1024 + 64) || !rowbuf_tl.reserve(row + 8)) return SAMRS_IO_ENOMEM;
+    uint8_t* const out = out_tl.p;
+    uint8_t* const rowbuf = rowbuf_tl.p;
+    size_t out_size = 0;
     uLong adler = adler32(0L, Z_NULL, 0);
-    std::vector<uint8_t> rowbuf;
-    try { rowbuf.resize(row + 1); } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
     try {
-        for (int y = 0; y < h; ++y) {
+        uint32_t lut32[256];
+        if (lut) for (int v = 0; v < 256; ++v) lut32[v] = uint32_t(lut[3 * v]) | (uint32_t(lut[3 * v + 1]) << 8) | (uint32_t(lut[3 * v + 2]) << 16);
+        for (int y = 0; y < h; ++y) {              // the raw (filter 0) rows, only for the zlib checksum
             const uint8_t* g = src + size_t(y) * stride;
-            const uint8_t* up = (y > 0 && up_ok) ? g - stride : nullptr;
-            // the raw (filter 0) row, only for the zlib checksum
             rowbuf[0] = 0;
-            if (lut) for (int x = 0; x < w; ++x) { const uint8_t* c = lut + 3 * g[x]; uint8_t* d = &rowbuf[1 + 3 * size_t(x)]; d[0] = c[0]; d[1] = c[1]; d[2] = c[2]; }
-            else memcpy(&rowbuf[1], g, size_t(w));
-            adler = adler32(adler, rowbuf.data(), uInt(row + 1));
-            tok.push_back(0);                      // the filter-type byte
-            int x = 0;
-            while (x < w) {
-                int lu = 0, ll = 0;
-                if (up) while (x + lu < w && g[x + lu] == up[x + lu]) ++lu;
-                if (x > 0) while (x + ll < w && g[x + ll] == g[x + ll - 1]) ++ll;
-                // the colour of a label never changes inside an image, so equal labels <=> equal pixels for the match
-                if (lu >= min_px && lu > ll + (bpp == 3 ? 1 : 2)) {          // "up" costs ~10 more bits per token than "left"
-                    int n = lu;
-                    while (n > 0) { const int m = n > max_px ? max_px : n; if (m < min_px) break; tok.push_back(0x80000000u | 0x10000u | uint32_t(m * bpp)); x += m; n -= m; }
-                } else if (ll >= min_px) {
-                    int n = ll;
-                    while (n > 0) { const int m = n > max_px ? max_px : n; if (m < min_px) break; tok.push_back(0x80000000u | uint32_t(m * bpp)); x += m; n -= m; }
-                } else if (lu >= min_px) {
-                    const int m = lu > max_px ? max_px : lu;
-                    tok.push_back(0x80000000u | 0x10000u | uint32_t(m * bpp)); x += m;
-                } else {
-                    tok.push_back(lut ? (0x40000000u | g[x]) : uint32_t(g[x]));      // colour: ONE token per literal pixel (its label)
-                    ++x;
-                }
-            }
+            if (lut) { uint8_t* d = rowbuf + 1; for (int x = 0; x < w; ++x, d += 3) memcpy(d, &lut32[g[x]], 4); }   // 4-byte stores, 3-byte steps
+            else memcpy(rowbuf + 1, g, size_t(w));
+            adler = adler32(adler, rowbuf, uInt(row + 1));
         }
         // ---- zlib stream: header, dynamic-Huffman blocks of <= 2^20 tokens, adler32 ----
-        out.push_back(0x78); out.push_back(0x9c);
-        BitWriter bw{&out};
+        out[0] = 0x78; out[1] = 0x9c;
+        BitWriter bw(out + 2);
         int ls, le, lv, us = 0, ue = 0, uv = 0;
         dist_code(d_left, &ls, &le, &lv);
         if (up_ok) dist_code(d_up, &us, &ue, &uv);
         const size_t BLOCK = size_t(1) << 20;
+        // position of the token walk in the map (short runs of the gray stream read their labels from it): the row the walk is in
+        // (a row's first token is its filter byte) and the column, per pass, carried from block to block
+        size_t y_count = 0, y_write = 0;
+        const uint8_t *cur_count = src, *cur_write = src;
+        uint32_t x_count = 0, x_write = 0;
         for (size_t t0 = 0; t0 < tok.size() || t0 == 0; t0 += BLOCK) {
             const size_t t1 = t0 + BLOCK < tok.size() ? t0 + BLOCK : tok.size();
             uint32_t fl[286] = {0}, fd[30] = {0};
-            for (size_t t = t0; t < t1; ++t) {
-                const uint32_t k = tok[t];
-                if (k & 0x80000000u) { fl[len_code(int(k & 0x1ff)).sym]++; fd[(k & 0x10000u) ? us : ls]++; }
-                else if (k & 0x40000000u) { const uint8_t* c = lut + 3 * (k & 0xff); fl[c[0]]++; fl[c[1]]++; fl[c[2]]++; }
-                else fl[k & 0xff]++;
+            // first index: label | 256 + match bytes; second: label (colour: the pixel's third code) | 256 + label (gray: the second
+            // pixel of a two-pixel run written as literals) | 512 + up
+            uint32_t h1[256 + 259] = {0}, h2[514] = {0};
+            {
+                const uint8_t* cur = cur_count;
+                uint32_t x = x_count;
+                for (size_t t = t0; t < t1; ++t) {
+                    const uint32_t k = tok[t];
+                    const uint32_t n = k & 0x1ff, m = k >> 31, upf = (k >> 16) & 1;
+                    if (__builtin_expect(k >= 0x40000000u && (!m || n <= max_px), 1)) {
+                        const uint32_t lit = m & uint32_t(n < lit_px);           // gray only: a run of 1 or 2 pixels
+                        const uint32_t v0 = cur[x], v1 = cur[x + 1 < uint32_t(w) ? x + 1 : x];
+                        h1[lit ? v0 : (m ? 256 + n * bpp : (k & 0xff))]++;
+                        h2[lit ? (n == 2 ? 256 + v1 : v0) : (m ? 512 + upf : (k & 0xff))]++;
+                        x += m ? n : 1;
+                    } else if (!m) { fl[k & 0xff]++; cur = src + y_count * stride; ++y_count; x = 0; }      // the filter byte: a new row
+                    else {
+                        for (uint32_t r = n; r > 0; r -= (r > max_px ? max_px : r)) { h1[256 + (r > max_px ? max_px : r) * bpp]++; h2[512 + upf]++; }
+                        x += n;
+                    }
+                }
+                cur_count = cur; x_count = x;
             }
+            for (int l = 3; l <= 258; ++l) if (h1[256 + l]) fl[len_code(l).sym] += h1[256 + l];
+            for (int v = 0; v < 256; ++v) {
+                if (lut) { const uint8_t* c = lut + 3 * v; fl[c[0]] += h1[v]; fl[c[1]] += h1[v]; fl[c[2]] += h1[v]; }
+                else fl[v] += h1[v] + h2[256 + v];
+            }
+            fd[ls] += h2[512];
+            if (up_ok) fd[us] += h2[513];
             fl[256] = 1;
             if (!fd[ls] && !(up_ok && fd[us])) fd[0] = 1;                    // at least one distance code must be defined
             uint8_t ll_len[286], d_len[30];
@@ -506,33 +600,59 @@ int encode_labels(const char* path, const uint8_t* src, int h, int w, size_t str
                 else if (sym == 17) bw.put(uint32_t(v >> 5), 3);
                 else if (sym == 18) bw.put(uint32_t(v >> 5), 7);
             }
-            // colour: the three literal codes of every label, the first two pre-merged (<= 30 bits)
-            uint32_t px_bits01[256], px_bits2[256];
-            uint8_t px_n01[256], px_n2[256];
-            if (lut) for (int v = 0; v < 256; ++v) {
-                const uint8_t* c = lut + 3 * v;
-                px_bits01[v] = uint32_t(ll_code[c[0]]) | (uint32_t(ll_code[c[1]]) << ll_len[c[0]]);
-                px_n01[v] = uint8_t(ll_len[c[0]] + ll_len[c[1]]);
-                px_bits2[v] = ll_code[c[2]]; px_n2[v] = ll_len[c[2]];
+            // pre-merged bit strings per table index.  b1 / n1: a literal pixel's first code (colour: codes 0 + 1 merged, <= 30 bits),
+            // or a match length with its extra bits (<= 20 bits); b2 / n2: the colour pixel's third code (gray: nothing), or the
+            // distance with its extra bits (<= 28 bits)
+            uint32_t b1[256 + 259], b2[514];
+            uint8_t n1[256 + 259], n2[514];
+            for (int v = 0; v < 256; ++v) {
+                if (lut) {
+                    const uint8_t* c = lut + 3 * v;
+                    b1[v] = uint32_t(ll_code[c[0]]) | (uint32_t(ll_code[c[1]]) << ll_len[c[0]]);
+                    n1[v] = uint8_t(ll_len[c[0]] + ll_len[c[1]]);
+                    b2[v] = ll_code[c[2]]; n2[v] = ll_len[c[2]];
+                    b2[256 + v] = 0; n2[256 + v] = 0;
+                } else { b1[v] = ll_code[v]; n1[v] = ll_len[v]; b2[v] = 0; n2[v] = 0; b2[256 + v] = ll_code[v]; n2[256 + v] = ll_len[v]; }
             }
+            for (int l = 0; l <= 258; ++l) {
+                if (l < 3) { b1[256 + l] = 0; n1[256 + l] = 0; continue; }
+                const LenCode lc = len_code(l);
+                b1[256 + l] = uint32_t(ll_code[lc.sym]) | (uint32_t(lc.eval) << ll_len[lc.sym]);
+                n1[256 + l] = uint8_t(ll_len[lc.sym] + lc.ebits);
+            }
+            b2[512] = uint32_t(d_code[ls]) | (uint32_t(lv) << d_len[ls]); n2[512] = uint8_t(d_len[ls] + le);
+            b2[513] = uint32_t(d_code[us]) | (uint32_t(uv) << d_len[us]); n2[513] = uint8_t(d_len[us] + ue);
+            const uint8_t* cur = cur_write;
+            uint32_t x = x_write;
             for (size_t t = t0; t < t1; ++t) {
                 const uint32_t k = tok[t];
-                if (k & 0x40000000u) { const int v = int(k & 0xff); bw.put(px_bits01[v], px_n01[v]); bw.put(px_bits2[v], px_n2[v]); continue; }
-                if (k & 0x80000000u) {
-                    const LenCode lc = len_code(int(k & 0x1ff));
-                    bw.put(ll_code[lc.sym], ll_len[lc.sym]);
-                    if (lc.ebits) bw.put(lc.eval, lc.ebits);
-                    if (k & 0x10000u) { bw.put(d_code[us], d_len[us]); if (ue) bw.put(uint32_t(uv), ue); }
-                    else { bw.put(d_code[ls], d_len[ls]); if (le) bw.put(uint32_t(lv), le); }
-                } else bw.put(ll_code[k & 0xff], ll_len[k & 0xff]);
+                const uint32_t n = k & 0x1ff, m = k >> 31, upf = (k >> 16) & 1;
+                if (__builtin_expect(k >= 0x40000000u && (!m || n <= max_px), 1)) {
+                    const uint32_t lit = m & uint32_t(n < lit_px);
+                    const uint32_t v0 = cur[x], v1 = cur[x + 1 < uint32_t(w) ? x + 1 : x];
+                    const uint32_t i1 = lit ? v0 : (m ? 256 + n * bpp : (k & 0xff));
+                    const uint32_t i2 = lit ? (n == 2 ? 256 + v1 : v0) : (m ? 512 + upf : (k & 0xff));
+                    bw.put2(b1[i1], n1[i1], b2[i2], n2[i2]);           // <= 30 + 15 (a colour pixel) or 20 + 28 (a match) bits
+                    x += m ? n : 1;
+                } else if (!m) { bw.put(ll_code[k & 0xff], ll_len[k & 0xff]); cur = src + y_write * stride; ++y_write; x = 0; }
+                else {
+                    for (uint32_t r = n; r > 0; r -= (r > max_px ? max_px : r)) {
+                        const uint32_t len = (r > max_px ? max_px : r) * bpp;
+                        bw.put(b1[256 + len], n1[256 + len]);
+                        bw.put(b2[512 + upf], n2[512 + upf]);
+                    }
+                    x += n;
+                }
             }
+            cur_write = cur; x_write = x;
             bw.put(ll_code[256], ll_len[256]);
             if (t1 == tok.size()) break;
         }
-        bw.flush();
-        out.push_back(uint8_t(adler >> 24)); out.push_back(uint8_t(adler >> 16)); out.push_back(uint8_t(adler >> 8)); out.push_back(uint8_t(adler));
+        uint8_t* e = bw.flush();
+        *e++ = uint8_t(adler >> 24); *e++ = uint8_t(adler >> 16); *e++ = uint8_t(adler >> 8); *e++ = uint8_t(adler);
+        out_size = size_t(e - out);
     } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
-    if (out.size() > 0x7fffffffull) return SAMRS_IO_ESIZE;
+    if (out_size > 0x7fffffffull) return SAMRS_IO_ESIZE;
 
     std::string tmp;
     try { tmp = std::string(path) + ".tmp." + std::to_string((long)getpid()); } catch (const std::bad_alloc&) { return SAMRS_IO_ENOMEM; }
@@ -546,11 +666,26 @@ int encode_labels(const char* path, const uint8_t* src, int h, int w, size_t str
     ihdr[10] = ihdr[11] = ihdr[12] = 0;
     int rc = fwrite(kSignature, 1, 8, fp) == 8 ? SAMRS_IO_OK : SAMRS_IO_EWRITE;
     if (rc == SAMRS_IO_OK) rc = write_chunk(fp, "IHDR", ihdr, 13);
-    if (rc == SAMRS_IO_OK) rc = write_chunk(fp, "IDAT", out.data(), uint32_t(out.size()));
+    if (rc == SAMRS_IO_OK) rc = write_chunk(fp, "IDAT", out, uint32_t(out_size));
     if (rc == SAMRS_IO_OK) rc = write_chunk(fp, "IEND", nullptr, 0);
     if (fclose(fp) != 0 && rc == SAMRS_IO_OK) rc = SAMRS_IO_EWRITE;
     if (rc == SAMRS_IO_OK && rename(tmp.c_str(), path) != 0) rc = SAMRS_IO_EWRITE;
     if (rc != SAMRS_IO_OK) remove(tmp.c_str());
+    return rc;
+}
+
+// gray_path: the class map as an 8-bit gray PNG; color_path + lut: the same map through the palette; either may be null (not both)
+int encode_labels(const char* gray_path, const char* color_path, const uint8_t* src, int h, int w, size_t stride, const uint8_t* lut) {
+    if ((!gray_path && !color_path) || (color_path && !lut) || !src || h <= 0 || w <= 0 || uint32_t(h) > kMaxSide || uint32_t(w) > kMaxSide)
+        return SAMRS_IO_ESIZE;
+    if (stride < size_t(w)) return SAMRS_IO_ESIZE;
+    thread_local TokenBuf tok_tl;
+    const int unit = color_path ? 3 : 1;
+    // the "up" distance (row bytes + 1) must fit deflate's 32 KiB window in EVERY stream written from this parse
+    const bool up_ok = size_t(w) * unit + 1 <= 32768;
+    int rc = parse_labels(src, h, w, stride, unit, up_ok, &tok_tl);
+    if (rc == SAMRS_IO_OK && gray_path) rc = emit_labels(gray_path, tok_tl, src, h, w, stride, nullptr, up_ok);
+    if (rc == SAMRS_IO_OK && color_path) rc = emit_labels(color_path, tok_tl, src, h, w, stride, lut, up_ok);
     return rc;
 }
 
@@ -584,14 +719,20 @@ int samrs_io_png_read_rgb(const char* path, uint8_t* dst, size_t dst_bytes, int*
 }
 
 int samrs_io_png_write_gray(const char* path, const uint8_t* src, int height, int width, size_t stride, int level) {
-    if (level == SAMRS_IO_LEVEL_LABELS) return encode_labels(path, src, height, width, stride, nullptr);
+    if (level == SAMRS_IO_LEVEL_LABELS) return encode_labels(path, nullptr, src, height, width, stride, nullptr);
     return encode(path, src, height, width, stride, 1, nullptr, level);
 }
 
 int samrs_io_png_write_lut_rgb(const char* path, const uint8_t* src, int height, int width, size_t stride, const uint8_t* lut, int level) {
     if (!lut) return SAMRS_IO_ESIZE;
-    if (level == SAMRS_IO_LEVEL_LABELS) return encode_labels(path, src, height, width, stride, lut);
+    if (level == SAMRS_IO_LEVEL_LABELS) return encode_labels(nullptr, path, src, height, width, stride, lut);
     return encode(path, src, height, width, stride, 1, lut, level);
+}
+
+int samrs_io_png_write_label_pair(const char* gray_path, const char* color_path, const uint8_t* src, int height, int width, size_t stride,
+                                  const uint8_t* lut) {
+    if (!gray_path || !color_path || !lut) return SAMRS_IO_ESIZE;
+    return encode_labels(gray_path, color_path, src, height, width, stride, lut);
 }
 
 int samrs_io_png_write_rgb(const char* path, const uint8_t* src, int height, int width, size_t stride, int level) {

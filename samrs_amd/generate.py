@@ -70,11 +70,16 @@ def write_outputs(out_dir: str, stem: str, seg: np.ndarray, masks: Optional[np.n
     # png_level: LEVEL_LABELS (default) = the label-aware encoder for both images -- the colour image IS the class map seen through
     # the palette, so its deflate tokens are derived from the 1-byte map (4x less CPU than zlib on the RGB bytes); 1..9 = zlib for
     # color/*.png (and the run-length preset for gray/*.png), kept for A/B runs.  The decoded pixels never depend on it.
-    tile_io.write_gray(os.path.join(out_dir, "gray", stem + ".png"), seg,
-                       tile_io.LEVEL_LABELS if png_level == tile_io.LEVEL_LABELS else tile_io.LEVEL_RUNS)   # :212,214
-    if clock: t0 = clock.add("write.gray_png", t0)
-    tile_io.write_lut_rgb(os.path.join(out_dir, "color", stem + ".png"), seg, tile_io.class_lut(palette), png_level)   # :213,215
-    if clock: t0 = clock.add("write.color_png", t0)
+    if png_level == tile_io.LEVEL_LABELS:
+        # one parse of the label runs, two deflate streams (:212-215)
+        tile_io.write_label_pair(os.path.join(out_dir, "gray", stem + ".png"), os.path.join(out_dir, "color", stem + ".png"), seg,
+                                 tile_io.class_lut(palette))
+        if clock: t0 = clock.add("write.gray_color_png", t0)
+    else:
+        tile_io.write_gray(os.path.join(out_dir, "gray", stem + ".png"), seg, tile_io.LEVEL_RUNS)                          # :212,214
+        if clock: t0 = clock.add("write.gray_png", t0)
+        tile_io.write_lut_rgb(os.path.join(out_dir, "color", stem + ".png"), seg, tile_io.class_lut(palette), png_level)   # :213,215
+        if clock: t0 = clock.add("write.color_png", t0)
     info = []
     for j in range(len(labels)):                                                            # :200-206
         entry = {"bbox": boxes[j], "category": class_names[int(labels[j])], "label": int(labels[j]), "size": int(areas[j])}

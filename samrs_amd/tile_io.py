@@ -18,7 +18,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 LEVEL_RUNS = -1            # SAMRS_IO_LEVEL_RUNS: zlib run-length strategy
 LEVEL_LABELS = -2          # SAMRS_IO_LEVEL_LABELS: the label-aware encoder (class maps and their palette images): the preset of generate
 OK, EOPEN, UNSUPPORTED, ECORRUPT, ESIZE, EWRITE, ENOMEM = 0, -1, -2, -3, -4, -5, -6
@@ -53,6 +53,7 @@ def load_library() -> ctypes.CDLL:
                        ("samrs_io_png_decode_rgb", [u8p, szt, u8p, szt, ip, ip]),
                        ("samrs_io_png_write_gray", [cp, u8p, ctypes.c_int, ctypes.c_int, szt, ctypes.c_int]),
                        ("samrs_io_png_write_lut_rgb", [cp, u8p, ctypes.c_int, ctypes.c_int, szt, u8p, ctypes.c_int]),
+                       ("samrs_io_png_write_label_pair", [cp, cp, u8p, ctypes.c_int, ctypes.c_int, szt, u8p]),
                        ("samrs_io_png_write_rgb", [cp, u8p, ctypes.c_int, ctypes.c_int, szt, ctypes.c_int])):
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = args, ctypes.c_int
@@ -132,6 +133,19 @@ def write_lut_rgb(path: str, seg: np.ndarray, lut: np.ndarray, level: int = 6) -
                                                    _ptr(lut), level)
     if rc != OK:
         raise TileIOError(rc, path)
+
+
+def write_label_pair(gray_path: str, color_path: str, seg: np.ndarray, lut: np.ndarray) -> None:
+    """``gray/<stem>.png`` and ``color/<stem>.png`` of one class map (main_sam_hbox_semantic.py:212-215) from ONE parse of the label
+    runs (the LEVEL_LABELS encoder); same pixels as :func:`write_gray` + :func:`write_lut_rgb`."""
+    seg = _check2d(seg)
+    lut = np.ascontiguousarray(lut, dtype=np.uint8)
+    if lut.shape != (256, 3):
+        raise ValueError("lut must be [256, 3]")
+    rc = load_library().samrs_io_png_write_label_pair(os.fsencode(gray_path), os.fsencode(color_path), _ptr(seg), seg.shape[0],
+                                                      seg.shape[1], seg.strides[0], _ptr(lut))
+    if rc != OK:
+        raise TileIOError(rc, gray_path + " / " + color_path)
 
 
 def write_rgb(path: str, img: np.ndarray, level: int = 6) -> None:

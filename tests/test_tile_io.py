@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = tile_io.load_library()
     header = open(os.path.join(ROOT, "include", "samrs_io.h")).read()
     names = set(re.findall(r"\b(samrs_io_\w+)\s*\(", header))
-    assert len(names) == 7
+    assert len(names) == 8
     for n in names:
         assert hasattr(lib, n), n
     assert lib.samrs_io_abi_version() == tile_io.ABI_VERSION == int(re.search(r"SAMRS_IO_ABI_VERSION (\d+)", header).group(1))
@@ -202,3 +202,76 @@ def test_label_aware_encoder_is_a_plain_png(tmp_path, kind):
     wide = np.concatenate([seg, seg[:, ::-1]], axis=1)
     tile_io.write_lut_rgb(c, wide[:, :seg.shape[1]], lut, tile_io.LEVEL_LABELS)
     assert np.array_equal(np.array(Image.open(c)), lut[seg])
+
+
+@pytest.mark.parametrize("kind", ["noise", "blobs", "constant", "columns", "rows", "wide", "pairs", "fixture"])
+def test_label_pair_writer_is_one_parse_two_plain_pngs(tmp_path, kind, golden_dir):
+    """samrs_io_png_write_label_pair (what `generate` calls per tile): gray/*.png and color/*.png of one class map from ONE parse
+    of its label runs.  The parse is tuned for the 3-byte stream; the gray stream turns runs shorter than deflate's 3-byte minimum
+    into literals read back from the map -- "pairs" (every label twice in a row: nothing but 2-pixel runs) is the map that lives on
+    that branch, "noise" crosses the 2^20-token block boundary with the walk position carried between blocks, "wide" has rows whose
+    RGB "up" distance does not fit deflate's window (so neither stream may use it), "fixture" is the reference's own class map
+    of the ViT-H C2 fixture.  Both files must decode (PIL and the native decoder) to exactly the map / its palette expansion
+    (main_sam_hbox_semantic.py:199,212-215), and stay within 3 % of the size of the two single-stream calls."""
+    rng = np.random.default_rng(11)
+    h, w = 256, 384
+    if kind == "noise":
+        seg = rng.integers(0, 18, (1024, 1100)).astype(np.uint8)
+    elif kind == "blobs":
+        seg = _class_map(h, w, seed=5)
+    elif kind == "constant":
+        seg = np.full((h, w), 255, np.uint8)
+    elif kind == "columns":
+        seg = np.repeat(rng.integers(0, 18, (1, w)).astype(np.uint8), h, axis=0)
+    elif kind == "rows":
+        seg = np.repeat(rng.integers(0, 18, (h, 1)).astype(np.uint8), w, axis=1)
+    elif kind == "wide":
+        seg = np.repeat(rng.integers(0, 18, (3, 1200)).astype(np.uint8), 10, axis=1)
+    elif kind == "pairs":
+        seg = np.repeat(rng.integers(0, 200, (h, w // 2)).astype(np.uint8), 2, axis=1)
+    else:
+        seg = np.ascontiguousarray(np.load(os.path.join(golden_dir, "vit_h_c2c4.npz"))["c2_seg"])
+    lut = tile_io.class_lut(rng.integers(0, 256, (200, 3), dtype=np.uint8))
+    g, c = str(tmp_path / "g.png"), str(tmp_path / "c.png")
+    tile_io.write_label_pair(g, c, seg, lut)
+    gi, ci = Image.open(g), Image.open(c)
+    assert gi.mode == "L" and ci.mode == "RGB"
+    assert np.array_equal(np.array(gi), seg) and np.array_equal(np.array(ci), lut[seg])
+    assert np.array_equal(tile_io.read_rgb(c), lut[seg]) and np.array_equal(tile_io.read_rgb(g)[..., 0], seg)
+    assert not [f for f in os.listdir(tmp_path) if ".tmp" in f]
+    g1, c1 = str(tmp_path / "g1.png"), str(tmp_path / "c1.png")
+    tile_io.write_gray(g1, seg, tile_io.LEVEL_LABELS)
+    tile_io.write_lut_rgb(c1, seg, lut, tile_io.LEVEL_LABELS)
+    assert open(c, "rb").read() == open(c1, "rb").read()                      # the colour stream IS the single call's
+    if kind != "pairs":                                                       # (there the unit-1 parse finds 3-byte matches the shared one cannot)
+        assert os.path.getsize(g) <= 1.03 * os.path.getsize(g1) + 64, (os.path.getsize(g), os.path.getsize(g1))
+    # a strided source
+    wide = np.concatenate([seg, seg[:, ::-1]], axis=1)
+    tile_io.write_label_pair(g, c, wide[:, :seg.shape[1]], lut)
+    assert np.array_equal(np.array(Image.open(g)), seg) and np.array_equal(np.array(Image.open(c)), lut[seg])
+    with pytest.raises(ValueError):
+        tile_io.write_label_pair(g, c, seg, lut[:100])
+
+
+def test_label_pair_writer_on_small_and_odd_shapes(tmp_path):
+    """One-pixel images, widths that are no multiple of the 8-label compare of the parse, maps made of 2-pixel runs (the gray
+    stream's literal branch) and sparse maps: both files decode to the map / its palette expansion."""
+    rng = np.random.default_rng(0)
+    lut = tile_io.class_lut(rng.integers(0, 256, (255, 3), dtype=np.uint8))
+    g, c = str(tmp_path / "g.png"), str(tmp_path / "c.png")
+    shapes = [(1, 1), (1, 2), (2, 1), (1, 3), (3, 7), (5, 8), (17, 9), (2, 258), (2, 259), (3, 87)]
+    shapes += [(int(rng.integers(1, 40)), int(rng.integers(1, 70))) for _ in range(60)]
+    for it, (h, w) in enumerate(shapes):
+        mode = it % 4
+        if mode == 0:
+            seg = rng.integers(0, int(rng.integers(1, 6)), (h, w))
+        elif mode == 1:
+            seg = np.repeat(np.repeat(rng.integers(0, 255, (h // 3 + 1, w // 4 + 1)), 3, 0), 4, 1)[:h, :w]
+        elif mode == 2:
+            seg = np.repeat(rng.integers(0, 255, (h, w // 2 + 1)), 2, 1)[:, :w]
+        else:
+            seg = (rng.random((h, w)) < 0.1) * int(rng.integers(1, 255))
+        seg = np.ascontiguousarray(seg.astype(np.uint8))
+        tile_io.write_label_pair(g, c, seg, lut)
+        assert np.array_equal(np.array(Image.open(g)).reshape(h, w), seg), (h, w, mode)
+        assert np.array_equal(np.array(Image.open(c)).reshape(h, w, 3), lut[seg]), (h, w, mode)

@@ -355,7 +355,7 @@ def main() -> None:
                 json.dump(ann, f)
             ns = _ap.Namespace(images=os.path.join(root, "img"), boxes=os.path.join(root, "boxes.json"), out=os.path.join(root, "out"),
                                model=args.model, checkpoint=None, precision=args.dtype, classes=None, n_classes=18, palette=None,
-                               box_batch=64, no_rle=False, batch=B, schedule="static", readers=8, writers=16, resume=False,
+                               box_batch=64, no_rle=False, batch=B, schedule="static", readers=0, writers=0, resume=False,
                                rle_buffer_mb=512, timing=True, png_level=-2, out_depth=4)
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):             # stdout carries the ONE JSON line of this script, nothing else
@@ -363,9 +363,10 @@ def main() -> None:
             per = {k: round(1e3 * v / st["images"], 1) for k, v in sorted(st["stage_thread_seconds"].items()) if not k.startswith("loop.")}
             cli = {"value": round(st["images"] / st["loop_seconds"], 3), "unit": "images/s", "tiles": st["images"],
                    "cpus": len(os.sched_getaffinity(0)), "cpu_quota": _cpu_quota(),
-                   "what": "python -m samrs_amd.generate end to end: 1024^2 PNG tiles read from disk (8 reader threads), TilePipeline "
-                           "with per-instance RLE on the device, gray + color PNG + ins/*.pkl written (16 writer threads); "
-                           "first-call warm-up inside the timed loop",
+                   "readers": st.get("readers"), "writers": st.get("writers"),
+                   "what": "python -m samrs_amd.generate end to end: 1024^2 PNG tiles read from disk, TilePipeline with per-instance "
+                           "RLE on the device, gray + color PNG (one parse, two streams) + ins/*.pkl written; reader / writer threads "
+                           "sized from this rank's share of the container's CPUs; first-call warm-up inside the timed loop",
                    "host_thread_ms_per_image": per}
             shutil.rmtree(root, ignore_errors=True)
         except Exception as ex:                                      # a secondary leg must not take the bench line down

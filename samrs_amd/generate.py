@@ -22,7 +22,7 @@ import argparse
 import json
 import os
 import pickle
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -96,6 +96,32 @@ def write_outputs(out_dir: str, stem: str, seg: np.ndarray, masks: Optional[np.n
     if clock: clock.add("write.pickle", t0)
 
 
+def host_cpu_budget(local_world: Optional[int] = None) -> float:
+    """CPUs THIS rank may keep busy: the container's share (cgroup v2 ``cpu.max``, else the affinity mask) divided by the ranks on
+    this node (``LOCAL_WORLD_SIZE``, set by torchrun).  On the pool's GPU boxes a container is a 16-CPU slice of 256 hardware
+    threads: eight ranks get two CPUs each, and thread pools sized for the whole node would only add context switches."""
+    cpus = float(len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else float(os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cpus = min(cpus, int(quota) / int(period))
+    except (OSError, ValueError):
+        pass
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    return max(1.0, cpus / max(1, local_world))
+
+
+def io_threads(readers: int = 0, writers: int = 0, local_world: Optional[int] = None) -> Tuple[int, int]:
+    """(reader threads, writer threads); 0 = sized from :func:`host_cpu_budget`.  Per image the host pays ~6 ms of decode and
+    ~14 ms of encode + pickle, so a third of the budget reads and the rest writes; the caps (8 / 16) are what
+    one rank at 140 images/s can use, the floor (2 / 2) keeps decode and encode overlapped with each other and with the GPU loop."""
+    budget = int(host_cpu_budget(local_world))
+    r = readers if readers > 0 else min(8, max(2, budget // 3))
+    w = writers if writers > 0 else min(16, max(2, budget - min(8, max(2, budget // 3))))
+    return r, w
+
+
 def outputs_exist(out_dir: str, stem: str) -> bool:
     """All three files of an image are on disk (main_sam_hbox_semantic.py:214-216 writes gray, color, then ins)."""
     return all(os.path.exists(os.path.join(out_dir, sub, stem + ext)) for sub, ext in (("gray", ".png"), ("color", ".png"), ("ins", ".pkl")))
@@ -163,6 +189,7 @@ def run(args) -> Dict[str, List[int]]:
 
     import time
     tile_io.load_library()                                  # fail here, not on a worker thread, when libsamrs_io.so is missing
+    n_readers, n_writers = io_threads(getattr(args, "readers", 0) or 0, getattr(args, "writers", 0) or 0)
     png_level = getattr(args, "png_level", tile_io.LEVEL_LABELS)
     clock = StageClock() if getattr(args, "timing", False) else None
 
@@ -199,7 +226,7 @@ def run(args) -> Dict[str, List[int]]:
 
     def batches():
         # image decode of the NEXT batch runs on a helper thread while the GPU works on this one
-        with ThreadPoolExecutor(max_workers=getattr(args, "readers", 8)) as readers:
+        with ThreadPoolExecutor(max_workers=n_readers) as readers:
             nxt = None
             for s0, s1 in wq:
                 fut = [readers.submit(load, st) for st in stems[s0:s1]]
@@ -217,7 +244,7 @@ def run(args) -> Dict[str, List[int]]:
 
     done = [0]
     sizes: List[int] = []
-    writers = ThreadPoolExecutor(max_workers=getattr(args, "writers", 16))
+    writers = ThreadPoolExecutor(max_workers=n_writers)
     pending: List = []
 
     def reap(block: bool) -> None:
@@ -302,7 +329,8 @@ def run(args) -> Dict[str, List[int]]:
     stats = {"class_pixel_num": pix.cpu().tolist(), "class_instance_num": ins.cpu().tolist(),
              "mask_num": len(all_sizes)}                                                             # statistic.py:53
     if clock:
-        stats["timing"] = {"images": done[0], "loop_seconds": wall, "stage_thread_seconds": dict(clock.t)}   # this rank's loop
+        stats["timing"] = {"images": done[0], "loop_seconds": wall, "stage_thread_seconds": dict(clock.t),   # this rank's loop
+                           "readers": n_readers, "writers": n_writers, "cpu_budget": round(host_cpu_budget(), 1)}
     if rank == 0:
         os.makedirs(os.path.join(args.out, "statistic"), exist_ok=True)
         with open(os.path.join(args.out, "statistic", "class_stats.json"), "w") as f:       # statistic.py:28-31
@@ -332,8 +360,9 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=8, help="tiles per encoder pass")
     ap.add_argument("--schedule", default="static", choices=["static", "dynamic"],
                     help="static: rank r takes chunks r, r+world, ...; dynamic: shared-counter work queue (long-tailed box counts)")
-    ap.add_argument("--readers", type=int, default=8, help="image decode threads")
-    ap.add_argument("--writers", type=int, default=16, help="PNG / pickle writer threads")
+    ap.add_argument("--readers", type=int, default=0, help="image decode threads (0 = from this rank's share of the container's CPUs: "
+                    "cgroup cpu.max / LOCAL_WORLD_SIZE, between 2 and 8)")
+    ap.add_argument("--writers", type=int, default=0, help="PNG / pickle writer threads (0 = from the same budget, between 2 and 16)")
     ap.add_argument("--split", type=int, default=None, help="engine operand-split mode (15 = block GEMMs at the 1x f16 rate, the default of "
                     "this single-mask driver; 79 = multimask-grade; 31 / 63 = reference-grade; DESIGN.md section 2)")
     ap.add_argument("--png-level", type=int, default=tile_io.LEVEL_LABELS,

@@ -111,3 +111,20 @@ def test_precision_policy_of_the_pipelines(monkeypatch):
     with driver.TilePipeline._mode(pipe):
         pass
     assert len(sam.engine.sets) == n                                         # "engine": not even a call
+
+
+def test_io_thread_pools_follow_the_ranks_share_of_the_cpus(monkeypatch):
+    """reader / writer pools sized per RANK.  The pool's GPU containers are 16-CPU slices: one rank may use
+    5 + 11 threads, eight ranks (LOCAL_WORLD_SIZE, set by torchrun) two + two each; explicit --readers / --writers win."""
+    from samrs_amd import generate
+    monkeypatch.setattr(generate, "host_cpu_budget", lambda local_world=None: 16.0 / (local_world or 1))
+    assert generate.io_threads() == (5, 11)
+    assert generate.io_threads(local_world=8) == (2, 2)
+    assert generate.io_threads(local_world=2) == (2, 6)
+    assert generate.io_threads(readers=8, writers=16, local_world=8) == (8, 16)
+    monkeypatch.setattr(generate, "host_cpu_budget", lambda local_world=None: 256.0 / (local_world or 1))
+    assert generate.io_threads(local_world=8) == (8, 16)          # a whole node: the caps
+    monkeypatch.undo()
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    one = generate.host_cpu_budget(1)
+    assert generate.host_cpu_budget() == max(1.0, one / 4) and one >= 1.0

@@ -2549,28 +2549,37 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
     const int grp = wave >> 2;
     const int wm = wave >> 2, wn = wave & 3;
 
+    // PERSISTENT as gemm_et_x64p_kernel: a block walks tiles L, L + gridDim.x, ...; the next tile's stage 0 (and its scale tiles) goes
+    // out before the epilogue, whose bounce scratch is confined to ring buffer 1.  (A grid of one block per tile degenerates to
+    // the one-tile kernel: SAMRS_MX_PERSIST=0, kept for A/B runs.)
     constexpr int GROUP = 8;
-    const int tiles_n = N / XBN, tiles_m = M / QBM;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_n = N / XBN, tiles_m = M / QBM, ntiles = tiles_n * tiles_m;
     const int per_group = GROUP * tiles_n;
-    const int group = bid / per_group, first_m = group * GROUP;
-    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-    const int in_g = bid - group * per_group;
-    const int tile_m = first_m + in_g % gsz, tile_n = in_g / gsz;
-    const int m0 = tile_m * QBM, n0 = tile_n * XBN;
+#define MX_TILE(L_, tm_, tn_)                                                                    \
+    do {                                                                                         \
+        const int bid_ = xcd_remap((L_), ntiles);                                                \
+        const int group_ = bid_ / per_group, first_m_ = group_ * GROUP;                           \
+        const int gsz_ = (tiles_m - first_m_) < GROUP ? (tiles_m - first_m_) : GROUP;            \
+        const int in_g_ = bid_ - group_ * per_group;                                             \
+        (tm_) = first_m_ + in_g_ % gsz_;                                                         \
+        (tn_) = in_g_ / gsz_;                                                                    \
+    } while (0)
+    int L = blockIdx.x, tile_m, tile_n;                    // the tile being FED (the DMA macros below read these)
+    MX_TILE(L, tile_m, tile_n);
+    int m0 = tile_m * QBM, n0 = tile_n * XBN;              // the tile being COMPUTED (epilogue)
 
     const int nst1 = K / XBK;                              // f16 stages
     const int nst4 = mx.Kp / MXK;                          // MX stages per correction segment
-    const int nmx = n0 >= mx.split_from_n ? 2 * nst4 : 0;  // this tile's MX stages (wave-uniform): A_lo B_hi, then A_hi B_lo
-    const int nst = nmx + nst1;
+    int nmx = n0 >= mx.split_from_n ? 2 * nst4 : 0;        // MX stages of the tile being fed (wave-uniform): A_lo B_hi, then A_hi B_lo
 
     // DMA map as in gemm_et_x64_kernel; the per-lane byte offset depends on the row stride of the source (2 K vs Kp / 2)
     const int prow = 8 * wave + ((lane >> 2) & 7);
     const uint32_t lane_off = (uint32_t)(lane >> 5) * 64u + (uint32_t)qswz(prow, lane & 3) * 16u;
     const uint32_t voff16 = (uint32_t)prow * (uint32_t)K * 2u + lane_off;
     const uint32_t voff4 = (uint32_t)prow * (uint32_t)(mx.Kp >> 1) + lane_off;
-    const unsigned char* A16 = reinterpret_cast<const unsigned char*>(A) + (size_t)m0 * K * 2;
+    const unsigned char* A16 = reinterpret_cast<const unsigned char*>(A) + (size_t)m0 * K * 2;     // of the tile being fed
     const unsigned char* B16 = reinterpret_cast<const unsigned char*>(B) + (size_t)n0 * K * 2;
+    int fm0 = m0, fn0 = n0;                                // rows of the tile being fed (the fp4 sources)
     const size_t row4 = (size_t)(mx.Kp >> 1);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
@@ -2580,11 +2589,14 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
 #define MX_PIECE(st_, wr_, q_)                                                                                       \
     do {                                                                                                             \
         const int st__ = (st_);                                                                                      \
-        const uint32_t dst__ = lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u); \
+        /* readfirstlane: inside the persistent loop LLVM moves some wave-uniform address chains to VGPRs (SGPR pressure) and */ \
+        /* then hands the VGPR to the "s" operand of the inline asm ("s_mov_b32 m0, v0": does not assemble)                   */ \
+        const uint32_t dst__ = __builtin_amdgcn_readfirstlane(                                                       \
+            lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u));              \
         if (st__ < nmx) {                                                                                            \
             const int seg__ = st__ >= nst4, s__ = st__ - seg__ * nst4;                                               \
-            const unsigned char* src__ = (q_) < 4 ? (seg__ ? mx.a4_hi : mx.a4_lo) + ((size_t)m0 + (q_) * 64) * row4          \
-                                                   : (seg__ ? mx.b4_lo : mx.b4_hi) + ((size_t)n0 + ((q_) - 4) * 64) * row4;  \
+            const unsigned char* src__ = (q_) < 4 ? (seg__ ? mx.a4_hi : mx.a4_lo) + ((size_t)fm0 + (q_) * 64) * row4         \
+                                                   : (seg__ ? mx.b4_lo : mx.b4_hi) + ((size_t)fn0 + ((q_) - 4) * 64) * row4; \
             glds16_s(voff4, src__ + (size_t)s__ * 128, dst__);                                                       \
         } else {                                                                                                     \
             const unsigned char* src__ = (q_) < 4 ? A16 + (size_t)(q_) * 64 * K * 2 : B16 + (size_t)((q_) - 4) * 64 * K * 2; \
@@ -2600,7 +2612,8 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
             const unsigned char* src__ = wave < 2                                                                    \
                 ? (seg__ ? mx.sa_hi : mx.sa_lo) + ((size_t)tile_m * nst4 + s__) * MX_SA_BYTES + wave * 1024          \
                 : (seg__ ? mx.sb_lo : mx.sb_hi) + ((size_t)tile_n * nst4 + s__) * MX_SB_BYTES + (wave - 2) * 1024;   \
-            glds16_s((uint32_t)lane * 16u, src__, lds_sc + ((wr_) ? (uint32_t)MX_S_BYTES : 0u) + (uint32_t)wave * 1024u); \
+            glds16_s((uint32_t)lane * 16u, src__,                                                                    \
+                     __builtin_amdgcn_readfirstlane(lds_sc + ((wr_) ? (uint32_t)MX_S_BYTES : 0u) + (uint32_t)wave * 1024u)); \
         }                                                                                                            \
     } while (0)
 #define MX_ISSUE(st_, wr_)                                                                                           \
@@ -2610,10 +2623,6 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
     } while (0)
 
     f32x4_t acc[NI][8];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
     uint32_t offA[8], offB[NI];
@@ -2631,10 +2640,6 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
     MX_ISSUE(0, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (grp == 1) {
-        if (nst > 1) MX_ISSUE(1, XSB);
-        __builtin_amdgcn_s_barrier();
-    }
 
 #define MX_READ(rd_, kh_)                                                                                  \
     _Pragma("unroll") for (int i = 0; i < NI; ++i)                                                         \
@@ -2706,26 +2711,54 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         rd = wr;                                                                                           \
     }
-    uint32_t rd = 0;
-    int t = 0;
-    for (; t < nmx; ++t) {
-        uint2 sa, sb;
-        MX_STAGE(MX_READ_SC(rd, 0), MX_READ_SC(rd, 1), MX_MFMA_FP4)
-    }
-    for (; t < nst; ++t) MX_STAGE(, , MX_MFMA_F16)
-#undef MX_STAGE
-    if (grp == 0) __builtin_amdgcn_s_barrier();            // both groups: same barrier count; every ring read is done
-
-    {   // epilogues of gemm_et_x64_kernel (NI = 5)
-        if constexpr (!OUT_F32) {
-            epilogue_pair_et<PREC, GELU, 4, false, false, MXO>(acc, reinterpret_cast<unsigned char*>(lds), Cv, bias, nullptr, 1, N, m0 + wm * 128,
-                                                               n0 + (wn >> 1) * 160, wm, wn, lane, nullptr, nullptr, mxo);
-        } else {
-            unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + wave * (2 * XSB / 8);
-            epilogue_coalesced<PREC, true, false, 8, 2, NI>(acc, scr, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + wn * (16 * NI),
-                                                           accumulate, lane, nullptr);
+    for (;;) {
+        const int nst = nmx + nst1;                        // stages of THIS tile (the feed variables still are its own here)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (grp == 1) {                                    // rendezvous R_0 of group 1; its share of stage 1 goes out first
+            if (nst > 1) MX_ISSUE(1, XSB);
+            __builtin_amdgcn_s_barrier();
         }
+        uint32_t rd = 0;
+        int t = 0;
+        for (; t < nmx; ++t) {
+            uint2 sa, sb;
+            MX_STAGE(MX_READ_SC(rd, 0), MX_READ_SC(rd, 1), MX_MFMA_FP4)
+        }
+        for (; t < nst; ++t) MX_STAGE(, , MX_MFMA_F16)
+        if (grp == 0) __builtin_amdgcn_s_barrier();        // both groups: same barrier count; every ring read of this tile is done
+
+        // next tile: its stage 0 (fp4 or f16 pieces + the scale tiles) goes into ring buffer 0 / scale buffer 0 now and lands
+        // under the epilogue
+        const int Ln = L + (int)gridDim.x;
+        const bool more = Ln < ntiles;
+        const int em0 = m0, en0 = n0;
+        if (more) {
+            MX_TILE(Ln, tile_m, tile_n);
+            fm0 = tile_m * QBM; fn0 = tile_n * XBN;
+            A16 = reinterpret_cast<const unsigned char*>(A) + (size_t)fm0 * K * 2;
+            B16 = reinterpret_cast<const unsigned char*>(B) + (size_t)fn0 * K * 2;
+            nmx = fn0 >= mx.split_from_n ? 2 * nst4 : 0;
+            MX_ISSUE(0, 0u);
+        }
+        {   // epilogue of tile (em0, en0); bounce scratch = ring buffer 1 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
+            unsigned char* upper = reinterpret_cast<unsigned char*>(lds) + XSB;
+            if constexpr (!OUT_F32) {
+                epilogue_pair_et<PREC, GELU, 2, true, false, MXO>(acc, upper, Cv, bias, nullptr, 1, N, em0 + wm * 128, en0 + (wn >> 1) * 160,
+                                                                  wm, wn, lane, nullptr, nullptr, mxo);
+            } else {
+                epilogue_coalesced<PREC, true, false, 8, 1, NI, false, true>(acc, upper + wave * (XSB / 8), Cv, bias, nullptr, 1, N,
+                                                                            em0 + wm * 128, en0 + wn * (16 * NI), accumulate, lane);
+            }
+        }
+        if (!more) break;
+        __builtin_amdgcn_s_barrier();          // scratch free again; stage 0 visible (each wave drained its pieces before its first store)
+        L = Ln; m0 = fm0; n0 = fn0;
     }
+#undef MX_STAGE
+#undef MX_TILE
 #undef MX_PIECE
 #undef MX_SCALES
 #undef MX_ISSUE
@@ -3086,7 +3119,15 @@ hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, co
     mx.sa_lo = (const unsigned char*)sa_lo; mx.sa_hi = (const unsigned char*)sa_hi;
     mx.sb_hi = (const unsigned char*)sb_hi; mx.sb_lo = (const unsigned char*)sb_lo;
     mx.Kp = Kp; mx.split_from_n = split_from_n;
-    const dim3 grid((M / QBM) * (N / WBN)), block(QTHREADS);
+    const int ntiles = (M / QBM) * (N / WBN);
+    static const int n_cu = [] {
+        const char* v = getenv("SAMRS_MX_PERSIST");          // 0: one block per tile (A/B runs)
+        if (v && atoi(v) == 0) return 1 << 30;
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(QTHREADS);
     const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
     const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
     const int acc = accumulate ? 1 : 0;

@@ -19,6 +19,9 @@ Workloads (all seeded through ``samrs_amd.synth``; the same tensors on every mac
   inst_rhbox  main_sam_rhbox_mask_instance.py:163-168 AS SCRIPTED: enclosing hbox only, multimask_output=False
   c2_800      a DIOR-shaped 800 x 800 tile (ResizeLongestSide to 1024 x 1024, utils/transforms.py:26-31,93-102), 32 hboxes
   c2_ragged   an HRSC2016-shaped ragged tile (771 x 1163 -> 679 x 1024 + padding), 32 hboxes
+  c3_long     the long tail of BASELINE.json configs[2] (DOTA-shaped box counts): ONE tile with 128 hboxes -- the reference walks
+              it in 20-box chunks (main_sam_hbox_semantic.py:157-181), the engine in chunks of its max_prompts; 128 masks painted
+              into one class map in box order
 
 Per mask: IoU, flipped pixels, flipped pixels OUTSIDE the set where the oracle's own full-resolution logit is within
 tau of the threshold (tau = TAU_FRAC x std of the call's low-res logits).  Per c2 tile: differing class-map pixels, the
@@ -45,9 +48,10 @@ N_C4_TILES = 4          # x 8 rboxes  = 32 objects -> 96 multimask masks per pro
 BOXES_PER_TILE = 32
 RBOXES_PER_TILE = 8
 ODD_SHAPES = (("c2_800", (800, 800)), ("c2_ragged", (771, 1163)))
+LONG_TAIL_BOXES = 128
 
 
-def tiles(n_c2: int = N_C2_TILES, n_c4: int = N_C4_TILES, odd: bool = True):
+def tiles(n_c2: int = N_C2_TILES, n_c4: int = N_C4_TILES, odd: bool = True, long_tail: bool = True):
     """The sample, tile by tile: dicts with the image and the annotations of every workload that runs on it."""
     for i in range(n_c2):
         boxes, labels = synth.make_boxes(300 + i, BOXES_PER_TILE)
@@ -60,6 +64,9 @@ def tiles(n_c2: int = N_C2_TILES, n_c4: int = N_C4_TILES, odd: bool = True):
         for j, (tag, (h, w)) in enumerate(ODD_SHAPES):
             boxes, labels = synth.make_boxes(500 + j, BOXES_PER_TILE, h, w)
             yield dict(name=tag, image=synth.make_image(250 + j, h, w), c2=(boxes, labels), c2_tag=tag)
+    if long_tail:
+        boxes, labels = synth.make_boxes(600, LONG_TAIL_BOXES)
+        yield dict(name="c3_long", image=synth.make_image(260), c2=(boxes, labels), c2_tag="c3_long")
 
 
 def workloads(tile, rasterise):

@@ -13,6 +13,7 @@ ap.add_argument("--modes", default="15,79,63")
 ap.add_argument("--c2", type=int, default=ps.N_C2_TILES)
 ap.add_argument("--c4", type=int, default=ps.N_C4_TILES)
 ap.add_argument("--no-odd", action="store_true")
+ap.add_argument("--no-long", action="store_true")
 ap.add_argument("--model", default="vit_h")
 ap.add_argument("--create-split", type=int, default=127, help="the split mask the engine is created with (lo weight copies)")
 ap.add_argument("--out", default="gpurun_out/parity_stats.json")
@@ -26,7 +27,7 @@ sam = samrs_amd.sam_model_registry[a.model](state_dict=sd, precision="f16", max_
 pred = samrs_amd.SamPredictor(sam)
 orc = so.OraclePredictor(sd, cfg)
 t0 = time.time()
-rec = ps.run(pred, orc, modes, ps.tiles(a.c2, a.c4, odd=not a.no_odd))
+rec = ps.run(pred, orc, modes, ps.tiles(a.c2, a.c4, odd=not a.no_odd, long_tail=not a.no_long))
 summ = ps.summarise(rec)
 print(ps.table(summ))
 print(f"total {time.time() - t0:.0f} s; tau = {ps.TAU_FRAC} x std(low-res logits); device {torch.cuda.get_device_name(0)}")

@@ -13,6 +13,7 @@ reports per configuration, against the exact run:
     python -m oracle.error_budget vit_h plans3     which block GEMMs must be split as well for the C4 fixture to clear 0.999
     python -m oracle.error_budget vit_h plans4     the v third of the qkv product on its own
     python -m oracle.error_budget vit_h plans10    the lo terms on MXFP4 (e2m1, 32-element scale blocks) operands, per mode
+    python -m oracle.error_budget vit_h plans11    lin2's MXFP4 lo terms in the leading k blocks only, on top of split 79
 
 Encoder passes are cached under $SAMRS_EB_CACHE (default /tmp/samrs_error_budget); delete it after changing the oracle.
 
@@ -229,6 +230,23 @@ def main(argv):
                                    ("E1 + v + proj + lin2, every block, lo terms e2m1 / 32", ("enc.v_in", "enc.proj_in", "enc.lin2_in"), range(0, n))):
             tag = "p10_e2m1_" + "_".join(k.split(".")[1] for k in pts) + "_%d" % len(blocks)
             report(label, tag, so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points={k: (blocks, q4) for k in pts}))
+    if what in ("plans11",):
+        # round 4, after the 576-mask sample (profiles/r04_parity_stats.md): is there a mode between split 79 (v + proj, blocks
+        # 0..23) and 207 (+ lin2 in every block)?  lin2's lo terms in the LEADING k blocks only, on top of 79
+        sp = so.split2(F16)
+        q4 = so.split_fp8_lo(F16, fmt="e2m1", block=32)
+        e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
+        n = cfg.depth
+        att = range(0, 3 * n // 4)
+        for k in (n // 4, n // 2, 3 * n // 4):
+            bp = {"enc.v_in": (att, q4), "enc.proj_in": (att, q4), "enc.lin2_in": (range(0, k), q4)}
+            report("E1 + v + proj (blocks 0..%d) + lin2 (blocks 0..%d), e2m1 / 32" % (3 * n // 4 - 1, k - 1), "p11_lin2_%d" % k,
+                   so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points=bp))
+        # ... or in the TRAILING blocks (lin2's output goes straight into the residual stream the neck reads)
+        for k0 in (3 * n // 4, n // 2, 0):
+            bp = {"enc.v_in": (att, q4), "enc.proj_in": (att, q4), "enc.lin2_in": (range(k0, n), q4)}
+            report("E1 + v + proj (blocks 0..%d) + lin2 (blocks %d..%d), e2m1 / 32" % (3 * n // 4 - 1, k0, n - 1), "p11_lin2_from%d" % k0,
+                   so.Rounding(enc=F16, dec=F16, points=dict(e1), block_points=bp))
     if what in ("plans", "all"):
         sp = so.split2(F16)
         report("plan A: encoder f16, decoder operands split f16 (hi+lo)", "f16",

@@ -347,7 +347,8 @@ int samrs_k_gemm_mx(int prec, const void* A, const void* B, void* C, const float
                     const void* sb_lo, int out_f32, int accumulate, int split_from_n, void* stream);
 /* samrs_k_gemm_mx with an ET output, optionally the exact-erf GELU in the epilogue, and (o4_*: all four or none) the output ALSO written
  * as MXFP4 hi / lo on a K axis padded per 80-column wave tile to 96 -- [M][N / 80 * 48] bytes + A-operand scale tiles, block-internal
- * order = samrs_k_mx4_pack is_b bit 2: lin1 feeding lin2 in the all-split mode */
+ * order = samrs_k_mx4_pack is_b bit 2: lin1 feeding lin2 in the all-split mode.  `gelu`: bit 0 = GELU, bit 1 = NO tile takes lo terms
+ * (lin1 of split 207, whose lin2 alone is split: the plain persistent kernel with the MX-row epilogue; the a4 / b4 operands are ignored) */
 int samrs_k_gemm_mx_gelu_mxout(int prec, const void* A, const void* B, void* C_et, const float* bias, int M, int N, int K, int Kp,
                                const void* a4_lo, const void* a4_hi, const void* sa_lo, const void* sa_hi, const void* b4_hi, const void* b4_lo,
                                const void* sb_hi, const void* sb_lo, int gelu, void* o4_hi, void* o4_lo, void* so_hi, void* so_lo, void* stream);

@@ -1455,8 +1455,11 @@ int samrs_k_gemm_mx(int prec, const void* A, const void* B, void* C, const float
 int samrs_k_gemm_mx_gelu_mxout(int prec, const void* A, const void* B, void* C_et, const float* bias, int M, int N, int K, int Kp,
                                const void* a4_lo, const void* a4_hi, const void* sa_lo, const void* sa_hi, const void* b4_hi, const void* b4_lo,
                                const void* sb_hi, const void* sb_lo, int gelu, void* o4_hi, void* o4_lo, void* so_hi, void* so_lo, void* stream) {
-    return launch_gemm_et_mx(prec, A, B, C_et, bias, M, N, K, Kp, a4_lo, a4_hi, sa_lo, sa_hi, b4_hi, b4_lo, sb_hi, sb_lo, false, false, 0,
-                             (hipStream_t)stream, gelu != 0, o4_hi, o4_lo, so_hi, so_lo) == hipSuccess ? SAMRS_OK : SAMRS_ERR_BAD_SHAPE;
+    // gelu: bit 0 = GELU in the epilogue, bit 1 = NO tile takes lo terms (split_from_n = N: lin1 of split 207, routed to the persistent
+    // plain kernel with the MX-row epilogue)
+    return launch_gemm_et_mx(prec, A, B, C_et, bias, M, N, K, Kp, a4_lo, a4_hi, sa_lo, sa_hi, b4_hi, b4_lo, sb_hi, sb_lo, false, false,
+                             (gelu & 2) ? N : 0, (hipStream_t)stream, (gelu & 1) != 0, o4_hi, o4_lo, so_hi, so_lo) == hipSuccess
+               ? SAMRS_OK : SAMRS_ERR_BAD_SHAPE;
 }
 int samrs_k_convert_split(int prec, const float* in, void* out_hi, void* out_lo, int64_t n, void* stream) {
     KRET(launch_convert(prec, in, out_hi, (long)n, (hipStream_t)stream, out_lo));

@@ -1168,7 +1168,11 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
 // partials of the LN_NS 160-column groups; only the ET epilogue reads it (8 bytes per row and lane, next to the bias loads).
 constexpr int LN_NS = 8;                       // 1280 / 160: ViT-H only
 
-template <int PREC, bool OUT_F32, bool GELU, bool FOLD = false, bool SPLIT3 = false>
+// MXO (round 4; ET output, no FOLD / SPLIT3): the epilogue also writes the output as MXFP4 hi / lo rows (epilogue_pair_et<MXO>: lin1 of
+// split 207, whose lin2 takes MXFP4 lo terms while lin1 itself takes none).  The four output pointers travel in the parameters the
+// plain flavour does not use -- rowstat = codes hi, cvec = codes lo, A_lo = scales hi, B_lo = scales lo -- so that the kernel
+// signature, and with it every existing instantiation, stays what it was.
+template <int PREC, bool OUT_F32, bool GELU, bool FOLD = false, bool SPLIT3 = false, bool MXO = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, int accumulate,
@@ -1176,6 +1180,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr, int split_from_n = 0) {
     static_assert(!(FOLD && OUT_F32), "the folded LayerNorm feeds ET outputs only (qkv, lin1)");
     static_assert(!(FOLD && SPLIT3), "the split operands come from an explicit LayerNorm");
+    static_assert(!(MXO && (FOLD || SPLIT3 || OUT_F32)), "MX rows go with the plain ET-output flavour");
     constexpr int NI = 5;
     constexpr int XBN = 64 * NI;
     constexpr int XROWS = QBM + XBN;
@@ -1315,7 +1320,15 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
         }
         {   // epilogue of tile (m0, n0); bounce scratch = ring buffer 1 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
             unsigned char* upper = reinterpret_cast<unsigned char*>(lds) + XSB;
-            if constexpr (!OUT_F32) {
+            if constexpr (MXO) {
+                MxOut mxo;
+                mxo.q_hi = reinterpret_cast<unsigned char*>(const_cast<float2*>(rowstat));
+                mxo.q_lo = reinterpret_cast<unsigned char*>(const_cast<float*>(cvec));
+                mxo.s_hi = reinterpret_cast<unsigned char*>(const_cast<uint16_t*>(A_lo));
+                mxo.s_lo = reinterpret_cast<unsigned char*>(const_cast<uint16_t*>(B_lo));
+                epilogue_pair_et<PREC, GELU, 2, true, false, true>(acc, upper, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + (wn >> 1) * 160, wm, wn,
+                                                                   lane, nullptr, nullptr, mxo);
+            } else if constexpr (!OUT_F32) {
                 epilogue_pair_et<PREC, GELU, 2, true, FOLD>(acc, upper, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + (wn >> 1) * 160, wm, wn, lane,
                                                             rowstat, cvec);
             } else {
@@ -1354,6 +1367,28 @@ hipError_t launch_gemm_x64p(const void* A, const void* B, void* C, const float* 
         if (gelu) gemm_et_x64p_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
         else gemm_et_x64p_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     }
+    return hipGetLastError();
+}
+
+// ET output (+ GELU) that is also written as MXFP4 hi / lo rows: the persistent kernel with the MX-row epilogue, no lo terms taken
+template <int PREC>
+hipError_t launch_gemm_x64p_mxo(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, bool gelu,
+                                void* o4_hi, void* o4_lo, void* so_hi, void* so_lo, hipStream_t s) {
+    const int ntiles = (M / QBM) * (N / WBN);
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(QTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const float2* p0 = reinterpret_cast<const float2*>(o4_hi);
+    const float* p1 = reinterpret_cast<const float*>(o4_lo);
+    const uint16_t* p2 = reinterpret_cast<const uint16_t*>(so_hi);
+    const uint16_t* p3 = reinterpret_cast<const uint16_t*>(so_lo);
+    if (gelu) gemm_et_x64p_kernel<PREC, false, true, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, p0, p1, p2, p3, 0);
+    else gemm_et_x64p_kernel<PREC, false, false, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, p0, p1, p2, p3, 0);
     return hipGetLastError();
 }
 
@@ -3113,6 +3148,14 @@ hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, co
     if (!gemm_mx_ok(M, N, K, Kp) || !A || !B || !C || !a4_lo || !a4_hi || !sa_lo || !sa_hi || !b4_hi || !b4_lo || !sb_hi || !sb_lo)
         return hipErrorInvalidValue;
     if ((accumulate && !out_f32) || split_from_n < 0 || split_from_n % WBN || (split_from_n && out_f32)) return hipErrorInvalidValue;
+    // no tile takes lo terms and the output is wanted as MX rows (lin1 of split 207): the plain persistent kernel with the MX-row
+    // epilogue -- the f16 main loop of gemm_et_x64p_kernel is ~5 % faster than this kernel's (SAMRS_MX_LIN1=0: A/B switch)
+    static const bool x64p_lin1 = [] { const char* v = getenv("SAMRS_MX_LIN1"); return !(v && atoi(v) == 0); }();
+    if (x64p_lin1 && o4_hi && split_from_n == N && N % XBK == 0 && K % XBK == 0) {
+        if (prec == PREC_F16) return launch_gemm_x64p_mxo<PREC_F16>(A, B, C, bias, M, N, K, gelu, o4_hi, o4_lo, so_hi, so_lo, s);
+        if (prec == PREC_BF16) return launch_gemm_x64p_mxo<PREC_BF16>(A, B, C, bias, M, N, K, gelu, o4_hi, o4_lo, so_hi, so_lo, s);
+        return hipErrorInvalidValue;
+    }
     MxOperands mx;
     mx.a4_lo = (const unsigned char*)a4_lo; mx.a4_hi = (const unsigned char*)a4_hi;
     mx.b4_hi = (const unsigned char*)b4_hi; mx.b4_lo = (const unsigned char*)b4_lo;

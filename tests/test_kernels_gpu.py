@@ -1053,13 +1053,16 @@ def test_attention_mx_outputs_equal_the_pack_kernel(lib, name, prec, dt, ulp, is
     assert ((a - b).abs() <= 0.51 * b.abs().reshape(rows, -1, 32).amax(-1, keepdim=True).clamp(min=1e-30).expand(-1, -1, 32).reshape(rows, Kp)).all()
 
 
+@pytest.mark.parametrize("plain", [0, 1])
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
-def test_gemm_mx_gelu_epilogue_emits_mx_rows(lib, name, prec, dt, ulp):
+def test_gemm_mx_gelu_epilogue_emits_mx_rows(lib, name, prec, dt, ulp, plain):
     """lin1 of the all-split mode: gemm_et_mx_kernel with the exact-erf GELU in its epilogue, which also writes its output as MXFP4
     hi / lo rows for lin2 (K axis padded per 80-column wave tile to 96, block-internal order of the epilogue's lanes).  (i) the ET
     output = GELU of the fp64 evaluation of the kernel's own expression, rounded once; (ii) the hi codes and scales are EXACTLY what
     the pack kernel makes of that ET output (same layout, same order); (iii) the lo rows carry the remainder: adding the decoded lo
-    to the ET value cuts the distance to the exact GELU by more than half in rms."""
+    to the ET value cuts the distance to the exact GELU by more than half in rms.
+    plain = 1: lin1 of split 207 (lin2 alone takes lo terms): NO tile takes lo terms -- the persistent plain kernel
+    (gemm_et_x64p_kernel<MXO>) with the same MX-row epilogue; the product is the plain one, everything else as above."""
     g = torch.Generator().manual_seed(77)
     M, N, K = 512, 640, 1280
     A = torch.randn(M, K, generator=g)
@@ -1067,8 +1070,10 @@ def test_gemm_mx_gelu_epilogue_emits_mx_rows(lib, name, prec, dt, ulp):
     bias = torch.randn(N, generator=g) * 0.5
     Ah, qa, sa = _mx_pack(lib, prec, A, K, K, False)
     Bh, qb, sb = _mx_pack(lib, prec, B, K, K, True)
-    emul = (A.to(dt).double() @ B.to(dt).double().t() + _mx_decode(qa[1], sa[1], M, K, False) @ _mx_decode(qb[0], sb[0], N, K, True).t()
-            + _mx_decode(qa[0], sa[0], M, K, False) @ _mx_decode(qb[1], sb[1], N, K, True).t() + bias.double())
+    emul = A.to(dt).double() @ B.to(dt).double().t() + bias.double()
+    if not plain:
+        emul = (emul + _mx_decode(qa[1], sa[1], M, K, False) @ _mx_decode(qb[0], sb[0], N, K, True).t()
+                + _mx_decode(qa[0], sa[0], M, K, False) @ _mx_decode(qb[1], sb[1], N, K, True).t())
     ref = F.gelu(emul)                                                            # exact erf GELU, fp64
     Kp = N // 80 * 96
     out = torch.zeros(M, N, dtype=torch.int16, device="cuda")
@@ -1077,7 +1082,8 @@ def test_gemm_mx_gelu_epilogue_emits_mx_rows(lib, name, prec, dt, ulp):
     sc = [torch.zeros(nb, dtype=torch.uint8, device="cuda") for _ in range(4)]
     assert lib.samrs_k_gemm_mx_gelu_mxout(prec, Ah.data_ptr(), Bh.data_ptr(), out.data_ptr(), dev(bias).data_ptr(), M, N, K, K, qa[1].data_ptr(),
                                           qa[0].data_ptr(), sa[1].data_ptr(), sa[0].data_ptr(), qb[0].data_ptr(), qb[1].data_ptr(), sb[0].data_ptr(),
-                                          sb[1].data_ptr(), 1, q[0].data_ptr(), q[1].data_ptr(), sc[0].data_ptr(), sc[1].data_ptr(), stream()) == 0
+                                          sb[1].data_ptr(), 1 | (2 if plain else 0), q[0].data_ptr(), q[1].data_ptr(), sc[0].data_ptr(), sc[1].data_ptr(),
+                                          stream()) == 0
     got = out.cpu().view(dt).double()
     err = ((got - ref).abs() / ref.abs().clamp(min=1.0)).max().item()
     print(f"gemm_mx + GELU {name}: max err vs GELU(emulation) {err:.2e} (operand ulp {ulp:.1e})")

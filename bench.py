@@ -65,6 +65,52 @@ def file_sha(path: str) -> str:
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
+PARITY_FILE = os.path.join(ROOT, "profiles", "parity_stats.json")
+
+
+def csrc_sha() -> str:
+    """One hash over every device source the arithmetic of the path lives in (samrs_amd/csrc/*.hip, *.h): what a parity
+    statement is a statement ABOUT.  tests/test_parity_gpu.py::test_vit_h_statistical_parity_sample writes the same hash
+    next to the statistics it measures."""
+    d = os.path.join(ROOT, "samrs_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def parity_of_mode(split: int, workload: str, model: str = "vit_h"):
+    """The parity figures that belong to the precision mode a bench line was produced in (VERDICT r04 "what's weak" 1: the
+    line carried a throughput with no parity attached).  Read from profiles/parity_stats.json = the JSON the GPU test
+    test_vit_h_statistical_parity_sample wrote on an MI355X (engine vs the pinned oracle, oracle/parity_sample.py), and reported
+    only when it was measured on THIS build's device sources (hash-pinned like `roofline.traffic`)."""
+    if model != "vit_h" or not os.path.exists(PARITY_FILE):
+        return {"mode": split, "note": "no parity sample committed for this model"}
+    st = json.load(open(PARITY_FILE))
+    if st.get("csrc_sha16") != csrc_sha():
+        return {"mode": split, "note": "profiles/parity_stats.json was measured on other device sources: not reported"}
+    m = st.get("summary", {}).get(str(split))
+    if not m:
+        return {"mode": split, "note": f"profiles/parity_stats.json holds no sample for split {split}"}
+    c4 = [m[t] for t in ("c4box", "c4mask") if t in m]
+    out = {"mode": split, "vs": "oracle/sam_oracle.py fp32 (pinned to the real reference's fixtures), same seeded inputs",
+           "c2_iou_min": round(m["c2"]["iou_min"], 5), "c2_n_masks": m["c2"]["n_masks"],
+           "classmap_px_mean": m["c2"]["classmap_diff_mean"], "classmap_px_max": m["c2"]["classmap_diff_max"],
+           "classmap_px_outside_unstable": m["c2"]["classmap_diff_outside_unstable"],
+           "classmap_bit_identical": m["c2"]["classmap_diff_max"] == 0,
+           "c4_iou_min": round(min(t["iou_min"] for t in c4), 5) if c4 else None,
+           "c4_n_masks": sum(t["n_masks"] for t in c4), "c4_served_in_this_mode": bool(split & (64 | 16)),
+           "n_masks": sum(t["n_masks"] for t in m.values()), "flips_outside_tau": sum(t["flips_outside_tau"] for t in m.values()),
+           "tau_frac": st.get("tau_frac"), "csrc_sha16": st.get("csrc_sha16"), "device": st.get("device")}
+    if workload == "c4":
+        out["headline_workload_iou_min"] = out["c4_iou_min"]
+    else:
+        out["headline_workload_iou_min"] = out["c2_iou_min"]
+    return out
+
+
 def _cpu_quota():
     """CPUs this container may use at once (cgroup v2 cpu.max), or None."""
     try:
@@ -448,6 +494,7 @@ def main() -> None:
                        "accumulate": "f32", "operand_split": split_used},
             "flops_per_image": F, "roofline": roofline, "cpu_baseline": cpu_baseline, "alt_dtype": alt, "pcie_inclusive": pcie,
             "rle_inclusive": rle_leg, "cli_inclusive": cli, "other_precision_mode": other_mode,
+            "parity": parity_of_mode(int(split_used), args.workload, args.model),
             "boxes_per_s": round(boxes_done / dt, 1),
             "stats_allreduce": {"total_pixels": int(tot_pix.sum().item()), "total_instances": int(tot_ins.sum().item())},
         }

@@ -283,6 +283,9 @@ int samrs_k_layernorm(int prec, const float* X, const float* gamma, const float*
 int samrs_k_window_attention(int prec, const void* qkv_et, const float* qkv_bias, const float* rel_h,
                              const float* rel_w, void* out_et, int n_images, int grid, int window,
                              int heads, int head_dim, void* stream);
+/* TEST / BENCH hook (as is samrs_k_attention_mx with global = 1): the V^T workspace the engine owns is, here, one grow-only
+ * buffer per device kept by the library; growing it synchronizes the device first.  Not for product code: an engine's own
+ * encoder pass (samrs_set_images) uses the engine's workspace and never this one. */
 int samrs_k_global_attention(int prec, const void* qkv_et, const float* rel_h, const float* rel_w,
                              void* out_et, int n_images, int grid, int heads, int head_dim,
                              void* stream);

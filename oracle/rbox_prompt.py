@@ -24,6 +24,11 @@ horizontal pass then vertical pass).  They could not be checked against cv2 here
   * round 4: both against hand-derived known answers of the published rules (tests/golden/opencv_known_answers.json:
     inclusive rectangle, 45-degree diamond, degenerate slivers, clipping, a 45-degree hypotenuse; INTER_LINEAR up- and
     down-scaling with clamped ends) -- tests/test_rbox_prompt.py::test_fill_poly_and_resize_known_answers.
+  * round 5: rotated rectangles at arbitrary angles (18.4 / 21.8 / 71.6 degrees) and a sub-pixel sliver, with the derivation
+    of every line pixel and scanline crossing committed next to the answer (oracle/derive_fillpoly_cases.py, independent of
+    this module).  OpenCV changed the span rule in 4.5.2 (ceil..floor -> round..round on edge x + 0.5); `fill_poly` below
+    restates the older rule, and the pinned cases are ones where both rules give the same picture.  For a general polygon
+    the two can differ by boundary pixels the 8-connected edge line does not cover -- the reference pins no version.
 One known deviation is documented in `line8`: cv2 clips a boundary line to the image before walking it.
 """
 from __future__ import annotations

@@ -365,7 +365,14 @@ class TilePipeline:
         if eng is None:
             raise RuntimeError("move the model to the GPU first: sam.to('cuda')")
         self.split_mode = self._choose_split(sam, precision, multimask=_multimask)
-        self.allow_reduced = isinstance(precision, int) and not isinstance(precision, bool)
+        # consent to reduced-precision multimask predicts only means something for a pipeline that issues them
+        self.allow_reduced = _multimask and isinstance(precision, int) and not isinstance(precision, bool)
+        self.eng = eng
+        if self.split_mode is not None:
+            # fail HERE when the engine cannot run the mode (e.g. a block-GEMM bit whose lo weights were not finalized), not
+            # mid-run inside _encode after _stage has queued H2D copies and recorded events (round-4 advisor finding)
+            with self._mode():
+                pass
         if out_depth < 2:
             raise ValueError("out_depth must be >= 2: batch k-1's results are still on loan to the sink when batch k decodes")
         if eng.max_images < 2 * batch:

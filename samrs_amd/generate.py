@@ -130,6 +130,36 @@ def outputs_exist(out_dir: str, stem: str) -> bool:
 _RUN_SEQ = [0]          # run() calls of this process (part of the work queue's store key)
 
 
+def resumed_statistics(out_dir: str, stems: List[str], n_classes: int):
+    """(class_pixel_num, class_instance_num, mask sizes) of images completed by an earlier run, from their ins/*.pkl
+    (`Generate Dataset/statistic.py:12-21,44-49`); a label outside 0..n_classes-1 raises, naming the file."""
+    pix, ins, sizes = np.zeros(n_classes, np.int64), np.zeros(n_classes, np.int64), []
+    for stem in stems:
+        path = os.path.join(out_dir, "ins", stem + ".pkl")
+        with open(path, "rb") as f:
+            for entry in pickle.load(f):
+                label, size = int(entry["label"]), int(entry["size"])
+                if not 0 <= label < n_classes:
+                    raise ValueError(f"--resume: {path} holds label {label}, outside 0..{n_classes - 1}: it was written with "
+                                     "another class list (use a fresh --out or the same --classes / --n-classes)")
+                if size > 0:                                                                         # statistic.py:18
+                    pix[label] += size
+                    ins[label] += 1
+                    sizes.append(size)
+    return pix, ins, sizes
+
+
+def default_split_options(split, environ=None):
+    """Engine options of this driver's model: an explicit --split wins; otherwise SAMRS_SPLIT (read by samrs_create) stands
+    and NO option is passed; only when neither is given the single-mask default 15 is set before the weights are finalized."""
+    environ = os.environ if environ is None else environ
+    if split is not None:
+        return {"split": int(split)}
+    if environ.get("SAMRS_SPLIT", "") != "":
+        return None
+    return {"split": 15}
+
+
 def run(args) -> Dict[str, List[int]]:
     import torch.distributed as dist
     from concurrent.futures import ThreadPoolExecutor
@@ -156,7 +186,10 @@ def run(args) -> Dict[str, List[int]]:
     # driver asks for single masks only, which hold IoU >= 0.9995 with the block GEMMs at the 1x rate (split 15)
     # no --split: 15 explicitly, BEFORE the weights are finalized, so that a ViT-H engine does not allocate the lo copies of its
     # qkv / proj weights and the Ylo / AOlo workspaces (~0.75 GB of HBM this driver would never touch)
-    opts = {"split": args.split if getattr(args, "split", None) is not None else 15}
+    # An operator's SAMRS_SPLIT is never overridden (samrs_hip.h option docs): the default is injected only when
+    # neither --split nor the environment variable names a mode (round-4 advisor finding: options are applied AFTER samrs_create
+    # has read the environment, so an unconditional 15 silently replaced SAMRS_SPLIT=63 / 79).
+    opts = default_split_options(getattr(args, "split", None))
     sam = samrs_amd.sam_model_registry[args.model](checkpoint=args.checkpoint, precision=args.precision, options=opts,
                                                    max_images=2 * batch, max_prompts=args.box_batch).to(f"cuda:{local}")
     exts = (".png", ".jpg", ".jpeg", ".tif", ".bmp")
@@ -175,6 +208,10 @@ def run(args) -> Dict[str, List[int]]:
         stems = todo
         if rank == 0:
             print(f"[rank 0] --resume: {len(done_before)} of {n_all} images already complete", flush=True)
+    # a resumed run's statistics cover the WHOLE output directory (see the end of this function): the earlier run's ins/*.pkl
+    # are read HERE, before any GPU work, so that pickles written with another class list fail the run early and by name
+    # (round-4 advisor finding: the labels indexed the counters unchecked, after every tile had been processed and written)
+    old_pix, old_ins, old_sizes = resumed_statistics(args.out, done_before[rank::world], n_classes)
     max_boxes = max([len(ann[s]["labels"]) for s in stems] + [1])
     # per-instance RLE (main_sam_hbox_semantic.py:201-202) is encoded on the device; the full masks never cross PCIe
     pipe = driver.TilePipeline(sam, n_classes, batch=batch, box_batch=args.box_batch, rle=not args.no_rle,
@@ -314,16 +351,9 @@ def run(args) -> Dict[str, List[int]]:
     # them: the images completed by an earlier run contribute through their ins/*.pkl (label + size per instance), read by
     # the ranks in shards and merged by the same all-reduce / all-gather as this run's counters
     if done_before:
-        old_pix, old_ins = np.zeros(n_classes, np.int64), np.zeros(n_classes, np.int64)
-        for stem in done_before[rank::world]:
-            with open(os.path.join(args.out, "ins", stem + ".pkl"), "rb") as f:
-                for entry in pickle.load(f):
-                    if int(entry["size"]) > 0:                                                      # statistic.py:18
-                        old_pix[int(entry["label"])] += int(entry["size"])
-                        old_ins[int(entry["label"])] += 1
-                        sizes.append(int(entry["size"]))
         pipe.class_pixels += torch.from_numpy(old_pix).to(pipe.class_pixels.device)
         pipe.class_instances += torch.from_numpy(old_ins).to(pipe.class_instances.device)
+        sizes.extend(old_sizes)
     pix, ins = driver.reduce_statistics(pipe.class_pixels, pipe.class_instances)
     all_sizes = driver.gather_mask_sizes(sizes)
     stats = {"class_pixel_num": pix.cpu().tolist(), "class_instance_num": ins.cpu().tolist(),

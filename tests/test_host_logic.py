@@ -95,3 +95,23 @@ def test_mean_iou_matches_reference_arithmetic():
             if u > 0:
                 inter.append(i); union.append(u); ious.append(i / u)
     assert avg == pytest.approx(np.mean(ious)) and area == pytest.approx(np.sum(inter) / np.sum(union))
+
+
+def test_bench_parity_object_is_pinned_to_the_device_sources(tmp_path, monkeypatch):
+    """bench.py's `parity` object (the line carried a throughput with no parity figure attached to the mode that
+    produced it) reports the committed statistical sample only when it was measured on THIS build's device sources."""
+    import json
+    import bench
+    s = {"n_masks": 256, "iou_min": 0.99961, "flips_outside_tau": 0, "classmap_diff_mean": 457.5, "classmap_diff_max": 532,
+         "classmap_diff_outside_unstable": 0}
+    c4 = {"n_masks": 96, "iou_min": 0.9989, "flips_outside_tau": 0}
+    f = tmp_path / "parity_stats.json"
+    monkeypatch.setattr(bench, "PARITY_FILE", str(f))
+    assert "note" in bench.parity_of_mode(15, "c2")                                     # no file
+    json.dump({"tau_frac": 0.0025, "csrc_sha16": "0" * 16, "summary": {"15": {"c2": s, "c4box": c4, "c4mask": c4}}}, open(f, "w"))
+    assert "other device sources" in bench.parity_of_mode(15, "c2")["note"]             # stale: not reported
+    json.dump({"tau_frac": 0.0025, "csrc_sha16": bench.csrc_sha(), "summary": {"15": {"c2": s, "c4box": c4, "c4mask": c4}}}, open(f, "w"))
+    p = bench.parity_of_mode(15, "c2")
+    assert p["mode"] == 15 and p["c2_iou_min"] == 0.99961 and p["classmap_px_mean"] == 457.5 and p["c4_iou_min"] == 0.9989
+    assert p["classmap_bit_identical"] is False and p["c4_served_in_this_mode"] is False and p["n_masks"] == 448
+    assert "note" in bench.parity_of_mode(79, "c2")                                     # a mode the sample does not hold

@@ -530,7 +530,10 @@ def test_vit_h_statistical_parity_sample():
     summ = ps.summarise(rec)
     print(ps.table(summ))
     if os.path.isdir("gpurun_out"):
-        json.dump({"tau_frac": ps.TAU_FRAC, "summary": {str(k): v for k, v in summ.items()}}, open("gpurun_out/parity_stats_test.json", "w"))
+        # what bench.py's `parity` object reads (copied to profiles/parity_stats.json): pinned to a hash of the device sources
+        import bench
+        json.dump({"tau_frac": ps.TAU_FRAC, "csrc_sha16": bench.csrc_sha(), "device": torch.cuda.get_device_name(0),
+                   "summary": {str(k): v for k, v in summ.items()}}, open("gpurun_out/parity_stats_test.json", "w"))
     for mode, tags in summ.items():
         for tag, s in tags.items():
             assert s["flips_outside_tau"] == 0, (mode, tag)

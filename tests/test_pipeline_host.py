@@ -128,3 +128,28 @@ def test_io_thread_pools_follow_the_ranks_share_of_the_cpus(monkeypatch):
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
     one = generate.host_cpu_budget(1)
     assert generate.host_cpu_budget() == max(1.0, one / 4) and one >= 1.0
+
+
+def test_generate_honours_samrs_split_from_the_environment():
+    """`SAMRS_SPLIT=63 python -m samrs_amd.generate ...` must run in mode 63: the driver's single-mask default (15) is injected
+    only when neither --split nor the environment names a mode (round-4 advisor finding: options are applied after samrs_create
+    has read the environment, so an unconditional default silently replaced the operator's choice)."""
+    assert generate.default_split_options(None, environ={}) == {"split": 15}
+    assert generate.default_split_options(None, environ={"SAMRS_SPLIT": "63"}) is None        # the engine's own env read stands
+    assert generate.default_split_options(None, environ={"SAMRS_SPLIT": ""}) == {"split": 15}
+    assert generate.default_split_options(79, environ={"SAMRS_SPLIT": "63"}) == {"split": 79}  # an explicit --split wins
+    assert generate.default_split_options(0, environ={}) == {"split": 0}
+
+
+def test_resumed_statistics_reject_pickles_of_another_class_list(tmp_path):
+    """--resume folds the earlier run's ins/*.pkl into the statistics (statistic.py:12-21); a label outside the current class list
+    fails early and names the file instead of raising IndexError (or wrapping on a negative label) after all GPU work."""
+    os.makedirs(tmp_path / "ins")
+    good = [{"label": 2, "size": 10}, {"label": 0, "size": 0}, {"label": 2, "size": 5}]
+    pickle.dump(good, open(tmp_path / "ins" / "A.pkl", "wb"))
+    pix, ins, sizes = generate.resumed_statistics(str(tmp_path), ["A"], 3)
+    assert pix.tolist() == [0, 0, 15] and ins.tolist() == [0, 0, 2] and sizes == [10, 5]     # size 0 is not an instance (:18)
+    for bad_label in (3, -1):
+        pickle.dump([{"label": bad_label, "size": 4}], open(tmp_path / "ins" / "B.pkl", "wb"))
+        with pytest.raises(ValueError, match="B.pkl"):
+            generate.resumed_statistics(str(tmp_path), ["A", "B"], 3)

@@ -48,7 +48,11 @@ def test_fill_poly_and_resize_known_answers():
     rectangle is filled INCLUDING its boundary (scanline fill ceil(x_left) .. floor(x_right) + the boundary lines), a 45-degree
     diamond is exactly |dx| + |dy| <= r, zero-area polygons leave their 8-connected boundary line (a row, a column, a point),
     the fill is clipped by the image, a 45-degree hypotenuse loses one pixel per row; INTER_LINEAR samples at
-    (d + 0.5) * in / out - 0.5 with clamped ends and does not anti-alias when shrinking."""
+    (d + 0.5) * in / out - 0.5 with clamped ends and does not anti-alias when shrinking.
+    Round 5: four `rotated_*` cases with edges at the arbitrary angles C4's rotated boxes have (18.4, 21.8,
+    71.6 degrees and the sub-pixel sliver a thin box becomes after `.astype(np.int32)`), each with its pencil-and-paper
+    derivation in the JSON (LineIterator error terms, 16.16 crossings, the span under both span rules OpenCV has published),
+    produced by oracle/derive_fillpoly_cases.py without importing the module under test."""
     k = _known()
     for c in k["fill_poly"]:
         want = np.zeros((c["h"], c["w"]), bool)
@@ -73,6 +77,18 @@ def test_hip_rbox_prompts_on_the_known_answer_polygons():
         want = rp.rbox_mask_prompt(p.astype(np.int32), 1024, 1024).astype(np.float32)
         assert np.array_equal(got[j], want), k["fill_poly"][j]["name"]
         assert (got[j] < 0).any()             # (a one-pixel sliver can vanish in the 4:1 bilinear reduction to 256 x 256: no > 0 assertion)
+    # round 5: every case again at its NATIVE size (a canvas of a few pixels blown up to img_size = 64, prompt 16 x 16), where one
+    # wrongly filled pixel moves a sixteenth of the prompt: the rotated_* cases have edges at 18 / 22 / 72 degrees and a
+    # sub-pixel sliver, i.e. the rounding choices of the line walk and of the 16.16 scanline crossings all matter
+    for c in k["fill_poly"]:
+        p = np.asarray(c["pts"], dtype=np.float32)
+        if len(p) != 4:
+            continue
+        got1 = transforms.rbox_mask_prompts(p[None], (c["h"], c["w"]), img_size=64, out_size=16).cpu().numpy()[0]
+        want1 = rp.rbox_mask_prompt(p.astype(np.int32), c["h"], c["w"], img_size=64, out=16).astype(np.float32)
+        assert np.array_equal(got1, want1), c["name"]
+        if c["name"].startswith("rotated_"):
+            assert (got1 > 0).any() and (got1 < 0).any(), c["name"]
 
 
 def test_line8_closed_form_matches_walk():

@@ -135,8 +135,9 @@ def main() -> None:
     ap.add_argument("--boxes", type=int, default=32, help="boxes per tile (c3: the mean of the long-tailed distribution)")
     ap.add_argument("--c4-prompt", default="box", choices=["box", "rbox_mask"])
     ap.add_argument("--box-batch", type=int, default=0,
-                    help="c3: boxes per predict call (default 20 = the reference's chunking, main_sam_hbox_semantic.py:91; the masks do "
-                         "not depend on it)")
+                    help="c3: boxes per predict call (default 64 = the product's chunking, samrs_amd.generate --box-batch; the masks do "
+                         "not depend on it: test_predict_batches_beyond_max_prompts.  The reference's 20, main_sam_hbox_semantic.py:91, "
+                         "is timed beside it as `reference_chunking`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second (bf16) timing leg")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the PCIe-inclusive measurement")
@@ -182,7 +183,9 @@ def main() -> None:
     dev_tiles = host_tiles.to(dev)
 
     if args.workload == "c3":
-        box_batch, max_boxes = (args.box_batch or 20), 400  # main_sam_hbox_semantic.py:91
+        # the product's chunking (generate.py --box-batch 64); chunking is proven bit-irrelevant, so the reference's 20-box chunks
+        # (main_sam_hbox_semantic.py:91) are a side leg, not the workload's definition (VERDICT r04 "what's weak" 10)
+        box_batch, max_boxes = (args.box_batch or 64), 400
     else:
         box_batch, max_boxes = args.boxes, args.boxes
 
@@ -202,11 +205,11 @@ def main() -> None:
                 ann_cache[global_index] = synth.make_boxes(global_index, int(counts_all[global_index]))
             return ann_cache[global_index]
 
-    def make_pipe(sam, device_inputs, rle=False):
+    def make_pipe(sam, device_inputs, rle=False, chunk=None):
         if args.workload == "c4":
             return driver.InstancePipeline(sam, n_classes, prompt=args.c4_prompt, batch=B, box_batch=box_batch,
                                            max_boxes=max_boxes, device_inputs=device_inputs, rle=rle, rle_buffer_mb=512)
-        return driver.TilePipeline(sam, n_classes, batch=B, box_batch=box_batch, max_boxes=max_boxes,
+        return driver.TilePipeline(sam, n_classes, batch=B, box_batch=chunk or box_batch, max_boxes=max_boxes,
                                    device_inputs=device_inputs, rle=rle, rle_buffer_mb=512)
 
     def make_pipeline(precision, device_inputs):
@@ -325,6 +328,16 @@ def main() -> None:
                    "what": "same loop with rle=True: + samrs_rle_encode per predict chunk (bit-pack, run boundaries, counts, "
                            "cocoapi string on the device) + D2H of the packed strings; masks stay in HBM"}
         del pipe_r
+
+    # ---- c3 only: the same stream in the reference's own 20-box chunks (main_sam_hbox_semantic.py:91,157-181) ----
+    chunk_leg = None
+    if args.workload == "c3" and rank == 0 and world == 1 and box_batch != 20:
+        pipe_c = make_pipe(sam, True, chunk=20)
+        n_c = max(2, args.steps)
+        dtc, tc, _ = timed(pipe_c, dev_tiles, n_c, 1, shared_queue=False)
+        chunk_leg = {"value": round(tc / dtc, 3), "unit": "images/s", "steps": n_c, "box_batch": 20, "vs_value": round(tc / dtc / value, 4),
+                     "what": "same loop, predict calls of 20 boxes like the reference's; bit-identical masks"}
+        del pipe_c
 
     # ---- the other precision mode.  The pipelines pick the engine's operand-split mode by output contract (driver.TilePipeline
     # precision="auto"): single-mask output (c2 / c3) = split 15, every block GEMM at the 1x f16 rate (C2 fixtures: IoU >= 0.9995);
@@ -494,7 +507,7 @@ def main() -> None:
                        "accumulate": "f32", "operand_split": split_used},
             "flops_per_image": F, "roofline": roofline, "cpu_baseline": cpu_baseline, "alt_dtype": alt, "pcie_inclusive": pcie,
             "rle_inclusive": rle_leg, "cli_inclusive": cli, "other_precision_mode": other_mode,
-            "parity": parity_of_mode(int(split_used), args.workload, args.model),
+            "parity": parity_of_mode(int(split_used), args.workload, args.model), "reference_chunking": chunk_leg,
             "boxes_per_s": round(boxes_done / dt, 1),
             "stats_allreduce": {"total_pixels": int(tot_pix.sum().item()), "total_instances": int(tot_ins.sum().item())},
         }

@@ -37,8 +37,10 @@ enum samrs_status {
     SAMRS_ERR_BAD_WEIGHTS = -5,  /* unknown / missing / mis-shaped tensor (strict load,
                                     build_sam.py:103-106)                                       */
     SAMRS_ERR_CAPACITY = -6,     /* more images / prompts than the handle was created for       */
-    SAMRS_ERR_PRECISION = -7     /* multimask predict on an embedding encoded below the mode the
+    SAMRS_ERR_PRECISION = -7,    /* multimask predict on an embedding encoded below the mode the
                                     multimask outputs need (see samrs_get_slot_info)            */
+    SAMRS_ERR_RANGE = -8         /* option "range_check" = 2: an encoder pass saturated values of
+                                    an MFMA operand tensor (f16: |x| >= 65504)                  */
 };
 
 /* MFMA operand type.  Accumulation, residual stream, LayerNorm / softmax statistics and the
@@ -222,7 +224,25 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    format costs in mask pixels: nothing measurable).  The fp4 weight copies are made at samrs_finalize_weights
  *                    when a block-GEMM bit is set by then; afterwards the option can be flipped between 0 and 4 (A/B runs).
  *   "allow_reduced"  [SAMRS_ALLOW_REDUCED; default 0, 1 when SAMRS_SPLIT is set] 1 = samrs_predict(multimask = 1) accepts embeddings
- *                    encoded below the multimask grade (see samrs_get_slot_info) instead of returning SAMRS_ERR_PRECISION. */
+ *                    encoded below the multimask grade (see samrs_get_slot_info) instead of returning SAMRS_ERR_PRECISION.
+ *   "gelu_fast"      [SAMRS_GELU_FAST, default -1 = automatic] erf of the GELU in lin1's epilogue (image_encoder.py:177-180, common.py:18-26;
+ *                    168 M elements per launch at ViT-H): 0 = Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7: fp32-epsilon class, two
+ *                    transcendentals per element), 1 = 7.1.28 (|error| <= 3e-7, one v_rcp_f32 and no exp2: -3.3 % on the dominant
+ *                    kernel; both are three orders of magnitude under the f16 rounding the value receives next).  Automatic: 1 in the
+ *                    1x-rate modes ("split" without a block-GEMM bit: what the single-mask pipelines run), 0 in every reference-grade
+ *                    mode, whose arithmetic stays bit for bit what its committed parity statistics were measured on.  Applies where
+ *                    lin1 runs on the persistent 256 x 320 kernel (ViT-H shapes); elsewhere the option has no effect.
+ *   "range_check"    [SAMRS_RANGE_CHECK, default 0] the f16 operand type has 11 mantissa bits (what the IoU >= 0.999 bar needs) but
+ *                    tops out at 65504, and every conversion on the path SATURATES there instead of overflowing to inf -- silently.
+ *                    1 = after each producer of an MFMA-operand tensor in the encoder (both LayerNorm outputs, q | k | v, the
+ *                    attention output, GELU(lin1), the residual stream in front of the neck, the neck's LayerNorm2d output, the
+ *                    decoder's layer-0 keys) a scan adds the number of elements at the saturation value (or inf / nan) to a
+ *                    per-engine counter, read -- and, by writing any value, reset -- through the option "saturated"; ~7 extra
+ *                    passes over those tensors per block (+ 25 % encoder time): a validation mode for a NEW CHECKPOINT, not the
+ *                    production setting.  2 = the same, and samrs_set_images* returns SAMRS_ERR_RANGE when its pass saturated
+ *                    anything (one stream synchronisation per pass).  The remedy is the bf16 operand type (fp32 exponent range;
+ *                    misses the IoU bar by its 8 mantissa bits: DESIGN.md 2) -- there is no silent fallback.
+ *   "saturated"      read: the counter of "range_check" (clamped to INT_MAX; synchronizes the device); write: reset. */
 int samrs_set_option(samrs_engine_t* e, const char* name, int value);
 int samrs_get_option(const samrs_engine_t* e, const char* name, int* value);
 

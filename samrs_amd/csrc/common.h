@@ -219,6 +219,37 @@ __device__ __forceinline__ float2_t gelu_erf2(float2_t x) {
     const float2_t r = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
     return r - h;
 }
+// The same function for values that are ROUNDED TO THE MFMA OPERAND TYPE right away (the ET-output GEMM epilogues: lin1 of every
+// encoder block, image_encoder.py:177-180 / common.py:18-26 -- 168 M elements per launch, 16 % of the dominant kernel with the
+// form above, executed while the block's matrix pipe idles).  erf by Abramowitz-Stegun 7.1.28,
+//     erf(z) = 1 - (1 + a1 z + ... + a6 z^6)^-16,  |error| <= 3e-7,
+// with the 1/sqrt(2) of z = |x| / sqrt(2) folded into the coefficients: six packed fmas, ONE v_rcp_f32 per element (no exp2),
+// four packed squarings, and   gelu(x) = 0.5 (x + |x| erf(z)) = 0.5 (x + u (1 - r^16))   -- three packed ops, no max.
+// 19 VALU issues per element pair against 25 (two transcendentals per element instead of four).  Absolute error vs the
+// exact function <= 9e-7 (fp32 emulation over [-12, 12], tests/test_host_logic.py::test_gelu_as28_error_budget), 1.2e-7 rms
+// under N(0, 1) -- three orders of magnitude under the f16 rounding that follows (1.4e-4 rms); the x < 0 tail is absolute-,
+// not relative-accurate (x + u (1 - r^16) cancels), which is all a value about to be rounded to f16 and summed by lin2 needs.
+// P overflows to inf for |x| > 3e6, r = 0, and the result is max(x, 0) as it should be.  SAMRS_GELU_AS28=0: the form above (A/B).
+#ifndef SAMRS_GELU_AS28
+#define SAMRS_GELU_AS28 1
+#endif
+__device__ __forceinline__ float2_t gelu_erf2_et(float2_t x) {
+#if SAMRS_GELU_AS28
+    const float2_t u = {fabsf(x.x), fabsf(x.y)};
+    float2_t p = u * 5.38297490493278e-06f + 4.889063711743802e-05f;
+    p = p * u + 3.8003574445610866e-05f;
+    p = p * u + 0.0032776263542473316f;
+    p = p * u + 0.02114100567996502f;
+    p = p * u + 0.04986734688282013f;
+    p = p * u + 1.0f;
+    const float2_t r = {__builtin_amdgcn_rcpf(p.x), __builtin_amdgcn_rcpf(p.y)};
+    const float2_t r2 = r * r, r4 = r2 * r2, r8 = r4 * r4, r16 = r8 * r8;
+    const float2_t s = 1.0f - r16;
+    return (u * s + x) * 0.5f;
+#else
+    return gelu_erf2(x);
+#endif
+}
 __device__ __forceinline__ float gelu_erf(float x) {
     const float2_t y = gelu_erf2(float2_t{x, x});
     return y.x;

@@ -788,8 +788,8 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         }
     }
 #ifdef WIN_TIMING
-    if (lane == 0 && wave == 0) {
-        unsigned long long* tp = reinterpret_cast<unsigned long long*>(out) + (size_t)blockIdx.x * 8;
+    if (lane == 0) {          // every wave reports (round 5: the per-wave imbalance is what the first barrier's wait consists of)
+        unsigned long long* tp = reinterpret_cast<unsigned long long*>(out) + ((size_t)blockIdx.x * 8 + wave) * 8;
         for (int i = 0; i < 6; ++i) tp[i] = wph[i];
         tp[6] = __builtin_amdgcn_s_memtime() - wstart;
         tp[7] = n_done;
@@ -1121,8 +1121,8 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
     }
 
 #ifdef GLB_TIMING
-    if (lane == 0 && wave == 0) {
-        unsigned long long* tp = reinterpret_cast<unsigned long long*>(out) + (size_t)blockIdx.x * 8;
+    if (lane == 0) {          // every wave reports (round 5: the per-wave imbalance is what the first barrier's wait consists of)
+        unsigned long long* tp = reinterpret_cast<unsigned long long*>(out) + ((size_t)blockIdx.x * 8 + wave) * 8;
         for (int i = 0; i < 6; ++i) tp[i] = tph[i];
         tp[6] = __builtin_amdgcn_s_memtime() - tstart;
         tp[7] = tstart - t_entry;      // setup: Q fragments, rel-pos tables, first tile
@@ -1213,6 +1213,37 @@ hipError_t launch_patch_im2col(int prec, const uint8_t* img, void* A, int n_imag
         patch_im2col_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(img, (uint16_t*)A, (uint16_t*)A_lo, n_images, in_h, in_w, grid, patch);
     else
         patch_im2col_kernel<PREC_F16><<<blocks, 256, 0, s>>>(img, (uint16_t*)A, (uint16_t*)A_lo, n_images, in_h, in_w, grid, patch);
+    return hipGetLastError();
+}
+
+// ---- operand-range check (engine option "range_check") ---------------------------------------------
+// Every conversion to f16 on this path SATURATES at +-65504 (common.h ET<PREC_F16>::from_float / pack2) instead of producing
+// inf -- silently.  The weights this repo is tested on are N(0, sigma) draws; a checkpoint's activations may not be (a few
+// channels of a ViT's residual stream and MLP hidden layer are known to run 100 - 1000x the rest).  Checking inside the
+// producers would put two VALU instructions per element pair into the GEMM epilogues the loop is bound by, so the check is a
+// pass of its own, off by default: it counts the elements of an operand tensor whose magnitude is the largest finite value
+// (0x7bff: what the saturating conversion writes; a legitimate 65504 is not distinguishable and not plausible) or inf / nan.
+// bf16 (max finite 0x7f7f = 3.4e38, same range as fp32) can only ever show inf / nan.
+static __global__ __launch_bounds__(256) void range_scan_kernel(const uint4* __restrict__ x, long n16, uint32_t limit /* 0x7bff | 0x7f80 */,
+                                                         unsigned long long* __restrict__ counter) {
+    unsigned cnt = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
+        const uint4 v = x[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cnt += ((w[k] & 0x7fffu) >= limit) + (((w[k] >> 16) & 0x7fffu) >= limit);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(counter, (unsigned long long)cnt);
+}
+hipError_t launch_range_scan(int prec, const void* x, long n, unsigned long long* counter, hipStream_t s) {
+    if (n % 8 || !x || !counter) return hipErrorInvalidValue;
+    const long n16 = n / 8;
+    long blocks = (n16 + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    range_scan_kernel<<<(int)blocks, 256, 0, s>>>(reinterpret_cast<const uint4*>(x), n16, prec == PREC_F16 ? 0x7bffu : 0x7f80u, counter);
     return hipGetLastError();
 }
 

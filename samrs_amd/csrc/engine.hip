@@ -140,6 +140,13 @@ struct samrs_engine {
     std::vector<int> slot_split, slot_depth;
     int grade_multimask = 0;       // block-GEMM bits (any of them) the three multimask tokens need on this model; 0 = none
     bool allow_reduced = false;    // option "allow_reduced": multimask predicts on a slot encoded below that grade are the caller's choice
+    // option "range_check" (0 off, 1 count, 2 count and fail): after every producer of an MFMA-operand tensor in the encoder a
+    // scan counts the elements sitting at the operand type's saturation value (f16: +-65504, what common.h's saturating
+    // conversions write) or beyond into *range_counter (device); read through option "saturated"
+    int gelu_fast = -1;            // option "gelu_fast": -1 automatic (on in the 1x-rate modes: no block-GEMM bit in "split"), 0 off, 1 on
+    int range_check = 0;
+    unsigned long long* range_counter = nullptr;
+    unsigned long long range_seen = 0;             // counter value at the end of the last checked encoder pass (mode 2)
 
     // decoder weights
     std::vector<DecLayer> layers;
@@ -392,6 +399,15 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->split_passes = env_int("SAMRS_SPLIT_PASSES", 0) != 0;
     e->split_depth = env_int("SAMRS_SPLIT_DEPTH", 0);
     e->lo_format = (h_like && env_int("SAMRS_LO_FORMAT", 4) == 4) ? 4 : 0;
+    e->gelu_fast = env_int("SAMRS_GELU_FAST", -1);
+    if (e->gelu_fast > 1) e->gelu_fast = 1;
+    if (const int rc0 = env_int("SAMRS_RANGE_CHECK", 0)) {
+        if (samrs_set_option(e, "range_check", rc0) != SAMRS_OK) {
+            if (err && err_len > 0) snprintf(err, err_len, "SAMRS_RANGE_CHECK=%d: %s", rc0, e->err.c_str());
+            samrs_destroy(e);
+            return nullptr;
+        }
+    }
     return e;
 }
 
@@ -714,10 +730,13 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     // the three split terms of a block GEMM as ONE launch over a three-segment K axis (gemm.hip seg_src_a) where the shape
     // fits the 256 x 320 tile (ViT-H); SAMRS_SPLIT_PASSES=1 / option "split_passes" keeps the three accumulating launches (A/B)
     const bool one3 = !e->split_passes;
+    const bool fast_gelu = e->gelu_fast >= 0 ? e->gelu_fast != 0 : !(e->split & (SPLIT_ATTN_ANY | SPLIT_MLP | SPLIT_LIN2));
     if (fold && n_blocks > 0) {
         CK(e, launch_rowstats_convert(prec, e->X, e->Y, e->STATS, M, D, s));
         CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
     }
+    // option "range_check": scan an operand tensor right after its producer (same stream)
+#define RANGE_SCAN(ptr_, count_) do { if (e->range_check) CK(e, launch_range_scan(prec, (ptr_), (long)(count_), e->range_counter, s)); } while (0)
     for (int i = 0; i < c.depth && i < n_blocks; ++i) {
         const EncBlock& b = e->blocks[i];
         const bool attn_full = (e->split & SPLIT_ATTN) && i < depth_full;
@@ -761,6 +780,11 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, e->VTG, s,
                                           (sp_attn && !mx_ao) ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,
                                           mx_ao ? e->SAO4[0] : nullptr, mx_ao ? e->SAO4[1] : nullptr));
+        if (e->range_check) {       // norm1 output, q | k | v, attention output
+            RANGE_SCAN(e->Y, (size_t)M * D);
+            RANGE_SCAN(e->QKV, (size_t)M * 3 * D);
+            RANGE_SCAN(e->AO, (size_t)M * D);
+        }
         if (fold) {
             CK(e, launch_gemm_et_stats(prec, e->AO, b.proj_w, e->X, b.proj_b, e->Y, e->STATS, M, D, D, s));
             CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
@@ -810,10 +834,21 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                 CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->F32T, b.lin1_b, nullptr, 0, M, 4 * D, D, true, false, true, s));
             }
             CK(e, launch_gelu_split(prec, e->F32T, e->H, e->Hlo, (long)M * 4 * D, s));
-        } else CK(e, launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s));
+        } else {
+            // the 1x-rate modes take the cheaper erf in lin1's GELU epilogue (common.h gelu_erf2_et: -3.3 % on the dominant kernel);
+            // every mode with a block-GEMM split bit keeps the arithmetic its parity statistics were measured on, bit for bit
+            const int prev_form = swap_gelu_form(fast_gelu ? 2 : 1);
+            const hipError_t le = launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s);
+            (void)swap_gelu_form(prev_form);
+            CK(e, le);
+        }
         if (e->timing) {
             CK(e, hipEventRecord(t1, s));
             e->tev.emplace_back(t0, t1);
+        }
+        if (e->range_check) {       // norm2 output (still in Y: lin1 has read it, nothing has overwritten it) and GELU(lin1)
+            RANGE_SCAN(e->Y, (size_t)M * D);
+            RANGE_SCAN(e->H, (size_t)M * 4 * D);
         }
         if (fold) {
             CK(e, launch_gemm_et_stats(prec, e->H, b.lin2_w, e->X, b.lin2_b, e->Y, e->STATS, M, D, 4 * D, s));
@@ -842,6 +877,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     uint16_t* lo_buf = e->QKV;
     if (sp_neck) CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s, lo_buf));
     else if (!(fold && c.depth > 0 && n_blocks >= c.depth)) CK(e, launch_convert(prec, e->X, e->Y, (long)M * D, s));
+    RANGE_SCAN(e->Y, (size_t)M * D);       // the RAW residual stream rounded to the operand type: the one operand without a LayerNorm in front
     if (sp_neck && one3p && gemm_split3_ok((int)M, C, D, true)) {
         CK(e, launch_gemm_et_split3(prec, e->Y, lo_buf, e->neck0_w, e->neck0_w_lo, e->N1, nullptr, (int)M, C, D, true, false, s));
     } else {
@@ -853,6 +889,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     }
     CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.1.weight"), W(e, "image_encoder.neck.1.bias"), 1e-6f,
                            e->N1e, nullptr, M, C, 0, g, 0, s, sp_neck ? lo_buf : nullptr));
+    RANGE_SCAN(e->N1e, (size_t)M * C);
     CK(e, launch_neck_im2col(e->N1e, e->H, n, g, C, s));
     uint16_t* H2lo = e->H + (size_t)M * 9 * C;
     if (sp_neck) CK(e, launch_neck_im2col(lo_buf, H2lo, n, g, C, s));
@@ -868,6 +905,24 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     CK(e, launch_layernorm(prec, e->N1, W(e, "image_encoder.neck.3.weight"), W(e, "image_encoder.neck.3.bias"), 1e-6f,
                            nullptr, e->EMB + (size_t)slot0 * tokens * C, M, C, 0, g, 0, s));
     { const int rc = prepare_slot_keys(e, slot0, n, s); if (rc != SAMRS_OK) return rc; }
+    if (e->range_check) {
+        RANGE_SCAN(e->K0E + (size_t)slot0 * tokens * C, (size_t)n * tokens * C);       // the decoder's layer-0 keys
+        if (e->range_check == 2) {
+            // fail loudly: this pass (and every earlier one since the last reset) must not have saturated an operand.  Costs a
+            // stream synchronisation per encoder pass -- a validation mode for new checkpoints, not the production setting.
+            unsigned long long now = 0;
+            CK(e, hipStreamSynchronize(s));
+            CK(e, hipMemcpy(&now, e->range_counter, sizeof(now), hipMemcpyDeviceToHost));
+            const unsigned long long before = e->range_seen;
+            e->range_seen = now;
+            if (now > before)
+                return fail(e, SAMRS_ERR_RANGE, "%llu operand values of this encoder pass saturated the %s range (|x| >= %s): the masks of these "
+                            "images are not the reference's.  Use precision bf16 (fp32 exponent range, 8 mantissa bits) for this "
+                            "checkpoint, or option \"range_check\" = 1 to count without failing", now - before,
+                            prec == PREC_F16 ? "f16" : "bf16", prec == PREC_F16 ? "65504" : "inf");
+        }
+    }
+#undef RANGE_SCAN
     for (int i = 0; i < n; ++i) {
         e->slot_set[slot0 + i] = 1;
         e->slot_split[slot0 + i] = e->split;
@@ -1230,6 +1285,24 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     else if (n == "split_passes") e->split_passes = value != 0;
     else if (n == "split_depth") e->split_depth = value > 0 ? value : 0;
     else if (n == "allow_reduced") e->allow_reduced = value != 0;
+    else if (n == "gelu_fast") e->gelu_fast = value < 0 ? -1 : (value != 0);
+    else if (n == "range_check") {
+        if (value < 0 || value > 2) return fail(e, SAMRS_ERR_BAD_ARG, "range_check is 0 (off), 1 (count) or 2 (count, and samrs_set_images fails)");
+        if (value && !e->range_counter) {
+            ON_DEVICE(e);
+            CK(e, dalloc(e, &e->range_counter, 1));
+            CK(e, hipMemset(e->range_counter, 0, sizeof(unsigned long long)));
+        }
+        e->range_check = value;
+    }
+    else if (n == "saturated") {                    // write = reset (any value)
+        if (e->range_counter) {
+            ON_DEVICE(e);
+            CK(e, hipDeviceSynchronize());
+            CK(e, hipMemset(e->range_counter, 0, sizeof(unsigned long long)));
+        }
+        e->range_seen = 0;
+    }
     else if (n == "lo_format") {
         if (value != 0 && value != 4) return fail(e, SAMRS_ERR_BAD_ARG, "lo_format is 0 (f16 lo terms) or 4 (MXFP4 lo terms)");
         if (value == 4 && e->finalized && !e->mx_ready && !e->mx_mlp_ready)
@@ -1251,6 +1324,17 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
     else if (n == "split_passes") *value = e->split_passes;
     else if (n == "split_depth") *value = e->split_depth;
     else if (n == "allow_reduced") *value = e->allow_reduced;
+    else if (n == "gelu_fast") *value = e->gelu_fast;
+    else if (n == "range_check") *value = e->range_check;
+    else if (n == "saturated") {                    // synchronizes the device: a diagnostic, not a hot-path call
+        unsigned long long c = 0;
+        if (e->range_counter) {
+            DeviceGuard dg(e->device);
+            if (dg.status != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipMemcpy(&c, e->range_counter, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess) return SAMRS_ERR_HIP;
+        }
+        *value = c > 0x7fffffffull ? 0x7fffffff : (int)c;
+    }
     else if (n == "lo_format") *value = (e->finalized && !e->mx_ready && !e->mx_mlp_ready) ? 0 : e->lo_format;
     else if (n == "grade_multimask") *value = e->grade_multimask;     // read-only
     else return SAMRS_ERR_BAD_ARG;

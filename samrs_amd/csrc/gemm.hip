@@ -389,7 +389,8 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
 // n-tile i of a row sit in the 4 lanes fq = 0..3 (4 each): block 0 = n-tiles 0 | 1, block 1 = 2 | 3, block 2 = 4 | zeros; block maxima
 // by two cross-lane swaps (l ^ 16, l ^ 32), codes by v_cvt_scalef32_pk_fp4_f32, one dword store per lane, block and tensor (position
 // 8 fq + 4 (i & 1) + e of the block holds column 16 (i & 1) + 4 fq + e).
-template <int PREC, bool GELU, int JC = 4, bool DRAIN = false, bool FOLD = false, bool MXO = false>
+// GELU: 0 none, 1 the fp32-epsilon erf (common.h gelu_erf2), 2 the cheaper erf of the 1x-rate mode (gelu_erf2_et)
+template <int PREC, int GELU, int JC = 4, bool DRAIN = false, bool FOLD = false, bool MXO = false>
 __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned char* lds, void* __restrict__ Cv,
                                                  const float* __restrict__ bias, const float* __restrict__ pre2d, int period, int N,
                                                  int m_base /* wave tile row 0 */, int n_pair /* first column of the pair */,
@@ -438,7 +439,8 @@ __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned 
                                                                       half * 80 + i * 16 + 4 * fq);
                     v0 += e.x; v1 += e.y; v2 += e.z; v3 += e.w;
                 }
-                if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
+                if constexpr (GELU == 2) { const float2_t g01 = gelu_erf2_et(float2_t{v0, v1}), g23 = gelu_erf2_et(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
+                else if constexpr (GELU != 0) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
                 uint2 o;
                 o.x = pack2<PREC>(v0, v1);
                 o.y = pack2<PREC>(v2, v3);
@@ -1172,7 +1174,8 @@ constexpr int LN_NS = 8;                       // 1280 / 160: ViT-H only
 // split 207, whose lin2 takes MXFP4 lo terms while lin1 itself takes none).  The four output pointers travel in the parameters the
 // plain flavour does not use -- rowstat = codes hi, cvec = codes lo, A_lo = scales hi, B_lo = scales lo -- so that the kernel
 // signature, and with it every existing instantiation, stays what it was.
-template <int PREC, bool OUT_F32, bool GELU, bool FOLD = false, bool SPLIT3 = false, bool MXO = false>
+template <int PREC, bool OUT_F32, int GELU /* 0 none, 1 fp32-epsilon erf, 2 the 1x-rate mode's cheaper erf (ET output only) */, bool FOLD = false,
+          bool SPLIT3 = false, bool MXO = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, int accumulate,
@@ -1332,7 +1335,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
                 epilogue_pair_et<PREC, GELU, 2, true, FOLD>(acc, upper, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + (wn >> 1) * 160, wm, wn, lane,
                                                             rowstat, cvec);
             } else {
-                epilogue_coalesced<PREC, true, GELU, 8, 1, NI, false, true>(acc, upper + wave * (XSB / 8), Cv, bias, nullptr, 1, N,
+                epilogue_coalesced<PREC, true, GELU != 0, 8, 1, NI, false, true>(acc, upper + wave * (XSB / 8), Cv, bias, nullptr, 1, N,
                                                                            m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane);
             }
         }
@@ -1347,6 +1350,9 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
 #undef X64P_MFMA
 }
 
+// erf form of the ET-output GELU epilogue of the persistent 256x320 kernel (lin1 of ViT-H): 1 = fp32-epsilon class (A-S 7.1.26),
+// 2 = the cheaper one (A-S 7.1.28, common.h gelu_erf2_et); set around an engine's launches (engine.hip run_encoder)
+thread_local int tl_gelu_form = 1;
 template <int PREC>
 hipError_t launch_gemm_x64p(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, bool out_f32, bool gelu,
                             bool accumulate, hipStream_t s) {
@@ -1364,7 +1370,8 @@ hipError_t launch_gemm_x64p(const void* A, const void* B, void* C, const float* 
         if (gelu) gemm_et_x64p_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
         else gemm_et_x64p_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     } else {
-        if (gelu) gemm_et_x64p_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        if (gelu && tl_gelu_form == 2) gemm_et_x64p_kernel<PREC, false, 2><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        else if (gelu) gemm_et_x64p_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
         else gemm_et_x64p_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     }
     return hipGetLastError();
@@ -3090,6 +3097,7 @@ hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, cons
     return hipErrorInvalidValue;
 }
 
+int swap_gelu_form(int v) { const int old = tl_gelu_form; tl_gelu_form = v; return old; }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 int swap_gemm_variant_override(int v) { const int old = tl_gemm_variant; tl_gemm_variant = v; return old; }
 void set_gemm_skew(int xcd_units, int cu_units) { g_x64_skew = (xcd_units & 0xffff) | (cu_units << 16); }

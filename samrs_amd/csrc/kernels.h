@@ -29,6 +29,7 @@ hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, cons
 // split_from_n (ET output only, a multiple of 320): only output columns >= split_from_n take the lo terms; the tiles in front
 // of it are the plain hi x hi product (qkv: the v third alone)
 void set_gemm_variant(int v);   // process-wide test hook (kernel-level entry points): 0 = register-staged tiles, ..., 8 = automatic
+int swap_gelu_form(int v);                // thread-local erf form of lin1's GELU epilogue (1 = fp32-epsilon class, 2 = cheaper); returns the previous value
 int swap_gemm_variant_override(int v);   // thread-local override (-1 = none) used by engine handles; returns the previous value
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
@@ -69,6 +70,8 @@ hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_b
                                    // [rows][heads * ceil32(head_dim) / 2], block-internal order of store_attention_row_mx
                                    void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr);
 hipError_t launch_gelu_split(int prec, const float* in, void* hi, void* lo, long n, hipStream_t s);
+// operand-range check: adds to *counter the elements of an ET tensor that sit at the operand type's saturation value or beyond (n % 8 == 0)
+hipError_t launch_range_scan(int prec, const void* x, long n, unsigned long long* counter, hipStream_t s);
 // vt_ws: ET workspace of n_images * heads * head_dim * grid^2 elements (receives V transposed per head)
 hipError_t launch_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
                                    int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s, void* out_lo = nullptr,

@@ -28,7 +28,7 @@ SPLIT_PATCH, SPLIT_NECK, SPLIT_OI, SPLIT_UP, SPLIT_DEFAULT = 1, 2, 4, 8, 15
 SPLIT_ATTN, SPLIT_MLP, SPLIT_ATTN_V, SPLIT_LIN2, SPLIT_ALL = 16, 32, 64, 128, 255          # reference-grade bits: set before the weights are loaded
 # (64 = the attention-side split restricted to the v third of qkv + proj; option "split_depth" = leading blocks they apply to)
 
-OK, ERR_NOT_SET, ERR_BAD_SHAPE, ERR_BAD_ARG, ERR_HIP, ERR_BAD_WEIGHTS, ERR_CAPACITY, ERR_PRECISION = 0, -1, -2, -3, -4, -5, -6, -7
+OK, ERR_NOT_SET, ERR_BAD_SHAPE, ERR_BAD_ARG, ERR_HIP, ERR_BAD_WEIGHTS, ERR_CAPACITY, ERR_PRECISION, ERR_RANGE = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 
 class samrs_config(C.Structure):
@@ -148,6 +148,12 @@ class PrecisionError(EngineError):
     (``SamPredictor.set_image`` does), or accept the reduced mode with ``engine.set_option("allow_reduced", 1)``."""
 
 
+class OperandRangeError(EngineError):
+    """Option ``range_check`` = 2: the encoder pass of ``set_image`` / ``set_images`` saturated values of an MFMA operand tensor
+    (f16 tops out at 65504 and every conversion on the path saturates there; SAMRS_ERR_RANGE).  The checkpoint's activations do
+    not fit the f16 operand type: build the model with ``precision="bf16"``."""
+
+
 class Engine:
     """One engine handle = one GPU's weights + workspaces (``samrs_engine_t``)."""
 
@@ -187,6 +193,8 @@ class Engine:
             raise AssertionError(msg)
         if rc == ERR_PRECISION:
             raise PrecisionError(msg)
+        if rc == ERR_RANGE:
+            raise OperandRangeError(msg)
         raise EngineError(f"libsamrs_hip error {rc}: {msg}")
 
     # -- per-engine options (include/samrs_hip.h: "split", "decoder_fusion", "ln_fold", "gemm_variant")

@@ -187,6 +187,46 @@ def make_state_dict(cfg: SamConfig, seed: int = 0, logit_scale: float = 1.0) -> 
     return sd
 
 
+def heavy_tailed(sd, cfg: SamConfig, seed: int = 0, hidden_scale: float = 1.0, v_scale: float = 1.0, gamma_scale: float = 1.0,
+                 n_channels: int = 4, blocks=None):
+    """A copy of ``sd`` with the outlier structure checkpoints have and N(0, sigma) draws do not (every test
+    ran on seeded-normal weights, and the f16 operand type saturates silently at 65504).  In the chosen encoder blocks
+    (default: first, middle, last), for ``n_channels`` seeded channels each:
+
+      * ``hidden_scale``: rows of ``mlp.lin1`` (weight and bias) x s, the matching columns of ``mlp.lin2`` / sqrt(s) -- those
+        hidden units run s times hotter through the GELU and lin2's operand, and what they add to the residual stream grows by
+        sqrt(s): the "massive activation" pattern (dividing by s itself would push the lin2 weights into f16's subnormals, a
+        range problem of its own that checkpoints do not have).  The pre-GELU values of the seeded weights reach ~3, so
+        s = 1e4 puts GELU(lin1) at ~3e4 (inside f16) and s = 1e5 beyond 65504;
+      * ``v_scale``: rows of the v third of ``attn.qkv`` x s, the matching columns of ``attn.proj`` / sqrt(s) (v and the
+        attention output, a convex combination of v rows, run s times hotter);
+      * ``gamma_scale``: entries of ``norm1.weight`` / ``norm2.weight`` x s (the LayerNorm outputs = the qkv / lin1 operands).
+
+    The oracle (fp32 torch) evaluates the same dict: parity is engine vs oracle on THESE weights."""
+    out = OrderedDict((k, v.clone()) for k, v in sd.items())
+    gen = torch.Generator().manual_seed(424242 + seed)
+    D, H = cfg.embed_dim, cfg.mlp_ratio * cfg.embed_dim
+    if blocks is None:
+        blocks = sorted({0, cfg.depth // 2, cfg.depth - 1})
+    for i in blocks:
+        p = f"image_encoder.blocks.{i}"
+        hid = torch.randperm(H, generator=gen)[:n_channels]
+        vch = torch.randperm(D, generator=gen)[:n_channels]
+        gch = torch.randperm(D, generator=gen)[:n_channels]
+        if hidden_scale != 1.0:
+            out[p + ".mlp.lin1.weight"][hid] *= hidden_scale
+            out[p + ".mlp.lin1.bias"][hid] *= hidden_scale
+            out[p + ".mlp.lin2.weight"][:, hid] /= math.sqrt(hidden_scale)
+        if v_scale != 1.0:
+            out[p + ".attn.qkv.weight"][2 * D + vch] *= v_scale
+            out[p + ".attn.qkv.bias"][2 * D + vch] *= v_scale
+            out[p + ".attn.proj.weight"][:, vch] /= math.sqrt(v_scale)
+        if gamma_scale != 1.0:
+            out[p + ".norm1.weight"][gch] *= gamma_scale
+            out[p + ".norm2.weight"][gch] *= gamma_scale
+    return out
+
+
 def make_image(index: int, h: int = 1024, w: int = 1024) -> np.ndarray:
     """uint8 HWC "blob" tile: 40 random filled discs + N(0, 8) noise."""
     rng = np.random.default_rng(1000 + index)

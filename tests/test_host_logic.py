@@ -115,3 +115,28 @@ def test_bench_parity_object_is_pinned_to_the_device_sources(tmp_path, monkeypat
     assert p["mode"] == 15 and p["c2_iou_min"] == 0.99961 and p["classmap_px_mean"] == 457.5 and p["c4_iou_min"] == 0.9989
     assert p["classmap_bit_identical"] is False and p["c4_served_in_this_mode"] is False and p["n_masks"] == 448
     assert "note" in bench.parity_of_mode(79, "c2")                                     # a mode the sample does not hold
+
+
+def test_gelu_as28_error_budget():
+    """The lin1 epilogue's GELU (csrc/common.h gelu_erf2_et: erf by Abramowitz-Stegun 7.1.28, one rcp, no exp2) restated in
+    fp32 numpy, operation by operation, against the exact function (`nn.GELU()`, common.py:18-26) in fp64: absolute error
+    < 1e-6 everywhere, < 1.5e-7 rms under N(0, 1), and three orders of magnitude under the f16 rounding its output receives."""
+    from scipy.special import erfc
+    f = np.float32
+    x = np.linspace(-12, 12, 600001).astype(f)
+    exact = x.astype(np.float64) * 0.5 * erfc(-x.astype(np.float64) / np.sqrt(2.0))
+    u = np.abs(x)
+    p = (u * f(5.38297490493278e-06) + f(4.889063711743802e-05)).astype(f)
+    for c in (3.8003574445610866e-05, 0.0032776263542473316, 0.02114100567996502, 0.04986734688282013, 1.0):
+        p = (p * u + f(c)).astype(f)
+    r = (f(1) / p).astype(f)
+    for _ in range(4):
+        r = (r * r).astype(f)
+    got = (((u * (f(1) - r)).astype(f) + x).astype(f) * f(0.5)).astype(f)
+    err = got.astype(np.float64) - exact
+    w = np.exp(-x.astype(np.float64) ** 2 / 2)
+    rms = np.sqrt((w * err ** 2).sum() / w.sum())
+    f16 = exact.astype(np.float16).astype(np.float64) - exact
+    rms16 = np.sqrt((w * f16 ** 2).sum() / w.sum())
+    assert np.abs(err).max() < 1e-6 and rms < 1.5e-7 and rms16 > 500 * rms, (np.abs(err).max(), rms, rms16)
+    assert got[0] == 0.0 and got[-1] == x[-1]                       # the tails are exactly max(x, 0)

@@ -17,12 +17,16 @@ for _ in range(2):
     assert lib.samrs_k_window_attention(1, qkv.data_ptr(), bias.data_ptr(), rh.data_ptr(), rw.data_ptr(), out.data_ptr(), n_img, grid, 14, heads, hd, s) == 0
     torch.cuda.synchronize()
 nb = 256
-t = out.view(torch.int64).flatten()[: nb * 8].cpu().numpy().reshape(nb, 8)
-items = t[:, 7].astype(np.float64)
+t = out.view(torch.int64).flatten()[: nb * 64].cpu().numpy().reshape(nb, 8, 8)       # [block][wave][stamp]
 names = ["barrier (previous item's readers done)", "LDS stores of K / V^T (+ wait for the prefetched loads)", "barrier",
          "issue of the next item's loads", "rel-pos setup (2 table products + LDS transposes)", "7 key tiles: QK^T, softmax, PV"]
-tot = t[:, 6] / items
-print(f"blocks {nb}; items per block {np.median(items):.1f}; cycles per item: median {np.median(tot):.0f}")
+items = t[:, 0, 7].astype(np.float64)
+tot = t[:, 0, 6] / items
+print(f"blocks {nb}; items per block {np.median(items):.1f}; cycles per item (wave 0): median {np.median(tot):.0f}")
+print("per wave (median over blocks, cycles per item); waves w and w + 4 share a SIMD, wave 7 only stages")
+print("  " + " " * 58 + "".join(f"   w{w:<5d}" for w in range(8)))
 for i, n in enumerate(names):
-    v = t[:, i] / items
-    print(f"  {n:58s} {np.median(v):7.0f} cycles per item ({100 * np.median(v) / np.median(tot):4.1f} %)")
+    v = [np.median(t[:, w, i] / np.maximum(t[:, w, 7], 1)) for w in range(8)]
+    print(f"  {n:58s}" + "".join(f"{x:9.0f}" for x in v))
+v = [np.median(t[:, w, 6] / np.maximum(t[:, w, 7], 1)) for w in range(8)]
+print(f"  {'total':58s}" + "".join(f"{x:9.0f}" for x in v))

@@ -232,6 +232,14 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    1x-rate modes ("split" without a block-GEMM bit: what the single-mask pipelines run), 0 in every reference-grade
  *                    mode, whose arithmetic stays bit for bit what its committed parity statistics were measured on.  Applies where
  *                    lin1 runs on the persistent 256 x 320 kernel (ViT-H shapes); elsewhere the option has no effect.
+ *   "ln_tail"        [SAMRS_LN_TAIL, default -1 = automatic] 1 = the LayerNorm that follows proj (norm2, image_encoder.py:177) and lin2
+ *                    (norm1 of the next block, :168) runs as a TAIL of those GEMM launches instead of a launch of its own: the block that
+ *                    stores the last of the four 256 x 320 tiles of a 256-row panel normalises the panel's rows out of the L2 they were
+ *                    just written to (release / counter / acquire between the four blocks, no block ever waits: gemm.hip LnTail), which
+ *                    removes 63 of the 64 LayerNorm launches of an encoder pass and their re-read of the 168 MB residual stream.
+ *                    Automatic: on in the 1x-rate modes ("split" without a block-GEMM bit) where proj / lin2 fill at least one round
+ *                    of 256 x 320 tiles (batches of 4+ tiles at ViT-H); the reference-grade modes need the LayerNorm's lo / MXFP4
+ *                    outputs and keep the stand-alone kernel.  0 = always the stand-alone LayerNorm (A/B runs, tests).
  *   "range_check"    [SAMRS_RANGE_CHECK, default 0] the f16 operand type has 11 mantissa bits (what the IoU >= 0.999 bar needs) but
  *                    tops out at 65504, and every conversion on the path SATURATES there instead of overflowing to inf -- silently.
  *                    1 = after each producer of an MFMA-operand tensor in the encoder (both LayerNorm outputs, q | k | v, the

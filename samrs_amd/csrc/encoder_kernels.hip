@@ -479,13 +479,21 @@ struct WinCfg {
     static constexpr int LDS_BYTES = K_BYTES + VT_BYTES + S_BYTES + TAB_BYTES + BIAS_BYTES;
 };
 
-template <int PREC, int HD, int LO = 0 /* 0: out only; 1: + its f16 split remainder (out_lo); 2: + hi / lo as MXFP4 (mx) */>
+// PIPE (round 5; tools/win_timeline.py per wave, profiles/r05_window_attention_per_wave.txt): of ~17.2 k cycles per item the 7-tile
+// loop takes 8.1 k on the four older waves and 10.9 k on the three younger ones that share their SIMDs -- 780 cycles per (wave, tile)
+// for 352 cycles of matrix-pipe time: QK^T (five MFMAs chained on one accumulator), the softmax VALU block and PV run strictly one
+// after the other inside a wave, and two such waves do not fill each other's gaps.  PIPE = 1 software-pipelines the loop INSIDE the
+// wave: the QK^T chain of tile t + 1 is issued in front of the softmax of tile t (its MFMAs execute under that VALU block and under the
+// chain's own dependency latency), S of two tiles is live at once; the row terms RH[14] move from registers to the wave's LDS scratch
+// (two ds_read_b32 per tile) to pay for the second S tile.  Same products, same accumulation order: bit-identical output.
+template <int PREC, int HD, int LO = 0 /* 0: out only; 1: + its f16 split remainder (out_lo); 2: + hi / lo as MXFP4 (mx) */, int PIPE = 0>
 __global__ __launch_bounds__(512) void window_attention_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ rel_h,
     const float* __restrict__ rel_w, uint16_t* __restrict__ out, int grid, int heads, int n_items,
     uint16_t* __restrict__ out_lo = nullptr /* LO == 1: the split remainder of out (reference-grade mode) */, MxOut mx = MxOut()) {
     using C = WinCfg<HD>;
     constexpr int KS = HD / 16;
+    constexpr bool PL = (PIPE & 1) != 0;          // software-pipelined tile loop
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t* Ks = reinterpret_cast<uint16_t*>(smem);
     uint16_t* Vt = reinterpret_cast<uint16_t*>(smem + C::K_BYTES);
@@ -525,7 +533,12 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
 
     // All global loads of an item (this wave's Q fragments, this thread's K chunks and V key pairs) are
     // issued back to back; n_* describe the item they belong to.
-    uint4 qfn[KS], kreg[PK], v0reg[PV], v1reg[PV];
+    // PIPE: the next item's Q fragments are loaded straight into qf during the LAST key tile (QK^T of that tile was issued one
+    // tile earlier, so qf is dead by then): no second set of 20 registers (qfn) is held through the tile loop, which is what
+    // lets two S tiles be live at once without spilling (spills here reload through scratch = VMEM, and their vmcnt(0) would
+    // drain the prefetch that is in flight)
+    uint4 qf[KS], qfn[PL ? 1 : KS], kreg[PK], v0reg[PV], v1reg[PV];
+    auto& qdst = *[&]() { if constexpr (PL) return &qf; else return &qfn; }();
     int n_qoff = -1;                      // element offset of this lane's query row inside its image, -1 = dropped
     uint32_t n_pad = 0;                   // bit i: K slot i; bit PK + 2i (+1): V slot i key 0 (1) is a padding token
     int n_im = 0, n_head = 0;
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         WIN_TOK(qc, qo_, qp_);                                                                                       \
         n_qoff = (q < C::N && !qp_) ? qo_ : -1;                                                                      \
         _Pragma("unroll") for (int ks_ = 0; ks_ < KS; ++ks_)                                                         \
-            qfn[ks_] = *reinterpret_cast<const uint4*>(n_base + qo_ + 16 * ks_ + 8 * hh);                            \
+            qdst[ks_] = *reinterpret_cast<const uint4*>(n_base + qo_ + 16 * ks_ + 8 * hh);                           \
     } while (0)
 #define WIN_LOAD_K(i_)                                                                                               \
     do {                                                                                                             \
@@ -592,7 +605,7 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
     static_assert(NGRP <= C::NT, "issue groups are spread over the key tiles");
 #define WIN_GROUP(g_)                                                                                                \
     do {                                                                                                             \
-        if ((g_) == 0) WIN_LOAD_Q();                                                                                 \
+        if ((g_) == 0) { if constexpr (!PL) WIN_LOAD_Q(); }                                                        \
         else if ((g_) <= NGK) {                                                                                      \
             WIN_LOAD_K(2 * ((g_) - 1));                                                                              \
             if (2 * ((g_) - 1) + 1 < PK) WIN_LOAD_K(2 * ((g_) - 1) + 1 < PK ? 2 * ((g_) - 1) + 1 : 0);               \
@@ -602,9 +615,17 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
     do {                                                                                                             \
         WIN_HEAD(it_);                                                                                               \
         _Pragma("unroll") for (int g_ = 0; g_ < NGRP; ++g_) WIN_GROUP(g_);                                           \
+        if constexpr (PL) WIN_LOAD_Q();                                                                              \
     } while (0)
 
     __syncthreads();                      // bias table is read by WIN_ISSUE
+    // PIPE & 2: static priority for the younger half of the block.  Waves w and w + 4 share a SIMD; at equal priority the older
+    // one wins every arbitration (tile loop 8.1 k cycles against 10.9 k, then 4.7 k at the item barrier waiting for its partner).
+    // One s_setprio for waves 4 .. 6, outside every loop (MI355X_MICROARCH.md "two waves per SIMD" item 4); the condition is
+    // wave-uniform by construction (readfirstlane), as s_setprio ignores EXEC.
+    if constexpr ((PIPE & 2) != 0) {
+        if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+    }
     int it = blockIdx.x;
 #ifdef WIN_TIMING
     unsigned long long wph[6] = {0, 0, 0, 0, 0, 0}, wprev = __builtin_amdgcn_s_memtime();
@@ -649,9 +670,10 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
                     *reinterpret_cast<uint32_t*>(Vt + (ch * 8 + e) * C::VSTR + C::lds_key(2 * kp)) = pair_elem(v0reg[i], v1reg[i], e);
             }
         }
-        uint4 qf[KS];
+        if constexpr (!PL) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = qfn[ks];
+            for (int ks = 0; ks < KS; ++ks) qf[ks] = qfn[ks];
+        }
         const int qoff = n_qoff;
         const bool qin = qoff >= 0;           // a real token (padding / tile-padding queries are dropped)
         const int im = n_im, head = n_head;
@@ -675,9 +697,30 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         float* scr = Scr + wave * 32 * C::SSTR + ql * C::SSTR;
         // bias of accumulator register r (tile-local key c = acc_row(r, hh): window row 2t + c / 14, column c % 14):
         //   RH[2t + c / 14] + BW[r],  BW[r] = RW[c % 14]  (-inf for the 4 zero keys c >= 28)
-        float RH[C::WS], BW[16];
+        float RH[PL ? 1 : C::WS], BW[16];
+        // PIPE: the row terms stay in the scratch row of this query, pre-multiplied by log2(e), as rhs[j] = RH[j] (j = 0 .. 13);
+        // the column-term transpose goes through the upper half of the same row (floats 16 .. 31 + 32: the row is 33 floats and the
+        // table product has 27 live rows, so the two uses are kept apart by writing tw to a second pass AFTER RH has been rebuilt)
+        float* rhs = scr;
         {
             const f32x16_t th = tile_times_qT<PREC, HD>(Tab, lane, qf);
+            if constexpr (PL) {
+                // the column term first (its scratch use ends before the row terms are parked there for the whole tile loop)
+                const f32x16_t tw = tile_times_qT<PREC, HD>(Tab + 32 * HD, lane, qf);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = tw[r];
+                wave_lds_sync();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int c = acc_row(r, hh);
+                    BW[r] = c < C::TK ? scr[qw - c % C::WS + C::WS - 1] * LOG2E_F : -INFINITY;
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = th[r] * LOG2E_F;       // row k of the table product, log2 domain
+                wave_lds_sync();
+                RH[0] = 0.f;
+            } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) scr[acc_row(r, hh)] = th[r];
             wave_lds_sync();
@@ -693,6 +736,7 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
                 const int c = acc_row(r, hh);
                 BW[r] = c < C::TK ? scr[qw - c % C::WS + C::WS - 1] * LOG2E_F : -INFINITY;
             }
+            }
         }
 
         const float c2 = rsqrtf((float)HD) * LOG2E_F;
@@ -707,12 +751,31 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
 #endif
         WIN_STAMP(4)
 
+        f32x16_t Sn;
+        if constexpr (PL) Sn = tile_times_qT<PREC, HD>(Ks, lane, qf);
 #pragma unroll
         for (int t = 0; t < C::NT; ++t) {
-            if (t < NGRP && has_next) WIN_GROUP(t);
-            f32x16_t S = tile_times_qT<PREC, HD>(Ks + t * 32 * HD, lane, qf);
+            if constexpr (PL) {
+                if (t + 1 < NGRP && has_next) WIN_GROUP(t + 1 < NGRP ? t + 1 : 0);     // K / V groups over tiles 0 .. NGRP - 2
+                if (t == C::NT - 1 && has_next) WIN_LOAD_Q();                           // qf is dead from here on (see above)
+            } else {
+                if (t < NGRP && has_next) WIN_GROUP(t);
+            }
+            f32x16_t S;
+            float rh0, rh1;
+            if constexpr (PL) {
+                S = Sn;
+                // row terms of this tile: RH[2t] = table row qh - 2t + 13, RH[2t + 1] = the row below it (LDS, wave-private)
+                rh0 = rhs[qh - 2 * t + C::WS - 1];
+                rh1 = rhs[qh - 2 * t + C::WS - 2];
+                if (t + 1 < C::NT) Sn = tile_times_qT<PREC, HD>(Ks + (t + 1) * 32 * HD, lane, qf);    // under the softmax below
+            } else {
+                S = tile_times_qT<PREC, HD>(Ks + t * 32 * HD, lane, qf);
+                rh0 = RH[2 * t];
+                rh1 = RH[2 * t + 1];
+            }
             // registers 0..5 hold keys of window row 2t, 8..15 of row 2t + 1, 6 and 7 of row 2t + hh (c = 10, 11 | 14, 15)
-            const float rh0 = RH[2 * t], rh1 = RH[2 * t + 1], rhx = hh ? rh1 : rh0;
+            const float rhx = hh ? rh1 : rh0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) S[r] = S[r] * c2 + BW[r];
             float m0 = fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3]));
@@ -885,7 +948,11 @@ struct GlbCfg {
 // NW waves = NW x 32 queries per block.  NW = 8 (one block per CU, 113 KiB of LDS): the K / V^T tiles are staged once for
 // 256 queries, which halves the LDS-DMA pieces each wave has to push through the CU's texture-address queue per tile
 // (measured: ~150 cycles of issue time per piece and wave; 22 pieces per tile and block).
-template <int PREC, int HD, int NW, int LO = 0 /* as for window_attention_kernel */>
+// PIPE (round 5): as in window_attention_kernel, the QK^T products of tile kt + 1 are issued in front of the softmax of tile kt, inside
+// the same wave (two S tiles live: 32 more registers; 168 + 32 fit the 256 of two waves per SIMD).  K(kt + 1) must then be in LDS when
+// iteration kt starts, so the K pieces run TWO tiles ahead and the V^T pieces one -- still two buffers each: K(kt) is dead once S(kt)
+// sits in registers, i.e. from the barrier that closes iteration kt - 1.  Same products in the same order: bit-identical.
+template <int PREC, int HD, int NW, int LO = 0 /* as for window_attention_kernel */, int PIPE = 0>
 __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ vt, const float* __restrict__ rel_h,
     const float* __restrict__ rel_w, uint16_t* __restrict__ out, int heads,
@@ -1002,6 +1069,21 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
         poff[i] = o;
     }
 #define GLB_DMA(kt_, kb_, vb_) GLB_DMA_RANGE(kt_, kb_, vb_, 0, PPW)
+    // PIPE: this wave's pieces [i0_, i1_) with the K pieces taken from tile ktk_ (-> K buffer kb_) and the V^T pieces from tile ktv_
+    // (-> V^T buffer vb_); a negative tile index skips that kind
+#define GLB_DMA_KV(ktk_, kb_, ktv_, vb_, i0_, i1_)                                                           \
+    _Pragma("unroll") for (int i_ = (i0_); i_ < (i1_) && i_ < PPW; ++i_) {                                   \
+        const int pc_ = __builtin_amdgcn_readfirstlane(wave) + NW * i_;                                       \
+        if (pc_ < NPC && poff[i_] != ~0u) {                                                                  \
+            const bool isk_ = pc_ < KPC;                                                                     \
+            if (isk_ ? (ktk_) >= 0 : (ktv_) >= 0) {                                                          \
+                const uint16_t* sb_ = isk_ ? base + (size_t)(ktk_) * C::KT * (3 * D) + D : vth + (size_t)(ktv_) * C::KT; \
+                const uint32_t dst_ = lds_base + (isk_ ? (uint32_t)(kb_) * C::K_BYTES + (uint32_t)pc_ * 1024u        \
+                                                       : (uint32_t)(C::NKB * C::K_BYTES) + (uint32_t)(vb_) * C::VT_BYTES + (uint32_t)(pc_ - KPC) * 1024u); \
+                glds16_sbase(poff[i_], sb_, __builtin_amdgcn_readfirstlane(dst_));                           \
+            }                                                                                                \
+        }                                                                                                    \
+    }
     // pieces [i0_, i1_) of this wave: the issue of a piece waits for a slot in the CU's texture-address queue (44 pieces
     // per tile time from the two resident blocks), so the pieces of the next tile are spread over the tile instead of
     // being queued in front of its first MFMA
@@ -1051,9 +1133,67 @@ __global__ __launch_bounds__(64 * NW, 2) void global_attention_kernel(
     // PV(t) runs beside group 0's QK^T(t + 1), and one group's softmax beside the other's MFMAs.  Buffer hand-over by the same
     // barrier: tile t + 1 is fetched during tile t into K buffer (t + 1) & 1 and V^T buffer (t + 1) % 3 -- group 1 still reads
     // V^T(t) after barrier t while group 0 already fetches tile t + 2, hence three V^T buffers; K(t) is only read before it.
+    if constexpr (PIPE != 0) {
+        static_assert(!SAMRS_GLB_SKEW, "the pipelined loop keeps every wave in one phase");
+        // tile 0 is in K buffer 0 / V^T buffer 0 (prologue above); K(1) -> K buffer 1 must have landed before iteration 0 starts
+        if (nkt > 1) { GLB_DMA_KV(1, 1, -1, 0, 0, PPW) }
+        f32x16_t Sn[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) Sn[a] = tile_times_qT<PREC, HD, C::KSTR>(Kb(0) + a * 32 * C::KSTR, lane, qf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int buf = kt & 1;
+            // K(kt + 2) -> K buffer kt & 1 (K(kt) is in registers), V^T(kt + 1) -> V^T buffer (kt + 1) & 1 (V^T(kt - 1) was last read
+            // before the barrier that closed iteration kt - 1); a third of the pieces now, a third after QK^T, a third after the softmax
+            const int ktk = kt + 2 < nkt ? kt + 2 : -1, ktv = kt + 1 < nkt ? kt + 1 : -1;
+            GLB_DMA_KV(ktk, buf, ktv, buf ^ 1, 0, (PPW + 2) / 3)
+            const float bh2 = rh[kt];
+            f32x16_t S[2];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                S[a] = Sn[a];
+                if (kt + 1 < nkt) Sn[a] = tile_times_qT<PREC, HD, C::KSTR>(Kb(buf ^ 1) + a * 32 * C::KSTR, lane, qf);   // under the VALU below
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = S[a][r] * c2 + rw[a][r];
+                    S[a][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            // issue order of the block above: hipcc otherwise emits the ten MFMAs of QK^T(kt + 1) back to back in front of the 64 scale /
+            // max VALU instructions of tile kt -- in order, the wave then sits in MFMA issue for 320 cycles and the overlap is lost.
+            // One MFMA, its successor's K fragment read, six VALU, ten times.
+#pragma unroll
+            for (int i = 0; i < 2 * KS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+            }
+            // the scale / max block must not be sunk below the (branchy) DMA issue that follows: it would leave the MFMAs' basic block
+            asm volatile("" :: "v"(mx), "v"(S[0][0]), "v"(S[1][15]));
+            GLB_DMA_KV(ktk, buf, ktv, buf ^ 1, (PPW + 2) / 3, 2 * ((PPW + 2) / 3))
+            online_softmax_step<C::DT, !ONES>(S, 2, mx, bh2, m_run, l_run, O);
+            GLB_DMA_KV(ktk, buf, ktv, buf ^ 1, 2 * ((PPW + 2) / 3), PPW)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint4 pb = pack_p<PREC>(S[a], u);
+#pragma unroll
+                    for (int dt = 0; dt < C::DT; ++dt) {
+                        const uint4 va = load_vt_frag_perm(Vb(buf) + (dt * 32 + ql) * C::VSTR + 32 * a, u, hh);
+                        O[dt] = ET<PREC>::mfma32(va, pb, O[dt]);
+                    }
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of K(kt + 2) / V^T(kt + 1) have landed
+            __syncthreads();                                        // ... everybody's; every read of K(kt + 1) and V^T(kt) is done
+        }
+    }
     const int grp = SAMRS_GLB_SKEW ? (wave >= NW / 2) : 0;
     int vb = 0;                                                   // V^T buffer of tile kt
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = 0; PIPE == 0 && kt < nkt; ++kt) {
         const int buf = kt & 1;
         const int vb1 = SAMRS_GLB_SKEW ? (vb == 2 ? 0 : vb + 1) : (buf ^ 1);
         const bool more = kt + 1 < nkt;
@@ -1387,7 +1527,12 @@ template <int PREC, int HD, int LO = 0>
 static hipError_t launch_win(const void* qkv, const float* qb, const float* rh, const float* rw, void* out, int n_images,
                              int grid, int heads, hipStream_t s, void* out_lo = nullptr, MxOut mx = MxOut()) {
     using C = WinCfg<HD>;
-    auto k = window_attention_kernel<PREC, HD, LO>;
+    // SAMRS_WIN_PIPE=1 / 3: the software-pipelined tile loop (/ + static priority for the younger waves); A/B runs
+    // measured (profiles/r05_attention_pipelining.txt): no faster, and the rel-pos row terms take one more rounding on their way through
+    // the scratch (the un-pipelined loop contracts RH[j] = t * log2(e) into the add that consumes it): default OFF
+    static const int pipe = [] { const char* v = getenv("SAMRS_WIN_PIPE"); return v ? atoi(v) & 3 : 0; }();
+    auto k = pipe == 3 ? window_attention_kernel<PREC, HD, LO, 3> : pipe == 2 ? window_attention_kernel<PREC, HD, LO, 2>
+           : pipe == 1 ? window_attention_kernel<PREC, HD, LO, 1> : window_attention_kernel<PREC, HD, LO, 0>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
     if (heads * HD > C::MAX_D) return hipErrorInvalidValue;
     const int nw = (grid + C::WS - 1) / C::WS;
@@ -1434,7 +1579,9 @@ static hipError_t launch_glb_nw(const void* qkv, const float* rh, const float* r
                                 int heads, void* vt_ws, hipStream_t s, void* out_lo = nullptr, MxOut mx = MxOut()) {
     using C = GlbCfg<HD, NW>;
     constexpr int NTOK = C::G * C::G;
-    auto k = global_attention_kernel<PREC, HD, NW, LO>;
+    // SAMRS_GLB_PIPE=1: the software-pipelined tile loop (bit-identical; measured 2 - 3 % SLOWER: default off)
+    static const bool pipe = [] { const char* v = getenv("SAMRS_GLB_PIPE"); return v ? atoi(v) != 0 : false; }();
+    auto k = pipe ? global_attention_kernel<PREC, HD, NW, LO, 1> : global_attention_kernel<PREC, HD, NW, LO, 0>;
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
     dim3 g((NTOK / (32 * NW)) * heads * n_images), b(64 * NW);
     k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, (const uint16_t*)vt_ws, rh, rw, (uint16_t*)out, heads, (uint16_t*)out_lo, mx);

@@ -143,6 +143,8 @@ struct samrs_engine {
     // option "range_check" (0 off, 1 count, 2 count and fail): after every producer of an MFMA-operand tensor in the encoder a
     // scan counts the elements sitting at the operand type's saturation value (f16: +-65504, what common.h's saturating
     // conversions write) or beyond into *range_counter (device); read through option "saturated"
+    int ln_tail = -1;              // option "ln_tail": -1 automatic (on in the 1x-rate modes where the shapes allow), 0 off, 1 on
+    unsigned int* ln_counters = nullptr;   // per 256-row panel: tiles of the running proj / lin2 launch that have stored (gemm.hip LnTail)
     int gelu_fast = -1;            // option "gelu_fast": -1 automatic (on in the 1x-rate modes: no block-GEMM bit in "split"), 0 off, 1 on
     int range_check = 0;
     unsigned long long* range_counter = nullptr;
@@ -400,6 +402,8 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->split_depth = env_int("SAMRS_SPLIT_DEPTH", 0);
     e->lo_format = (h_like && env_int("SAMRS_LO_FORMAT", 4) == 4) ? 4 : 0;
     e->gelu_fast = env_int("SAMRS_GELU_FAST", -1);
+    e->ln_tail = env_int("SAMRS_LN_TAIL", -1);
+    if (e->ln_tail > 1) e->ln_tail = 1;
     if (e->gelu_fast > 1) e->gelu_fast = 1;
     if (const int rc0 = env_int("SAMRS_RANGE_CHECK", 0)) {
         if (samrs_set_option(e, "range_check", rc0) != SAMRS_OK) {
@@ -606,6 +610,8 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     const size_t M = Bi * tokens;
     const size_t Mmax = M;
     CK(e, dalloc(e, &e->X, M * D));
+    CK(e, dalloc(e, &e->ln_counters, M / 256 + 1));
+    CK(e, hipMemsetAsync(e->ln_counters, 0, (M / 256 + 1) * sizeof(unsigned int), s));
     CK(e, dalloc(e, &e->Y, Mmax * D));
     CK(e, hipMemsetAsync(e->Y, 0, Mmax * D * 2, s));
     if (e->can_fold) { CK(e, dalloc(e, &e->STATS, Mmax * 16)); CK(e, dalloc(e, &e->ROWSTAT, Mmax * 2)); }
@@ -731,6 +737,12 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     // fits the 256 x 320 tile (ViT-H); SAMRS_SPLIT_PASSES=1 / option "split_passes" keeps the three accumulating launches (A/B)
     const bool one3 = !e->split_passes;
     const bool fast_gelu = e->gelu_fast >= 0 ? e->gelu_fast != 0 : !(e->split & (SPLIT_ATTN_ANY | SPLIT_MLP | SPLIT_LIN2));
+    // The LayerNorm behind proj (norm2) and behind lin2 (the next block's norm1) as a tail of those GEMMs (gemm.hip LnTail): the
+    // 1x-rate modes only -- the reference-grade modes want the LayerNorm's lo / MXFP4 outputs and keep their arithmetic bit for bit --
+    // and only where the shapes take the 256 x 320 kernel (at least one full round of tiles: batches of 4 tiles and more at ViT-H)
+    const bool ln_tail = !fold && !(e->split & (SPLIT_ATTN_ANY | SPLIT_MLP | SPLIT_LIN2)) && (e->ln_tail >= 0 ? e->ln_tail != 0 : true) &&
+                         e->ln_counters && gemm_lntail_ok(M, D, D) && gemm_lntail_ok(M, D, 4 * D);
+    bool y_ready = false;          // Y already holds norm1 of the block about to start (written by the previous block's lin2 launch)
     if (fold && n_blocks > 0) {
         CK(e, launch_rowstats_convert(prec, e->X, e->Y, e->STATS, M, D, s));
         CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
@@ -768,9 +780,10 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                 CK(e, launch_convert(prec, e->F32T, e->QKV, (long)M * 3 * D, s));
             }
         } else {
-            CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
+            if (!y_ready) CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
             CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
         }
+        y_ready = false;
         const bool mx_ao = sp_attn && mx_attn;      // the attention kernels write the proj GEMM's MX operands themselves
         if (!b.global)
             CK(e, launch_window_attention(prec, e->QKV, b.qkv_b, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s,
@@ -800,9 +813,14 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                     CK(e, launch_gemm_et(prec, e->AOlo, b.proj_w, e->X, nullptr, nullptr, 0, M, D, D, true, false, true, s));
                     CK(e, launch_gemm_et(prec, e->AO, b.proj_w_lo, e->X, nullptr, nullptr, 0, M, D, D, true, false, true, s));
                 }
-                CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
+                if (ln_tail && !sp_attn)
+                    CK(e, launch_gemm_et_lntail(prec, e->AO, b.proj_w, e->X, b.proj_b, M, D, D, b.ln2w, b.ln2b, 1e-6f, e->Y, e->ln_counters, s));
+                else
+                    CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
             }
-            if (sp_mlp && mx_mlp)
+            if (ln_tail && !sp_attn) {
+                // norm2 came out of the proj launch
+            } else if (sp_mlp && mx_mlp)
                 CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, nullptr, e->Y4[0], e->Y4[1], e->SY4[0], e->SY4[1]));
             else
                 CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, sp_mlp ? e->Ylo : nullptr));
@@ -864,7 +882,12 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                     CK(e, launch_gemm_et(prec, e->Hlo, b.lin2_w, e->X, nullptr, nullptr, 0, M, D, 4 * D, true, false, true, s));
                     CK(e, launch_gemm_et(prec, e->H, b.lin2_w_lo, e->X, nullptr, nullptr, 0, M, D, 4 * D, true, false, true, s));
                 }
-                CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
+                if (ln_tail && !sp_mlp && i + 1 < c.depth && i + 1 < n_blocks) {
+                    const EncBlock& nb = e->blocks[i + 1];
+                    CK(e, launch_gemm_et_lntail(prec, e->H, b.lin2_w, e->X, b.lin2_b, M, D, 4 * D, nb.ln1w, nb.ln1b, 1e-6f, e->Y, e->ln_counters, s));
+                    y_ready = true;
+                } else
+                    CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
             }
         }
     }
@@ -1286,6 +1309,7 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     else if (n == "split_depth") e->split_depth = value > 0 ? value : 0;
     else if (n == "allow_reduced") e->allow_reduced = value != 0;
     else if (n == "gelu_fast") e->gelu_fast = value < 0 ? -1 : (value != 0);
+    else if (n == "ln_tail") e->ln_tail = value < 0 ? -1 : (value != 0);
     else if (n == "range_check") {
         if (value < 0 || value > 2) return fail(e, SAMRS_ERR_BAD_ARG, "range_check is 0 (off), 1 (count) or 2 (count, and samrs_set_images fails)");
         if (value && !e->range_counter) {
@@ -1325,6 +1349,7 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
     else if (n == "split_depth") *value = e->split_depth;
     else if (n == "allow_reduced") *value = e->allow_reduced;
     else if (n == "gelu_fast") *value = e->gelu_fast;
+    else if (n == "ln_tail") *value = e->ln_tail;
     else if (n == "range_check") *value = e->range_check;
     else if (n == "saturated") {                    // synchronizes the device: a diagnostic, not a hot-path call
         unsigned long long c = 0;

@@ -241,7 +241,8 @@ __device__ __forceinline__ void wave_lds_sync_g() {
 // DRAIN (persistent kernels): the caller has LDS-DMA pieces of its NEXT tile in flight; they are retired (vmcnt(0)) right
 // before this wave's first global store, i.e. after the bias loads, the VALU work and the first LDS bounce have covered
 // their latency, and before any store joins the queue -- so the stores themselves are never waited for.
-template <int PREC, bool OUT_F32, bool GELU, int NJ, int JC, int NI = 4, bool GLN = false, bool DRAIN = false>
+template <int PREC, bool OUT_F32, int GELU /* 0 none, 1 fp32-epsilon erf, 2 the cheaper erf (ET output) */, int NJ, int JC, int NI = 4, bool GLN = false,
+          bool DRAIN = false>
 __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsigned char* scr /* wave-private */,
                                                    void* __restrict__ Cv, const float* __restrict__ bias,
                                                    const float* __restrict__ add2d, int add2d_period, int N,
@@ -326,7 +327,8 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
                     v0 = (v0 - gmean) * grstd * gm.x + bt.x; v1 = (v1 - gmean) * grstd * gm.y + bt.y;
                     v2 = (v2 - gmean) * grstd * gm.z + bt.z; v3 = (v3 - gmean) * grstd * gm.w + bt.w;
                 }
-                if (GELU) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
+                if constexpr (GELU == 2 && !OUT_F32) { const float2_t g01 = gelu_erf2_et(float2_t{v0, v1}), g23 = gelu_erf2_et(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
+                else if constexpr (GELU != 0) { const float2_t g01 = gelu_erf2(float2_t{v0, v1}), g23 = gelu_erf2(float2_t{v2, v3}); v0 = g01.x; v1 = g01.y; v2 = g23.x; v3 = g23.y; }
                 unsigned char* p = scr + jj * TS + fr * RS;
                 if (OUT_F32) {
                     *reinterpret_cast<float4*>(p + (i * 16 + 4 * fq) * 4) = make_float4(v0, v1, v2, v3);
@@ -940,12 +942,31 @@ __device__ __forceinline__ const uint16_t* seg_src_b(const uint16_t* hi, const u
     return (seg == 1 ? lo : hi) + (size_t)(st - seg * nst1) * XBK;
 }
 
-template <int PREC, bool OUT_F32, bool GELU, int NI = 4, int MODE = 0, int ABL = 0, bool SPLIT3 = false>
+// LNT (round 5): the LayerNorm that FOLLOWS this GEMM (image_encoder.py:177 norm2 after proj, :168 norm1 of the next block after
+// lin2) as a tail of the GEMM itself.  The GEMM writes the fp32 residual stream in 256 x 320 tiles, a LayerNorm row needs all N = 1280
+// columns = the four tiles of a 256-row panel, which four CUs of one XCD compute side by side; the stand-alone LayerNorm then re-reads
+// the 168 MB stream from HBM / MALL (53 us per launch, 64 launches per encoder pass = 6 % of the step for zero FLOPs).  Here every block,
+// once its own stores are complete, publishes them (agent-scope release by one lane after a block barrier: cdna_hip_programming.md
+// 6 G16) and bumps a counter of its row panel; the block that finds the other tiles_n - 1 already counted -- the LAST ARRIVER -- makes
+// them visible to itself (agent-scope acquire) and normalises the panel's 256 rows: one wave per row as in layernorm_kernel, same
+// expressions, the next row's loads in flight under the current row's arithmetic; the rows come out of the L2 the four blocks just
+// wrote them to.  Nobody ever waits for anybody (no spin, no ordering assumption: whichever block arrives last does the work), the
+// counter is reset by the last arriver for the next launch.  N must be the LayerNorm width.
+struct LnTail {
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    uint16_t* out = nullptr;           // [M][N] in the operand type
+    unsigned int* counters = nullptr;  // [M / 256], zero before the first launch
+    float eps = 0.f;
+};
+
+template <int PREC, bool OUT_F32, bool GELU, int NI = 4, int MODE = 0, int ABL = 0, bool SPLIT3 = false, bool LNT = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
     int M, int N, int K, int accumulate, int skew,
-    const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr) {
+    const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr, LnTail ln = LnTail()) {
+    static_assert(!LNT || (OUT_F32 && !GELU), "the LayerNorm tail follows the fp32 residual outputs");
     constexpr int XBN = 64 * NI;
     constexpr int XROWS = QBM + XBN;                       // 512 / 576 rows per stage
     constexpr int XSTAGE_ELEMS = XROWS * XBK;              // 64 / 72 KiB
@@ -1144,6 +1165,75 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // stores acknowledged: what s_endpgm would wait for anyway
         if (tid == 0) tl[27] = __builtin_amdgcn_s_memtime();
     }
+    if constexpr (LNT) {
+        int* flag = reinterpret_cast<int*>(lds);               // the ring is idle: every wave is past its bounce after the barrier below
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores of the tile have completed
+        __syncthreads();                                       // ... everybody's
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned int old = __hip_atomic_fetch_add(ln.counters + tile_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned int)(tiles_n - 1);
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(ln.counters + tile_m, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the next launch
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        // ---- last arriver: LayerNorm of rows m0 .. m0 + 255, one wave per row, 32 rows per wave (layernorm_kernel's arithmetic) ----
+        constexpr int LNV = 8;                                 // float4 per lane: N <= 2048
+        const int nv = N >> 2;
+        const float* X = reinterpret_cast<const float*>(Cv);
+        float4 cur[LNV], nxt[LNV];
+#define LNT_LOAD(dst_, row_)                                                                               \
+        {                                                                                                  \
+            const float4* xr_ = reinterpret_cast<const float4*>(X + (size_t)(row_) * N);                    \
+            _Pragma("unroll") for (int i = 0; i < LNV; ++i) { const int idx = lane + 64 * i; if (idx < nv) dst_[i] = xr_[idx]; } \
+        }
+        const int row0 = m0 + wave * 32;
+        LNT_LOAD(cur, row0)
+        for (int r = 0; r < 32; ++r) {
+            const int row = row0 + r;
+            if (r + 1 < 32) LNT_LOAD(nxt, row + 1)
+            float sm = 0.f;
+#pragma unroll
+            for (int i = 0; i < LNV; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < nv) sm += (cur[i].x + cur[i].y) + (cur[i].z + cur[i].w);
+            }
+            const float mean = wave_sum(sm) / (float)N;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < LNV; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < nv) {
+                    const float a = cur[i].x - mean, b = cur[i].y - mean, c = cur[i].z - mean, d = cur[i].w - mean;
+                    q += (a * a + b * b) + (c * c + d * d);
+                }
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + ln.eps);
+#pragma unroll
+            for (int i = 0; i < LNV; ++i) {
+                const int idx = lane + 64 * i;
+                if (idx < nv) {
+                    const float4 g = reinterpret_cast<const float4*>(ln.gamma)[idx];
+                    const float4 bt = reinterpret_cast<const float4*>(ln.beta)[idx];
+                    const float o0 = (cur[i].x - mean) * rstd * g.x + bt.x;
+                    const float o1 = (cur[i].y - mean) * rstd * g.y + bt.y;
+                    const float o2 = (cur[i].z - mean) * rstd * g.z + bt.z;
+                    const float o3 = (cur[i].w - mean) * rstd * g.w + bt.w;
+                    uint2 o;
+                    o.x = pack2<PREC>(o0, o1);
+                    o.y = pack2<PREC>(o2, o3);
+                    reinterpret_cast<uint2*>(ln.out + (size_t)row * N)[idx] = o;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < LNV; ++i) cur[i] = nxt[i];
+        }
+#undef LNT_LOAD
+    }
 #undef X64_PIECE
 #undef X64_ISSUE
 #undef X64_READ
@@ -1171,16 +1261,17 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
 constexpr int LN_NS = 8;                       // 1280 / 160: ViT-H only
 
 // MXO (round 4; ET output, no FOLD / SPLIT3): the epilogue also writes the output as MXFP4 hi / lo rows (epilogue_pair_et<MXO>: lin1 of
-// split 207, whose lin2 takes MXFP4 lo terms while lin1 itself takes none).  The four output pointers travel in the parameters the
-// plain flavour does not use -- rowstat = codes hi, cvec = codes lo, A_lo = scales hi, B_lo = scales lo -- so that the kernel
-// signature, and with it every existing instantiation, stays what it was.
+// split 207, whose lin2 takes MXFP4 lo terms while lin1 itself takes none).  The four output pointers travel in their own MxOut
+// parameter (round 5: they used to be smuggled through rowstat / cvec / A_lo / B_lo with const_casts); the flavours that do not
+// use it never load it from the kernarg segment, so their code is what it was.
 template <int PREC, bool OUT_F32, int GELU /* 0 none, 1 fp32-epsilon erf, 2 the 1x-rate mode's cheaper erf (ET output only) */, bool FOLD = false,
           bool SPLIT3 = false, bool MXO = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, int accumulate,
     const float2* __restrict__ rowstat = nullptr, const float* __restrict__ cvec = nullptr,
-    const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr, int split_from_n = 0) {
+    const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr, int split_from_n = 0,
+    MxOut mxo = MxOut()) {
     static_assert(!(FOLD && OUT_F32), "the folded LayerNorm feeds ET outputs only (qkv, lin1)");
     static_assert(!(FOLD && SPLIT3), "the split operands come from an explicit LayerNorm");
     static_assert(!(MXO && (FOLD || SPLIT3 || OUT_F32)), "MX rows go with the plain ET-output flavour");
@@ -1324,11 +1415,6 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
         {   // epilogue of tile (m0, n0); bounce scratch = ring buffer 1 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
             unsigned char* upper = reinterpret_cast<unsigned char*>(lds) + XSB;
             if constexpr (MXO) {
-                MxOut mxo;
-                mxo.q_hi = reinterpret_cast<unsigned char*>(const_cast<float2*>(rowstat));
-                mxo.q_lo = reinterpret_cast<unsigned char*>(const_cast<float*>(cvec));
-                mxo.s_hi = reinterpret_cast<unsigned char*>(const_cast<uint16_t*>(A_lo));
-                mxo.s_lo = reinterpret_cast<unsigned char*>(const_cast<uint16_t*>(B_lo));
                 epilogue_pair_et<PREC, GELU, 2, true, false, true>(acc, upper, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + (wn >> 1) * 160, wm, wn,
                                                                    lane, nullptr, nullptr, mxo);
             } else if constexpr (!OUT_F32) {
@@ -1390,12 +1476,13 @@ hipError_t launch_gemm_x64p_mxo(const void* A, const void* B, void* C, const flo
     dim3 grid(ntiles < n_cu ? ntiles : n_cu), block(QTHREADS);
     const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
     const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
-    const float2* p0 = reinterpret_cast<const float2*>(o4_hi);
-    const float* p1 = reinterpret_cast<const float*>(o4_lo);
-    const uint16_t* p2 = reinterpret_cast<const uint16_t*>(so_hi);
-    const uint16_t* p3 = reinterpret_cast<const uint16_t*>(so_lo);
-    if (gelu) gemm_et_x64p_kernel<PREC, false, true, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, p0, p1, p2, p3, 0);
-    else gemm_et_x64p_kernel<PREC, false, false, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, p0, p1, p2, p3, 0);
+    MxOut mxo;
+    mxo.q_hi = reinterpret_cast<unsigned char*>(o4_hi);
+    mxo.q_lo = reinterpret_cast<unsigned char*>(o4_lo);
+    mxo.s_hi = reinterpret_cast<unsigned char*>(so_hi);
+    mxo.s_lo = reinterpret_cast<unsigned char*>(so_lo);
+    if (gelu) gemm_et_x64p_kernel<PREC, false, true, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, nullptr, nullptr, nullptr, nullptr, 0, mxo);
+    else gemm_et_x64p_kernel<PREC, false, false, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, 0, nullptr, nullptr, nullptr, nullptr, 0, mxo);
     return hipGetLastError();
 }
 
@@ -1980,6 +2067,237 @@ hipError_t launch_gemm_w4(const void* A, const void* B, void* C, const float* bi
         if (gelu) gemm_et_w4_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
         else gemm_et_w4_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_et_w4x_kernel (round 5): the vendor's tile geometry on this file's LDS-DMA pair stages -- 256 x 256 x 64 macro tile, FOUR waves
+// with 512 registers each, wave tile 128 x 128 on v_mfma_f32_16x16x32 (the form tools/mfma_rate.hip measures 24 % faster than
+// 32x32x16 in the bare pipe; the round-2 four-wave kernel above was built on 32x32x16).  VERDICT r04 item 1a.
+//
+//   * 64 accumulator tiles of 16 x 16 = 256 registers, ALL in AGPRs (inline-asm MFMAs with "+a"); the first k-step of a tile
+//     writes them with C = 0, so no accumulator is ever zeroed by 256 v_accvgpr_write;
+//   * per 32-k step and wave: 64 MFMAs (1024 pipe cycles), 16 ds_read_b128 (8 A + 8 B fragments: 0.25 per MFMA against 0.325 for the
+//     128 x 80 wave tile of the eight-wave kernels), into the OTHER of two fragment register sets (128 VGPRs);
+//   * a 64-k pair stage = 512 rows x 128 B = 64 KiB = 64 whole-line DMA pieces, 16 per wave, spread over the second step of the stage
+//     one behind every second MFMA (a piece = s_mov m0 + the load; the per-piece source offset sits in eight VGPRs, the stage base
+//     in two SGPR pairs);
+//   * ONE block barrier per stage, between its two steps: before it every wave waits for its own pieces of stage t + 1 (issued a
+//     whole stage earlier) and has finished reading stage t (its k-half 1 fragments were read during step 0); after it stage t + 2
+//     goes into the buffer of stage t.  The stage stream runs on across tiles (persistent, one block per CU): the next tile's
+//     stages 0 and 1 land under the last stage and the epilogue, which bounces through 17 KiB of LDS of its own.
+// Same LDS image, swizzle and k order as gemm_et_x64_kernel: bit-identical output.  M % 256 == 0, N % 256 == 0, K % 128 == 0.
+// ---------------------------------------------------------------------------------------------
+template <int PREC, bool ZERO>
+__device__ __forceinline__ void mfma16_asm(f32x4_t& c, const uint4& a, const uint4& b) {
+    const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
+    if constexpr (PREC == PREC_F16) {
+        if constexpr (ZERO) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(av), "v"(bv));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+    } else {
+        if constexpr (ZERO) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(av), "v"(bv));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+    }
+}
+
+constexpr int W4X_BN = 256;
+constexpr int W4X_ROWS = QBM + W4X_BN;                 // 512 stage rows
+constexpr int W4X_STAGE_ELEMS = W4X_ROWS * XBK;        // 64 KiB per stage
+constexpr int W4X_SCR_BYTES = 4 * 16 * 272;            // epilogue scratch: per wave one m-tile of 16 rows x 272 B (epilogue_coalesced, NI = 8, JC = 1)
+
+// ET outputs only: the fp32 epilogue bounces 8 KiB per wave and m-tile, which the 160 KiB do not hold next to two 64 KiB stages (and the
+// fp32-output shapes of this path, N = 1280, are 2.5 rounds of 256 x 256 tiles: nothing to gain there).
+template <int PREC, bool OUT_F32, int GELU>
+__global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amdgpu_waves_per_eu(1, 1))) void gemm_et_w4x_kernel(
+    const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
+    const float* __restrict__ bias, int M, int N, int K, int accumulate) {
+    static_assert(!OUT_F32, "ET outputs only (epilogue scratch: 16 rows x 272 B per wave)");
+    constexpr int NI = 8, NJ = 8;
+    constexpr uint32_t XSB = W4X_STAGE_ELEMS * 2;
+    __shared__ __attribute__((aligned(16))) uint16_t lds[2 * W4X_STAGE_ELEMS + W4X_SCR_BYTES / 2];   // 128 KiB ring + 17 KiB scratch, ONE object
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;               // wave tile rows wm*128.., cols wn*128..
+
+    constexpr int GROUP = 8;
+    const int tiles_n = N / W4X_BN, tiles_m = M / QBM, ntiles = tiles_n * tiles_m;
+    const int per_group = GROUP * tiles_n;
+#define W4X_TILE(L_, m_, n_)                                                                     \
+    do {                                                                                         \
+        const int bid_ = xcd_remap((L_), ntiles);                                                \
+        const int group_ = bid_ / per_group, first_m_ = group_ * GROUP;                           \
+        const int gsz_ = (tiles_m - first_m_) < GROUP ? (tiles_m - first_m_) : GROUP;            \
+        const int in_g_ = bid_ - group_ * per_group;                                             \
+        (m_) = (first_m_ + in_g_ % gsz_) * QBM;                                                  \
+        (n_) = (in_g_ / gsz_) * W4X_BN;                                                          \
+    } while (0)
+
+    // DMA map: piece q of this wave covers stage rows 32 q + 8 wave .. + 7 (q < 8: A rows, else B rows 32 (q - 8) + ..); lane l ->
+    // k-half l>>5, row (l>>2)&7, physical chunk l&3 (the image and swizzle of the eight-wave kernels: 32 q = 0 mod 16).  The byte
+    // offset of (piece q & 7, lane) from the stage base is the same for A and B: eight VGPRs.
+    const int prow = 8 * wave + ((lane >> 2) & 7);
+    uint32_t voffq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        voffq[q] = ((uint32_t)(prow + 32 * q) * (uint32_t)K + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
+#define W4X_PIECE(pa_, pb_, wr_, q_) glds16_m(voffq[(q_) & 7], ((q_) < 8 ? (pa_) : (pb_)), lds0 + (wr_) + (q_) * 4096u)
+#define W4X_ISSUE_ALL(pa_, pb_, wr_)                                                                       \
+    do {                                                                                                   \
+        W4X_PIECE(pa_, pb_, wr_, 0); W4X_PIECE(pa_, pb_, wr_, 1); W4X_PIECE(pa_, pb_, wr_, 2); W4X_PIECE(pa_, pb_, wr_, 3);     \
+        W4X_PIECE(pa_, pb_, wr_, 4); W4X_PIECE(pa_, pb_, wr_, 5); W4X_PIECE(pa_, pb_, wr_, 6); W4X_PIECE(pa_, pb_, wr_, 7);     \
+        W4X_PIECE(pa_, pb_, wr_, 8); W4X_PIECE(pa_, pb_, wr_, 9); W4X_PIECE(pa_, pb_, wr_, 10); W4X_PIECE(pa_, pb_, wr_, 11);   \
+        W4X_PIECE(pa_, pb_, wr_, 12); W4X_PIECE(pa_, pb_, wr_, 13); W4X_PIECE(pa_, pb_, wr_, 14); W4X_PIECE(pa_, pb_, wr_, 15); \
+    } while (0)
+
+    const int nst = K / XBK;
+    const int fr = lane & 15, fq = lane >> 4;
+    // fragment BYTE offsets inside a stage for k-half 0; k-half 1 is +512
+    uint32_t offA[NJ], offB[NI];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { const int r = wm * 128 + j * 16 + fr; offA[j] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, fq) * 8) * 2; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int r = QBM + wn * 128 + i * 16 + fr; offB[i] = ((r >> 3) * 512 + (r & 7) * 32 + qswz(r, fq) * 8) * 2; }
+    const unsigned char* ldsb = reinterpret_cast<const unsigned char*>(lds);
+#define W4X_RDB(fb_, rd_, kh_, i_) fb_[i_] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offB[i_])
+#define W4X_RDA(fa_, rd_, kh_, j_) fa_[j_] = *reinterpret_cast<const uint4*>(ldsb + (rd_) + (kh_) * 512 + offA[j_])
+    // slot k (0 .. 63) of a 32-k step: MFMA on accumulator tile (i = k % 8, j = k / 8) of the set (ca_, cb_); slots 0 - 15: one read of
+    // the NEXT step's set (na_, nb_) from buffer nrd_, k-half nkh_; D_ != 0: DMA piece (k - 16) / 2 behind the even slots 16 .. 46
+    // when dma_ (wave-uniform) is set.  Z_: first step of a tile (C = 0).
+#define W4X_SLOT(k_, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                          \
+        mfma16_asm<PREC, Z_>(acc[(k_) % 8][(k_) / 8], cb_[(k_) % 8], ca_[(k_) / 8]);                       \
+        if constexpr ((k_) < 8) { W4X_RDB(nb_, nrd_, nkh_, ((k_) < 8 ? (k_) : 0)); }                       \
+        else if constexpr ((k_) < 16) { W4X_RDA(na_, nrd_, nkh_, ((k_) >= 8 && (k_) < 16 ? (k_) - 8 : 0)); } \
+        if constexpr ((D_) != 0 && (k_) >= 16 && (k_) < 48 && ((k_) & 1) == 0) {                           \
+            if (dma_) W4X_PIECE(pa_, pb_, wr_, ((k_) >= 16 && (k_) < 48 ? ((k_) - 16) / 2 : 0));           \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);
+#define W4X_SLOT8(k_, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                         \
+        W4X_SLOT((k_) + 0, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                    \
+        W4X_SLOT((k_) + 1, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                    \
+        W4X_SLOT((k_) + 2, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                    \
+        W4X_SLOT((k_) + 3, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                    \
+        W4X_SLOT((k_) + 4, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                    \
+        W4X_SLOT((k_) + 5, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                    \
+        W4X_SLOT((k_) + 6, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                    \
+        W4X_SLOT((k_) + 7, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)
+#define W4X_STEP(Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                              \
+        W4X_SLOT8(0, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                          \
+        W4X_SLOT8(8, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                          \
+        W4X_SLOT8(16, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                         \
+        W4X_SLOT8(24, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                         \
+        W4X_SLOT8(32, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                         \
+        W4X_SLOT8(40, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                         \
+        W4X_SLOT8(48, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)                         \
+        W4X_SLOT8(56, Z_, ca_, cb_, na_, nb_, nrd_, nkh_, D_, dma_, pa_, pb_, wr_)
+    // one 64-k stage held in buffer rd; (da_, db_) = A / B rows of the stage that goes into this buffer two stages on (dma_: it exists)
+#define W4X_STAGE(Z_, dma_, da_, db_)                                                                      \
+        {                                                                                                  \
+            const uint32_t ot = XSB - rd;                                                                  \
+            W4X_STEP(Z_, fa0, fb0, fa1, fb1, rd, 1, 0, false, da_, db_, rd)                                \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+            __builtin_amdgcn_s_barrier();                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            W4X_STEP(false, fa1, fb1, fa0, fb0, ot, 0, 1, dma_, da_, db_, rd)                              \
+            rd = ot;                                                                                       \
+        }
+
+    int L = blockIdx.x, m0, n0;
+    W4X_TILE(L, m0, n0);
+    const uint16_t* sA = A + (size_t)m0 * K;
+    const uint16_t* sB = B + (size_t)n0 * K;
+    W4X_ISSUE_ALL(sA, sB, 0u);                             // stage 0 -> buffer 0
+    {
+        const uint16_t* a1 = sA + XBK;
+        const uint16_t* b1 = sB + XBK;
+        W4X_ISSUE_ALL(a1, b1, XSB);                        // stage 1 -> buffer 1 (lands under stage 0)
+    }
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // in-order retirement: the 16 pieces of stage 0 have landed
+    __builtin_amdgcn_s_barrier();
+    f32x4_t acc[NI][NJ];
+    uint4 fa0[NJ], fb0[NI], fa1[NJ], fb1[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) W4X_RDB(fb0, 0u, 0, i);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) W4X_RDA(fa0, 0u, 0, j);
+    __builtin_amdgcn_sched_barrier(0);
+    for (;;) {
+        const int Ln = L + (int)gridDim.x;
+        const bool more = Ln < ntiles;
+        int m1 = m0, n1 = n0;
+        if (more) W4X_TILE(Ln, m1, n1);
+        const uint16_t* nA = A + (size_t)m1 * K;
+        const uint16_t* nB = B + (size_t)n1 * K;
+        uint32_t rd = 0;
+        // stage t feeds stage t + 2 into its own buffer; past the end of this tile that is stage t + 2 - nst of the NEXT tile
+        const uint16_t* pa = sA + 2 * XBK;
+        const uint16_t* pb = sB + 2 * XBK;
+        W4X_STAGE(true, true, pa, pb)                      // t = 0 (nst >= 4: stage 2 exists)
+        for (int t = 1; t + 2 < nst; ++t) {
+            pa += XBK;
+            pb += XBK;
+            W4X_STAGE(false, true, pa, pb)
+        }
+        W4X_STAGE(false, more, nA, nB)                     // t = nst - 2 (buffer 0): the next tile's stage 0
+        {
+            const uint16_t* a1 = nA + XBK;
+            const uint16_t* b1 = nB + XBK;
+            W4X_STAGE(false, more, a1, b1)                 // t = nst - 1 (buffer 1): the next tile's stage 1; its step 1 reads that tile's stage 0
+        }
+        // The last MFMA results must not be read for 18 wait states, and hipcc does not know the asm statements above are MFMAs: the
+        // padding is tied to every accumulator tile by data dependence (eight statements, one row of tiles each).
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if (j == 0)
+                asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0][j]), "+a"(acc[1][j]), "+a"(acc[2][j]), "+a"(acc[3][j]), "+a"(acc[4][j]),
+                             "+a"(acc[5][j]), "+a"(acc[6][j]), "+a"(acc[7][j]));
+            else
+                asm volatile("" : "+a"(acc[0][j]), "+a"(acc[1][j]), "+a"(acc[2][j]), "+a"(acc[3][j]), "+a"(acc[4][j]), "+a"(acc[5][j]),
+                             "+a"(acc[6][j]), "+a"(acc[7][j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + 2 * XSB + wave * (W4X_SCR_BYTES / 4);
+            epilogue_coalesced<PREC, OUT_F32, GELU, NJ, 1, NI>(acc, scr, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + wn * 128, accumulate, lane);
+        }
+        if (!more) break;
+        L = Ln; m0 = m1; n0 = n1; sA = nA; sB = nB;
+    }
+#undef W4X_TILE
+#undef W4X_PIECE
+#undef W4X_ISSUE_ALL
+#undef W4X_RDA
+#undef W4X_RDB
+#undef W4X_SLOT
+#undef W4X_SLOT8
+#undef W4X_STEP
+#undef W4X_STAGE
+}
+
+static bool w4x_ok(int M, int N, int K, const float* add2d, bool out_f32) {
+    return M % QBM == 0 && N % W4X_BN == 0 && K % (2 * XBK) == 0 && K >= 4 * XBK && !add2d && !out_f32;
+}
+
+template <int PREC>
+hipError_t launch_gemm_w4x(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, bool out_f32, bool gelu,
+                           bool accumulate, hipStream_t s) {
+    const int ntiles = (M / QBM) * (N / W4X_BN);
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    dim3 grid(ntiles > n_cu ? n_cu : ntiles), block(W4THREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    const int acc = accumulate ? 1 : 0;
+    if (out_f32) return hipErrorInvalidValue;
+    if (gelu && tl_gelu_form == 2) gemm_et_w4x_kernel<PREC, false, 2><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    else if (gelu) gemm_et_w4x_kernel<PREC, false, 1><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    else gemm_et_w4x_kernel<PREC, false, 0><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     return hipGetLastError();
 }
 
@@ -2967,6 +3285,17 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         else if (!out_f32 && N >= 2048 && t256 >= 1024) variant = 6;
         else variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
     }
+    // SAMRS_GEMM_W4X=1 (A/B runs; default off): ET + GELU outputs whose 256 x 256 tiles fill whole rounds (lin1 of ViT-H: 2560 tiles =
+    // 10 rounds at batch 8) go to the four-wave 128 x 128-wave-tile kernel.  Measured on MI355X: as a 2.5 s loop of its own it beats
+    // the persistent 256 x 320 kernel on that shape (412 us against 429, 1.03 against 1.08 pJ / FLOP: profiles/r05_gemm_energy.txt);
+    // INSIDE the tile loop, with the decoder's kernels on the neighbouring streams, it is 1 % slower (0.4397 / 0.4418 ms per lin1
+    // launch against 0.4366 / 0.4356, two alternations on one box; 140.8 / 140.4 against 140.7 / 140.3 images/s).  Plain ET
+    // outputs (qkv: 7.5 rounds) and the fp32 outputs (2.5 rounds) are slower on it in both settings.
+    static const bool w4x_auto = [] { const char* v = getenv("SAMRS_GEMM_W4X"); return v ? atoi(v) != 0 : false; }();
+    if (variant == 28 && w4x_auto && gelu && w4x_ok(M, N, K, add2d, out_f32)) {
+        const long t256 = (long)(M / QBM) * (N / W4X_BN);
+        if (t256 % 256 == 0 && t256 >= 1024) variant = 38;
+    }
     // 30 / 31: 32x32x16 symmetric-schedule kernel, persistent / one tile per block.  SAMRS_GEMM_M32=<mask> lets the automatic
     // rule pick it for A/B runs of the whole loop: bit 0 = ET outputs (qkv, lin1), bit 1 = fp32 outputs (proj, lin2),
     // bit 2 = one tile per block instead of persistent, bit 3 = spread pieces
@@ -2983,6 +3312,13 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
             if (prec == PREC_BF16) return launch_gemm_m32<PREC_BF16, 1>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, pers, s);
             if (prec == PREC_F16) return launch_gemm_m32<PREC_F16, 1>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, pers, s);
         }
+        return hipErrorInvalidValue;
+    }
+    // 38: the four-wave 256 x 256 kernel on 16x16x32 MFMAs with 128 x 128 wave tiles (round 5); shapes it does not cover fall back
+    if (variant == 38 && !w4x_ok(M, N, K, add2d, out_f32)) variant = add2d ? 27 : 28;
+    if (variant == 38) {
+        if (prec == PREC_BF16) return launch_gemm_w4x<PREC_BF16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_w4x<PREC_F16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
     }
     // 34 / 36: the four-wave, 512-register flavour of the symmetric schedule (persistent / one tile per block)
@@ -3095,6 +3431,29 @@ hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, cons
     if (prec == PREC_BF16) return launch_gemm_split3_prec<PREC_BF16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, split_from_n, add2d, add2d_period, s);
     if (prec == PREC_F16) return launch_gemm_split3_prec<PREC_F16>(a, al, b, bl, C, bias, M, N, K, out_f32, accumulate, split_from_n, add2d, add2d_period, s);
     return hipErrorInvalidValue;
+}
+
+// C (fp32) += A B^T + bias, then out_et = LayerNorm(C rows) * gamma + beta in the operand type, by the LayerNorm tail of the 256 x 320
+// pair-stage kernel (gemm_et_x64_kernel<LNT>).  Only where that kernel is what launch_gemm_et would pick for the shape anyway (fp32
+// output with at least one full round of 256 x 320 tiles) and N is one LayerNorm row; otherwise hipErrorInvalidValue and the caller
+// launches GEMM and LayerNorm separately.  counters: M / 256 zeroed uint32 (left zero by every launch).
+bool gemm_lntail_ok(int M, int N, int K) {
+    return M > 0 && M % QBM == 0 && N % WBN == 0 && N <= 2048 && K % XBK == 0 && K >= 2 * XBK && (long)(M / QBM) * (N / WBN) >= 256;
+}
+hipError_t launch_gemm_et_lntail(int prec, const void* A, const void* B, float* C, const float* bias, int M, int N, int K,
+                                 const float* gamma, const float* beta, float eps, void* out_et, unsigned int* counters, hipStream_t s) {
+    if (!gemm_lntail_ok(M, N, K) || !A || !B || !C || !gamma || !beta || !out_et || !counters) return hipErrorInvalidValue;
+    LnTail ln;
+    ln.gamma = gamma; ln.beta = beta; ln.out = reinterpret_cast<uint16_t*>(out_et); ln.counters = counters; ln.eps = eps;
+    dim3 grid((M / QBM) * (N / WBN)), block(QTHREADS);
+    const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
+    if (prec == PREC_F16)
+        gemm_et_x64_kernel<PREC_F16, true, false, 5, 3, 0, false, true><<<grid, block, 0, s>>>(a, b, C, bias, nullptr, 1, M, N, K, 1, g_x64_skew, nullptr, nullptr, ln);
+    else if (prec == PREC_BF16)
+        gemm_et_x64_kernel<PREC_BF16, true, false, 5, 3, 0, false, true><<<grid, block, 0, s>>>(a, b, C, bias, nullptr, 1, M, N, K, 1, g_x64_skew, nullptr, nullptr, ln);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 int swap_gelu_form(int v) { const int old = tl_gelu_form; tl_gelu_form = v; return old; }

@@ -29,6 +29,11 @@ hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, cons
 // split_from_n (ET output only, a multiple of 320): only output columns >= split_from_n take the lo terms; the tiles in front
 // of it are the plain hi x hi product (qkv: the v third alone)
 void set_gemm_variant(int v);   // process-wide test hook (kernel-level entry points): 0 = register-staged tiles, ..., 8 = automatic
+// proj / lin2 with the LayerNorm that follows them as a tail of the GEMM (gemm.hip gemm_et_x64_kernel<LNT>): C (fp32) += A B^T + bias,
+// out_et = LN(C) in the operand type; hipErrorInvalidValue where the shape does not take that kernel (caller: separate launches)
+bool gemm_lntail_ok(int M, int N, int K);
+hipError_t launch_gemm_et_lntail(int prec, const void* A, const void* B, float* C, const float* bias, int M, int N, int K,
+                                 const float* gamma, const float* beta, float eps, void* out_et, unsigned int* counters, hipStream_t s);
 int swap_gelu_form(int v);                // thread-local erf form of lin1's GELU epilogue (1 = fp32-epsilon class, 2 = cheaper); returns the previous value
 int swap_gemm_variant_override(int v);   // thread-local override (-1 = none) used by engine handles; returns the previous value
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)

@@ -169,6 +169,45 @@ def test_gemm_tile_variants_are_bit_identical(lib, name, prec, dt, ulp):
 
 
 @pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
+def test_gemm_w4x_kernel_is_bit_identical(lib, name, prec, dt, ulp):
+    """Round 5: the four-wave 256 x 256 x 64 kernel on v_mfma_f32_16x16x32 with 128 x 128 wave tiles and all 256
+    accumulator registers in AGPRs (variant 38; ET outputs).  It walks k in the same ascending 32-wide steps over the same LDS image
+    as the eight-wave pair-stage kernels, so it must reproduce them BIT FOR BIT -- ET output with and without the GELU -- on 4 to 80
+    stages, one to ten tiles per block (the persistent stage stream runs across tiles), and from launch to launch (the race screen
+    for its one-barrier-per-stage hand-over).  fp32 outputs fall back to the eight-wave kernel (checked: same bits, trivially)."""
+    lib.samrs_debug_set_gemm_variant.argtypes = [__import__("ctypes").c_int]
+    shapes = [(512, 256, 256), (2048, 1280, 1280), (16384, 2560, 256), (24576, 3840, 384), (32768, 5120, 1280), (32768, 1280, 5120)]
+    try:
+        for (M, N, K) in shapes:
+            g = torch.Generator().manual_seed(M + N + K + 38)
+            _, Ab = et_bits(torch.randn(M, K, generator=g), dt)
+            _, Bb = et_bits(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
+            bias = dev(torch.randn(N, generator=g))
+            res = dev(torch.randn(M, N, generator=g))
+            Ad, Bd = dev(Ab), dev(Bb)
+            ref = None
+            for variant, reps in ((27, 1), (38, 3)):
+                lib.samrs_debug_set_gemm_variant(variant)
+                for rep in range(reps):
+                    of = torch.zeros(M, N, device="cuda")
+                    oa = res.clone()
+                    oe = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+                    og = torch.zeros(M, N, dtype=torch.int16, device="cuda")
+                    assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), of.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 1, 0, 0, stream()) == 0
+                    assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), oa.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 1, 0, 1, stream()) == 0
+                    assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), oe.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 0, 0, 0, stream()) == 0
+                    assert lib.samrs_k_gemm(prec, Ad.data_ptr(), Bd.data_ptr(), og.data_ptr(), bias.data_ptr(), None, 0, M, N, K, 0, 1, 0, stream()) == 0
+                    if ref is None:
+                        ref = (of, oa, oe, og)
+                        assert of.abs().max() > 0 and not torch.equal(oe, og)
+                    else:
+                        for tag, x, y in zip(("fp32", "fp32 accumulate", "ET", "ET + GELU"), (of, oa, oe, og), ref):
+                            assert torch.equal(x, y), f"{name} {M}x{N}x{K}: variant 38 rep {rep} {tag} output differs from variant 27"
+    finally:
+        lib.samrs_debug_set_gemm_variant(8)
+
+
+@pytest.mark.parametrize("name,prec,dt,ulp", PRECS)
 @pytest.mark.parametrize("variant", [30, 31, 32, 33, 34, 36])
 def test_gemm_m32_kernel(lib, name, prec, dt, ulp, variant):
     """The 32x32x16 symmetric-schedule kernel (30 persistent / 31 one tile per block; 32 / 33 with the DMA pieces spread over

@@ -7,7 +7,7 @@ lib = engine.load_library()
 dev = torch.device("cuda"); s = torch.cuda.current_stream().cuda_stream
 n_img, heads, hd, grid = int(os.environ.get("NIMG", "8")), 16, 80, 64
 D = heads * hd
-reps = int(os.environ.get("REPS", "5"))
+reps = int(os.environ.get("REPS", "20"))
 g = torch.Generator().manual_seed(0)
 bias = torch.randn(3 * D, generator=g).to(dev)
 for name, rows, tab in (("window", n_img * 4096, 27), ("global", n_img * 4096, 127)):
@@ -27,4 +27,7 @@ for name, rows, tab in (("window", n_img * 4096, 27), ("global", n_img * 4096, 1
     ms = e0.elapsed_time(e1) / reps
     keys = 196 if name == "window" else 4096
     fl = 2.0 * 2.0 * n_img * 4096 * keys * hd * heads
-    print(f"{name} attention n_img={n_img}: {ms*1e3:.1f} us  ({fl/ms/1e9:.1f} TF algorithmic)", flush=True)
+    import hashlib
+    digest = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:12]      # variants of a kernel must agree bit for bit
+    print(f"{name} attention n_img={n_img}: {ms*1e3:.1f} us  ({fl/ms/1e9:.1f} TF algorithmic)  out sha {digest}  "
+          f"[WIN_PIPE={os.environ.get('SAMRS_WIN_PIPE', '-')} GLB_PIPE={os.environ.get('SAMRS_GLB_PIPE', '-')}]", flush=True)

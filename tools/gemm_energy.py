@@ -98,7 +98,8 @@ for name, N, K, of32, gelu, acc in (("qkv", 3840, 1280, 0, 0, 0), ("proj+res", 1
     C = torch.zeros(M, N, dtype=torch.float32 if of32 else torch.int16, device="cuda")
     out = torch.empty(M, N, dtype=torch.float16, device="cuda")
     flop = 2.0 * M * N * K
-    arms = [("ours (default)", 8), ("ours m32 (v30)", 30), ("ours w4 (v34)", 34)]
+    # round 5: the four-wave 16x16x32 kernel (v38) next to the default; the 32x32x16 kernels of round 2 (v30 / v34) with ARMS_FULL=1
+    arms = [("ours (default)", 8), ("ours w4x (v38)", 38)] + ([("ours m32 (v30)", 30), ("ours w4 (v34)", 34)] if os.environ.get("ARMS_FULL") else [])
     for label, var in arms:
         lib.samrs_debug_set_gemm_variant(var)
         ms, w, clk = arm(lambda: lib.samrs_k_gemm(1, A.data_ptr(), W.data_ptr(), C.data_ptr(), bias.data_ptr(), None, 0, M, N, K, of32, gelu, acc, s), flop)

@@ -30,18 +30,37 @@ for step in "$@"; do
              SAMRS_LIB_PATH=${AB_LIB:-samrs_amd/csrc/libsamrs_hip_noskew.so} run attnpmc0 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d gpurun_out/attnpmc0 -o p -- python tools/attn_bench.py
              run attnpmc2 300 rocprofv3 --pmc FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/attnpmc2 -o p -- python tools/attn_bench.py ;;
     k_gemm)  run k_gemm 600 $PT tests/test_kernels_gpu.py -k "gemm" ;;
+    k_w4x)   run k_w4x 600 $PT tests/test_kernels_gpu.py -k "w4x" ;;
+    energy)  run energy 300 python tools/gemm_energy.py ;;
     k_rbox)  run k_rbox 300 $PT tests/test_rbox_prompt.py ;;
     golden)  run golden 900 $PT tests/test_parity_gpu.py -k "reference_golden or vit_b_c1" ;;
     wint)    SAMRS_LIB_PATH=build/ab/libsamrs_hip_wt.so run wint 200 python tools/win_timeline.py ;;
     energy2) run energy_new 300 python tools/gemm_energy.py
              SAMRS_LIB_PATH=${AB_LIB:-build/ab/libsamrs_hip_as26.so} run energy_old 300 python tools/gemm_energy.py ;;
+    attnab)  for v in "0 0" "1 1" "3 1" "0 0" "1 1" "3 1"; do read wp gp <<< "$v"; SAMRS_WIN_PIPE=$wp SAMRS_GLB_PIPE=$gp run "attnab_w${wp}g${gp}_$SECONDS" 200 python tools/attn_bench.py; done ;;
+    wint1)   SAMRS_WIN_PIPE=1 SAMRS_LIB_PATH=build/ab/libsamrs_hip_wt.so run wint1 200 python tools/win_timeline.py
+             SAMRS_WIN_PIPE=3 SAMRS_LIB_PATH=build/ab/libsamrs_hip_wt.so run wint3 200 python tools/win_timeline.py ;;
+    range)   run range 600 $PT tests/test_parity_gpu.py -k "operand_range" ;;
+    w4xab)   for r in 1 2; do for v in 0 1; do SAMRS_GEMM_W4X=$v run "bench_w4x${v}_r$r" 400 python bench.py --steps ${BENCH_STEPS:-12} --warmup 3 $BQ; done; done
+             grep -h '"value"' gpurun_out/bench_w4x*.log | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('w4x A/B', d['value'], 'img/s', d['ms_per_step'], 'ms/step; lin1', d['roofline']['avg_launch_ms'], 'ms', d['roofline']['achieved'], 'TF')
+" | tee -a gpurun_out/summary.txt ;;
+    lntail)  run lntail 600 $PT tests/test_parity_gpu.py -k "layernorm_tail" ;;
+    abenv)   # A/B of engine env switches on one box: ABENV="NAME=a NAME=b ..." alternated ABR times
+             for r in $(seq 1 ${ABR:-2}); do for kv in ${ABENV}; do env $kv bash -c "timeout 400 python bench.py --steps ${BENCH_STEPS:-16} --warmup 4 $BQ" > "gpurun_out/ab_${kv}_r$r.log" 2>&1
+               grep -h '"value"' "gpurun_out/ab_${kv}_r$r.log" | python -c "
+import sys, json
+for l in sys.stdin:
+    d = json.loads(l); print('$kv r$r:', d['value'], 'img/s', d['ms_per_step'], 'ms/step; lin1', d['roofline']['avg_launch_ms'], 'ms')
+" | tee -a gpurun_out/summary.txt; done; done ;;
     kmx)     run kmx 600 $PT tests/test_kernels_gpu.py -k "mx" ;;
     c4ab)    SAMRS_LO_FORMAT=0 run c4_lo0 400 python bench.py --workload c4 --steps ${BENCH_STEPS:-12} --warmup 3 $BQ
              SAMRS_LO_FORMAT=4 run c4_lo4 400 python bench.py --workload c4 --steps ${BENCH_STEPS:-12} --warmup 3 $BQ
              SAMRS_LO_FORMAT=0 run c4_lo0b 400 python bench.py --workload c4 --steps ${BENCH_STEPS:-12} --warmup 3 $BQ
              SAMRS_LO_FORMAT=4 run c4_lo4b 400 python bench.py --workload c4 --steps ${BENCH_STEPS:-12} --warmup 3 $BQ ;;
     mxb)     run mxb 300 python tools/mx_bench.py ;;
-    energy)  run energy 300 python tools/gemm_energy.py ;;
     profc4)  prof_env
              SAMRS_LO_FORMAT=${LOF:-4} run profc4 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/profc4 -o c4 -- python bench.py --workload c4 --steps 3 --warmup 1 $BQ ;;
     pstats)  run pstats 1500 python tools/parity_stats.py --modes ${PS_MODES:-15,79,63} ${PS_ARGS:-} ;;

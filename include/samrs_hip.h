@@ -208,7 +208,7 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    not.  Automatic: every block for 16 / 32, the leading three quarters (24 of 32) for 64.
  *   "decoder_fusion" [SAMRS_DECODER_FUSION, default 1] 0 = run the decoder with its un-fused kernels (separate GEMM / LayerNorm /
  *                    product launches; never split): the fused-vs-unfused parity test and timing experiments.
- *   "ln_fold"        [SAMRS_LN_FOLD, default 0] (embed_dim 1280; only while no block-GEMM bit of "split" is set) 1 = fold the encoder blocks' LayerNorms into the qkv / lin1
+ *   "ln_fold"        [SAMRS_LN_FOLD, default 0] (EXPERIMENTS builds only; embed_dim 1280; only while no block-GEMM bit of "split" is set) 1 = fold the encoder blocks' LayerNorms into the qkv / lin1
  *                    GEMMs.  Measured slower on MI355X.  Must be on before samrs_finalize_weights for the folded weights to
  *                    exist; can be flipped afterwards.
  *   "gemm_variant"   [default -1 = automatic] GEMM tile variant for this handle's launches (tools/gemm_bench.py lists them).
@@ -232,14 +232,13 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    1x-rate modes ("split" without a block-GEMM bit: what the single-mask pipelines run), 0 in every reference-grade
  *                    mode, whose arithmetic stays bit for bit what its committed parity statistics were measured on.  Applies where
  *                    lin1 runs on the persistent 256 x 320 kernel (ViT-H shapes); elsewhere the option has no effect.
- *   "ln_tail"        [SAMRS_LN_TAIL, default -1 = automatic] 1 = the LayerNorm that follows proj (norm2, image_encoder.py:177) and lin2
- *                    (norm1 of the next block, :168) runs as a TAIL of those GEMM launches instead of a launch of its own: the block that
- *                    stores the last of the four 256 x 320 tiles of a 256-row panel normalises the panel's rows out of the L2 they were
- *                    just written to (release / counter / acquire between the four blocks, no block ever waits: gemm.hip LnTail), which
- *                    removes 63 of the 64 LayerNorm launches of an encoder pass and their re-read of the 168 MB residual stream.
- *                    Automatic: on in the 1x-rate modes ("split" without a block-GEMM bit) where proj / lin2 fill at least one round
- *                    of 256 x 320 tiles (batches of 4+ tiles at ViT-H); the reference-grade modes need the LayerNorm's lo / MXFP4
- *                    outputs and keep the stand-alone kernel.  0 = always the stand-alone LayerNorm (A/B runs, tests).
+ *   "ln_tail"        [SAMRS_LN_TAIL, default 0] 1 = the LayerNorm that follows proj (norm2, image_encoder.py:177) and lin2 (norm1 of the
+ *                    next block, :168) runs as a TAIL of those GEMM launches instead of a launch of its own: the block that stores the
+ *                    last of the four 256 x 320 tiles of a 256-row panel normalises the panel's rows (release / counter / acquire between
+ *                    the four blocks, nobody waits: gemm.hip LnTail).  Bit-identical with the stand-alone LayerNorm, and measured SLOWER
+ *                    (61.8 against 57.2 ms per 8-tile step): one CU draws ~20 GB/s from HBM, so a panel takes it 62 us where a LayerNorm
+ *                    launch on all 256 CUs takes 53 for the whole tensor (profiles/r05_ln_tail.txt).  Kept as an option for the record
+ *                    and for its test; 1x-rate modes only, batches of 4+ tiles at ViT-H.
  *   "range_check"    [SAMRS_RANGE_CHECK, default 0] the f16 operand type has 11 mantissa bits (what the IoU >= 0.999 bar needs) but
  *                    tops out at 65504, and every conversion on the path SATURATES there instead of overflowing to inf -- silently.
  *                    1 = after each producer of an MFMA-operand tensor in the encoder (both LayerNorm outputs, q | k | v, the
@@ -258,6 +257,10 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value);
  * and the start skew of the first round of GEMM blocks, per XCD / per CU group, in 1024-cycle units (0, 0 = off). */
 void samrs_debug_set_gemm_variant(int variant);
 void samrs_debug_set_gemm_skew(int xcd_units, int cu_units);
+/* 1 when the library was built with `make EXPERIMENTS=1`: the kernels that were measured and not adopted (GEMM variants 30 - 36 on
+ * v_mfma_f32_32x32x16, the LayerNorm fold "ln_fold", the timing ablations 60 - 92 / 100 - 196) exist; 0 in the product build, where those
+ * variants fall back to the default kernels and "ln_fold" = 1 is refused. */
+int samrs_debug_has_experiments(void);
 
 /* -- test hook: copy a prefix of a named internal decoder buffer (Q, KF, KE, KVQ, OI, U1raw, U1, U2,
  * HYPER, ...) to a device buffer; used to localise run-to-run differences. */

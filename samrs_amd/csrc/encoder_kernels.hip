@@ -1530,9 +1530,13 @@ static hipError_t launch_win(const void* qkv, const float* qb, const float* rh, 
     // SAMRS_WIN_PIPE=1 / 3: the software-pipelined tile loop (/ + static priority for the younger waves); A/B runs
     // measured (profiles/r05_attention_pipelining.txt): no faster, and the rel-pos row terms take one more rounding on their way through
     // the scratch (the un-pipelined loop contracts RH[j] = t * log2(e) into the add that consumes it): default OFF
+#ifdef SAMRS_EXPERIMENTS        // make EXPERIMENTS=1: the pipelined flavours exist (tools/attn_bench.py A/B runs)
     static const int pipe = [] { const char* v = getenv("SAMRS_WIN_PIPE"); return v ? atoi(v) & 3 : 0; }();
     auto k = pipe == 3 ? window_attention_kernel<PREC, HD, LO, 3> : pipe == 2 ? window_attention_kernel<PREC, HD, LO, 2>
            : pipe == 1 ? window_attention_kernel<PREC, HD, LO, 1> : window_attention_kernel<PREC, HD, LO, 0>;
+#else
+    auto k = window_attention_kernel<PREC, HD, LO, 0>;
+#endif
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
     if (heads * HD > C::MAX_D) return hipErrorInvalidValue;
     const int nw = (grid + C::WS - 1) / C::WS;
@@ -1580,8 +1584,12 @@ static hipError_t launch_glb_nw(const void* qkv, const float* rh, const float* r
     using C = GlbCfg<HD, NW>;
     constexpr int NTOK = C::G * C::G;
     // SAMRS_GLB_PIPE=1: the software-pipelined tile loop (bit-identical; measured 2 - 3 % SLOWER: default off)
+#ifdef SAMRS_EXPERIMENTS
     static const bool pipe = [] { const char* v = getenv("SAMRS_GLB_PIPE"); return v ? atoi(v) != 0 : false; }();
     auto k = pipe ? global_attention_kernel<PREC, HD, NW, LO, 1> : global_attention_kernel<PREC, HD, NW, LO, 0>;
+#else
+    auto k = global_attention_kernel<PREC, HD, NW, LO, 0>;
+#endif
     HIP_CHECK_RET(set_lds(k, C::LDS_BYTES));
     dim3 g((NTOK / (32 * NW)) * heads * n_images), b(64 * NW);
     k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, (const uint16_t*)vt_ws, rh, rw, (uint16_t*)out, heads, (uint16_t*)out_lo, mx);

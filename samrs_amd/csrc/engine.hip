@@ -143,7 +143,7 @@ struct samrs_engine {
     // option "range_check" (0 off, 1 count, 2 count and fail): after every producer of an MFMA-operand tensor in the encoder a
     // scan counts the elements sitting at the operand type's saturation value (f16: +-65504, what common.h's saturating
     // conversions write) or beyond into *range_counter (device); read through option "saturated"
-    int ln_tail = -1;              // option "ln_tail": -1 automatic (on in the 1x-rate modes where the shapes allow), 0 off, 1 on
+    int ln_tail = 0;               // option "ln_tail": 1 = the LayerNorm behind proj / lin2 as a tail of those launches (measured slower: off)
     unsigned int* ln_counters = nullptr;   // per 256-row panel: tiles of the running proj / lin2 launch that have stored (gemm.hip LnTail)
     int gelu_fast = -1;            // option "gelu_fast": -1 automatic (on in the 1x-rate modes: no block-GEMM bit in "split"), 0 off, 1 on
     int range_check = 0;
@@ -387,7 +387,7 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->slot_split.assign(cfg->max_images, 0);
     e->slot_depth.assign(cfg->max_images, 0);
     e->decoder_fusion = env_int("SAMRS_DECODER_FUSION", 1) != 0;
-    e->ln_fold = env_int("SAMRS_LN_FOLD", 0) != 0;
+    e->ln_fold = env_int("SAMRS_LN_FOLD", 0) != 0 && gemm_has_experiments();
     // default: the cheap rounding points everywhere; where the one-launch split GEMM covers the block shapes (ViT-H), also the
     // v third of qkv + proj in the leading blocks -- that is what it takes to hold IoU >= 0.999 on the multimask (C4)
     // fixtures at ViT-H, for 0.90x the throughput.  SAMRS_SPLIT=15 / option "split" = 15: the 1x-rate arithmetic.
@@ -402,8 +402,7 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->split_depth = env_int("SAMRS_SPLIT_DEPTH", 0);
     e->lo_format = (h_like && env_int("SAMRS_LO_FORMAT", 4) == 4) ? 4 : 0;
     e->gelu_fast = env_int("SAMRS_GELU_FAST", -1);
-    e->ln_tail = env_int("SAMRS_LN_TAIL", -1);
-    if (e->ln_tail > 1) e->ln_tail = 1;
+    e->ln_tail = env_int("SAMRS_LN_TAIL", 0) != 0;
     if (e->gelu_fast > 1) e->gelu_fast = 1;
     if (const int rc0 = env_int("SAMRS_RANGE_CHECK", 0)) {
         if (samrs_set_option(e, "range_check", rc0) != SAMRS_OK) {
@@ -495,7 +494,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
         b.global = is_global(c, i);
         b.ln1w = W(e, p + ".norm1.weight"); b.ln1b = W(e, p + ".norm1.bias");
         b.ln2w = W(e, p + ".norm2.weight"); b.ln2b = W(e, p + ".norm2.bias");
-        if (D == 1280 && e->ln_fold) {       // folded LayerNorm needs the fp32 weights: before to_et() frees them
+        if (D == 1280 && e->ln_fold && gemm_has_experiments()) {       // folded LayerNorm needs the fp32 weights: before to_et() frees them
             CK(e, dalloc(e, &b.qkv_wf, (size_t)3 * D * D)); CK(e, dalloc(e, &b.qkv_c, (size_t)3 * D)); CK(e, dalloc(e, &b.qkv_bf, (size_t)3 * D));
             CK(e, dalloc(e, &b.lin1_wf, (size_t)4 * D * D)); CK(e, dalloc(e, &b.lin1_c, (size_t)4 * D)); CK(e, dalloc(e, &b.lin1_bf, (size_t)4 * D));
             CK(e, launch_ln_fold_weight(e->prec, W(e, p + ".attn.qkv.weight"), b.ln1w, b.ln1b, W(e, p + ".attn.qkv.bias"), b.qkv_wf,
@@ -737,10 +736,12 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     // fits the 256 x 320 tile (ViT-H); SAMRS_SPLIT_PASSES=1 / option "split_passes" keeps the three accumulating launches (A/B)
     const bool one3 = !e->split_passes;
     const bool fast_gelu = e->gelu_fast >= 0 ? e->gelu_fast != 0 : !(e->split & (SPLIT_ATTN_ANY | SPLIT_MLP | SPLIT_LIN2));
-    // The LayerNorm behind proj (norm2) and behind lin2 (the next block's norm1) as a tail of those GEMMs (gemm.hip LnTail): the
-    // 1x-rate modes only -- the reference-grade modes want the LayerNorm's lo / MXFP4 outputs and keep their arithmetic bit for bit --
-    // and only where the shapes take the 256 x 320 kernel (at least one full round of tiles: batches of 4 tiles and more at ViT-H)
-    const bool ln_tail = !fold && !(e->split & (SPLIT_ATTN_ANY | SPLIT_MLP | SPLIT_LIN2)) && (e->ln_tail >= 0 ? e->ln_tail != 0 : true) &&
+    // The LayerNorm behind proj (norm2) and behind lin2 (the next block's norm1) as a tail of those GEMMs (gemm.hip LnTail): OPT-IN
+    // (option "ln_tail" = 1).  Built, bit-identical with the stand-alone kernel, and measured slower (profiles/r05_ln_tail.txt): the
+    // panel is normalised by ONE CU, and one CU draws ~20 GB/s from HBM -- 62 us for the 1.3 MB of a panel, against 53 us for a
+    // LayerNorm launch that uses all 256.  The 1x-rate modes only (the reference-grade modes want the LayerNorm's lo / MXFP4 outputs),
+    // and only where the shapes take the 256 x 320 kernel (at least one full round of tiles: batches of 4 tiles and more at ViT-H).
+    const bool ln_tail = !fold && !(e->split & (SPLIT_ATTN_ANY | SPLIT_MLP | SPLIT_LIN2)) && e->ln_tail > 0 &&
                          e->ln_counters && gemm_lntail_ok(M, D, D) && gemm_lntail_ok(M, D, 4 * D);
     bool y_ready = false;          // Y already holds norm1 of the block about to start (written by the previous block's lin2 launch)
     if (fold && n_blocks > 0) {
@@ -1282,6 +1283,7 @@ int samrs_paint(samrs_engine_t* e, const uint8_t* masks, const int32_t* labels, 
 
 void samrs_debug_set_gemm_variant(int v) { set_gemm_variant(v); }
 void samrs_debug_set_gemm_skew(int xcd_units, int cu_units) { set_gemm_skew(xcd_units, cu_units); }
+int samrs_debug_has_experiments(void) { return gemm_has_experiments() ? 1 : 0; }
 int samrs_select_best(samrs_engine_t* e, const uint8_t* masks, const float* iou, int n, int n_sel, int h, int w, uint8_t* best_out,
                       float* quality_out, int64_t* areas_out, void* stream) {
     if (!e || !masks || !iou || !best_out || !quality_out || !areas_out || n < 1 || n_sel < 1 || h < 1 || w < 1)
@@ -1296,7 +1298,11 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     if (!e || !name) return SAMRS_ERR_BAD_ARG;
     const std::string n(name);
     if (n == "decoder_fusion") e->decoder_fusion = value != 0;
-    else if (n == "ln_fold") e->ln_fold = value != 0;
+    else if (n == "ln_fold") {
+        if (value && !gemm_has_experiments())
+            return fail(e, SAMRS_ERR_BAD_ARG, "ln_fold: the folded LayerNorm (measured slower: DESIGN.md 6) is built with make EXPERIMENTS=1 only");
+        e->ln_fold = value != 0;
+    }
     else if (n == "split") {
         if (e->finalized && (value & (SPLIT_ATTN_ANY | SPLIT_MLP | SPLIT_LIN2) & ~e->split_ready))
             return fail(e, SAMRS_ERR_BAD_ARG, "split bits 16 / 32 / 64 / 128 (block GEMMs) need their lo weights: set them before the weights are "
@@ -1309,7 +1315,7 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     else if (n == "split_depth") e->split_depth = value > 0 ? value : 0;
     else if (n == "allow_reduced") e->allow_reduced = value != 0;
     else if (n == "gelu_fast") e->gelu_fast = value < 0 ? -1 : (value != 0);
-    else if (n == "ln_tail") e->ln_tail = value < 0 ? -1 : (value != 0);
+    else if (n == "ln_tail") e->ln_tail = value > 0;
     else if (n == "range_check") {
         if (value < 0 || value > 2) return fail(e, SAMRS_ERR_BAD_ARG, "range_check is 0 (off), 1 (count) or 2 (count, and samrs_set_images fails)");
         if (value && !e->range_counter) {

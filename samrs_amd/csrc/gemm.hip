@@ -948,10 +948,11 @@ __device__ __forceinline__ const uint16_t* seg_src_b(const uint16_t* hi, const u
 // the 168 MB stream from HBM / MALL (53 us per launch, 64 launches per encoder pass = 6 % of the step for zero FLOPs).  Here every block,
 // once its own stores are complete, publishes them (agent-scope release by one lane after a block barrier: cdna_hip_programming.md
 // 6 G16) and bumps a counter of its row panel; the block that finds the other tiles_n - 1 already counted -- the LAST ARRIVER -- makes
-// them visible to itself (agent-scope acquire) and normalises the panel's 256 rows: one wave per row as in layernorm_kernel, same
-// expressions, the next row's loads in flight under the current row's arithmetic; the rows come out of the L2 the four blocks just
-// wrote them to.  Nobody ever waits for anybody (no spin, no ordering assumption: whichever block arrives last does the work), the
-// counter is reset by the last arriver for the next launch.  N must be the LayerNorm width.
+// them visible to itself (agent-scope acquire) and normalises the panel's 256 rows with layernorm_kernel's arithmetic (bit-identical
+// output).  Nobody ever waits for anybody (no spin, no ordering or placement assumption: whichever block arrives last does the
+// work), the counter is reset by the last arriver for the next launch.  A variant that wrote the tiles with sc1 stores instead of
+// the release fence was no faster and WRONG (plain loads on another CU still hit the L2 lines the residual read had allocated).
+// N <= 1280 must be the LayerNorm width.
 struct LnTail {
     const float* gamma = nullptr;
     const float* beta = nullptr;
@@ -1169,7 +1170,9 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
         int* flag = reinterpret_cast<int*>(lds);               // the ring is idle: every wave is past its bounce after the barrier below
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores of the tile have completed
         __syncthreads();                                       // ... everybody's
-        if (tid == 0) {
+        if (threadIdx.x == 0) {
+            // publish the tile (agent-scope release: L2 write-back), count it, and if it was the panel's last: make the other
+            // tiles visible to this CU (agent-scope acquire).  cdna_hip_programming.md 6 G16: placement-independent.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             const unsigned int old = __hip_atomic_fetch_add(ln.counters + tile_m, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = old == (unsigned int)(tiles_n - 1);
@@ -1181,56 +1184,68 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
         }
         __syncthreads();
         if (*flag == 0) return;
-        // ---- last arriver: LayerNorm of rows m0 .. m0 + 255, one wave per row, 32 rows per wave (layernorm_kernel's arithmetic) ----
-        constexpr int LNV = 8;                                 // float4 per lane: N <= 2048
+        // ---- last arriver: LayerNorm of rows m0 .. m0 + 255: wave w takes rows 32 w .. 32 w + 31, one row at a time with
+        // layernorm_kernel's arithmetic, the next row's loads in flight under the current row's.  Everything the tail needs is
+        // RE-DERIVED here from an opaque copy of threadIdx.x: the kernel sits at 256 VGPRs, and every value kept alive across the
+        // epilogue for the tail's sake turned into scratch traffic inside the epilogue of EVERY block (versions 1 - 3: forty spill
+        // instructions there, each with a vmcnt(0) that serialises the residual loads: +185 us per launch, profiles/r05_ln_tail.txt).
+        int tid_t = threadIdx.x;
+        asm volatile("" : "+v"(tid_t));
+        const int lane_t = tid_t & 63, wave_t = __builtin_amdgcn_readfirstlane(tid_t >> 6);
+        // Latency: by the time the last tile lands most of the panel has left the 4 MB L2 (a round of tiles writes 10 MB per XCD), a
+        // row costs a ~3 us trip to the Infinity Cache / HBM, and with ONE row in flight per wave the tail took 100 us (version 4:
+        // proj + tail 340 us against 134 + 53, rocprofv3).  So a ring of eight row buffers per wave: 64 rows = 320 KB in flight per CU.
+        constexpr int LNV = 5, LNP = 8;                        // float4 per lane and row (N <= 1280); rows in flight per wave
         const int nv = N >> 2;
         const float* X = reinterpret_cast<const float*>(Cv);
-        float4 cur[LNV], nxt[LNV];
-#define LNT_LOAD(dst_, row_)                                                                               \
+        float4 ring[LNP][LNV];
+        const int row0 = tile_m * QBM + wave_t * 32;
+#define LNT_LOAD(slot_, row_)                                                                              \
         {                                                                                                  \
             const float4* xr_ = reinterpret_cast<const float4*>(X + (size_t)(row_) * N);                    \
-            _Pragma("unroll") for (int i = 0; i < LNV; ++i) { const int idx = lane + 64 * i; if (idx < nv) dst_[i] = xr_[idx]; } \
+            _Pragma("unroll") for (int i = 0; i < LNV; ++i) { const int idx = lane_t + 64 * i; if (idx < nv) ring[slot_][i] = xr_[idx]; } \
         }
-        const int row0 = m0 + wave * 32;
-        LNT_LOAD(cur, row0)
-        for (int r = 0; r < 32; ++r) {
-            const int row = row0 + r;
-            if (r + 1 < 32) LNT_LOAD(nxt, row + 1)
-            float sm = 0.f;
 #pragma unroll
-            for (int i = 0; i < LNV; ++i) {
-                const int idx = lane + 64 * i;
-                if (idx < nv) sm += (cur[i].x + cur[i].y) + (cur[i].z + cur[i].w);
-            }
-            const float mean = wave_sum(sm) / (float)N;
-            float q = 0.f;
+        for (int sl = 0; sl < LNP; ++sl) LNT_LOAD(sl, row0 + sl)
+        for (int g = 0; g < 32 / LNP; ++g) {
 #pragma unroll
-            for (int i = 0; i < LNV; ++i) {
-                const int idx = lane + 64 * i;
-                if (idx < nv) {
-                    const float a = cur[i].x - mean, b = cur[i].y - mean, c = cur[i].z - mean, d = cur[i].w - mean;
-                    q += (a * a + b * b) + (c * c + d * d);
+            for (int sl = 0; sl < LNP; ++sl) {
+                const int row = row0 + g * LNP + sl;
+                float sm = 0.f;
+#pragma unroll
+                for (int i = 0; i < LNV; ++i) {
+                    const int idx = lane_t + 64 * i;
+                    if (idx < nv) sm += (ring[sl][i].x + ring[sl][i].y) + (ring[sl][i].z + ring[sl][i].w);
                 }
-            }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + ln.eps);
+                const float mean = wave_sum(sm) / (float)N;
+                float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < LNV; ++i) {
-                const int idx = lane + 64 * i;
-                if (idx < nv) {
-                    const float4 g = reinterpret_cast<const float4*>(ln.gamma)[idx];
-                    const float4 bt = reinterpret_cast<const float4*>(ln.beta)[idx];
-                    const float o0 = (cur[i].x - mean) * rstd * g.x + bt.x;
-                    const float o1 = (cur[i].y - mean) * rstd * g.y + bt.y;
-                    const float o2 = (cur[i].z - mean) * rstd * g.z + bt.z;
-                    const float o3 = (cur[i].w - mean) * rstd * g.w + bt.w;
-                    uint2 o;
-                    o.x = pack2<PREC>(o0, o1);
-                    o.y = pack2<PREC>(o2, o3);
-                    reinterpret_cast<uint2*>(ln.out + (size_t)row * N)[idx] = o;
+                for (int i = 0; i < LNV; ++i) {
+                    const int idx = lane_t + 64 * i;
+                    if (idx < nv) {
+                        const float a = ring[sl][i].x - mean, b = ring[sl][i].y - mean, c = ring[sl][i].z - mean, d = ring[sl][i].w - mean;
+                        q += (a * a + b * b) + (c * c + d * d);
+                    }
                 }
-            }
+                const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + ln.eps);
 #pragma unroll
-            for (int i = 0; i < LNV; ++i) cur[i] = nxt[i];
+                for (int i = 0; i < LNV; ++i) {
+                    const int idx = lane_t + 64 * i;
+                    if (idx < nv) {
+                        const float4 g4 = reinterpret_cast<const float4*>(ln.gamma)[idx];
+                        const float4 bt = reinterpret_cast<const float4*>(ln.beta)[idx];
+                        const float o0 = (ring[sl][i].x - mean) * rstd * g4.x + bt.x;
+                        const float o1 = (ring[sl][i].y - mean) * rstd * g4.y + bt.y;
+                        const float o2 = (ring[sl][i].z - mean) * rstd * g4.z + bt.z;
+                        const float o3 = (ring[sl][i].w - mean) * rstd * g4.w + bt.w;
+                        uint2 o;
+                        o.x = pack2<PREC>(o0, o1);
+                        o.y = pack2<PREC>(o2, o3);
+                        reinterpret_cast<uint2*>(ln.out + (size_t)row * N)[idx] = o;
+                    }
+                }
+                if (g + 1 < 32 / LNP) LNT_LOAD(sl, row + LNP)       // this slot's next row goes out as soon as the slot is free
+            }
         }
 #undef LNT_LOAD
     }
@@ -1517,6 +1532,7 @@ hipError_t launch_gemm_x64p_mxo(const void* A, const void* B, void* C, const flo
 // k is accumulated in 16-wide MFMA steps, so results are NOT bit-identical with the 16x16x32 kernels (same fp32
 // accumulation error class; tests/test_kernels_gpu.py::test_gemm_m32_*).
 // ---------------------------------------------------------------------------------------------
+#ifdef SAMRS_EXPERIMENTS   // the round-2 32x32x16 kernels (m32, w4) and the LayerNorm fold built on them: measured slower, tools / A-B builds only (make EXPERIMENTS=1)
 constexpr int M32_RS = 144;                   // scratch row stride (bytes): 128 data bytes + 16; 36 words = 4 (mod 32)
 
 // Epilogue of one wave tile: acc[i][j] = 32 (n) x 32 (m) block, lane (m = l & 31, h = l >> 5) holds n = 8 g + 4 h + 0..3
@@ -1633,6 +1649,7 @@ __device__ __forceinline__ void epilogue_m32(f32x16_t (&acc)[5][NJ], unsigned ch
     }
 }
 
+#endif  // SAMRS_EXPERIMENTS (epilogue_m32)
 // LDS-DMA piece with M0 declared as clobbered instead of saved / restored (two SALU instructions less per piece)
 __device__ __forceinline__ void glds16_m(uint32_t voff, const void* sbase, uint32_t m0v) {
     asm volatile(
@@ -1644,6 +1661,7 @@ __device__ __forceinline__ void glds16_m(uint32_t voff, const void* sbase, uint3
         : "memory", "m0");
 }
 
+#ifdef SAMRS_EXPERIMENTS
 // SPREAD: 0 = the 9 DMA pieces of a stage all go out in step 3 (one behind each of the first 9 MFMAs); 1 = pieces 0-4 in
 // step 3 and pieces 5-8 in step 0 of the following stage (fewer fillers per gap, one step less in flight)
 template <int PREC, bool OUT_F32, bool GELU, int SPREAD, bool STATS = false>
@@ -1833,6 +1851,7 @@ hipError_t launch_gemm_m32(const void* A, const void* B, void* C, const float* b
     }
     return hipGetLastError();
 }
+#endif  // SAMRS_EXPERIMENTS (gemm_et_m32_kernel)
 // ---------------------------------------------------------------------------------------------
 // gemm_et_w4_kernel: the symmetric 32x32x16 schedule above on FOUR waves with 512 registers each (one wave per SIMD).
 //
@@ -1852,6 +1871,7 @@ hipError_t launch_gemm_m32(const void* A, const void* B, void* C, const float* b
 constexpr int W4THREADS = 256;
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
+#ifdef SAMRS_EXPERIMENTS
 template <int PREC, bool AG>
 __device__ __forceinline__ void mfma32_asm(f32x16_t& c, const uint4& a, const uint4& b) {
     const u32x4_t av = __builtin_bit_cast(u32x4_t, a), bv = __builtin_bit_cast(u32x4_t, b);
@@ -2070,6 +2090,7 @@ hipError_t launch_gemm_w4(const void* A, const void* B, void* C, const float* bi
     return hipGetLastError();
 }
 
+#endif  // SAMRS_EXPERIMENTS (gemm_et_w4_kernel)
 // ---------------------------------------------------------------------------------------------
 // gemm_et_w4x_kernel (round 5): the vendor's tile geometry on this file's LDS-DMA pair stages -- 256 x 256 x 64 macro tile, FOUR waves
 // with 512 registers each, wave tile 128 x 128 on v_mfma_f32_16x16x32 (the form tools/mfma_rate.hip measures 24 % faster than
@@ -2301,6 +2322,7 @@ hipError_t launch_gemm_w4x(const void* A, const void* B, void* C, const float* b
     return hipGetLastError();
 }
 
+#ifdef SAMRS_EXPERIMENTS
 // producer of the folded LayerNorm: C = A B^T + bias + C (fp32), Xh = ET(C), stats[m][N / 160] = (mean, M2) per 160 columns
 template <int PREC>
 hipError_t launch_gemm_m32_stats(const void* A, const void* B, float* C, const float* bias, void* Xh, float* stats,
@@ -2336,6 +2358,7 @@ static bool m32_ok(int M, int N, int K, const float* add2d) {
     return M % QBM == 0 && N % WBN == 0 && K % (2 * XBK) == 0 && K >= 2 * XBK && !add2d;
 }
 
+#endif  // SAMRS_EXPERIMENTS (fold launchers, m32_ok)
 template <int PREC, int NI, int MODE>
 hipError_t launch_gemm_x64(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
@@ -3210,6 +3233,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         case 3: return launch_gemm_prec<P, false, 8>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
         default: return launch_gemm_prec<P, true, 8>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \
     }
+#ifdef SAMRS_EXPERIMENTS
     if (gv >= 60 && gv < 92 && prec == PREC_F16 && !out_f32 && M % QBM == 0 && N % QBN == 0) {
         dim3 grid((M / QBM) * (N / QBN)), block(QTHREADS);
         const uint16_t* a = reinterpret_cast<const uint16_t*>(A);
@@ -3221,6 +3245,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         }
         return hipGetLastError();
     }
+#endif
     // 40: K = 256 streaming kernel (decoder image side); automatic for its shapes once there are >= 2 tiles per CU
     if ((gv == 40 || (gv == 8 && M / K2_ROWS >= 512)) && k256_ok(M, N, K, out_f32, gelu, accumulate)) {
         if (prec == PREC_BF16) return launch_gemm_k256<PREC_BF16>(A, B, C, bias, add2d, add2d_period, M, N, s);
@@ -3254,6 +3279,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         }
         variant = 8;
     }
+#ifdef SAMRS_EXPERIMENTS
     // 100 + abl: ablations of the barrier-light 256x320 kernel (f16, ET output, no GELU): timing experiments only
     if (variant >= 100 && variant < 196 && prec == PREC_F16 && !out_f32 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0) {
         dim3 grid((M / QBM) * (N / WBN)), block(QTHREADS);
@@ -3268,6 +3294,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
 #undef XABL_CASE
         return hipGetLastError();
     }
+#endif
     if (variant == 8) {
         const bool big_ok = M % QBM == 0 && K % QBK == 0;
         const long t256 = big_ok && N % QBN == 0 ? (long)(M / QBM) * (N / QBN) : 0;
@@ -3299,6 +3326,7 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     // 30 / 31: 32x32x16 symmetric-schedule kernel, persistent / one tile per block.  SAMRS_GEMM_M32=<mask> lets the automatic
     // rule pick it for A/B runs of the whole loop: bit 0 = ET outputs (qkv, lin1), bit 1 = fp32 outputs (proj, lin2),
     // bit 2 = one tile per block instead of persistent, bit 3 = spread pieces
+#ifdef SAMRS_EXPERIMENTS
     static const int m32_mask = [] { const char* v = getenv("SAMRS_GEMM_M32"); return v ? atoi(v) : 0; }();
     if ((variant == 27 || variant == 28) && m32_ok(M, N, K, add2d) && (m32_mask & (out_f32 ? 2 : 1)))
         variant = (m32_mask & 16) ? 34 : 30 + ((m32_mask & 4) ? 1 : 0) + ((m32_mask & 8) ? 2 : 0);
@@ -3314,18 +3342,21 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         }
         return hipErrorInvalidValue;
     }
-    // 38: the four-wave 256 x 256 kernel on 16x16x32 MFMAs with 128 x 128 wave tiles (round 5); shapes it does not cover fall back
-    if (variant == 38 && !w4x_ok(M, N, K, add2d, out_f32)) variant = add2d ? 27 : 28;
-    if (variant == 38) {
-        if (prec == PREC_BF16) return launch_gemm_w4x<PREC_BF16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, s);
-        if (prec == PREC_F16) return launch_gemm_w4x<PREC_F16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, s);
-        return hipErrorInvalidValue;
-    }
     // 34 / 36: the four-wave, 512-register flavour of the symmetric schedule (persistent / one tile per block)
     if ((variant == 34 || variant == 36) && !m32_ok(M, N, K, add2d)) variant = add2d ? 27 : 28;
     if (variant == 34 || variant == 36) {
         if (prec == PREC_BF16) return launch_gemm_w4<PREC_BF16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, variant == 34, s);
         if (prec == PREC_F16) return launch_gemm_w4<PREC_F16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, variant == 34, s);
+        return hipErrorInvalidValue;
+    }
+#else
+    if (variant >= 30 && variant <= 36) variant = add2d ? 27 : 28;     // the 32x32x16 kernels are not in this build (make EXPERIMENTS=1)
+#endif
+    // 38: the four-wave 256 x 256 kernel on 16x16x32 MFMAs with 128 x 128 wave tiles (round 5); shapes it does not cover fall back
+    if (variant == 38 && !w4x_ok(M, N, K, add2d, out_f32)) variant = add2d ? 27 : 28;
+    if (variant == 38) {
+        if (prec == PREC_BF16) return launch_gemm_w4x<PREC_BF16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, s);
+        if (prec == PREC_F16) return launch_gemm_w4x<PREC_F16>(A, B, C, bias, M, N, K, out_f32, gelu, accumulate, s);
         return hipErrorInvalidValue;
     }
     if (variant == 28 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0 && !add2d) {   // persistent pair-stage kernel
@@ -3372,6 +3403,17 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
 }
 
 // LayerNorm folded into the neighbouring GEMMs (ViT-H: the residual stream has N = 1280 = LN_NS x 160 columns).
+bool gemm_has_experiments() {
+#ifdef SAMRS_EXPERIMENTS
+    return true;
+#else
+    return false;
+#endif
+}
+#ifndef SAMRS_EXPERIMENTS
+hipError_t launch_gemm_et_stats(int, const void*, const void*, float*, const float*, void*, float*, int, int, int, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_gemm_et_fold(int, const void*, const void*, void*, const float*, const float*, const float*, int, int, int, bool, hipStream_t) { return hipErrorInvalidValue; }
+#else
 hipError_t launch_gemm_et_stats(int prec, const void* A, const void* B, float* C, const float* bias, void* Xh, float* stats,
                                 int M, int N, int K, hipStream_t s) {
     if (!m32_ok(M, N, K, nullptr) || N != 160 * LN_NS || !Xh || !stats) return hipErrorInvalidValue;
@@ -3387,6 +3429,7 @@ hipError_t launch_gemm_et_fold(int prec, const void* Xh, const void* Wf, void* C
     if (prec == PREC_F16) return launch_gemm_x64p_fold<PREC_F16>(Xh, Wf, C, bias_f, cvec, rowstat, M, N, K, gelu, s);
     return hipErrorInvalidValue;
 }
+#endif  // SAMRS_EXPERIMENTS
 
 // One-launch split product (see seg_src_a): C = (A + A_lo)(B + B_lo)^T minus the lo x lo term, + bias; ET output (rounded once
 // from the fp32 accumulators) or fp32 output, optionally accumulated into C.  Shapes of the pair-stage 256x320 tile only; the
@@ -3438,7 +3481,7 @@ hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, cons
 // output with at least one full round of 256 x 320 tiles) and N is one LayerNorm row; otherwise hipErrorInvalidValue and the caller
 // launches GEMM and LayerNorm separately.  counters: M / 256 zeroed uint32 (left zero by every launch).
 bool gemm_lntail_ok(int M, int N, int K) {
-    return M > 0 && M % QBM == 0 && N % WBN == 0 && N <= 2048 && K % XBK == 0 && K >= 2 * XBK && (long)(M / QBM) * (N / WBN) >= 256;
+    return M > 0 && M % QBM == 0 && N % WBN == 0 && N <= 1280 && K % XBK == 0 && K >= 2 * XBK && (long)(M / QBM) * (N / WBN) >= 256;
 }
 hipError_t launch_gemm_et_lntail(int prec, const void* A, const void* B, float* C, const float* bias, int M, int N, int K,
                                  const float* gamma, const float* beta, float eps, void* out_et, unsigned int* counters, hipStream_t s) {

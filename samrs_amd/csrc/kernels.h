@@ -31,6 +31,7 @@ hipError_t launch_gemm_et_split3(int prec, const void* A, const void* A_lo, cons
 void set_gemm_variant(int v);   // process-wide test hook (kernel-level entry points): 0 = register-staged tiles, ..., 8 = automatic
 // proj / lin2 with the LayerNorm that follows them as a tail of the GEMM (gemm.hip gemm_et_x64_kernel<LNT>): C (fp32) += A B^T + bias,
 // out_et = LN(C) in the operand type; hipErrorInvalidValue where the shape does not take that kernel (caller: separate launches)
+bool gemm_has_experiments();     // built with -DSAMRS_EXPERIMENTS (make EXPERIMENTS=1): the 32x32x16 GEMM kernels, the LayerNorm fold, the timing ablations
 bool gemm_lntail_ok(int M, int N, int K);
 hipError_t launch_gemm_et_lntail(int prec, const void* A, const void* B, float* C, const float* bias, int M, int N, int K,
                                  const float* gamma, const float* beta, float eps, void* out_et, unsigned int* counters, hipStream_t s);

@@ -386,6 +386,8 @@ class TilePipeline:
         self.class_pixels = torch.zeros(n_classes, dtype=torch.int64, device=self.dev)
         self.class_instances = torch.zeros(n_classes, dtype=torch.int64, device=self.dev)
         dev, side = self.dev, self.side
+        # (round 5, measured: creating the encoder stream at the device's highest priority changes nothing -- 143.7 against 144.0
+        # images/s over three alternations on one box; the streams stay at the default priority)
         self.s_h2d, self.s_enc, self.s_dec = (torch.cuda.Stream(dev) for _ in range(3))
         self.device_inputs = device_inputs
         self.pin_in = None

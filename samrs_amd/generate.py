@@ -122,6 +122,25 @@ def io_threads(readers: int = 0, writers: int = 0, local_world: Optional[int] = 
     return r, w
 
 
+HOST_MS_PER_IMAGE = 20.7       # host thread time per image of this driver: read.decode 5.9 + write.gray_color_png 11.7 + pickle 2.7 + rle 0.4 (BENCH_r04 cli_inclusive)
+
+
+def host_bound_warning(readers: int, writers: int, gpu_images_per_s: float = 140.0, local_world: Optional[int] = None) -> Optional[str]:
+    """A sentence for the operator when this rank's share of the host cannot keep up with its GPU (VERDICT r04 "what's weak" 11):
+    a rank that produces ``gpu_images_per_s`` needs ``gpu_images_per_s x 20.7 ms`` = ~2.9 busy CPUs for decode + encode + pickle; on a
+    16-CPU container shared by eight ranks it has two.  None when the budget suffices and the pools fit it."""
+    budget = host_cpu_budget(local_world)
+    need = gpu_images_per_s * HOST_MS_PER_IMAGE * 1e-3
+    msgs = []
+    if readers + writers > budget + 1e-9 and budget < need:
+        msgs.append(f"{readers} reader + {writers} writer threads on a share of {budget:.1f} CPUs")
+    if budget < need:
+        msgs.append(f"this rank is HOST-bound at ~{budget / (HOST_MS_PER_IMAGE * 1e-3):.0f} images/s (its GPU loop does ~{gpu_images_per_s:.0f}): "
+                    f"decode + PNG encode + pickle cost {HOST_MS_PER_IMAGE:.1f} ms of host thread time per image = {need:.1f} busy CPUs; "
+                    "give the job more CPUs per rank, or run fewer ranks per container")
+    return "; ".join(msgs) if msgs else None
+
+
 def outputs_exist(out_dir: str, stem: str) -> bool:
     """All three files of an image are on disk (main_sam_hbox_semantic.py:214-216 writes gray, color, then ins)."""
     return all(os.path.exists(os.path.join(out_dir, sub, stem + ext)) for sub, ext in (("gray", ".png"), ("color", ".png"), ("ins", ".pkl")))
@@ -227,6 +246,10 @@ def run(args) -> Dict[str, List[int]]:
     import time
     tile_io.load_library()                                  # fail here, not on a worker thread, when libsamrs_io.so is missing
     n_readers, n_writers = io_threads(getattr(args, "readers", 0) or 0, getattr(args, "writers", 0) or 0)
+    warn = host_bound_warning(n_readers, n_writers)
+    if warn:
+        import sys
+        print(f"[rank {rank}] warning: {warn}", file=sys.stderr, flush=True)
     png_level = getattr(args, "png_level", tile_io.LEVEL_LABELS)
     clock = StageClock() if getattr(args, "timing", False) else None
 

@@ -28,6 +28,14 @@ def dev(t):
     return t.cuda().contiguous()
 
 
+def need_experiments(lib):
+    """Kernels that were measured and not adopted (32x32x16 GEMMs, the LayerNorm fold) are left out of the product build
+    (samrs_amd/csrc/Makefile: make EXPERIMENTS=1 builds them); their tests run against such a build only."""
+    lib.samrs_debug_has_experiments.restype = __import__("ctypes").c_int
+    if not lib.samrs_debug_has_experiments():
+        pytest.skip("built without EXPERIMENTS=1: the retired kernels are not in this library")
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -215,6 +223,7 @@ def test_gemm_m32_kernel(lib, name, prec, dt, ulp, variant):
     it to fp32-summation-order accuracy (fp32 output: rel. L2 < 2e-6; ET output: <= 1 ulp apart, and only where the fp32 value
     sits on a rounding boundary), with fp64 on the small shapes, and with ITSELF bit for bit across repeated launches (the race
     screen: 2, 4, 6 and 80 stages, one to three tiles per block, the real proj / lin2 / qkv shapes of an 8-tile batch)."""
+    need_experiments(lib)
     lib.samrs_debug_set_gemm_variant.argtypes = [__import__("ctypes").c_int]
     shapes = [(256, 640, 128), (512, 640, 256), (8192, 3200, 256), (16384, 3840, 384), (32768, 1280, 1280)]
     if variant in (30, 34):
@@ -317,6 +326,7 @@ def test_gemm_stats_epilogue(lib, name, prec, dt, ulp):
     """Producer of the folded LayerNorm (proj / lin2): C += A B^T + bias on the 32x32x16 kernel, plus Xh = ET(C) and the
     per-row partial statistics of C.  C must equal the plain fp32-residual GEMM, Xh must be ET(C) bit for bit, the merged
     statistics must match float64 statistics of C; repeated launches are bit-identical."""
+    need_experiments(lib)
     for (M, K) in [(512, 128), (8192, 1280), (32768, 1280), (32768, 5120)]:
         N = 1280
         g = torch.Generator().manual_seed(M + K)
@@ -356,6 +366,7 @@ def test_gemm_folded_layernorm(lib, name, prec, dt, ulp, gelu):
     """Consumer of the folded LayerNorm (qkv / lin1): rstd (Xh Wf^T - mean cvec) + bias_f [GELU] against float64
     LayerNorm + Linear [+ GELU], next to the engine's other path (stand-alone LayerNorm kernel -> ET -> GEMM) on the same data:
     same error class.  Rows carry means of several sigma and a massive-activation channel."""
+    need_experiments(lib)
     for (M, N) in [(512, 640), (8192, 3840)]:
         K = 1280
         g = torch.Generator().manual_seed(M + N + gelu)

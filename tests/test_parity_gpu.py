@@ -108,7 +108,7 @@ def test_layernorm_tail_of_the_gemms_matches_the_standalone_kernel(precision):
     sam = samrs_amd.sam_model_registry[name](precision=precision, max_prompts=8, max_images=4, max_points=1, options={"split": 15})
     sam.to(device="cuda")
     eng = sam.engine
-    assert eng.get_option("ln_tail") == -1                     # automatic
+    assert eng.get_option("ln_tail") in (0, -1)                # off unless asked for (measured slower: profiles/r05_ln_tail.txt)
     imgs = [synth.make_image(0), synth.make_image(1)]
     taps = [{}, {}]
     with torch.no_grad():
@@ -131,7 +131,7 @@ def test_layernorm_tail_of_the_gemms_matches_the_standalone_kernel(precision):
                   f"{' (bit-identical)' if torch.equal(x0, x1) else ''}")
             assert e1 < tol and d < 1e-5, (nb, e1, d)
     finally:
-        eng.set_option("ln_tail", -1)
+        eng.set_option("ln_tail", 0)
         eng.close()
 
 
@@ -141,6 +141,11 @@ def test_folded_layernorm_matches_unfolded(precision):
     its statistics come out of the proj / lin2 epilogues).  Both paths against the oracle after every block: the folded path's
     error must be in the same class as the stand-alone-LayerNorm path's (it rounds x instead of LN(x) to the operand type), and
     the two paths must agree with each other to the same tolerance."""
+    from samrs_amd import engine as _eng
+    _lib = _eng.load_library()
+    _lib.samrs_debug_has_experiments.restype = __import__("ctypes").c_int
+    if not _lib.samrs_debug_has_experiments():
+        pytest.skip("the LayerNorm fold is built with make EXPERIMENTS=1 only (measured slower: DESIGN.md 6)")
     so = _oracle()
     import samrs_amd
     from samrs_amd import engine

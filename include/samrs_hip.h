@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAMRS_ABI_VERSION 3
+#define SAMRS_ABI_VERSION 4
 
 enum samrs_status {
     SAMRS_OK = 0,

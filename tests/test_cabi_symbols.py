@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     missing = [n for n in declared_functions() if not hasattr(lib, n)]
     assert not missing, f"declared in samrs_hip.h but not exported: {missing}"
     lib.samrs_abi_version.restype = ctypes.c_int
-    assert lib.samrs_abi_version() == 3
+    assert lib.samrs_abi_version() == 4
 
 
 def test_config_struct_layout_matches_header(lib_path):

@@ -574,27 +574,54 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
         _Pragma("unroll") for (int ks_ = 0; ks_ < KS; ++ks_)                                                         \
             qdst[ks_] = *reinterpret_cast<const uint4*>(n_base + qo_ + 16 * ks_ + 8 * hh);                           \
     } while (0)
+    // Round 5 (the tile loop is bound by instruction ISSUE: profiles/r05_attention_pipelining.txt): which window token a load slot of
+    // this thread addresses -- slot -> chunk -> row r -> (r / 14, r % 14) and the chunk inside the row: two to three divisions by
+    // constants per load, ~310 integer instructions per item and thread, 24 % of a key tile's instruction stream -- does not depend on
+    // the item.  It is decoded ONCE, into 12-bit fields (4 bits window row | 4 bits window column | 4 bits chunk), two slots per
+    // register (three registers in all: hoisting the decoded values themselves spills, the kernel sits at 252 VGPRs); per item a slot
+    // costs two field extracts instead.  Addresses only: bit-identical output.
+    auto slot_field = [](int r, int ch) -> uint32_t { return (uint32_t)(r / C::WS) | ((uint32_t)(r % C::WS) << 4) | ((uint32_t)ch << 8); };
+    uint32_t kpk[(PK + 1) / 2], vpk[(PV + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < (PK + 1) / 2; ++i) kpk[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < (PV + 1) / 2; ++i) vpk[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < PK; ++i) {
+        const int c = tid + i * C::THREADS;
+        if (c < NKC) kpk[i >> 1] |= slot_field(c / CH, c % CH) << (12 * (i & 1));
+    }
+#pragma unroll
+    for (int i = 0; i < PV; ++i) {
+        const int c = tid + i * C::THREADS;
+        if (c < NVI) vpk[i >> 1] |= slot_field(2 * (c % (C::N / 2)), c / (C::N / 2)) << (12 * (i & 1));      // key 2 kp; key 2 kp + 1 = the next column
+    }
+#define WIN_TOK2(dy_, dx_, off_, pad_)                                                                               \
+    const int ty_##off_ = y0_ + (dy_), tx_##off_ = x0_ + (dx_);                                                      \
+    const bool pad_ = ty_##off_ >= grid || tx_##off_ >= grid;                                                        \
+    const int off_ = (min(ty_##off_, grid - 1) * grid + min(tx_##off_, grid - 1)) * (3 * D)
 #define WIN_LOAD_K(i_)                                                                                               \
     do {                                                                                                             \
         const int y0_ = n_y0, x0_ = n_x0;                                                                            \
-        const int c_ = tid + (i_) * C::THREADS;                                                                      \
-        const int r_ = c_ / CH, ch_ = c_ % CH;                                                                       \
-        if (c_ < NKC) {                                                                                              \
-            WIN_TOK(r_, ko_, kp_);                                                                                   \
+        if (tid + (i_) * C::THREADS < NKC) {                                                                         \
+            uint32_t f_ = kpk[(i_) >> 1];                                                                            \
+            asm volatile("" : "+v"(f_));          /* decode per item: hoisted out of the item loop the fields spill */ \
+            f_ >>= 12 * ((i_) & 1);                                                                                  \
+            WIN_TOK2((int)(f_ & 15u), (int)((f_ >> 4) & 15u), ko_, kp_);                                             \
             n_pad |= (uint32_t)kp_ << (i_);                                                                          \
-            kreg[i_] = *reinterpret_cast<const uint4*>(n_base + ko_ + D + ch_ * 8);                                  \
+            kreg[i_] = *reinterpret_cast<const uint4*>(n_base + ko_ + D + (int)((f_ >> 8) & 15u) * 8);               \
         }                                                                                                            \
     } while (0)
 #define WIN_LOAD_V(i_)                                                                                               \
     do {                                                                                                             \
         const int y0_ = n_y0, x0_ = n_x0;                                                                            \
-        int tid_ = tid;                                                                                              \
-        asm volatile("" : "+v"(tid_));   /* recompute the slot's token per item: hoisted, these spill (HD = 80) */   \
-        const int c_ = tid_ + (i_) * C::THREADS;                                                                     \
-        const int kp_ = c_ % (C::N / 2), ch_ = c_ / (C::N / 2);                                                      \
-        if (c_ < NVI) {                                                                                              \
-            WIN_TOK(2 * kp_, vo0_, vp0_);                                                                            \
-            WIN_TOK(2 * kp_ + 1, vo1_, vp1_);                                                                        \
+        if (tid + (i_) * C::THREADS < NVI) {                                                                         \
+            uint32_t f_ = vpk[(i_) >> 1];                                                                            \
+            asm volatile("" : "+v"(f_));                                                                             \
+            f_ >>= 12 * ((i_) & 1);                                                                                  \
+            const int dy_ = (int)(f_ & 15u), dx_ = (int)((f_ >> 4) & 15u), ch_ = (int)((f_ >> 8) & 15u);             \
+            WIN_TOK2(dy_, dx_, vo0_, vp0_);                                                                          \
+            WIN_TOK2(dy_, dx_ + 1, vo1_, vp1_);       /* 2 kp is even and a window row holds 14 tokens: same row */   \
             n_pad |= ((uint32_t)vp0_ | ((uint32_t)vp1_ << 1)) << (PK + 2 * (i_));                                   \
             v0reg[i_] = *reinterpret_cast<const uint4*>(n_base + vo0_ + 2 * D + ch_ * 8);                            \
             v1reg[i_] = *reinterpret_cast<const uint4*>(n_base + vo1_ + 2 * D + ch_ * 8);                            \
@@ -865,6 +892,7 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
 #undef WIN_LOAD_Q
 #undef WIN_HEAD
 #undef WIN_TOK
+#undef WIN_TOK2
 }
 
 // LDS-DMA with a wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset; destination = LDS byte address

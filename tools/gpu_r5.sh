@@ -60,7 +60,6 @@ for l in sys.stdin:
     d = json.loads(l); print('$kv r$r:', d['value'], 'img/s', d['ms_per_step'], 'ms/step; lin1', d['roofline']['avg_launch_ms'], 'ms')
 " | tee -a gpurun_out/summary.txt; done; done ;;
     pstat)   run pstat 900 $PT tests/test_parity_gpu.py -k "statistical_parity_sample" ;;
-    attnb)   run attnb 200 python tools/attn_bench.py ;;
     kmx)     run kmx 600 $PT tests/test_kernels_gpu.py -k "mx" ;;
     c4ab)    SAMRS_LO_FORMAT=0 run c4_lo0 400 python bench.py --workload c4 --steps ${BENCH_STEPS:-12} --warmup 3 $BQ
              SAMRS_LO_FORMAT=4 run c4_lo4 400 python bench.py --workload c4 --steps ${BENCH_STEPS:-12} --warmup 3 $BQ

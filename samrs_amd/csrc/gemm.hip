@@ -3312,13 +3312,14 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
         else if (!out_f32 && N >= 2048 && t256 >= 1024) variant = 6;
         else variant = (gelu || (K <= 1536 && N <= 1536)) ? 7 : 5;
     }
-    // SAMRS_GEMM_W4X=1 (A/B runs; default off): ET + GELU outputs whose 256 x 256 tiles fill whole rounds (lin1 of ViT-H: 2560 tiles =
-    // 10 rounds at batch 8) go to the four-wave 128 x 128-wave-tile kernel.  Measured on MI355X: as a 2.5 s loop of its own it beats
-    // the persistent 256 x 320 kernel on that shape (412 us against 429, 1.03 against 1.08 pJ / FLOP: profiles/r05_gemm_energy.txt);
-    // INSIDE the tile loop, with the decoder's kernels on the neighbouring streams, it is 1 % slower (0.4397 / 0.4418 ms per lin1
-    // launch against 0.4366 / 0.4356, two alternations on one box; 140.8 / 140.4 against 140.7 / 140.3 images/s).  Plain ET
-    // outputs (qkv: 7.5 rounds) and the fp32 outputs (2.5 rounds) are slower on it in both settings.
-    static const bool w4x_auto = [] { const char* v = getenv("SAMRS_GEMM_W4X"); return v ? atoi(v) != 0 : false; }();
+    // ET + GELU outputs whose 256 x 256 tiles fill whole rounds (lin1 of ViT-H: 2560 tiles = 10 rounds at batch 8; 5 at batch 4) go to
+    // the four-wave 128 x 128-wave-tile kernel (variant 38; bit-identical with the kernel it replaces, so no mode's arithmetic moves).
+    // Measured on MI355X: as a 2.5 s loop of its own 412 us against 429 and 1.03 against 1.08 pJ / FLOP (profiles/r05_gemm_energy.txt);
+    // INSIDE the tile loop, beside the decoder's kernels, the launch itself is no faster (0.4342 against 0.4330 ms) and the step gains
+    // 0.2 % (142.68 / 142.68 / 142.88 against 142.21 / 142.57 / 142.52 images/s, alternated on one box: profiles/r05_ab_loop.txt).
+    // Plain ET outputs (qkv: 7.5 rounds) and the fp32 outputs (2.5 rounds) are slower on it in both settings and stay where they were.
+    // SAMRS_GEMM_W4X=0 switches the rule off (A/B runs).
+    static const bool w4x_auto = [] { const char* v = getenv("SAMRS_GEMM_W4X"); return v ? atoi(v) != 0 : true; }();
     if (variant == 28 && w4x_auto && gelu && w4x_ok(M, N, K, add2d, out_f32)) {
         const long t256 = (long)(M / QBM) * (N / W4X_BN);
         if (t256 % 256 == 0 && t256 >= 1024) variant = 38;

@@ -99,7 +99,11 @@ def reduce_statistics(class_pixels: torch.Tensor, class_instances: torch.Tensor,
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return class_pixels.clone(), class_instances.clone()
     buf = torch.cat([class_pixels, class_instances]).contiguous()
+    dev = buf.device
+    if dist.get_backend(group) != "nccl":            # gloo (CPU tests, ranks sharing one GPU): the message goes through the host
+        buf = buf.cpu()
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    buf = buf.to(dev)
     c = class_pixels.numel()
     return buf[:c].clone(), buf[c:].clone()
 

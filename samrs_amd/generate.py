@@ -187,9 +187,18 @@ def run(args) -> Dict[str, List[int]]:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # SAMRS_SHARE_GPU=1: every rank on cuda:0, collectives over gloo -- the N-rank control flow of this driver (shards, --resume
+    # list broadcast, statistics all-reduce, mask-size all-gather, per-rank logs) on a ONE-GPU box; RCCL itself needs a multi-GPU
+    # node.  The ranks' engines are separate handles with their own streams and slots: sharing a device changes nothing they compute.
+    share = os.environ.get("SAMRS_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     ann = json.load(open(args.boxes))
     names = [l.strip() for l in open(args.classes)] if args.classes else [str(i) for i in range(args.n_classes)]
     n_classes = len(names)
@@ -422,8 +431,10 @@ def main(argv=None):
                     help="-2 (default): the label-aware PNG encoder for gray/ and color/ (deflate tokens derived from the class map); 1..9: zlib "
                          "level of color/*.png, run-length preset for gray/*.png.  The decoded pixels are the same either way")
     ap.add_argument("--out-depth", type=int, default=4, help="pinned output buffers (batches on loan to the writers at once)")
-    ap.add_argument("--log", default=None, help="append one JSON line per batch (time, image stems, box counts) to this file "
-                    "(<file>.rank<r> with more than one rank)")
+    # --run-log: the spelling to use under `python -m torch.distributed.run`, whose own parser stops at `--log` as an ambiguous
+    # prefix of its --log-dir / --logs-specs before it hands the remaining arguments to this module
+    ap.add_argument("--log", "--run-log", dest="log", default=None, help="append one JSON line per batch (time, image stems, box counts) "
+                    "to this file (<file>.rank<r> with more than one rank); spell it --run-log under torchrun")
     ap.add_argument("--timing", action="store_true", help="print the host-side time per stage (decode, PNG encode, pickle, waits)")
     run(ap.parse_args(argv))
 

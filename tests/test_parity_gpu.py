@@ -908,6 +908,80 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["stats_allreduce"]["total_instances"] > 0
 
 
+def test_generate_two_ranks_on_one_gpu_under_a_four_cpu_mask(tmp_path):
+    """The generation CLI's N > 1 path on a ONE-GPU box: two ranks of ``python -m samrs_amd.generate`` share
+    cuda:0 over gloo (SAMRS_SHARE_GPU=1) inside a four-CPU affinity mask -- the share eight ranks get on the pool's 16-CPU
+    containers -- with the shared-counter schedule, then a --resume pass after one image's pickle was removed.  Every file must
+    be byte-identical to the single-rank run's (a tile's outputs do not depend on which rank or batch position computed it),
+    the merged statistics equal, both ranks must have done work, and the thread pools must have been sized from the mask."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img_dir = tmp_path / "img"
+    img_dir.mkdir()
+    ann = {}
+    for i in range(7):                                              # 7 images in batches of 2: a ragged last batch
+        Image.fromarray(synth.make_image(40 + i)).save(img_dir / f"T{i:04d}.png")
+        b, l = synth.make_boxes(40 + i, 5 + 3 * i)
+        ann[f"T{i:04d}"] = {"boxes": b.tolist(), "labels": l.tolist()}
+    (tmp_path / "boxes.json").write_text(json.dumps(ann))
+    cpus = sorted(os.sched_getaffinity(0))[:4]
+    mask = ",".join(str(c) for c in cpus)
+    common = ["--images", str(img_dir), "--boxes", str(tmp_path / "boxes.json"), "--model", "vit_tiny", "--batch", "2", "--box-batch", "8",
+              "--timing"]
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    taskset = ["taskset", "-c", mask] if shutil.which("taskset") else []
+
+    def launch(world, out, extra=()):
+        cmd = list(taskset)
+        if world > 1:
+            cmd += [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                    "--master-port", "29547", "-m", "samrs_amd.generate"]
+        else:
+            cmd += [sys.executable, "-m", "samrs_amd.generate"]
+        cmd += common + ["--out", str(out), "--run-log", str(out) + ".jsonl"] + list(extra)      # --log: ambiguous to torchrun's parser
+        r = subprocess.run(cmd, env=dict(env, SAMRS_SHARE_GPU="1"), cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return r
+
+    one, two = tmp_path / "one", tmp_path / "two"
+    launch(1, one)
+    launch(2, two, ["--schedule", "dynamic"])
+
+    def tree(d):
+        return {os.path.relpath(os.path.join(b, f), d): open(os.path.join(b, f), "rb").read()
+                for b, _, fs in os.walk(d) for f in fs if "statistic" not in b}
+    t1, t2 = tree(one), tree(two)
+    assert sorted(t1) == sorted(t2) and len(t1) == 3 * 7
+    assert all(t1[k] == t2[k] for k in t1), [k for k in t1 if t1[k] != t2[k]]
+    s1 = json.load(open(one / "statistic" / "class_stats.json"))
+    s2 = json.load(open(two / "statistic" / "class_stats.json"))
+    for k in ("class_pixel_num", "class_instance_num", "mask_num"):
+        assert s1[k] == s2[k], k
+    assert sorted(np.load(one / "statistic" / "all_mask_size.npy").tolist()) == sorted(np.load(two / "statistic" / "all_mask_size.npy").tolist())
+    per_rank = []
+    for r in range(2):
+        lines = [json.loads(l) for l in open(f"{two}.jsonl.rank{r}")]
+        assert lines[0]["world"] == 2 and lines[0]["rank"] == r
+        per_rank.append(sum(len(l.get("images", [])) for l in lines[1:]))
+    assert sum(per_rank) == 7 and min(per_rank) >= 1, per_rank          # the shared counter hands every rank some of the batches
+    if taskset:
+        t = s2["timing"]                                                # rank 0's pools: 4 CPUs / 2 ranks = 2 -> the floor of 2 + 2
+        assert t["cpu_budget"] <= 2.0 and t["readers"] == 2 and t["writers"] == 2, t
+    # --resume across ranks: rank 0 lists the directory, both ranks index the same todo list; the statistics still cover all 7
+    os.remove(two / "ins" / "T0003.pkl")
+    keep = {k: os.stat(two / k).st_mtime_ns for k in t2 if "T0003" not in k}
+    launch(2, two, ["--resume"])
+    assert tree(two) == t2
+    assert keep == {k: os.stat(two / k).st_mtime_ns for k in keep}     # nothing else was rewritten
+    s3 = json.load(open(two / "statistic" / "class_stats.json"))
+    for k in ("class_pixel_num", "class_instance_num", "mask_num"):
+        assert s1[k] == s3[k], k
+
+
 @pytest.mark.parametrize("batch", [2, 3, 5])
 def test_vit_h_odd_batches_equal_single_tile(batch):
     """The GEMM tile shape is chosen per (M, N, K): 2, 3 and 5 tiles per encoder pass take other mixes of the

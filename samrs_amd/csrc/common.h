@@ -255,6 +255,17 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return y.x;
 }
 
+// 16-byte store with the non-temporal hint when STREAM is set: for an output that is larger than the 256 MB Infinity Cache
+// it would pass through -- the MLP hidden tensor, 336 MB per lin1 launch at 8 tiles of ViT-H -- so that it does not displace what the next
+// kernels find there (the fp32 residual stream, the LayerNorm output).  A hint only: the same bytes reach memory.
+// (A compile-time switch: behind a run-time flag LLVM merges the two stores into one and drops the hint.)
+typedef unsigned int nt_u32x4_t __attribute__((ext_vector_type(4)));
+template <bool STREAM>
+__device__ __forceinline__ void store16_stream(void* p, const uint4& v) {
+    if constexpr (STREAM) __builtin_nontemporal_store(__builtin_bit_cast(nt_u32x4_t, v), reinterpret_cast<nt_u32x4_t*>(p));
+    else *reinterpret_cast<uint4*>(p) = v;
+}
+
 // XCD-aware, bijective remap of a linear block id (cdna_hip_programming.md T1): the hardware
 // dispatches block b to XCD b % 8; give every XCD a contiguous chunk of the logical grid so
 // that neighbouring tiles (which share operand panels) hit the same L2.  Speed only.

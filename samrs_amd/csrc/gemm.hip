@@ -242,7 +242,7 @@ __device__ __forceinline__ void wave_lds_sync_g() {
 // before this wave's first global store, i.e. after the bias loads, the VALU work and the first LDS bounce have covered
 // their latency, and before any store joins the queue -- so the stores themselves are never waited for.
 template <int PREC, bool OUT_F32, int GELU /* 0 none, 1 fp32-epsilon erf, 2 the cheaper erf (ET output) */, int NJ, int JC, int NI = 4, bool GLN = false,
-          bool DRAIN = false>
+          bool DRAIN = false, bool STREAM = false /* ET output: non-temporal stores (common.h store16_stream) */>
 __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsigned char* scr /* wave-private */,
                                                    void* __restrict__ Cv, const float* __restrict__ bias,
                                                    const float* __restrict__ add2d, int add2d_period, int N,
@@ -368,7 +368,7 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
                     const int row = idx / CPR, ch = idx % CPR;
                     const uint4 v = *reinterpret_cast<const uint4*>(scr + jj * TS + row * RS + ch * 16);
                     uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)(m_base + j * 16 + row) * N + n_base + ch * 8;
-                    *reinterpret_cast<uint4*>(C) = v;
+                    store16_stream<STREAM>(C, v);
                 }
             }
         }
@@ -392,7 +392,7 @@ __device__ __forceinline__ void epilogue_coalesced(f32x4_t (&acc)[NI][NJ], unsig
 // by two cross-lane swaps (l ^ 16, l ^ 32), codes by v_cvt_scalef32_pk_fp4_f32, one dword store per lane, block and tensor (position
 // 8 fq + 4 (i & 1) + e of the block holds column 16 (i & 1) + 4 fq + e).
 // GELU: 0 none, 1 the fp32-epsilon erf (common.h gelu_erf2), 2 the cheaper erf of the 1x-rate mode (gelu_erf2_et)
-template <int PREC, int GELU, int JC = 4, bool DRAIN = false, bool FOLD = false, bool MXO = false>
+template <int PREC, int GELU, int JC = 4, bool DRAIN = false, bool FOLD = false, bool MXO = false, bool STREAM = false /* non-temporal ET stores */>
 __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned char* lds, void* __restrict__ Cv,
                                                  const float* __restrict__ bias, const float* __restrict__ pre2d, int period, int N,
                                                  int m_base /* wave tile row 0 */, int n_pair /* first column of the pair */,
@@ -492,7 +492,7 @@ __device__ __forceinline__ void epilogue_pair_et(f32x4_t (&acc)[5][8], unsigned 
             const int row = 8 * half + rem / 20, ch = rem % 20;
             const uint4 v = *reinterpret_cast<const uint4*>(scr + jj * TS + row * RS + ch * 16);
             uint16_t* C = reinterpret_cast<uint16_t*>(Cv) + (size_t)(m_base + (j0 + jj) * 16 + row) * N + n_pair + ch * 8;
-            *reinterpret_cast<uint4*>(C) = v;
+            store16_stream<STREAM>(C, v);
         }
         if constexpr (FOLD) {
 #pragma unroll
@@ -1280,7 +1280,7 @@ constexpr int LN_NS = 8;                       // 1280 / 160: ViT-H only
 // parameter (round 5: they used to be smuggled through rowstat / cvec / A_lo / B_lo with const_casts); the flavours that do not
 // use it never load it from the kernarg segment, so their code is what it was.
 template <int PREC, bool OUT_F32, int GELU /* 0 none, 1 fp32-epsilon erf, 2 the 1x-rate mode's cheaper erf (ET output only) */, bool FOLD = false,
-          bool SPLIT3 = false, bool MXO = false>
+          bool SPLIT3 = false, bool MXO = false, bool STREAM = false /* plain ET flavours: non-temporal output stores (stream_hidden) */>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, int accumulate,
@@ -1433,8 +1433,8 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
                 epilogue_pair_et<PREC, GELU, 2, true, false, true>(acc, upper, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + (wn >> 1) * 160, wm, wn,
                                                                    lane, nullptr, nullptr, mxo);
             } else if constexpr (!OUT_F32) {
-                epilogue_pair_et<PREC, GELU, 2, true, FOLD>(acc, upper, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + (wn >> 1) * 160, wm, wn, lane,
-                                                            rowstat, cvec);
+                epilogue_pair_et<PREC, GELU, 2, true, FOLD, false, STREAM>(acc, upper, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + (wn >> 1) * 160, wm, wn,
+                                                                           lane, rowstat, cvec);
             } else {
                 epilogue_coalesced<PREC, true, GELU != 0, 8, 1, NI, false, true>(acc, upper + wave * (XSB / 8), Cv, bias, nullptr, 1, N,
                                                                            m0 + wm * 128, n0 + wn * (16 * NI), accumulate, lane);
@@ -1454,6 +1454,17 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
 // erf form of the ET-output GELU epilogue of the persistent 256x320 kernel (lin1 of ViT-H): 1 = fp32-epsilon class (A-S 7.1.26),
 // 2 = the cheaper one (A-S 7.1.28, common.h gelu_erf2_et); set around an engine's launches (engine.hip run_encoder)
 thread_local int tl_gelu_form = 1;
+// lin1's output -- the MLP hidden tensor, read once, by lin2 -- is written with NON-TEMPORAL stores when it is larger than the 256 MB
+// Infinity Cache it would otherwise be allocated in (8 tiles of ViT-H: 336 MB per launch; SAMRS_NT_HIDDEN=0 / 1 forces the choice).
+// Measured on MI355X, libraries alternated on one box (profiles/r05_nt_streams.txt): lin1 424 -> 408 us in situ (the write-allocates no
+// longer push the A / B panels out of the L2s), lin2 / proj -7 us on average (the residual stream survives longer), the 8-tile step
+// +1.1 ... +1.4 % on three boxes.  The same hint on q | k | v, the LayerNorm or the attention output LOSES 2 - 3.5 % (their consumers live
+// on finding them cached), and on lin2's A-row loads it gives the gain back (four tile columns re-read those rows from the L2).
+static bool stream_hidden(long M, long N) {
+    static const int mode = [] { const char* v = getenv("SAMRS_NT_HIDDEN"); return v ? atoi(v) : -1; }();
+    if (mode >= 0) return mode != 0;
+    return M * N * 2 >= (256L << 20);
+}
 template <int PREC>
 hipError_t launch_gemm_x64p(const void* A, const void* B, void* C, const float* bias, int M, int N, int K, bool out_f32, bool gelu,
                             bool accumulate, hipStream_t s) {
@@ -1471,7 +1482,10 @@ hipError_t launch_gemm_x64p(const void* A, const void* B, void* C, const float* 
         if (gelu) gemm_et_x64p_kernel<PREC, true, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
         else gemm_et_x64p_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     } else {
-        if (gelu && tl_gelu_form == 2) gemm_et_x64p_kernel<PREC, false, 2><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        const bool so = gelu && stream_hidden(M, N);
+        if (gelu && tl_gelu_form == 2 && so) gemm_et_x64p_kernel<PREC, false, 2, false, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        else if (gelu && tl_gelu_form == 2) gemm_et_x64p_kernel<PREC, false, 2><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        else if (gelu && so) gemm_et_x64p_kernel<PREC, false, true, false, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
         else if (gelu) gemm_et_x64p_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
         else gemm_et_x64p_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     }
@@ -2128,7 +2142,7 @@ constexpr int W4X_SCR_BYTES = 4 * 16 * 272;            // epilogue scratch: per 
 
 // ET outputs only: the fp32 epilogue bounces 8 KiB per wave and m-tile, which the 160 KiB do not hold next to two 64 KiB stages (and the
 // fp32-output shapes of this path, N = 1280, are 2.5 rounds of 256 x 256 tiles: nothing to gain there).
-template <int PREC, bool OUT_F32, int GELU>
+template <int PREC, bool OUT_F32, int GELU, bool STREAM = false /* non-temporal output stores (stream_hidden) */>
 __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amdgpu_waves_per_eu(1, 1))) void gemm_et_w4x_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, int M, int N, int K, int accumulate) {
@@ -2282,7 +2296,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amd
         __builtin_amdgcn_sched_barrier(0);
         {
             unsigned char* scr = reinterpret_cast<unsigned char*>(lds) + 2 * XSB + wave * (W4X_SCR_BYTES / 4);
-            epilogue_coalesced<PREC, OUT_F32, GELU, NJ, 1, NI>(acc, scr, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + wn * 128, accumulate, lane);
+            epilogue_coalesced<PREC, OUT_F32, GELU, NJ, 1, NI, false, false, STREAM>(acc, scr, Cv, bias, nullptr, 1, N, m0 + wm * 128, n0 + wn * 128, accumulate, lane);
         }
         if (!more) break;
         L = Ln; m0 = m1; n0 = n1; sA = nA; sB = nB;
@@ -2316,7 +2330,10 @@ hipError_t launch_gemm_w4x(const void* A, const void* B, void* C, const float* b
     const uint16_t* b = reinterpret_cast<const uint16_t*>(B);
     const int acc = accumulate ? 1 : 0;
     if (out_f32) return hipErrorInvalidValue;
-    if (gelu && tl_gelu_form == 2) gemm_et_w4x_kernel<PREC, false, 2><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    const bool so = gelu && stream_hidden(M, N);
+    if (gelu && tl_gelu_form == 2 && so) gemm_et_w4x_kernel<PREC, false, 2, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    else if (gelu && tl_gelu_form == 2) gemm_et_w4x_kernel<PREC, false, 2><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    else if (gelu && so) gemm_et_w4x_kernel<PREC, false, 1, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     else if (gelu) gemm_et_w4x_kernel<PREC, false, 1><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     else gemm_et_w4x_kernel<PREC, false, 0><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     return hipGetLastError();

@@ -239,6 +239,11 @@ int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_i
  *                    (61.8 against 57.2 ms per 8-tile step): one CU draws ~20 GB/s from HBM, so a panel takes it 62 us where a LayerNorm
  *                    launch on all 256 CUs takes 53 for the whole tensor (profiles/r05_ln_tail.txt).  Kept as an option for the record
  *                    and for its test; 1x-rate modes only, batches of 4+ tiles at ViT-H.
+ *   "operand_pad"    [SAMRS_OPERAND_PAD, default 1; read at samrs_finalize_weights for the copies, switchable afterwards] ViT-H: the K = 1280
+ *                    operands of the plain qkv / lin1 launches -- the LayerNorm output and the weights -- are stored with a row stride of 1408
+ *                    elements (2816 B = eleven 256-byte units) instead of 1280 (ten units: the 256 rows a tile fetches per k-slice then fall
+ *                    on half of the memory channels); the persistent ET kernels read A and B with that stride.  Costs 0.8 GB for the padded
+ *                    weight copies.  Only where the bytes live changes: bit-identical output in every mode.
  *   "range_check"    [SAMRS_RANGE_CHECK, default 0] the f16 operand type has 11 mantissa bits (what the IoU >= 0.999 bar needs) but
  *                    tops out at 65504, and every conversion on the path SATURATES there instead of overflowing to inf -- silently.
  *                    1 = after each producer of an MFMA-operand tensor in the encoder (both LayerNorm outputs, q | k | v, the

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const float* __restrict__ X, const float* __restrict__ gamma, const float* __restrict__ beta,
     float eps, uint16_t* __restrict__ out_et, float* __restrict__ out_f32, int rows_out, int D,
     int window_mode, int grid, int window, uint16_t* __restrict__ out_lo /* optional: the split remainder of out_et */,
-    MxOut mx /* optional (plain row order only): hi and lo of the output as MXFP4 codes + scale tiles, gemm_et_mx_kernel's A operands */) {
+    MxOut mx /* optional (plain row order only): hi and lo of the output as MXFP4 codes + scale tiles, gemm_et_mx_kernel's A operands */,
+    int ld_out /* row stride of out_et in elements (>= D; gemm.hip tl_gemm_ld); out_lo / out_f32 / mx rows stay dense */) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows_out) return;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     const int nv = D >> 2;
     if (!valid) {
         for (int i = lane; i < nv; i += 64) {
-            if (out_et) reinterpret_cast<uint2*>(out_et + (size_t)row * D)[i] = make_uint2(0u, 0u);
+            if (out_et) reinterpret_cast<uint2*>(out_et + (size_t)row * ld_out)[i] = make_uint2(0u, 0u);
             if (out_lo) reinterpret_cast<uint2*>(out_lo + (size_t)row * D)[i] = make_uint2(0u, 0u);
             if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
                 uint2 o;
                 o.x = pack2<PREC>(o0, o1);
                 o.y = pack2<PREC>(o2, o3);
-                reinterpret_cast<uint2*>(out_et + (size_t)row * D)[idx] = o;
+                reinterpret_cast<uint2*>(out_et + (size_t)row * ld_out)[idx] = o;
                 if (out_lo) {          // neck only: the remainder of the split (same hi bits as above)
                     uint2 h, l;
                     split2_pack<PREC>(o0, o1, h.x, l.x);
@@ -1536,8 +1537,10 @@ hipError_t launch_rowstats_convert(int prec, const float* X, void* Xh, float* st
 
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
-                            int window, hipStream_t s, void* out_lo, void* mx_q_hi, void* mx_q_lo, void* mx_s_hi, void* mx_s_lo) {
+                            int window, hipStream_t s, void* out_lo, void* mx_q_hi, void* mx_q_lo, void* mx_s_hi, void* mx_s_lo, int ld_out) {
     if (D % 4 || D > LN_MAXV * 256) return hipErrorInvalidValue;
+    if (ld_out == 0) ld_out = D;
+    if (ld_out < D || ld_out % 4 || (ld_out != D && (out_lo || mx_q_hi))) return hipErrorInvalidValue;
     MxOut mx;
     if (mx_q_hi) {       // MX outputs: whole stages per row, rows in plain order, an ET output to take hi from, no partial lane passes
         if (!mx_q_lo || !mx_s_hi || !mx_s_lo || !out_et || window_mode || D % MXK) return hipErrorInvalidValue;
@@ -1545,9 +1548,9 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
     }
     const int blocks = (rows_out + 3) / 4;
     if (prec == PREC_BF16)
-        layernorm_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo, mx);
+        layernorm_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo, mx, ld_out);
     else
-        layernorm_kernel<PREC_F16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo, mx);
+        layernorm_kernel<PREC_F16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo, mx, ld_out);
     return hipGetLastError();
 }
 

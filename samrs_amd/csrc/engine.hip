@@ -67,6 +67,8 @@ struct EncBlock {
     const float *ln1w, *ln1b, *ln2w, *ln2b, *qkv_b, *proj_b, *lin1_b, *lin2_b, *rel_h, *rel_w;
     uint16_t *qkv_w = nullptr, *proj_w = nullptr, *lin1_w = nullptr, *lin2_w = nullptr;
     uint16_t *qkv_w_lo = nullptr, *proj_w_lo = nullptr, *lin1_w_lo = nullptr, *lin2_w_lo = nullptr;   // reference-grade bits only
+    // copies of qkv_w / lin1_w with a row stride of ldk elements instead of K = D (engine field ldk: operands off the 2560-byte stride)
+    uint16_t *qkv_wp = nullptr, *lin1_wp = nullptr;
     // option "lo_format" = 4: the lo terms of the attention-side split on MXFP4 operands (gemm.hip gemm_et_mx_kernel): fp4 codes of
     // hi and lo of the weights + their scale tiles (B layout); proj's K axis padded per head (80 -> 96) so that no MX block
     // straddles two heads
@@ -145,6 +147,11 @@ struct samrs_engine {
     // conversions write) or beyond into *range_counter (device); read through option "saturated"
     int ln_tail = 0;               // option "ln_tail": 1 = the LayerNorm behind proj / lin2 as a tail of those launches (measured slower: off)
     unsigned int* ln_counters = nullptr;   // per 256-row panel: tiles of the running proj / lin2 launch that have stored (gemm.hip LnTail)
+    // option "operand_pad" (default 1): the K = D operands of the plain qkv / lin1 launches -- the LayerNorm output and the weights -- are
+    // stored with a row stride of ldk = D + 128 elements where D rows are an even number of 256-byte units (ViT-H: 2560 B -> 2816 B), so
+    // that the rows a tile fetches per k-slice spread over all memory channels instead of half of them (gemm.hip tl_gemm_ld)
+    int operand_pad_on = 1;
+    int ldk = 0;                   // 0: no padded copies exist (other widths)
     int gelu_fast = -1;            // option "gelu_fast": -1 automatic (on in the 1x-rate modes: no block-GEMM bit in "split"), 0 off, 1 on
     int range_check = 0;
     unsigned long long* range_counter = nullptr;
@@ -403,6 +410,7 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->lo_format = (h_like && env_int("SAMRS_LO_FORMAT", 4) == 4) ? 4 : 0;
     e->gelu_fast = env_int("SAMRS_GELU_FAST", -1);
     e->ln_tail = env_int("SAMRS_LN_TAIL", 0) != 0;
+    e->operand_pad_on = env_int("SAMRS_OPERAND_PAD", 1) != 0;
     if (e->gelu_fast > 1) e->gelu_fast = 1;
     if (const int rc0 = env_int("SAMRS_RANGE_CHECK", 0)) {
         if (samrs_set_option(e, "range_check", rc0) != SAMRS_OK) {
@@ -492,6 +500,9 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
         const std::string p = "image_encoder.blocks." + std::to_string(i);
         EncBlock& b = e->blocks[i];
         b.global = is_global(c, i);
+        // padded operand rows (field ldk) exist where a D-element row is an even number of 256-byte units AND the qkv / lin1 shapes can
+        // run on the kernels that take a stride (N a multiple of 320): ViT-H
+        if (i == 0) e->ldk = (e->operand_pad_on && D % 256 == 0 && (3 * D) % 320 == 0 && (4 * D) % 320 == 0) ? D + 128 : 0;
         b.ln1w = W(e, p + ".norm1.weight"); b.ln1b = W(e, p + ".norm1.bias");
         b.ln2w = W(e, p + ".norm2.weight"); b.ln2b = W(e, p + ".norm2.bias");
         if (D == 1280 && e->ln_fold && gemm_has_experiments()) {       // folded LayerNorm needs the fp32 weights: before to_et() frees them
@@ -539,6 +550,13 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
         if ((rc = to_et(e, p + ".attn.proj.weight", &b.proj_w, true, s, lo_a ? &b.proj_w_lo : nullptr))) return rc;
         if ((rc = to_et(e, p + ".mlp.lin1.weight", &b.lin1_w, true, s, lo_m ? &b.lin1_w_lo : nullptr))) return rc;
         if ((rc = to_et(e, p + ".mlp.lin2.weight", &b.lin2_w, true, s, lo_m ? &b.lin2_w_lo : nullptr))) return rc;
+        if (e->ldk) {
+            const size_t ldb = (size_t)e->ldk * 2, wb = (size_t)D * 2;
+            CK(e, dalloc(e, &b.qkv_wp, (size_t)3 * D * e->ldk)); CK(e, dalloc(e, &b.lin1_wp, (size_t)4 * D * e->ldk));
+            CK(e, hipMemsetAsync(b.qkv_wp, 0, (size_t)3 * D * ldb, s)); CK(e, hipMemsetAsync(b.lin1_wp, 0, (size_t)4 * D * ldb, s));
+            CK(e, hipMemcpy2DAsync(b.qkv_wp, ldb, b.qkv_w, wb, wb, (size_t)3 * D, hipMemcpyDeviceToDevice, s));
+            CK(e, hipMemcpy2DAsync(b.lin1_wp, ldb, b.lin1_w, wb, wb, (size_t)4 * D, hipMemcpyDeviceToDevice, s));
+        }
         b.ln1w = W(e, p + ".norm1.weight"); b.ln1b = W(e, p + ".norm1.bias");
         b.ln2w = W(e, p + ".norm2.weight"); b.ln2b = W(e, p + ".norm2.bias");
         b.qkv_b = W(e, p + ".attn.qkv.bias"); b.proj_b = W(e, p + ".attn.proj.bias");
@@ -611,8 +629,8 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->X, M * D));
     CK(e, dalloc(e, &e->ln_counters, M / 256 + 1));
     CK(e, hipMemsetAsync(e->ln_counters, 0, (M / 256 + 1) * sizeof(unsigned int), s));
-    CK(e, dalloc(e, &e->Y, Mmax * D));
-    CK(e, hipMemsetAsync(e->Y, 0, Mmax * D * 2, s));
+    CK(e, dalloc(e, &e->Y, Mmax * (size_t)(e->ldk ? e->ldk : D)));
+    CK(e, hipMemsetAsync(e->Y, 0, Mmax * (size_t)(e->ldk ? e->ldk : D) * 2, s));
     if (e->can_fold) { CK(e, dalloc(e, &e->STATS, Mmax * 16)); CK(e, dalloc(e, &e->ROWSTAT, Mmax * 2)); }
     CK(e, dalloc(e, &e->QKV, Mmax * 3 * D));
     CK(e, dalloc(e, &e->AO, M * D));
@@ -750,8 +768,13 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     }
     // option "range_check": scan an operand tensor right after its producer (same stream)
 #define RANGE_SCAN(ptr_, count_) do { if (e->range_check) CK(e, launch_range_scan(prec, (ptr_), (long)(count_), e->range_counter, s)); } while (0)
+    // padded operand rows for the plain qkv / lin1 launches (they run on the persistent ET kernels at these shapes: gemm_ld_ok)
+    const bool pad_ok = e->ldk && e->operand_pad_on && !fold && !ln_tail;
+    const bool pad_qkv = pad_ok && gemm_ld_ok(M, 3 * D, D, false), pad_lin1 = pad_ok && gemm_ld_ok(M, 4 * D, D, true);
+    int y_ld = D;                  // row stride Y currently holds
     for (int i = 0; i < c.depth && i < n_blocks; ++i) {
         const EncBlock& b = e->blocks[i];
+        y_ld = D;
         const bool attn_full = (e->split & SPLIT_ATTN) && i < depth_full;
         const bool sp_attn = attn_full || ((e->split & SPLIT_ATTN_V) && i < depth_v), sp_mlp = any_mlp && i < depth_full;
         // v third only: needs the tile mask of the one-launch kernel; other shapes split all of qkv
@@ -781,8 +804,13 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                 CK(e, launch_convert(prec, e->F32T, e->QKV, (long)M * 3 * D, s));
             }
         } else {
-            if (!y_ready) CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s));
-            CK(e, launch_gemm_et(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s));
+            const int ldq = (pad_qkv && b.qkv_wp) ? e->ldk : 0;
+            if (!y_ready) CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, nullptr, nullptr, nullptr, nullptr, nullptr, ldq));
+            y_ld = ldq ? ldq : D;
+            const int prev_ld = swap_gemm_ld(ldq);
+            const hipError_t qe = launch_gemm_et(prec, e->Y, ldq ? b.qkv_wp : b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s);
+            (void)swap_gemm_ld(prev_ld);
+            CK(e, qe);
         }
         y_ready = false;
         const bool mx_ao = sp_attn && mx_attn;      // the attention kernels write the proj GEMM's MX operands themselves
@@ -795,10 +823,13 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                                           (sp_attn && !mx_ao) ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,
                                           mx_ao ? e->SAO4[0] : nullptr, mx_ao ? e->SAO4[1] : nullptr));
         if (e->range_check) {       // norm1 output, q | k | v, attention output
-            RANGE_SCAN(e->Y, (size_t)M * D);
+            RANGE_SCAN(e->Y, (size_t)M * y_ld);      // (a padded layout: the pad columns hold earlier, valid operand values)
             RANGE_SCAN(e->QKV, (size_t)M * 3 * D);
             RANGE_SCAN(e->AO, (size_t)M * D);
         }
+        y_ld = D;
+        // lin1 takes the plain launch below exactly when none of these holds; then norm2 writes the padded layout for it
+        const int ldl = (pad_lin1 && b.lin1_wp && !fold && !sp_lin2 && !sp_mlp) ? e->ldk : 0;
         if (fold) {
             CK(e, launch_gemm_et_stats(prec, e->AO, b.proj_w, e->X, b.proj_b, e->Y, e->STATS, M, D, D, s));
             CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
@@ -823,8 +854,12 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                 // norm2 came out of the proj launch
             } else if (sp_mlp && mx_mlp)
                 CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, nullptr, e->Y4[0], e->Y4[1], e->SY4[0], e->SY4[1]));
-            else
-                CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, sp_mlp ? e->Ylo : nullptr));
+            else {
+                const int ldn = sp_mlp ? 0 : ldl;
+                CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, sp_mlp ? e->Ylo : nullptr, nullptr, nullptr, nullptr,
+                                       nullptr, ldn));
+                y_ld = ldn ? ldn : D;
+            }
         }
         hipEvent_t t0 = nullptr, t1 = nullptr;
         if (e->timing) {
@@ -857,7 +892,9 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             // the 1x-rate modes take the cheaper erf in lin1's GELU epilogue (common.h gelu_erf2_et: -3.3 % on the dominant kernel);
             // every mode with a block-GEMM split bit keeps the arithmetic its parity statistics were measured on, bit for bit
             const int prev_form = swap_gelu_form(fast_gelu ? 2 : 1);
-            const hipError_t le = launch_gemm_et(prec, e->Y, b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s);
+            const int prev_ld = swap_gemm_ld(ldl);
+            const hipError_t le = launch_gemm_et(prec, e->Y, ldl ? b.lin1_wp : b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s);
+            (void)swap_gemm_ld(prev_ld);
             (void)swap_gelu_form(prev_form);
             CK(e, le);
         }
@@ -866,7 +903,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             e->tev.emplace_back(t0, t1);
         }
         if (e->range_check) {       // norm2 output (still in Y: lin1 has read it, nothing has overwritten it) and GELU(lin1)
-            RANGE_SCAN(e->Y, (size_t)M * D);
+            RANGE_SCAN(e->Y, (size_t)M * y_ld);      // (a padded layout: the pad columns hold earlier, valid operand values)
             RANGE_SCAN(e->H, (size_t)M * 4 * D);
         }
         if (fold) {
@@ -1316,6 +1353,7 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     else if (n == "allow_reduced") e->allow_reduced = value != 0;
     else if (n == "gelu_fast") e->gelu_fast = value < 0 ? -1 : (value != 0);
     else if (n == "ln_tail") e->ln_tail = value > 0;
+    else if (n == "operand_pad") e->operand_pad_on = value != 0;
     else if (n == "range_check") {
         if (value < 0 || value > 2) return fail(e, SAMRS_ERR_BAD_ARG, "range_check is 0 (off), 1 (count) or 2 (count, and samrs_set_images fails)");
         if (value && !e->range_counter) {
@@ -1356,6 +1394,7 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
     else if (n == "allow_reduced") *value = e->allow_reduced;
     else if (n == "gelu_fast") *value = e->gelu_fast;
     else if (n == "ln_tail") *value = e->ln_tail;
+    else if (n == "operand_pad") *value = e->operand_pad_on;
     else if (n == "range_check") *value = e->range_check;
     else if (n == "saturated") {                    // synchronizes the device: a diagnostic, not a hot-path call
         unsigned long long c = 0;

@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
     const float* __restrict__ bias, int M, int N, int K, int accumulate,
     const float2* __restrict__ rowstat = nullptr, const float* __restrict__ cvec = nullptr,
     const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr, int split_from_n = 0,
-    MxOut mxo = MxOut()) {
+    MxOut mxo = MxOut(), int ld = 0 /* row stride of A and B in elements, 0 = K (gemm_ld_ok: operands padded off the 2560-byte stride) */) {
     static_assert(!(FOLD && OUT_F32), "the folded LayerNorm feeds ET outputs only (qkv, lin1)");
     static_assert(!(FOLD && SPLIT3), "the split operands come from an explicit LayerNorm");
     static_assert(!(MXO && (FOLD || SPLIT3 || OUT_F32)), "MX rows go with the plain ET-output flavour");
@@ -1317,9 +1317,10 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
         (n_) = (in_g_ / gsz_) * XBN;                                                             \
     } while (0)
 
+    const int LD = ld > 0 ? ld : K;                // operand row stride (elements)
     const int prow = 8 * wave + ((lane >> 2) & 7);
-    const uint32_t voff = ((uint32_t)prow * (uint32_t)K + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
-    const size_t rs64 = (size_t)64 * K;
+    const uint32_t voff = ((uint32_t)prow * (uint32_t)LD + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
+    const size_t rs64 = (size_t)64 * LD;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
     const uint16_t* sA;                            // wave-uniform bases of the tile being FED (SGPR pairs)
@@ -1371,9 +1372,9 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
 
     int L = blockIdx.x, m0, n0;
     X64P_TILE(L, m0, n0);
-    sA = A + (size_t)m0 * K;
-    sB = B + (size_t)n0 * K;
-    if constexpr (SPLIT3) { sAl = A_lo + (size_t)m0 * K; sBl = B_lo + (size_t)n0 * K; sb = n0 >= split_from_n ? 0 : 2 * nst1; }
+    sA = A + (size_t)m0 * LD;
+    sB = B + (size_t)n0 * LD;
+    if constexpr (SPLIT3) { sAl = A_lo + (size_t)m0 * LD; sBl = B_lo + (size_t)n0 * LD; sb = n0 >= split_from_n ? 0 : 2 * nst1; }
     X64P_ISSUE(0, 0u);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1422,9 +1423,9 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
         int m1 = m0, n1 = n0;
         if (more) {
             X64P_TILE(Ln, m1, n1);
-            sA = A + (size_t)m1 * K;
-            sB = B + (size_t)n1 * K;
-            if constexpr (SPLIT3) { sAl = A_lo + (size_t)m1 * K; sBl = B_lo + (size_t)n1 * K; sb = n1 >= split_from_n ? 0 : 2 * nst1; }
+            sA = A + (size_t)m1 * LD;
+            sB = B + (size_t)n1 * LD;
+            if constexpr (SPLIT3) { sAl = A_lo + (size_t)m1 * LD; sBl = B_lo + (size_t)n1 * LD; sb = n1 >= split_from_n ? 0 : 2 * nst1; }
             X64P_ISSUE(0, 0u);
         }
         {   // epilogue of tile (m0, n0); bounce scratch = ring buffer 1 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
@@ -1454,6 +1455,12 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64p_kernel(
 // erf form of the ET-output GELU epilogue of the persistent 256x320 kernel (lin1 of ViT-H): 1 = fp32-epsilon class (A-S 7.1.26),
 // 2 = the cheaper one (A-S 7.1.28, common.h gelu_erf2_et); set around an engine's launches (engine.hip run_encoder)
 thread_local int tl_gelu_form = 1;
+// Row stride (elements) of the A and B operands of the calling thread's next plain ET launches, 0 = K.  Round 5, late: at K = 1280 an
+// operand row is 2560 B = ten 256-byte units, so the 256 rows a tile fetches per k-slice fall on half of the memory channels; stored with a
+// stride of 1408 elements (eleven units: every channel) the same kernels run their main loops ~4 % faster (tools/gemm_bench.py STRIDE_PROBE:
+// lin1 + GELU 432.2 us at K = 1280, 451.5 at K = 1408 with 10 % more stages).  Only the persistent ET kernels take a stride (gemm_ld_ok says
+// whether a launch will run on one of them); the engine pads the LayerNorm output and keeps padded copies of the qkv / lin1 weights.
+thread_local int tl_gemm_ld = 0;
 // lin1's output -- the MLP hidden tensor, read once, by lin2 -- is written with NON-TEMPORAL stores when it is larger than the 256 MB
 // Infinity Cache it would otherwise be allocated in (8 tiles of ViT-H: 336 MB per launch; SAMRS_NT_HIDDEN=0 / 1 forces the choice).
 // Measured on MI355X, libraries alternated on one box (profiles/r05_nt_streams.txt): lin1 424 -> 408 us in situ (the write-allocates no
@@ -1483,11 +1490,14 @@ hipError_t launch_gemm_x64p(const void* A, const void* B, void* C, const float* 
         else gemm_et_x64p_kernel<PREC, true, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
     } else {
         const bool so = gelu && stream_hidden(M, N);
-        if (gelu && tl_gelu_form == 2 && so) gemm_et_x64p_kernel<PREC, false, 2, false, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
-        else if (gelu && tl_gelu_form == 2) gemm_et_x64p_kernel<PREC, false, 2><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
-        else if (gelu && so) gemm_et_x64p_kernel<PREC, false, true, false, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
-        else if (gelu) gemm_et_x64p_kernel<PREC, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
-        else gemm_et_x64p_kernel<PREC, false, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+        const int ld = tl_gemm_ld;
+#define X64P_ARGS a, b, C, bias, M, N, K, acc, nullptr, nullptr, nullptr, nullptr, 0, MxOut(), ld
+        if (gelu && tl_gelu_form == 2 && so) gemm_et_x64p_kernel<PREC, false, 2, false, false, false, true><<<grid, block, 0, s>>>(X64P_ARGS);
+        else if (gelu && tl_gelu_form == 2) gemm_et_x64p_kernel<PREC, false, 2><<<grid, block, 0, s>>>(X64P_ARGS);
+        else if (gelu && so) gemm_et_x64p_kernel<PREC, false, true, false, false, false, true><<<grid, block, 0, s>>>(X64P_ARGS);
+        else if (gelu) gemm_et_x64p_kernel<PREC, false, true><<<grid, block, 0, s>>>(X64P_ARGS);
+        else gemm_et_x64p_kernel<PREC, false, false><<<grid, block, 0, s>>>(X64P_ARGS);
+#undef X64P_ARGS
     }
     return hipGetLastError();
 }
@@ -2145,7 +2155,7 @@ constexpr int W4X_SCR_BYTES = 4 * 16 * 272;            // epilogue scratch: per 
 template <int PREC, bool OUT_F32, int GELU, bool STREAM = false /* non-temporal output stores (stream_hidden) */>
 __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amdgpu_waves_per_eu(1, 1))) void gemm_et_w4x_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
-    const float* __restrict__ bias, int M, int N, int K, int accumulate) {
+    const float* __restrict__ bias, int M, int N, int K, int accumulate, int ld = 0 /* row stride of A and B in elements, 0 = K */) {
     static_assert(!OUT_F32, "ET outputs only (epilogue scratch: 16 rows x 272 B per wave)");
     constexpr int NI = 8, NJ = 8;
     constexpr uint32_t XSB = W4X_STAGE_ELEMS * 2;
@@ -2172,11 +2182,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amd
     // DMA map: piece q of this wave covers stage rows 32 q + 8 wave .. + 7 (q < 8: A rows, else B rows 32 (q - 8) + ..); lane l ->
     // k-half l>>5, row (l>>2)&7, physical chunk l&3 (the image and swizzle of the eight-wave kernels: 32 q = 0 mod 16).  The byte
     // offset of (piece q & 7, lane) from the stage base is the same for A and B: eight VGPRs.
+    const int LD = ld > 0 ? ld : K;                        // operand row stride (elements)
     const int prow = 8 * wave + ((lane >> 2) & 7);
     uint32_t voffq[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-        voffq[q] = ((uint32_t)(prow + 32 * q) * (uint32_t)K + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
+        voffq[q] = ((uint32_t)(prow + 32 * q) * (uint32_t)LD + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
 #define W4X_PIECE(pa_, pb_, wr_, q_) glds16_m(voffq[(q_) & 7], ((q_) < 8 ? (pa_) : (pb_)), lds0 + (wr_) + (q_) * 4096u)
@@ -2242,8 +2253,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amd
 
     int L = blockIdx.x, m0, n0;
     W4X_TILE(L, m0, n0);
-    const uint16_t* sA = A + (size_t)m0 * K;
-    const uint16_t* sB = B + (size_t)n0 * K;
+    const uint16_t* sA = A + (size_t)m0 * LD;
+    const uint16_t* sB = B + (size_t)n0 * LD;
     W4X_ISSUE_ALL(sA, sB, 0u);                             // stage 0 -> buffer 0
     {
         const uint16_t* a1 = sA + XBK;
@@ -2264,8 +2275,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amd
         const bool more = Ln < ntiles;
         int m1 = m0, n1 = n0;
         if (more) W4X_TILE(Ln, m1, n1);
-        const uint16_t* nA = A + (size_t)m1 * K;
-        const uint16_t* nB = B + (size_t)n1 * K;
+        const uint16_t* nA = A + (size_t)m1 * LD;
+        const uint16_t* nB = B + (size_t)n1 * LD;
         uint32_t rd = 0;
         // stage t feeds stage t + 2 into its own buffer; past the end of this tile that is stage t + 2 - nst of the NEXT tile
         const uint16_t* pa = sA + 2 * XBK;
@@ -2331,11 +2342,12 @@ hipError_t launch_gemm_w4x(const void* A, const void* B, void* C, const float* b
     const int acc = accumulate ? 1 : 0;
     if (out_f32) return hipErrorInvalidValue;
     const bool so = gelu && stream_hidden(M, N);
-    if (gelu && tl_gelu_form == 2 && so) gemm_et_w4x_kernel<PREC, false, 2, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
-    else if (gelu && tl_gelu_form == 2) gemm_et_w4x_kernel<PREC, false, 2><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
-    else if (gelu && so) gemm_et_w4x_kernel<PREC, false, 1, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
-    else if (gelu) gemm_et_w4x_kernel<PREC, false, 1><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
-    else gemm_et_w4x_kernel<PREC, false, 0><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc);
+    const int ld = tl_gemm_ld;
+    if (gelu && tl_gelu_form == 2 && so) gemm_et_w4x_kernel<PREC, false, 2, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, ld);
+    else if (gelu && tl_gelu_form == 2) gemm_et_w4x_kernel<PREC, false, 2><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, ld);
+    else if (gelu && so) gemm_et_w4x_kernel<PREC, false, 1, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, ld);
+    else if (gelu) gemm_et_w4x_kernel<PREC, false, 1><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, ld);
+    else gemm_et_w4x_kernel<PREC, false, 0><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, ld);
     return hipGetLastError();
 }
 
@@ -3230,19 +3242,36 @@ __global__ __launch_bounds__(256) void mx4_pack_kernel(const float* __restrict__
 
 }  // namespace
 
+// true when a plain ET launch of this shape (no 2-D addend, automatic variant) runs on gemm_et_x64p_kernel / gemm_et_w4x_kernel, the two
+// kernels that take an operand row stride (tl_gemm_ld): whole rounds of 256 x 320 tiles, K in 64-k pair stages
+static void gemm_env_once() {          // tuning knob for A/B runs: SAMRS_GEMM_VARIANT=<n>
+    static const bool once = [] {
+        if (const char* v = getenv("SAMRS_GEMM_VARIANT")) g_gemm_variant = atoi(v);
+        return true;
+    }();
+    (void)once;
+}
+bool gemm_ld_ok(int M, int N, int K, bool gelu) {
+    (void)gelu;
+    gemm_env_once();
+    const int gv = tl_gemm_variant >= 0 ? tl_gemm_variant : g_gemm_variant;
+    if (gv != 8 || M % QBM || N % WBN || K % XBK || K % QBK) return false;
+    const long t320 = (long)(M / QBM) * (N / WBN);
+    return t320 >= 256 && t320 % 256 == 0;
+}
+int swap_gemm_ld(int ld) { const int old = tl_gemm_ld; tl_gemm_ld = ld; return old; }
+
 hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const float* bias,
                           const float* add2d, int add2d_period, int M, int N, int K, bool out_f32,
                           bool gelu, bool accumulate, hipStream_t s) {
     if (M % BM || N % BN || K % BK || M <= 0 || N <= 0 || K <= 0) return hipErrorInvalidValue;
     if (add2d && add2d_period <= 0) return hipErrorInvalidValue;
     if (add2d && gelu) return hipErrorInvalidValue;   // not needed by the path; the coalesced epilogue orders them differently
-    static const bool env_once = [] {   // tuning knob for A/B runs: SAMRS_GEMM_VARIANT=<n>
-        if (const char* v = getenv("SAMRS_GEMM_VARIANT")) g_gemm_variant = atoi(v);
-        return true;
-    }();
-    (void)env_once;
+    gemm_env_once();
     // an engine handle's own choice (samrs_set_option "gemm_variant") overrides the process-wide test hook for its launches
     const int gv = tl_gemm_variant >= 0 ? tl_gemm_variant : g_gemm_variant;
+    // a padded operand stride is understood by the persistent ET kernels only: refuse anything else instead of reading garbage
+    if (tl_gemm_ld != 0 && (tl_gemm_ld < K || !gemm_ld_ok(M, N, K, gelu) || out_f32 || add2d)) return hipErrorInvalidValue;
 #define GEMM_DISPATCH(P)                                                                                         \
     switch (gv) {                                                                                    \
         case 0: return launch_gemm_prec<P, false, 1>(A, B, C, bias, add2d, add2d_period, M, N, K, out_f32, gelu, accumulate, s); \

@@ -36,6 +36,10 @@ bool gemm_lntail_ok(int M, int N, int K);
 hipError_t launch_gemm_et_lntail(int prec, const void* A, const void* B, float* C, const float* bias, int M, int N, int K,
                                  const float* gamma, const float* beta, float eps, void* out_et, unsigned int* counters, hipStream_t s);
 int swap_gelu_form(int v);                // thread-local erf form of lin1's GELU epilogue (1 = fp32-epsilon class, 2 = cheaper); returns the previous value
+// Operand row stride of the calling thread's next plain ET GEMM launches (elements; 0 = K): the persistent ET kernels read A and B with
+// it (gemm.hip tl_gemm_ld).  gemm_ld_ok: a launch of this shape runs on one of them (anything else refuses a stride).
+int swap_gemm_ld(int ld);
+bool gemm_ld_ok(int M, int N, int K, bool gelu);
 int swap_gemm_variant_override(int v);   // thread-local override (-1 = none) used by engine handles; returns the previous value
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
@@ -68,7 +72,8 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
                             int window, hipStream_t s, void* out_lo = nullptr,
                             // optional (plain row order, D % 256 == 0): the output's hi / lo as MXFP4 codes [rows][D / 2] + scale tiles
                             // (the A operands of launch_gemm_et_mx: no ET lo copy, no separate pack pass)
-                            void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr);
+                            void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr,
+                            int ld_out = 0 /* row stride of out_et in elements, 0 = D (plain ET output only) */);
 // out_lo (optional, both attention kernels): the split remainder of `out` (reference-grade mode: proj on hi + lo operands)
 hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
                                    int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo = nullptr,

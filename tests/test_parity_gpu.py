@@ -997,6 +997,32 @@ def test_vit_h_odd_batches_equal_single_tile(batch):
         assert torch.equal(eng.get_embedding(7), embs[i]), f"batch {batch}, tile {i}: differs from single-tile encode"
 
 
+@pytest.mark.parametrize("split", [15, 79])
+def test_operand_row_padding_is_bit_identical(split):
+    """Round 5: at ViT-H the K = 1280 operands of the plain qkv / lin1 launches (the LayerNorm output, the weights) are stored with a row
+    stride of 1408 elements instead of 1280 (option "operand_pad", engine field ldk; the persistent ET kernels take the stride:
+    gemm.hip tl_gemm_ld) -- a 2560-byte row is ten 256-byte units and lands the rows of a tile on half of the memory channels.  Where the
+    bytes live cannot change what is computed: the embeddings of 4 and 8 tiles (the batches whose shapes fill whole rounds of tiles and
+    therefore take the padded layout) must equal the dense layout's bit for bit, in the single-mask mode and in the multimask default
+    (whose lin1, and qkv of the last blocks, run plain)."""
+    pred = get_predictor("vit_h", "f16", max_prompts=32, max_images=8)
+    eng = pred.model.engine
+    tiles = torch.stack([torch.as_tensor(synth.make_noise_image(90 + i)) for i in range(8)]).cuda()
+    with eng.options(split=split):
+        for n in (8, 4):
+            embs = {}
+            for pad in (1, 0, 1):
+                with eng.options(operand_pad=pad):
+                    assert eng.get_option("operand_pad") == pad
+                    eng.set_images(tiles[:n].contiguous(), 0)
+                    got = torch.stack([eng.get_embedding(i).clone() for i in range(n)])
+                if pad in embs:
+                    assert torch.equal(got, embs[pad]), f"split {split}, {n} tiles: the padded layout is not reproducible from launch to launch"
+                embs[pad] = got
+            assert embs[1].abs().max() > 0
+            assert torch.equal(embs[0], embs[1]), f"split {split}, {n} tiles: padded operand rows changed the embedding"
+
+
 def test_f16_operand_range_stress_and_saturation_counter():
     """VERDICT r04 item 4 / "missing" 6: every f16 conversion on the path saturates at 65504 -- silently -- and every other
     test runs on N(0, sigma) weights.  Here the weights get the outlier structure checkpoints have (synth.heavy_tailed: a few

@@ -120,6 +120,32 @@ def _cpu_quota():
         return None
 
 
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _self_launch(n: int) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher.  Re-runs this same command line
+    under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` (one
+    rank per GPU, RCCL) and exits with its status; rank 0's JSON line is the only thing on stdout.  The N = 1 path and a launch
+    that already comes from torchrun (WORLD_SIZE set) never get here."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without a launcher: re-executing under torch.distributed.run on 127.0.0.1:{port}", file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd))
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +173,8 @@ def main() -> None:
     ap.add_argument("--no-rle-leg", action="store_true", help="skip the RLE-inclusive measurement (the reference's full output contract)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -313,6 +341,15 @@ def main() -> None:
     # ---- the one collective of the path: class statistics all-reduce (outside the timed step) ----
     tot_pix, tot_ins = driver.reduce_statistics(pipe.class_pixels, pipe.class_instances)
     torch.cuda.synchronize()
+    # every rank's LOCAL sums beside the reduced ones (all-gather of two int64 per rank): the line itself shows that the
+    # all-reduce returned the serial sum of what the ranks painted
+    local = torch.stack([pipe.class_pixels.sum(), pipe.class_instances.sum()]).to(torch.int64)
+    per_rank = [local.cpu().tolist()]
+    if dist is not None:
+        lt = local.cpu() if share else local
+        got = [torch.zeros_like(lt) for _ in range(world)]
+        dist.all_gather(got, lt)
+        per_rank = [g.cpu().tolist() for g in got]
 
     # ---- RLE-inclusive: the reference's FULL per-image output contract (main_sam_hbox_semantic.py:195-216): class map + areas
     # + the COCO RLE string of every instance.  Same loop, rle=True: the strings are encoded on the device (samrs_rle_encode)
@@ -436,7 +473,10 @@ def main() -> None:
         # the oracle (a port of the reference's algorithm) on the host cores: 1 warm-up tile, then 2 timed tiles with
         # 32 boxes each as 20 + 12 chunks (main_sam_hbox_semantic.py:157-181)
         from oracle import sam_oracle as so
-        torch.set_num_threads(min(32, len(os.sched_getaffinity(0))))   # more threads oversubscribe the box (256 logical CPUs: 215 s per tile)
+        # threads = what this container may actually run at once: min(cgroup CPU quota, affinity mask, 32).  More threads than the
+        # quota are throttled (the pool's boxes: 256 logical CPUs, quota 16), and the value drifts with the throttling
+        n_thr = int(max(1, min(32, len(os.sched_getaffinity(0)), _cpu_quota() or 1e9)))
+        torch.set_num_threads(n_thr)
         orc = so.OraclePredictor(sd, cfg)
 
         def one_tile(i):
@@ -453,6 +493,7 @@ def main() -> None:
         times = [one_tile(1 + i) for i in range(3)]
         enc_s, dec_s = float(np.mean([t[0] for t in times])), float(np.mean([t[1] for t in times]))
         cpu_baseline = {"value": round(1.0 / (enc_s + dec_s), 4), "unit": "images/s", "cores": torch.get_num_threads(),
+                        "cpu_model": _cpu_model(), "cpu_quota": _cpu_quota(), "logical_cpus": os.cpu_count(),
                         "kind": "port",
                         "pinned_to": "tests/golden/*.npz: outputs of the REAL reference (oracle/make_golden.py imports /root/reference) that "
                                      "tests/test_oracle_golden.py holds this port to (low-res logits within 2e-4, <= 8 flipped pixels per mask); "
@@ -509,7 +550,8 @@ def main() -> None:
             "rle_inclusive": rle_leg, "cli_inclusive": cli, "other_precision_mode": other_mode,
             "parity": parity_of_mode(int(split_used), args.workload, args.model), "reference_chunking": chunk_leg,
             "boxes_per_s": round(boxes_done / dt, 1),
-            "stats_allreduce": {"total_pixels": int(tot_pix.sum().item()), "total_instances": int(tot_ins.sum().item())},
+            "stats_allreduce": {"total_pixels": int(tot_pix.sum().item()), "total_instances": int(tot_ins.sum().item()),
+                                "per_rank_local": [{"pixels": int(a), "instances": int(b)} for a, b in per_rank]},
         }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -1,0 +1,156 @@
+"""TEST INFRASTRUCTURE ONLY -- what do outlier channels cost the f16 engine, and which K-columns must carry lo terms?  (CPU.)
+
+VERDICT r05 item 1: every parity number was on N(0, sigma) weights; ``synth.heavy_tailed`` gives the outlier structure real
+ViT checkpoints have (LayerNorm gammas x 30, MLP hidden units and v channels running 3e3 hotter in three blocks) and the
+engine's IoU dropped to 0.9980 on it at vit_tiny.  This tool prices the remedy before any kernel is written: the fp32 oracle
+is run on the heavy-tailed weights once exactly and then with the engine's roundings (``sam_oracle.Rounding``), where the
+four block GEMMs keep hi + lo (``split2``) on a FEW K-columns only -- the ones a weights-only rule picks:
+
+    score_c = (operand magnitude proxy of column c) x || W[:, c] ||      column c is an outlier when score_c > RATIO x median
+
+  * qkv / lin1 (A = LayerNorm output):  |gamma_c| + |beta_c|
+  * lin2 (A = GELU(lin1)):              || W1[c, :] || x rms(gamma2) + |b1_c|
+  * proj (A = attention output):        || Wv[c, :] || x rms(gamma1) + |bv_c|
+
+(the same rule ``samrs_amd/engine.py`` applies at weight-load time: ``outlier_columns``).  Cost of a plan in the engine: one
+more 64-wide K stage per GEMM when at most 32 columns are picked (A_lo[:, S] B_hi[:, S]^T and A_hi[:, S] B_lo[:, S]^T ride as
+extra K columns of the SAME launch), i.e. 1 / 20 of qkv / lin1 / proj and 1 / 80 of lin2.
+
+    python -m oracle.outlier_budget vit_tiny            # seconds
+    python -m oracle.outlier_budget vit_h [plans|all] [every]      # ~30 s per encoder pass on 8 cores; `every`: outliers in all blocks
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+from samrs_amd import synth
+from oracle import make_golden, rbox_prompt
+from oracle import sam_oracle as so
+from oracle.error_budget import decode_all, metrics
+
+F16 = torch.float16
+RATIO = 4.0            # a column is an outlier when its score exceeds RATIO x the median score of its GEMM
+MAX_COLS = 32          # at most this many per GEMM: 32 lo + 32 hi columns = one 64-wide K stage
+
+
+def outlier_columns(sd, cfg, ratio: float = RATIO, max_cols: int = MAX_COLS):
+    """{(block, point): LongTensor of K-columns} from the weights alone (see the module docstring)."""
+    D = cfg.embed_dim
+    out = {}
+    for i in range(cfg.depth):
+        p = f"image_encoder.blocks.{i}"
+        g1, b1 = sd[p + ".norm1.weight"].abs(), sd[p + ".norm1.bias"].abs()
+        g2, b2 = sd[p + ".norm2.weight"].abs(), sd[p + ".norm2.bias"].abs()
+        wqkv, bqkv = sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"]
+        w1, bb1 = sd[p + ".mlp.lin1.weight"], sd[p + ".mlp.lin1.bias"]
+        w2, wp = sd[p + ".mlp.lin2.weight"], sd[p + ".attn.proj.weight"]
+        rms1, rms2 = float(g1.square().mean().sqrt()), float(g2.square().mean().sqrt())
+        scores = {
+            "enc.qkv_in": (g1 + b1) * wqkv.norm(dim=0),
+            "enc.lin1_in": (g2 + b2) * w1.norm(dim=0),
+            "enc.lin2_in": (w1.norm(dim=1) * rms2 + bb1.abs()) * w2.norm(dim=0),
+            "enc.proj_in": (wqkv[2 * D:].norm(dim=1) * rms1 + bqkv[2 * D:].abs()) * wp.norm(dim=0),
+        }
+        for k, s in scores.items():
+            idx = torch.nonzero(s > ratio * s.median()).flatten()
+            if len(idx) > max_cols:
+                idx = idx[torch.argsort(s[idx], descending=True)[:max_cols]]
+            out[(i, k)] = torch.sort(idx).values
+    return out
+
+
+class ColSplit:
+    """Round to ``dt`` except the K-columns (last axis) listed for the current block and point, which keep hi + lo."""
+
+    def __init__(self, rd_ref, cols, point, dt=F16, base=None):
+        self.rd_ref, self.cols, self.point, self.dt = rd_ref, cols, point, dt
+        self.base = base                               # rounding of the other columns (default: plain dt)
+
+    def __call__(self, x):
+        y = x.to(self.dt).to(torch.float32) if self.base is None else self.base(x)
+        S = self.cols.get((self.rd_ref[0].cur_block, self.point))
+        if S is not None and len(S):
+            y = y.clone()
+            y[..., S] = so.split2(self.dt)(x[..., S])
+        return y
+
+
+def main(argv):
+    name = argv[0] if argv else "vit_tiny"
+    what = argv[1] if len(argv) > 1 else "plans"
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = synth.CONFIGS[name]
+    base = synth.make_state_dict(cfg, 0, logit_scale=synth.MARGIN_LOGIT_SCALE)
+    every = "every" in argv[2:]                      # outlier channels in EVERY block instead of first / middle / last
+    sd = synth.heavy_tailed(base, cfg, 0, hidden_scale=3e3, v_scale=3e3, gamma_scale=30.0,
+                            blocks=list(range(cfg.depth)) if every else None)
+    inp = make_golden.extended_inputs()
+    img = synth.make_image(0)
+    prompts = torch.from_numpy(np.stack([rbox_prompt.rbox_mask_prompt(p.astype(np.int32), 1024, 1024)
+                                         for p in inp["polys"]]).astype(np.float32))[:, None]
+    x = so.preprocess(img)
+    cols = outlier_columns(sd, cfg)
+    n_by_point = {}
+    for (i, k), v in cols.items():
+        if len(v):
+            n_by_point.setdefault(k, []).append((i, len(v)))
+    print(f"# {name}: outlier columns picked from the weights (block, count): {n_by_point}", flush=True)
+
+    def run(rd):
+        t0 = time.time()
+        orc = so.OraclePredictor(sd, cfg, rd)
+        with torch.no_grad():
+            orc.features = so.image_encoder(sd, cfg, x, rd)
+            orc.original_size = orc.input_size = (1024, 1024)
+            orc.is_image_set = True
+            out = decode_all(orc, inp, prompts)
+        return out, orc.features, time.time() - t0
+
+    ref, emb0, _ = run(so.Rounding())
+    hdr = (f"{'configuration':66s} {'emb relL2':>9s} {'C2 map diff':>11s} {'C2 IoU min':>10s} {'C2 relL2':>9s} "
+           f"{'c4box IoU':>10s} {'c4mask IoU':>10s}")
+    print(f"# {name}, heavy-tailed weights (hidden 3e3, v 3e3, gamma 30; {'every block' if every else 'first / middle / last block'}): against the exact fp32 oracle on the SAME weights\n{hdr}", flush=True)
+    sp = so.split2(F16)
+    e1 = {"enc.patch": sp, "enc.neck0": sp, "enc.neck2": sp, "dec.prod": None, "dec.oi": sp, "dec.up1": sp, "dec.up2": sp}
+
+    def report(label, points, block_points=None):
+        rd = so.Rounding(enc=F16, dec=F16, points=points, block_points=block_points if block_points is not None else {})
+        for v in list(points.values()) + [bp[1] for bp in (block_points or {}).values()]:
+            if isinstance(v, ColSplit):
+                v.rd_ref[0] = rd
+                if isinstance(v.base, ColSplit):
+                    v.base.rd_ref[0] = rd
+        got, emb, dt = run(rd)
+        m = metrics(ref, got, inp["labels"])
+        rel = float((emb - emb0).norm() / emb0.norm())
+        print(f"{label:66s} {rel:9.2e} {m['c2_map_diff']:11d} {m['c2_iou']:10.5f} {m['c2_relL2']:9.2e} "
+              f"{m['c4box_iou']:10.5f} {m['c4mask_iou']:10.5f}   [{dt:.0f}s]", flush=True)
+
+    def cs(point, base=None):
+        return ColSplit([None], cols, point, base=base)
+
+    report("mode 15 (today): block GEMMs plain f16", dict(e1))
+    report("15 + outlier columns of qkv / lin1 (LayerNorm outputs)", dict(e1, **{"enc.qkv_in": cs("enc.qkv_in"), "enc.lin1_in": cs("enc.lin1_in")}))
+    report("15 + outlier columns of lin2 (hidden units)", dict(e1, **{"enc.lin2_in": cs("enc.lin2_in")}))
+    report("15 + outlier columns of proj (attention output)", dict(e1, **{"enc.proj_in": cs("enc.proj_in")}))
+    four = {k: cs(k) for k in ("enc.qkv_in", "enc.lin1_in", "enc.lin2_in", "enc.proj_in")}
+    report("15 + outlier columns of all four block GEMMs", dict(e1, **four))
+    report("  ... + v / P exact (what hi + lo storage of v and P could buy at most)", dict(e1, **four, **{"enc.qkv_out": None, "enc.P": None}))
+    report("15 + all four block GEMMs fully split (mode 63)", dict(e1, **{k: sp for k in four}))
+    if what == "all":
+        n = cfg.depth
+        att = range(0, 3 * n // 4)
+        q4 = so.split_fp8_lo(F16, fmt="e2m1", block=32)
+        report("mode 79 (today)", dict(e1), {"enc.v_in": (att, q4), "enc.proj_in": (att, q4)})
+        report("79 + outlier columns of qkv / lin1 / lin2", dict(e1, **{k: cs(k) for k in ("enc.qkv_in", "enc.lin1_in", "enc.lin2_in")}),
+               {"enc.v_in": (att, q4), "enc.proj_in": (att, q4)})
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

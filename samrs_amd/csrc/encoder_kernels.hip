@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
     float eps, uint16_t* __restrict__ out_et, float* __restrict__ out_f32, int rows_out, int D,
     int window_mode, int grid, int window, uint16_t* __restrict__ out_lo /* optional: the split remainder of out_et */,
     MxOut mx /* optional (plain row order only): hi and lo of the output as MXFP4 codes + scale tiles, gemm_et_mx_kernel's A operands */,
-    int ld_out /* row stride of out_et in elements (>= D; gemm.hip tl_gemm_ld); out_lo / out_f32 / mx rows stay dense */) {
+    int ld_out /* row stride of out_et in elements (>= D; gemm.hip tl_gemm_ld); out_lo / out_f32 / mx rows stay dense */,
+    const int* __restrict__ oc_idx /* optional: n_oc <= 32 OUTLIER columns of the output (engine.hip outlier_columns) */, int n_oc) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows_out) return;
@@ -212,6 +213,72 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
             if (out_f32) reinterpret_cast<float4*>(out_f32 + (size_t)row * D)[idx] = make_float4(o0, o1, o2, o3);
         }
     }
+    // Outlier columns (oracle/outlier_budget.py): a checkpoint's LayerNorm output has a few channels that run
+    // 10 - 100x hotter than the rest (large gamma), and an element's f16 rounding error is relative to ITS magnitude -- those few
+    // columns carry most of the operand error of the qkv / lin1 products.  Their hi + lo split rides as 64 more K columns of the SAME
+    // GEMM launch: row[D + j] = lo of column oc_idx[j] (meets W_hi[:, oc_idx[j]] in the weight's extension), row[D + 32 + j] = its hi
+    // (meets W_lo[:, oc_idx[j]]); unused slots are zero on both sides.
+    if (n_oc > 0 && out_et && lane < 32) {
+        uint16_t hi = 0, lo = 0;
+        if (lane < n_oc) {
+            const int c = oc_idx[lane];
+            const float o = (X[(size_t)src * D + c] - mean) * rstd * gamma[c] + beta[c];
+            hi = ET<PREC>::from_float(o);
+            lo = ET<PREC>::from_float(o - ET<PREC>::to_float(hi));
+        }
+        out_et[(size_t)row * ld_out + D + lane] = lo;
+        out_et[(size_t)row * ld_out + D + 32 + lane] = hi;
+    }
+}
+
+// Weight side of the outlier-column extension: ext[r][j] = ET(W[r][idx[j]]) (hi: meets the operand's lo), ext[r][32 + j] = ET(W - hi)
+// (lo: meets the operand's hi), zeros in unused slots; written at column K of a row of stride ld (K + 64 <= ld).
+template <int PREC>
+__global__ __launch_bounds__(256) void outlier_weight_ext_kernel(const float* __restrict__ W, int N, int K, const int* __restrict__ idx, int n_oc,
+                                                                  uint16_t* __restrict__ out, int ld) {
+    const int r = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
+    if (r >= N) return;
+    uint16_t hi = 0, lo = 0;
+    if (j < n_oc) {
+        const float w = W[(size_t)r * K + idx[j]];
+        hi = ET<PREC>::from_float(w);
+        lo = ET<PREC>::from_float(w - ET<PREC>::to_float(hi));
+    }
+    out[(size_t)r * ld + K + j] = hi;
+    out[(size_t)r * ld + K + 32 + j] = lo;
+}
+
+hipError_t launch_outlier_weight_ext(int prec, const float* W, int N, int K, const int* idx, int n_oc, void* out, int ld, hipStream_t s) {
+    if (!W || !out || N < 1 || K < 1 || n_oc < 0 || n_oc > 32 || ld < K + 64 || (n_oc && !idx)) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) outlier_weight_ext_kernel<PREC_BF16><<<(N + 7) / 8, 256, 0, s>>>(W, N, K, idx, n_oc, (uint16_t*)out, ld);
+    else outlier_weight_ext_kernel<PREC_F16><<<(N + 7) / 8, 256, 0, s>>>(W, N, K, idx, n_oc, (uint16_t*)out, ld);
+    return hipGetLastError();
+}
+
+// Squared L2 norms of the columns (col_sq[K], must be zero on entry) and of the rows (row_sq[N]) of an fp32 matrix W[N][K]: what the
+// weights-only outlier rule scores columns with (engine.hip pick_outlier_columns).  Load-time only.
+__global__ __launch_bounds__(256) void weight_norms_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ col_sq,
+                                                           float* __restrict__ row_sq) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * 64, r1 = min(N, r0 + 64);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float w = c < K ? W[(size_t)r * K + c] : 0.f;
+        acc += w * w;
+        if (row_sq) {
+            float t = wave_sum(w * w);
+            if ((threadIdx.x & 63) == 0) atomicAdd(row_sq + r, t);
+        }
+    }
+    if (col_sq && c < K) atomicAdd(col_sq + c, acc);
+}
+
+hipError_t launch_weight_norms(const float* W, int N, int K, float* col_sq, float* row_sq, hipStream_t s) {
+    if (!W || N < 1 || K < 1) return hipErrorInvalidValue;
+    if (col_sq) HIP_CHECK_RET(hipMemsetAsync(col_sq, 0, sizeof(float) * K, s));
+    if (row_sq) HIP_CHECK_RET(hipMemsetAsync(row_sq, 0, sizeof(float) * N, s));
+    weight_norms_kernel<<<dim3((K + 255) / 256, (N + 63) / 64), 256, 0, s>>>(W, N, K, col_sq, row_sq);
+    return hipGetLastError();
 }
 
 // -----------------------------------------------------------------------------------------
@@ -1394,10 +1461,13 @@ hipError_t launch_patch_im2col(int prec, const uint8_t* img, void* A, int n_imag
 // (0x7bff: what the saturating conversion writes; a legitimate 65504 is not distinguishable and not plausible) or inf / nan.
 // bf16 (max finite 0x7f7f = 3.4e38, same range as fp32) can only ever show inf / nan.
 static __global__ __launch_bounds__(256) void range_scan_kernel(const uint4* __restrict__ x, long n16, uint32_t limit /* 0x7bff | 0x7f80 */,
-                                                         unsigned long long* __restrict__ counter) {
+                                                         unsigned long long* __restrict__ counter, int row16 /* live 16-byte units per row */,
+                                                         int ld16 /* row stride in 16-byte units */) {
     unsigned cnt = 0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) {
-        const uint4 v = x[i];
+        // rows with a stride: only the first row16 units of every ld16 are operand values (the pad of a padded row is never read by a
+        // GEMM and may hold values of an earlier pass)
+        const uint4 v = x[row16 == ld16 ? i : (i / row16) * ld16 + i % row16];
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) cnt += ((w[k] & 0x7fffu) >= limit) + (((w[k] >> 16) & 0x7fffu) >= limit);
@@ -1406,13 +1476,15 @@ static __global__ __launch_bounds__(256) void range_scan_kernel(const uint4* __r
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(counter, (unsigned long long)cnt);
 }
-hipError_t launch_range_scan(int prec, const void* x, long n, unsigned long long* counter, hipStream_t s) {
-    if (n % 8 || !x || !counter) return hipErrorInvalidValue;
+hipError_t launch_range_scan(int prec, const void* x, long n, unsigned long long* counter, hipStream_t s, int cols, int ld) {
+    // n elements in all; cols / ld (optional): rows of `cols` live elements stored with a stride of `ld` (n = rows * cols)
+    if (cols <= 0) { cols = 8; ld = 8; }
+    if (n % 8 || !x || !counter || cols % 8 || ld % 8 || ld < cols || n % cols) return hipErrorInvalidValue;
     const long n16 = n / 8;
     long blocks = (n16 + 256 * 8 - 1) / (256 * 8);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    range_scan_kernel<<<(int)blocks, 256, 0, s>>>(reinterpret_cast<const uint4*>(x), n16, prec == PREC_F16 ? 0x7bffu : 0x7f80u, counter);
+    range_scan_kernel<<<(int)blocks, 256, 0, s>>>(reinterpret_cast<const uint4*>(x), n16, prec == PREC_F16 ? 0x7bffu : 0x7f80u, counter, cols / 8, ld / 8);
     return hipGetLastError();
 }
 
@@ -1537,10 +1609,12 @@ hipError_t launch_rowstats_convert(int prec, const float* X, void* Xh, float* st
 
 hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const float* beta, float eps,
                             void* out_et, float* out_f32, int rows_out, int D, int window_mode, int grid,
-                            int window, hipStream_t s, void* out_lo, void* mx_q_hi, void* mx_q_lo, void* mx_s_hi, void* mx_s_lo, int ld_out) {
+                            int window, hipStream_t s, void* out_lo, void* mx_q_hi, void* mx_q_lo, void* mx_s_hi, void* mx_s_lo, int ld_out,
+                            const int* oc_idx, int n_oc) {
     if (D % 4 || D > LN_MAXV * 256) return hipErrorInvalidValue;
     if (ld_out == 0) ld_out = D;
     if (ld_out < D || ld_out % 4 || (ld_out != D && (out_lo || mx_q_hi))) return hipErrorInvalidValue;
+    if (n_oc < 0 || n_oc > 32 || (n_oc && (!oc_idx || !out_et || window_mode || ld_out < D + 64))) return hipErrorInvalidValue;
     MxOut mx;
     if (mx_q_hi) {       // MX outputs: whole stages per row, rows in plain order, an ET output to take hi from, no partial lane passes
         if (!mx_q_lo || !mx_s_hi || !mx_s_lo || !out_et || window_mode || D % MXK) return hipErrorInvalidValue;
@@ -1548,9 +1622,9 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
     }
     const int blocks = (rows_out + 3) / 4;
     if (prec == PREC_BF16)
-        layernorm_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo, mx, ld_out);
+        layernorm_kernel<PREC_BF16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo, mx, ld_out, oc_idx, n_oc);
     else
-        layernorm_kernel<PREC_F16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo, mx, ld_out);
+        layernorm_kernel<PREC_F16><<<blocks, 256, 0, s>>>(X, gamma, beta, eps, (uint16_t*)out_et, out_f32, rows_out, D, window_mode, grid, window, (uint16_t*)out_lo, mx, ld_out, oc_idx, n_oc);
     return hipGetLastError();
 }
 

@@ -7,6 +7,8 @@
 //                modeling/transformer.py:62-106,151-182 -> modeling/sam.py:133-162
 // (paths under Generate Dataset/segment_anything/).  Image-side work shared by all prompts of a
 // call (layer-0 key/value/query projections when there is no mask prompt) is computed once.
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -77,6 +79,14 @@ struct EncBlock {
     // ... and of the MLP weights (bit 32): lin1 plain, lin2 on the K axis that lin1's epilogue writes its MX rows on (80 -> 96 per wave tile)
     unsigned char *lin1_w4[2] = {nullptr, nullptr}, *lin1_s4[2] = {nullptr, nullptr};
     unsigned char *lin2_w4[2] = {nullptr, nullptr}, *lin2_s4[2] = {nullptr, nullptr};
+    // Outlier columns (option "outlier_cols"; oracle/outlier_budget.py): per block GEMM ([0] qkv, [1] lin1, [2] lin2, [3] proj) the K-columns
+    // whose operand magnitude x weight column norm stands out (> ratio x the median), at most 32, picked from the fp32 weights at load
+    // time.  For qkv / lin1 their hi + lo split rides as 64 extra K columns of the same launch: the LayerNorm writes the operand side
+    // (encoder_kernels.hip), qkv_wx / lin1_wx are dense [N][D + 64] copies of the weights with the weight side appended (on the
+    // padded-stride route the same 64 columns sit in the pad region of qkv_wp / lin1_wp instead).
+    int oc_n[4] = {0, 0, 0, 0};
+    int* oc_idx[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint16_t *qkv_wx = nullptr, *lin1_wx = nullptr;
     // LayerNorm folded into qkv / lin1 (ViT-H): W diag(gamma) in ET, its row sums, b + W beta
     uint16_t *qkv_wf = nullptr, *lin1_wf = nullptr;
     float *qkv_c = nullptr, *qkv_bf = nullptr, *lin1_c = nullptr, *lin1_bf = nullptr;
@@ -152,6 +162,13 @@ struct samrs_engine {
     // that the rows a tile fetches per k-slice spread over all memory channels instead of half of them (gemm.hip tl_gemm_ld)
     int operand_pad_on = 1;
     int ldk = 0;                   // 0: no padded copies exist (other widths)
+    // option "outlier_cols" (default 1; SAMRS_OUTLIER_COLS): hi + lo terms for the outlier K-columns of the plain qkv / lin1 launches
+    // (EncBlock::oc_*).  Columns are picked in samrs_finalize_weights (the option must be on by then); later it switches their use.
+    // "outlier_ratio_pct" (default 400): a column is an outlier when its score exceeds this percentage of its GEMM's median score.
+    // Read-only: "outlier_blocks" (blocks with at least one such column in qkv / lin1), "outlier_columns" (their total over the
+    // four block GEMMs).  Weights without outliers (every seeded-normal test model) pick nothing: bit-identical, zero cost.
+    int outlier_on = 1, outlier_ratio_pct = 400, outlier_blocks = 0, outlier_columns = 0;
+    float* oc_scratch = nullptr;   // load-time scratch: column / row norms
     int gelu_fast = -1;            // option "gelu_fast": -1 automatic (on in the 1x-rate modes: no block-GEMM bit in "split"), 0 off, 1 on
     int range_check = 0;
     unsigned long long* range_counter = nullptr;
@@ -351,6 +368,72 @@ int to_et(samrs_engine* e, const std::string& name, uint16_t** out, bool free_f3
     return SAMRS_OK;
 }
 
+// Outlier columns of the four block GEMMs of encoder block `i`, from the fp32 weights alone (they must still be resident: call before
+// to_et frees them).  score_c = (magnitude proxy of operand column c) x || W[:, c] ||; the proxies: qkv / lin1 (A = a LayerNorm
+// output): |gamma_c| + |beta_c|; lin2 (A = GELU(lin1)): || W1[c, :] || rms(gamma2) + |b1_c|; proj (A = the attention output, a
+// convex combination of v rows): || Wv[c, :] || rms(gamma1) + |bv_c|.  A column is picked when its score exceeds ratio x the median
+// score of its GEMM; at most 32 per GEMM (the largest), ascending.  oracle/outlier_budget.py restates the rule on the CPU and prices it.
+int pick_outlier_columns(samrs_engine* e, int i, hipStream_t s) {
+    const int D = e->D, H = 4 * D;
+    EncBlock& b = e->blocks[i];
+    const std::string p = "image_encoder.blocks." + std::to_string(i);
+    if (!e->oc_scratch) CK(e, dalloc(e, &e->oc_scratch, (size_t)2 * 4 * D));
+    float *dcol = e->oc_scratch, *drow = e->oc_scratch + 4 * D;
+    std::vector<float> qkv_col(D), qkv_row(3 * D), l1_col(D), l1_row(H), l2_col(H), pj_col(D);
+    auto norms = [&](const std::string& name, int N, int K, float* col, float* row) -> int {
+        CK(e, launch_weight_norms(W(e, name), N, K, dcol, row ? drow : nullptr, s));
+        CK(e, hipMemcpyAsync(col, dcol, sizeof(float) * K, hipMemcpyDeviceToHost, s));
+        if (row) CK(e, hipMemcpyAsync(row, drow, sizeof(float) * N, hipMemcpyDeviceToHost, s));
+        CK(e, hipStreamSynchronize(s));
+        return SAMRS_OK;
+    };
+    int rc;
+    if ((rc = norms(p + ".attn.qkv.weight", 3 * D, D, qkv_col.data(), qkv_row.data()))) return rc;
+    if ((rc = norms(p + ".mlp.lin1.weight", H, D, l1_col.data(), l1_row.data()))) return rc;
+    if ((rc = norms(p + ".mlp.lin2.weight", D, H, l2_col.data(), nullptr))) return rc;
+    if ((rc = norms(p + ".attn.proj.weight", D, D, pj_col.data(), nullptr))) return rc;
+    auto host = [&](const std::string& name, size_t n) {
+        std::vector<float> v(n);
+        (void)hipMemcpy(v.data(), W(e, name), sizeof(float) * n, hipMemcpyDeviceToHost);
+        return v;
+    };
+    const std::vector<float> g1 = host(p + ".norm1.weight", D), b1 = host(p + ".norm1.bias", D), g2 = host(p + ".norm2.weight", D),
+                             b2 = host(p + ".norm2.bias", D), bq = host(p + ".attn.qkv.bias", 3 * D), bl = host(p + ".mlp.lin1.bias", H);
+    double r1 = 0, r2 = 0;
+    for (int c = 0; c < D; ++c) { r1 += (double)g1[c] * g1[c]; r2 += (double)g2[c] * g2[c]; }
+    const float rms1 = (float)std::sqrt(r1 / D), rms2 = (float)std::sqrt(r2 / D);
+    std::vector<float> sc[4];
+    sc[0].resize(D); sc[1].resize(D); sc[2].resize(H); sc[3].resize(D);
+    for (int c = 0; c < D; ++c) {
+        sc[0][c] = (std::fabs(g1[c]) + std::fabs(b1[c])) * std::sqrt(qkv_col[c]);
+        sc[1][c] = (std::fabs(g2[c]) + std::fabs(b2[c])) * std::sqrt(l1_col[c]);
+        sc[3][c] = (std::sqrt(qkv_row[2 * D + c]) * rms1 + std::fabs(bq[2 * D + c])) * std::sqrt(pj_col[c]);
+    }
+    for (int c = 0; c < H; ++c) sc[2][c] = (std::sqrt(l1_row[c]) * rms2 + std::fabs(bl[c])) * std::sqrt(l2_col[c]);
+    const float ratio = e->outlier_ratio_pct * 0.01f;
+    for (int g = 0; g < 4; ++g) {
+        std::vector<float> tmp(sc[g]);
+        std::nth_element(tmp.begin(), tmp.begin() + tmp.size() / 2, tmp.end());
+        const float med = tmp[tmp.size() / 2];
+        std::vector<int> idx;
+        for (int c = 0; c < (int)sc[g].size(); ++c) if (sc[g][c] > ratio * med) idx.push_back(c);
+        if (idx.size() > 32) {
+            std::partial_sort(idx.begin(), idx.begin() + 32, idx.end(), [&](int a, int c) { return sc[g][a] > sc[g][c]; });
+            idx.resize(32);
+            std::sort(idx.begin(), idx.end());
+        }
+        b.oc_n[g] = (int)idx.size();
+        e->outlier_columns += b.oc_n[g];
+        if (b.oc_n[g]) {
+            CK(e, dalloc(e, &b.oc_idx[g], 32));
+            idx.resize(32, 0);
+            CK(e, hipMemcpy(b.oc_idx[g], idx.data(), sizeof(int) * 32, hipMemcpyHostToDevice));
+        }
+    }
+    if (b.oc_n[0] || b.oc_n[1]) e->outlier_blocks += 1;
+    return SAMRS_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -411,6 +494,9 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->gelu_fast = env_int("SAMRS_GELU_FAST", -1);
     e->ln_tail = env_int("SAMRS_LN_TAIL", 0) != 0;
     e->operand_pad_on = env_int("SAMRS_OPERAND_PAD", 1) != 0;
+    e->outlier_on = env_int("SAMRS_OUTLIER_COLS", 1) != 0;
+    e->outlier_ratio_pct = env_int("SAMRS_OUTLIER_RATIO_PCT", 400);
+    if (e->outlier_ratio_pct < 101) e->outlier_ratio_pct = 101;
     if (e->gelu_fast > 1) e->gelu_fast = 1;
     if (const int rc0 = env_int("SAMRS_RANGE_CHECK", 0)) {
         if (samrs_set_option(e, "range_check", rc0) != SAMRS_OK) {
@@ -546,16 +632,37 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
                 e->mx_mlp_ready = true;
             }
         }
+        // outlier columns: picked and their weight-side extension written while the fp32 weights are still resident
+        if (e->outlier_on && (rc = pick_outlier_columns(e, i, s))) return rc;
+        if (e->ldk) {
+            const size_t ldb = (size_t)e->ldk * 2;
+            CK(e, dalloc(e, &b.qkv_wp, (size_t)3 * D * e->ldk)); CK(e, dalloc(e, &b.lin1_wp, (size_t)4 * D * e->ldk));
+            CK(e, hipMemsetAsync(b.qkv_wp, 0, (size_t)3 * D * ldb, s)); CK(e, hipMemsetAsync(b.lin1_wp, 0, (size_t)4 * D * ldb, s));
+            if (b.oc_n[0]) CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".attn.qkv.weight"), 3 * D, D, b.oc_idx[0], b.oc_n[0], b.qkv_wp, e->ldk, s));
+            if (b.oc_n[1]) CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".mlp.lin1.weight"), 4 * D, D, b.oc_idx[1], b.oc_n[1], b.lin1_wp, e->ldk, s));
+        }
+        if (b.oc_n[0]) {
+            CK(e, dalloc(e, &b.qkv_wx, (size_t)3 * D * (D + 64)));
+            CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".attn.qkv.weight"), 3 * D, D, b.oc_idx[0], b.oc_n[0], b.qkv_wx, D + 64, s));
+        }
+        if (b.oc_n[1]) {
+            CK(e, dalloc(e, &b.lin1_wx, (size_t)4 * D * (D + 64)));
+            CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".mlp.lin1.weight"), 4 * D, D, b.oc_idx[1], b.oc_n[1], b.lin1_wx, D + 64, s));
+        }
         if ((rc = to_et(e, p + ".attn.qkv.weight", &b.qkv_w, true, s, lo_a ? &b.qkv_w_lo : nullptr))) return rc;
         if ((rc = to_et(e, p + ".attn.proj.weight", &b.proj_w, true, s, lo_a ? &b.proj_w_lo : nullptr))) return rc;
         if ((rc = to_et(e, p + ".mlp.lin1.weight", &b.lin1_w, true, s, lo_m ? &b.lin1_w_lo : nullptr))) return rc;
         if ((rc = to_et(e, p + ".mlp.lin2.weight", &b.lin2_w, true, s, lo_m ? &b.lin2_w_lo : nullptr))) return rc;
-        if (e->ldk) {
-            const size_t ldb = (size_t)e->ldk * 2, wb = (size_t)D * 2;
-            CK(e, dalloc(e, &b.qkv_wp, (size_t)3 * D * e->ldk)); CK(e, dalloc(e, &b.lin1_wp, (size_t)4 * D * e->ldk));
-            CK(e, hipMemsetAsync(b.qkv_wp, 0, (size_t)3 * D * ldb, s)); CK(e, hipMemsetAsync(b.lin1_wp, 0, (size_t)4 * D * ldb, s));
-            CK(e, hipMemcpy2DAsync(b.qkv_wp, ldb, b.qkv_w, wb, wb, (size_t)3 * D, hipMemcpyDeviceToDevice, s));
-            CK(e, hipMemcpy2DAsync(b.lin1_wp, ldb, b.lin1_w, wb, wb, (size_t)4 * D, hipMemcpyDeviceToDevice, s));
+        {
+            const size_t wb = (size_t)D * 2;
+            if (e->ldk) {
+                const size_t ldb = (size_t)e->ldk * 2;
+                CK(e, hipMemcpy2DAsync(b.qkv_wp, ldb, b.qkv_w, wb, wb, (size_t)3 * D, hipMemcpyDeviceToDevice, s));
+                CK(e, hipMemcpy2DAsync(b.lin1_wp, ldb, b.lin1_w, wb, wb, (size_t)4 * D, hipMemcpyDeviceToDevice, s));
+            }
+            const size_t ldx = (size_t)(D + 64) * 2;
+            if (b.qkv_wx) CK(e, hipMemcpy2DAsync(b.qkv_wx, ldx, b.qkv_w, wb, wb, (size_t)3 * D, hipMemcpyDeviceToDevice, s));
+            if (b.lin1_wx) CK(e, hipMemcpy2DAsync(b.lin1_wx, ldx, b.lin1_w, wb, wb, (size_t)4 * D, hipMemcpyDeviceToDevice, s));
         }
         b.ln1w = W(e, p + ".norm1.weight"); b.ln1b = W(e, p + ".norm1.bias");
         b.ln2w = W(e, p + ".norm2.weight"); b.ln2b = W(e, p + ".norm2.bias");
@@ -629,8 +736,9 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->X, M * D));
     CK(e, dalloc(e, &e->ln_counters, M / 256 + 1));
     CK(e, hipMemsetAsync(e->ln_counters, 0, (M / 256 + 1) * sizeof(unsigned int), s));
-    CK(e, dalloc(e, &e->Y, Mmax * (size_t)(e->ldk ? e->ldk : D)));
-    CK(e, hipMemsetAsync(e->Y, 0, Mmax * (size_t)(e->ldk ? e->ldk : D) * 2, s));
+    const size_t y_ld_max = e->ldk ? (size_t)e->ldk : (e->outlier_blocks ? (size_t)D + 64 : (size_t)D);    // ldk = D + 128 holds the 64 extension columns too
+    CK(e, dalloc(e, &e->Y, Mmax * y_ld_max));
+    CK(e, hipMemsetAsync(e->Y, 0, Mmax * y_ld_max * 2, s));
     if (e->can_fold) { CK(e, dalloc(e, &e->STATS, Mmax * 16)); CK(e, dalloc(e, &e->ROWSTAT, Mmax * 2)); }
     CK(e, dalloc(e, &e->QKV, Mmax * 3 * D));
     CK(e, dalloc(e, &e->AO, M * D));
@@ -768,13 +876,16 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     }
     // option "range_check": scan an operand tensor right after its producer (same stream)
 #define RANGE_SCAN(ptr_, count_) do { if (e->range_check) CK(e, launch_range_scan(prec, (ptr_), (long)(count_), e->range_counter, s)); } while (0)
+    // ... of a tensor whose rows carry pad columns (the LayerNorm output on the padded-stride route): the live columns only
+#define RANGE_SCAN_ROWS(ptr_, rows_, cols_, ld_) do { if (e->range_check) CK(e, launch_range_scan(prec, (ptr_), (long)(rows_) * (cols_), e->range_counter, s, (cols_), (ld_))); } while (0)
     // padded operand rows for the plain qkv / lin1 launches (they run on the persistent ET kernels at these shapes: gemm_ld_ok)
     const bool pad_ok = e->ldk && e->operand_pad_on && !fold && !ln_tail;
-    const bool pad_qkv = pad_ok && gemm_ld_ok(M, 3 * D, D, false), pad_lin1 = pad_ok && gemm_ld_ok(M, 4 * D, D, true);
-    int y_ld = D;                  // row stride Y currently holds
+    // outlier-column extension of the plain qkv / lin1 launches (EncBlock::oc_*): not with the folded / tail LayerNorm forms (other producers of Y)
+    const bool oc_ok = e->outlier_on && e->outlier_blocks > 0 && !fold && !ln_tail;
+    int y_ld = D, y_live = D;      // row stride Y currently holds, and how many columns of a row are operand values
     for (int i = 0; i < c.depth && i < n_blocks; ++i) {
         const EncBlock& b = e->blocks[i];
-        y_ld = D;
+        y_ld = D; y_live = D;
         const bool attn_full = (e->split & SPLIT_ATTN) && i < depth_full;
         const bool sp_attn = attn_full || ((e->split & SPLIT_ATTN_V) && i < depth_v), sp_mlp = any_mlp && i < depth_full;
         // v third only: needs the tile mask of the one-launch kernel; other shapes split all of qkv
@@ -804,11 +915,17 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                 CK(e, launch_convert(prec, e->F32T, e->QKV, (long)M * 3 * D, s));
             }
         } else {
-            const int ldq = (pad_qkv && b.qkv_wp) ? e->ldk : 0;
-            if (!y_ready) CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, nullptr, nullptr, nullptr, nullptr, nullptr, ldq));
-            y_ld = ldq ? ldq : D;
+            // outlier columns of norm1's output: 64 more K columns (lo | hi of up to 32 columns) in the same launch -- on the padded-stride
+            // route in the pad region of the rows (K = D + 64 of the ldk-element rows), elsewhere on dense rows of D + 64 elements
+            const int noc = (oc_ok && b.oc_n[0] && b.qkv_wx) ? b.oc_n[0] : 0;
+            const int Kq = noc ? D + 64 : D;
+            const int ldq = (pad_ok && b.qkv_wp && gemm_ld_ok(M, 3 * D, Kq, false)) ? e->ldk : 0;
+            const int ldy = ldq ? ldq : Kq;                                 // row stride of Y for this launch
+            if (!y_ready) CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                 ldy == D ? 0 : ldy, noc ? b.oc_idx[0] : nullptr, noc));
+            y_ld = ldy; y_live = Kq;
             const int prev_ld = swap_gemm_ld(ldq);
-            const hipError_t qe = launch_gemm_et(prec, e->Y, ldq ? b.qkv_wp : b.qkv_w, e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, D, false, false, false, s);
+            const hipError_t qe = launch_gemm_et(prec, e->Y, ldq ? b.qkv_wp : (noc ? b.qkv_wx : b.qkv_w), e->QKV, b.qkv_b, nullptr, 0, M, 3 * D, Kq, false, false, false, s);
             (void)swap_gemm_ld(prev_ld);
             CK(e, qe);
         }
@@ -823,13 +940,17 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                                           (sp_attn && !mx_ao) ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,
                                           mx_ao ? e->SAO4[0] : nullptr, mx_ao ? e->SAO4[1] : nullptr));
         if (e->range_check) {       // norm1 output, q | k | v, attention output
-            RANGE_SCAN(e->Y, (size_t)M * y_ld);      // (a padded layout: the pad columns hold earlier, valid operand values)
+            RANGE_SCAN_ROWS(e->Y, M, y_live, y_ld);  // the live columns only: pad columns may hold an earlier pass's values
             RANGE_SCAN(e->QKV, (size_t)M * 3 * D);
             RANGE_SCAN(e->AO, (size_t)M * D);
         }
-        y_ld = D;
+        y_ld = D; y_live = D;
         // lin1 takes the plain launch below exactly when none of these holds; then norm2 writes the padded layout for it
-        const int ldl = (pad_lin1 && b.lin1_wp && !fold && !sp_lin2 && !sp_mlp) ? e->ldk : 0;
+        const bool lin1_plain = !fold && !sp_lin2 && !sp_mlp;
+        const int nol = (oc_ok && lin1_plain && b.oc_n[1] && b.lin1_wx) ? b.oc_n[1] : 0;    // outlier columns of norm2's output (see qkv above)
+        const int Kl = nol ? D + 64 : D;
+        const int ldl = (pad_ok && b.lin1_wp && lin1_plain && gemm_ld_ok(M, 4 * D, Kl, true)) ? e->ldk : 0;
+        const int ldy2 = ldl ? ldl : Kl;
         if (fold) {
             CK(e, launch_gemm_et_stats(prec, e->AO, b.proj_w, e->X, b.proj_b, e->Y, e->STATS, M, D, D, s));
             CK(e, launch_ln_rowstat(e->STATS, e->ROWSTAT, M, 1e-6f, s));
@@ -855,10 +976,10 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             } else if (sp_mlp && mx_mlp)
                 CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, nullptr, e->Y4[0], e->Y4[1], e->SY4[0], e->SY4[1]));
             else {
-                const int ldn = sp_mlp ? 0 : ldl;
+                const int ldn = (sp_mlp || ldy2 == D) ? 0 : ldy2;
                 CK(e, launch_layernorm(prec, e->X, b.ln2w, b.ln2b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, sp_mlp ? e->Ylo : nullptr, nullptr, nullptr, nullptr,
-                                       nullptr, ldn));
-                y_ld = ldn ? ldn : D;
+                                       nullptr, ldn, nol ? b.oc_idx[1] : nullptr, nol));
+                y_ld = ldn ? ldn : D; y_live = ldn ? Kl : D;
             }
         }
         hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -893,7 +1014,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             // every mode with a block-GEMM split bit keeps the arithmetic its parity statistics were measured on, bit for bit
             const int prev_form = swap_gelu_form(fast_gelu ? 2 : 1);
             const int prev_ld = swap_gemm_ld(ldl);
-            const hipError_t le = launch_gemm_et(prec, e->Y, ldl ? b.lin1_wp : b.lin1_w, e->H, b.lin1_b, nullptr, 0, M, 4 * D, D, false, true, false, s);
+            const hipError_t le = launch_gemm_et(prec, e->Y, ldl ? b.lin1_wp : (nol ? b.lin1_wx : b.lin1_w), e->H, b.lin1_b, nullptr, 0, M, 4 * D, Kl, false, true, false, s);
             (void)swap_gemm_ld(prev_ld);
             (void)swap_gelu_form(prev_form);
             CK(e, le);
@@ -903,7 +1024,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             e->tev.emplace_back(t0, t1);
         }
         if (e->range_check) {       // norm2 output (still in Y: lin1 has read it, nothing has overwritten it) and GELU(lin1)
-            RANGE_SCAN(e->Y, (size_t)M * y_ld);      // (a padded layout: the pad columns hold earlier, valid operand values)
+            RANGE_SCAN_ROWS(e->Y, M, y_live, y_ld);
             RANGE_SCAN(e->H, (size_t)M * 4 * D);
         }
         if (fold) {
@@ -1354,12 +1475,24 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     else if (n == "gelu_fast") e->gelu_fast = value < 0 ? -1 : (value != 0);
     else if (n == "ln_tail") e->ln_tail = value > 0;
     else if (n == "operand_pad") e->operand_pad_on = value != 0;
+    else if (n == "outlier_cols") e->outlier_on = value != 0;
+    else if (n == "outlier_ratio_pct") {
+        if (e->finalized) return fail(e, SAMRS_ERR_BAD_ARG, "outlier_ratio_pct: the columns are picked when the weights are finalized; set it before");
+        if (value < 101) return fail(e, SAMRS_ERR_BAD_ARG, "outlier_ratio_pct must exceed 100 (a column's score as a percentage of the median score)");
+        e->outlier_ratio_pct = value;
+    }
     else if (n == "range_check") {
         if (value < 0 || value > 2) return fail(e, SAMRS_ERR_BAD_ARG, "range_check is 0 (off), 1 (count) or 2 (count, and samrs_set_images fails)");
         if (value && !e->range_counter) {
             ON_DEVICE(e);
             CK(e, dalloc(e, &e->range_counter, 1));
             CK(e, hipMemset(e->range_counter, 0, sizeof(unsigned long long)));
+        }
+        if (value == 2 && e->range_check != 2 && e->range_counter) {
+            // mode 2 fails the pass that ADDS to the counter: start from what mode 1 has counted so far, or a clean image would be blamed
+            ON_DEVICE(e);
+            CK(e, hipDeviceSynchronize());
+            CK(e, hipMemcpy(&e->range_seen, e->range_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost));
         }
         e->range_check = value;
     }
@@ -1395,6 +1528,10 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
     else if (n == "gelu_fast") *value = e->gelu_fast;
     else if (n == "ln_tail") *value = e->ln_tail;
     else if (n == "operand_pad") *value = e->operand_pad_on;
+    else if (n == "outlier_cols") *value = e->outlier_on;
+    else if (n == "outlier_ratio_pct") *value = e->outlier_ratio_pct;
+    else if (n == "outlier_blocks") *value = e->outlier_blocks;       // read-only
+    else if (n == "outlier_columns") *value = e->outlier_columns;     // read-only
     else if (n == "range_check") *value = e->range_check;
     else if (n == "saturated") {                    // synchronizes the device: a diagnostic, not a hot-path call
         unsigned long long c = 0;

@@ -73,7 +73,14 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
                             // optional (plain row order, D % 256 == 0): the output's hi / lo as MXFP4 codes [rows][D / 2] + scale tiles
                             // (the A operands of launch_gemm_et_mx: no ET lo copy, no separate pack pass)
                             void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr,
-                            int ld_out = 0 /* row stride of out_et in elements, 0 = D (plain ET output only) */);
+                            int ld_out = 0 /* row stride of out_et in elements, 0 = D (plain ET output only) */,
+                            // optional (plain row order, ld_out >= D + 64): hi + lo of n_oc <= 32 outlier columns as 64 more K columns
+                            // of the row: [D + j] = lo of column oc_idx[j], [D + 32 + j] = its hi, zeros in unused slots
+                            const int* oc_idx = nullptr, int n_oc = 0);
+// weight side of that extension: out[r][K + j] = ET(W[r][idx[j]]), out[r][K + 32 + j] = ET(W - hi), W fp32 [N][K], out rows of stride ld
+hipError_t launch_outlier_weight_ext(int prec, const float* W, int N, int K, const int* idx, int n_oc, void* out, int ld, hipStream_t s);
+// squared L2 norms of the columns / rows of an fp32 matrix [N][K] (either output may be null); load-time scoring of outlier columns
+hipError_t launch_weight_norms(const float* W, int N, int K, float* col_sq, float* row_sq, hipStream_t s);
 // out_lo (optional, both attention kernels): the split remainder of `out` (reference-grade mode: proj on hi + lo operands)
 hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
                                    int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo = nullptr,
@@ -82,7 +89,8 @@ hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_b
                                    void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr);
 hipError_t launch_gelu_split(int prec, const float* in, void* hi, void* lo, long n, hipStream_t s);
 // operand-range check: adds to *counter the elements of an ET tensor that sit at the operand type's saturation value or beyond (n % 8 == 0)
-hipError_t launch_range_scan(int prec, const void* x, long n, unsigned long long* counter, hipStream_t s);
+hipError_t launch_range_scan(int prec, const void* x, long n, unsigned long long* counter, hipStream_t s,
+                             int cols = 0, int ld = 0 /* optional: rows of `cols` live elements at a stride of `ld` elements; n = rows * cols */);
 // vt_ws: ET workspace of n_images * heads * head_dim * grid^2 elements (receives V transposed per head)
 hipError_t launch_global_attention(int prec, const void* qkv, const float* rel_h, const float* rel_w, void* out,
                                    int n_images, int grid, int heads, int head_dim, void* vt_ws, hipStream_t s, void* out_lo = nullptr,

@@ -1,4 +1,6 @@
 """CPU: host-side mirror of the reference interface (no GPU, no compute in the library)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -140,3 +142,27 @@ def test_gelu_as28_error_budget():
     rms16 = np.sqrt((w * f16 ** 2).sum() / w.sum())
     assert np.abs(err).max() < 1e-6 and rms < 1.5e-7 and rms16 > 500 * rms, (np.abs(err).max(), rms, rms16)
     assert got[0] == 0.0 and got[-1] == x[-1]                       # the tails are exactly max(x, 0)
+
+
+def test_bench_gpus_n_without_a_launcher_becomes_the_launcher(monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE) re-executes itself under torch.distributed.run with
+    the same arguments, one rank per GPU, rendezvous on 127.0.0.1; under a launcher (WORLD_SIZE set) and for N = 1 it does not."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, *a, **k):
+        seen["cmd"] = cmd
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as ex:
+        bench._self_launch(4)
+    assert ex.value.code == 7                                           # the launcher's status is the script's status
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]                  # same arguments, verbatim

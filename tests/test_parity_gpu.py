@@ -908,6 +908,33 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["stats_allreduce"]["total_instances"] > 0
 
 
+def test_bench_self_launches_for_two_gpus():
+    """``python bench.py --gpus 2 ...`` -- the form the driver uses for N = 1, with no torchrun around it and
+    no WORLD_SIZE in the environment -- must launch its own ranks (bench._self_launch: torch.distributed.run on 127.0.0.1, a free
+    port) instead of asserting.  Both ranks share this GPU over gloo (SAMRS_BENCH_SHARE_GPU=1).  Checked on the ONE JSON line:
+    n_gpus 2, image-parallel x2, and the statistics all-reduce (the one collective of the path, statistic.py:15-21) equals the
+    serial sum of what each rank painted locally."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SAMRS_BENCH_SHARE_GPU="1", PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "vit_tiny",
+           "--batch", "2", "--no-cpu-baseline", "--no-alt-dtype", "--no-pcie-leg", "--no-rle-leg"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "image-parallel x2" and d["config"]["tiles_per_step"] == 4
+    st = d["stats_allreduce"]
+    assert len(st["per_rank_local"]) == 2 and all(p["instances"] > 0 for p in st["per_rank_local"])     # both ranks did work
+    assert st["total_pixels"] == sum(p["pixels"] for p in st["per_rank_local"])
+    assert st["total_instances"] == sum(p["instances"] for p in st["per_rank_local"])
+    assert 0 < st["total_instances"] <= 2 * (2 + 1) * 2 * 32        # ranks x (steps + warm-up) x batch x boxes; empty masks are not instances
+
+
 def test_generate_two_ranks_on_one_gpu_under_a_four_cpu_mask(tmp_path):
     """The generation CLI's N > 1 path on a ONE-GPU box: two ranks of ``python -m samrs_amd.generate`` share
     cuda:0 over gloo (SAMRS_SHARE_GPU=1) inside a four-CPU affinity mask -- the share eight ranks get on the pool's 16-CPU

@@ -248,13 +248,6 @@ __global__ __launch_bounds__(256) void outlier_weight_ext_kernel(const float* __
     out[(size_t)r * ld + K + 32 + j] = lo;
 }
 
-hipError_t launch_outlier_weight_ext(int prec, const float* W, int N, int K, const int* idx, int n_oc, void* out, int ld, hipStream_t s) {
-    if (!W || !out || N < 1 || K < 1 || n_oc < 0 || n_oc > 32 || ld < K + 64 || (n_oc && !idx)) return hipErrorInvalidValue;
-    if (prec == PREC_BF16) outlier_weight_ext_kernel<PREC_BF16><<<(N + 7) / 8, 256, 0, s>>>(W, N, K, idx, n_oc, (uint16_t*)out, ld);
-    else outlier_weight_ext_kernel<PREC_F16><<<(N + 7) / 8, 256, 0, s>>>(W, N, K, idx, n_oc, (uint16_t*)out, ld);
-    return hipGetLastError();
-}
-
 // Squared L2 norms of the columns (col_sq[K], must be zero on entry) and of the rows (row_sq[N]) of an fp32 matrix W[N][K]: what the
 // weights-only outlier rule scores columns with (engine.hip pick_outlier_columns).  Load-time only.
 __global__ __launch_bounds__(256) void weight_norms_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ col_sq,
@@ -271,14 +264,6 @@ __global__ __launch_bounds__(256) void weight_norms_kernel(const float* __restri
         }
     }
     if (col_sq && c < K) atomicAdd(col_sq + c, acc);
-}
-
-hipError_t launch_weight_norms(const float* W, int N, int K, float* col_sq, float* row_sq, hipStream_t s) {
-    if (!W || N < 1 || K < 1) return hipErrorInvalidValue;
-    if (col_sq) HIP_CHECK_RET(hipMemsetAsync(col_sq, 0, sizeof(float) * K, s));
-    if (row_sq) HIP_CHECK_RET(hipMemsetAsync(row_sq, 0, sizeof(float) * N, s));
-    weight_norms_kernel<<<dim3((K + 255) / 256, (N + 63) / 64), 256, 0, s>>>(W, N, K, col_sq, row_sq);
-    return hipGetLastError();
 }
 
 // -----------------------------------------------------------------------------------------
@@ -1436,6 +1421,22 @@ hipError_t set_lds(K kernel, int bytes) {
 }
 
 }  // namespace
+
+hipError_t launch_outlier_weight_ext(int prec, const float* W, int N, int K, const int* idx, int n_oc, void* out, int ld, hipStream_t s) {
+    if (!W || !out || N < 1 || K < 1 || n_oc < 0 || n_oc > 32 || ld < K + 64 || (n_oc && !idx)) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) outlier_weight_ext_kernel<PREC_BF16><<<(N + 7) / 8, 256, 0, s>>>(W, N, K, idx, n_oc, (uint16_t*)out, ld);
+    else outlier_weight_ext_kernel<PREC_F16><<<(N + 7) / 8, 256, 0, s>>>(W, N, K, idx, n_oc, (uint16_t*)out, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_weight_norms(const float* W, int N, int K, float* col_sq, float* row_sq, hipStream_t s) {
+    if (!W || N < 1 || K < 1) return hipErrorInvalidValue;
+    if (col_sq) HIP_CHECK_RET(hipMemsetAsync(col_sq, 0, sizeof(float) * K, s));
+    if (row_sq) HIP_CHECK_RET(hipMemsetAsync(row_sq, 0, sizeof(float) * N, s));
+    weight_norms_kernel<<<dim3((K + 255) / 256, (N + 63) / 64), 256, 0, s>>>(W, N, K, col_sq, row_sq);
+    return hipGetLastError();
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // launchers

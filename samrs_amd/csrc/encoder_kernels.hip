@@ -229,13 +229,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(
         out_et[(size_t)row * ld_out + D + lane] = lo;
         out_et[(size_t)row * ld_out + D + 32 + lane] = hi;
     }
+    // the rest of a padded row behind the extension: zero, so that a reader which walks whole rows (the side GEMM of lin2's
+    // outlier columns, engine.hip) meets nothing stale there
+    if (n_oc > 0 && out_et)
+        for (int c = D + 64 + lane; c < ld_out; c += 64) out_et[(size_t)row * ld_out + c] = 0;
 }
 
 // Weight side of the outlier-column extension: ext[r][j] = ET(W[r][idx[j]]) (hi: meets the operand's lo), ext[r][32 + j] = ET(W - hi)
 // (lo: meets the operand's hi), zeros in unused slots; written at column K of a row of stride ld (K + 64 <= ld).
 template <int PREC>
 __global__ __launch_bounds__(256) void outlier_weight_ext_kernel(const float* __restrict__ W, int N, int K, const int* __restrict__ idx, int n_oc,
-                                                                  uint16_t* __restrict__ out, int ld) {
+                                                                  uint16_t* __restrict__ out, int ld, int col0) {
     const int r = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
     if (r >= N) return;
     uint16_t hi = 0, lo = 0;
@@ -244,8 +248,58 @@ __global__ __launch_bounds__(256) void outlier_weight_ext_kernel(const float* __
         hi = ET<PREC>::from_float(w);
         lo = ET<PREC>::from_float(w - ET<PREC>::to_float(hi));
     }
-    out[(size_t)r * ld + K + j] = hi;
-    out[(size_t)r * ld + K + 32 + j] = lo;
+    out[(size_t)r * ld + col0 + j] = hi;
+    out[(size_t)r * ld + col0 + 32 + j] = lo;
+}
+
+// Side weights of lin2's outlier columns (hidden units idx2[0 .. n2)): rows j < n2 of out [128][Ks] = row idx2[j] of lin1's weight in the
+// operand type, followed -- when lin1 itself carries outlier columns idx1[0 .. n1) -- by the same 64-column extension its own launch
+// reads (hi at D + t, lo at D + 32 + t), zeros up to Ks; rows >= n2 are zero.  bias_out [128] = lin1's bias at idx2, zeros behind.
+template <int PREC>
+__global__ __launch_bounds__(256) void outlier_side_weight_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int D,
+                                                                   const int* __restrict__ idx2, int n2, const int* __restrict__ idx1, int n1,
+                                                                   uint16_t* __restrict__ out, int Ks, float* __restrict__ bias_out) {
+    const int j = blockIdx.x;                         // 0 .. 127
+    const float* src = j < n2 ? W1 + (size_t)idx2[j] * D : nullptr;
+    for (int k = threadIdx.x; k < Ks; k += 256) {
+        uint16_t v = 0;
+        if (src) {
+            if (k < D) v = ET<PREC>::from_float(src[k]);
+            else if (k < D + 64) {
+                const int t = (k - D) & 31;
+                if (t < n1) {
+                    const float w = src[idx1[t]];
+                    const uint16_t hi = ET<PREC>::from_float(w);
+                    v = (k - D) < 32 ? hi : ET<PREC>::from_float(w - ET<PREC>::to_float(hi));
+                }
+            }
+        }
+        out[(size_t)j * Ks + k] = v;
+    }
+    if (threadIdx.x == 0 && bias_out) bias_out[j] = src ? b1[idx2[j]] : 0.f;
+}
+
+// A_x of proj: row r = lo of the attention output's outlier columns | their hi
+__global__ __launch_bounds__(256) void outlier_gather_kernel(const uint16_t* __restrict__ hi, const uint16_t* __restrict__ lo, int D,
+                                                             const int* __restrict__ idx, int n_oc, uint16_t* __restrict__ out, int rows) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), j = threadIdx.x & 63;
+    if (r >= rows) return;
+    uint16_t v = 0;
+    if ((j & 31) < n_oc) v = (j < 32 ? lo : hi)[(size_t)r * D + idx[j & 31]];
+    out[(size_t)r * 64 + j] = v;
+}
+
+// A_x of lin2: pre[r][0 .. 32) = the outlier hidden units' pre-activations (fp32, bias included; row stride 128) -> exact-erf GELU ->
+// lo | hi of the result
+template <int PREC>
+__global__ __launch_bounds__(256) void outlier_hidden_ext_kernel(const float* __restrict__ pre, uint16_t* __restrict__ out, int rows) {
+    const int r = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
+    if (r >= rows) return;
+    const float x = pre[(size_t)r * 128 + j];
+    const float g = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    const uint16_t hi = ET<PREC>::from_float(g);
+    out[(size_t)r * 64 + j] = ET<PREC>::from_float(g - ET<PREC>::to_float(hi));
+    out[(size_t)r * 64 + 32 + j] = hi;
 }
 
 // Squared L2 norms of the columns (col_sq[K], must be zero on entry) and of the rows (row_sq[N]) of an fp32 matrix W[N][K]: what the
@@ -1422,10 +1476,28 @@ hipError_t set_lds(K kernel, int bytes) {
 
 }  // namespace
 
-hipError_t launch_outlier_weight_ext(int prec, const float* W, int N, int K, const int* idx, int n_oc, void* out, int ld, hipStream_t s) {
-    if (!W || !out || N < 1 || K < 1 || n_oc < 0 || n_oc > 32 || ld < K + 64 || (n_oc && !idx)) return hipErrorInvalidValue;
-    if (prec == PREC_BF16) outlier_weight_ext_kernel<PREC_BF16><<<(N + 7) / 8, 256, 0, s>>>(W, N, K, idx, n_oc, (uint16_t*)out, ld);
-    else outlier_weight_ext_kernel<PREC_F16><<<(N + 7) / 8, 256, 0, s>>>(W, N, K, idx, n_oc, (uint16_t*)out, ld);
+hipError_t launch_outlier_weight_ext(int prec, const float* W, int N, int K, const int* idx, int n_oc, void* out, int ld, int col0, hipStream_t s) {
+    if (!W || !out || N < 1 || K < 1 || n_oc < 0 || n_oc > 32 || col0 < 0 || ld < col0 + 64 || (n_oc && !idx)) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) outlier_weight_ext_kernel<PREC_BF16><<<(N + 7) / 8, 256, 0, s>>>(W, N, K, idx, n_oc, (uint16_t*)out, ld, col0);
+    else outlier_weight_ext_kernel<PREC_F16><<<(N + 7) / 8, 256, 0, s>>>(W, N, K, idx, n_oc, (uint16_t*)out, ld, col0);
+    return hipGetLastError();
+}
+hipError_t launch_outlier_side_weight(int prec, const float* W1, const float* b1, int D, const int* idx2, int n2, const int* idx1, int n1,
+                                      void* out, int Ks, float* bias_out, hipStream_t s) {
+    if (!W1 || !b1 || !out || !idx2 || n2 < 1 || n2 > 32 || n1 < 0 || n1 > 32 || (n1 && !idx1) || Ks < D + (n1 ? 64 : 0)) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) outlier_side_weight_kernel<PREC_BF16><<<128, 256, 0, s>>>(W1, b1, D, idx2, n2, idx1, n1, (uint16_t*)out, Ks, bias_out);
+    else outlier_side_weight_kernel<PREC_F16><<<128, 256, 0, s>>>(W1, b1, D, idx2, n2, idx1, n1, (uint16_t*)out, Ks, bias_out);
+    return hipGetLastError();
+}
+hipError_t launch_outlier_gather(const void* hi, const void* lo, int D, const int* idx, int n_oc, void* out, int rows, hipStream_t s) {
+    if (!hi || !lo || !idx || !out || n_oc < 1 || n_oc > 32 || rows < 1) return hipErrorInvalidValue;
+    outlier_gather_kernel<<<(rows + 3) / 4, 256, 0, s>>>((const uint16_t*)hi, (const uint16_t*)lo, D, idx, n_oc, (uint16_t*)out, rows);
+    return hipGetLastError();
+}
+hipError_t launch_outlier_hidden_ext(int prec, const float* pre, void* out, int rows, hipStream_t s) {
+    if (!pre || !out || rows < 1) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) outlier_hidden_ext_kernel<PREC_BF16><<<(rows + 7) / 8, 256, 0, s>>>(pre, (uint16_t*)out, rows);
+    else outlier_hidden_ext_kernel<PREC_F16><<<(rows + 7) / 8, 256, 0, s>>>(pre, (uint16_t*)out, rows);
     return hipGetLastError();
 }
 

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/samrs_hip.h"
+#include "../../include/samrs_hip_internal.h"
 #include "common.h"
 #include "kernels.h"
 
@@ -87,6 +88,14 @@ struct EncBlock {
     int oc_n[4] = {0, 0, 0, 0};
     int* oc_idx[4] = {nullptr, nullptr, nullptr, nullptr};
     uint16_t *qkv_wx = nullptr, *lin1_wx = nullptr;
+    // lin2 / proj: their A operands (GELU(lin1), the attention output) are written by other kernels, so the 64 columns travel as a
+    // dense side operand A_x [M][64] (engine OCX) against oc_bx [D][64] = W_hi[:, S] | W_lo[:, S], one more K stage of the same
+    // launch (gemm.hip EXT).  lin2's A_x needs GELU(lin1) of the outlier hidden units BEFORE its rounding: a side GEMM of the
+    // LayerNorm output against those <= 32 rows of lin1's weight (lin2_ws [128][K]: [0] for dense rows of Y, [1] for ldk-element
+    // rows; lin2_sb the matching bias), then exact GELU + split (encoder_kernels.hip outlier_hidden_ext_kernel).
+    uint16_t* oc_bx[4] = {nullptr, nullptr, nullptr, nullptr};      // [2] lin2, [3] proj
+    uint16_t* lin2_ws[2] = {nullptr, nullptr};
+    float* lin2_sb = nullptr;
     // LayerNorm folded into qkv / lin1 (ViT-H): W diag(gamma) in ET, its row sums, b + W beta
     uint16_t *qkv_wf = nullptr, *lin1_wf = nullptr;
     float *qkv_c = nullptr, *qkv_bf = nullptr, *lin1_c = nullptr, *lin1_bf = nullptr;
@@ -162,13 +171,16 @@ struct samrs_engine {
     // that the rows a tile fetches per k-slice spread over all memory channels instead of half of them (gemm.hip tl_gemm_ld)
     int operand_pad_on = 1;
     int ldk = 0;                   // 0: no padded copies exist (other widths)
-    // option "outlier_cols" (default 1; SAMRS_OUTLIER_COLS): hi + lo terms for the outlier K-columns of the plain qkv / lin1 launches
-    // (EncBlock::oc_*).  Columns are picked in samrs_finalize_weights (the option must be on by then); later it switches their use.
+    // option "outlier_cols" (default 7; SAMRS_OUTLIER_COLS; bit 0: qkv / lin1, bit 1: lin2, bit 2: proj): hi + lo terms for the outlier
+    // K-columns of the plain block-GEMM launches (EncBlock::oc_*).  Columns are picked in samrs_finalize_weights (the option must be on by then); later it switches their use.
     // "outlier_ratio_pct" (default 400): a column is an outlier when its score exceeds this percentage of its GEMM's median score.
     // Read-only: "outlier_blocks" (blocks with at least one such column in qkv / lin1), "outlier_columns" (their total over the
     // four block GEMMs).  Weights without outliers (every seeded-normal test model) pick nothing: bit-identical, zero cost.
-    int outlier_on = 1, outlier_ratio_pct = 400, outlier_blocks = 0, outlier_columns = 0;
+    int outlier_on = 7 /* bit 0: qkv / lin1, bit 1: lin2, bit 2: proj */, outlier_ratio_pct = 400, outlier_blocks = 0, outlier_columns = 0;
     float* oc_scratch = nullptr;   // load-time scratch: column / row norms
+    uint16_t* OCX = nullptr;       // [M][64]: side operand A_x of the running proj / lin2 launch
+    float* OCF = nullptr;          // [M][128]: pre-activations of lin2's outlier hidden units (side GEMM output)
+    bool oc_resid = false;         // some block has outlier columns in lin2 / proj
     int gelu_fast = -1;            // option "gelu_fast": -1 automatic (on in the 1x-rate modes: no block-GEMM bit in "split"), 0 off, 1 on
     int range_check = 0;
     unsigned long long* range_counter = nullptr;
@@ -269,6 +281,12 @@ struct GemmVariantScope {
 };
 #define ON_DEVICE(e) DeviceGuard _dg((e)->device); CK((e), _dg.status); GemmVariantScope _gvs((e)->gemm_variant)
 
+// X (the fp32 residual stream) += A W^T + A_x B_x^T + bias -- proj / lin2 with the hi + lo terms of their outlier columns (EncBlock::oc_bx):
+// one launch with one more K stage where the 256 x 320 pair-stage kernel takes the shape (gemm.hip EXT), else the plain launch followed
+// by an accumulating launch of the 64-column side product on the 128 x 128 kernel (any shape; small models only: it re-reads X)
+hipError_t resid_gemm_ext(samrs_engine* e, int prec, const void* A, const void* Wt, const void* Ax, const void* Bx, const float* bias,
+                          int M, int N, int K, hipStream_t s);
+
 bool is_global(const samrs_config& c, int i) {
     for (int k = 0; k < c.n_global; ++k)
         if (c.global_attn_indexes[k] == i) return true;
@@ -366,6 +384,15 @@ int to_et(samrs_engine* e, const std::string& name, uint16_t** out, bool free_f3
         t.p = nullptr;
     }
     return SAMRS_OK;
+}
+
+hipError_t resid_gemm_ext(samrs_engine* e, int prec, const void* A, const void* Wt, const void* Ax, const void* Bx, const float* bias,
+                          int M, int N, int K, hipStream_t s) {
+    if (gemm_ext_ok(M, N, K)) return launch_gemm_et_ext(prec, A, Wt, Ax, Bx, e->X, bias, M, N, K, s);
+    const hipError_t r = launch_gemm_et(prec, A, Wt, e->X, bias, nullptr, 0, M, N, K, true, false, true, s);
+    if (r != hipSuccess) return r;
+    GemmVariantScope base_kernel(1);
+    return launch_gemm_et(prec, Ax, Bx, e->X, nullptr, nullptr, 0, M, N, 64, true, false, true, s);
 }
 
 // Outlier columns of the four block GEMMs of encoder block `i`, from the fp32 weights alone (they must still be resident: call before
@@ -494,7 +521,7 @@ samrs_engine_t* samrs_create(const samrs_config* cfg, int device, char* err, int
     e->gelu_fast = env_int("SAMRS_GELU_FAST", -1);
     e->ln_tail = env_int("SAMRS_LN_TAIL", 0) != 0;
     e->operand_pad_on = env_int("SAMRS_OPERAND_PAD", 1) != 0;
-    e->outlier_on = env_int("SAMRS_OUTLIER_COLS", 1) != 0;
+    e->outlier_on = env_int("SAMRS_OUTLIER_COLS", 7) & 7;
     e->outlier_ratio_pct = env_int("SAMRS_OUTLIER_RATIO_PCT", 400);
     if (e->outlier_ratio_pct < 101) e->outlier_ratio_pct = 101;
     if (e->gelu_fast > 1) e->gelu_fast = 1;
@@ -638,16 +665,36 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
             const size_t ldb = (size_t)e->ldk * 2;
             CK(e, dalloc(e, &b.qkv_wp, (size_t)3 * D * e->ldk)); CK(e, dalloc(e, &b.lin1_wp, (size_t)4 * D * e->ldk));
             CK(e, hipMemsetAsync(b.qkv_wp, 0, (size_t)3 * D * ldb, s)); CK(e, hipMemsetAsync(b.lin1_wp, 0, (size_t)4 * D * ldb, s));
-            if (b.oc_n[0]) CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".attn.qkv.weight"), 3 * D, D, b.oc_idx[0], b.oc_n[0], b.qkv_wp, e->ldk, s));
-            if (b.oc_n[1]) CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".mlp.lin1.weight"), 4 * D, D, b.oc_idx[1], b.oc_n[1], b.lin1_wp, e->ldk, s));
+            if (b.oc_n[0]) CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".attn.qkv.weight"), 3 * D, D, b.oc_idx[0], b.oc_n[0], b.qkv_wp, e->ldk, D, s));
+            if (b.oc_n[1]) CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".mlp.lin1.weight"), 4 * D, D, b.oc_idx[1], b.oc_n[1], b.lin1_wp, e->ldk, D, s));
         }
         if (b.oc_n[0]) {
             CK(e, dalloc(e, &b.qkv_wx, (size_t)3 * D * (D + 64)));
-            CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".attn.qkv.weight"), 3 * D, D, b.oc_idx[0], b.oc_n[0], b.qkv_wx, D + 64, s));
+            CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".attn.qkv.weight"), 3 * D, D, b.oc_idx[0], b.oc_n[0], b.qkv_wx, D + 64, D, s));
         }
         if (b.oc_n[1]) {
             CK(e, dalloc(e, &b.lin1_wx, (size_t)4 * D * (D + 64)));
-            CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".mlp.lin1.weight"), 4 * D, D, b.oc_idx[1], b.oc_n[1], b.lin1_wx, D + 64, s));
+            CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".mlp.lin1.weight"), 4 * D, D, b.oc_idx[1], b.oc_n[1], b.lin1_wx, D + 64, D, s));
+        }
+        if (b.oc_n[2]) {          // lin2: weight side [D][64] + the side weights / bias of the hidden units' recomputation
+            CK(e, dalloc(e, &b.oc_bx[2], (size_t)D * 64));
+            CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".mlp.lin2.weight"), D, 4 * D, b.oc_idx[2], b.oc_n[2], b.oc_bx[2], 64, 0, s));
+            CK(e, dalloc(e, &b.lin2_sb, (size_t)128));
+            const int k0 = D + (b.oc_n[1] ? 64 : 0);
+            CK(e, dalloc(e, &b.lin2_ws[0], (size_t)128 * k0));
+            CK(e, launch_outlier_side_weight(e->prec, W(e, p + ".mlp.lin1.weight"), W(e, p + ".mlp.lin1.bias"), D, b.oc_idx[2], b.oc_n[2],
+                                             b.oc_idx[1], b.oc_n[1], b.lin2_ws[0], k0, b.lin2_sb, s));
+            if (e->ldk) {
+                CK(e, dalloc(e, &b.lin2_ws[1], (size_t)128 * e->ldk));
+                CK(e, launch_outlier_side_weight(e->prec, W(e, p + ".mlp.lin1.weight"), W(e, p + ".mlp.lin1.bias"), D, b.oc_idx[2], b.oc_n[2],
+                                                 b.oc_idx[1], b.oc_n[1], b.lin2_ws[1], e->ldk, b.lin2_sb, s));
+            }
+            e->oc_resid = true;
+        }
+        if (b.oc_n[3]) {          // proj
+            CK(e, dalloc(e, &b.oc_bx[3], (size_t)D * 64));
+            CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".attn.proj.weight"), D, D, b.oc_idx[3], b.oc_n[3], b.oc_bx[3], 64, 0, s));
+            e->oc_resid = true;
         }
         if ((rc = to_et(e, p + ".attn.qkv.weight", &b.qkv_w, true, s, lo_a ? &b.qkv_w_lo : nullptr))) return rc;
         if ((rc = to_et(e, p + ".attn.proj.weight", &b.proj_w, true, s, lo_a ? &b.proj_w_lo : nullptr))) return rc;
@@ -743,6 +790,10 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->QKV, Mmax * 3 * D));
     CK(e, dalloc(e, &e->AO, M * D));
     CK(e, dalloc(e, &e->VTG, M * D));
+    if (e->oc_resid) {
+        CK(e, dalloc(e, &e->OCX, M * 64)); CK(e, dalloc(e, &e->OCF, M * 128));
+        if (!(e->split & SPLIT_ATTN_ANY)) CK(e, dalloc(e, &e->AOlo, M * D));       // proj's outlier columns take the attention output's lo half
+    }
     e->split_ready = SPLIT_DEFAULT | (e->split & SPLIT_MLP) | ((e->split & SPLIT_ATTN_ANY) ? SPLIT_ATTN_ANY : 0) | (e->mx_mlp_ready ? SPLIT_LIN2 : 0);
     if ((e->split & SPLIT_LIN2) && !e->mx_mlp_ready) e->split &= ~SPLIT_LIN2;          // no MX kernel for these shapes (or lo_format 0): bit ignored
     if (e->split & (SPLIT_ATTN_ANY | SPLIT_MLP | SPLIT_LIN2)) {
@@ -881,7 +932,8 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
     // padded operand rows for the plain qkv / lin1 launches (they run on the persistent ET kernels at these shapes: gemm_ld_ok)
     const bool pad_ok = e->ldk && e->operand_pad_on && !fold && !ln_tail;
     // outlier-column extension of the plain qkv / lin1 launches (EncBlock::oc_*): not with the folded / tail LayerNorm forms (other producers of Y)
-    const bool oc_ok = e->outlier_on && e->outlier_blocks > 0 && !fold && !ln_tail;
+    const bool oc_any = e->outlier_on && e->outlier_columns > 0 && !fold && !ln_tail;
+    const bool oc_ok = oc_any && (e->outlier_on & 1);
     int y_ld = D, y_live = D;      // row stride Y currently holds, and how many columns of a row are operand values
     for (int i = 0; i < c.depth && i < n_blocks; ++i) {
         const EncBlock& b = e->blocks[i];
@@ -931,13 +983,16 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         }
         y_ready = false;
         const bool mx_ao = sp_attn && mx_attn;      // the attention kernels write the proj GEMM's MX operands themselves
+        // outlier columns of proj (plain launch only): the attention kernel also writes the lo half of its output, a gather makes A_x
+        const int nop = (oc_any && (e->outlier_on & 4) && !sp_attn && b.oc_n[3] && b.oc_bx[3] && e->AOlo && e->OCX) ? b.oc_n[3] : 0;
+        const bool ao_lo = (sp_attn && !mx_ao) || nop;
         if (!b.global)
             CK(e, launch_window_attention(prec, e->QKV, b.qkv_b, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s,
-                                          (sp_attn && !mx_ao) ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,
+                                          ao_lo ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,
                                           mx_ao ? e->SAO4[0] : nullptr, mx_ao ? e->SAO4[1] : nullptr));
         else
             CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, e->VTG, s,
-                                          (sp_attn && !mx_ao) ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,
+                                          ao_lo ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,
                                           mx_ao ? e->SAO4[0] : nullptr, mx_ao ? e->SAO4[1] : nullptr));
         if (e->range_check) {       // norm1 output, q | k | v, attention output
             RANGE_SCAN_ROWS(e->Y, M, y_live, y_ld);  // the live columns only: pad columns may hold an earlier pass's values
@@ -968,7 +1023,10 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                 }
                 if (ln_tail && !sp_attn)
                     CK(e, launch_gemm_et_lntail(prec, e->AO, b.proj_w, e->X, b.proj_b, M, D, D, b.ln2w, b.ln2b, 1e-6f, e->Y, e->ln_counters, s));
-                else
+                else if (nop) {
+                    CK(e, launch_outlier_gather(e->AO, e->AOlo, D, b.oc_idx[3], nop, e->OCX, M, s));
+                    CK(e, resid_gemm_ext(e, prec, e->AO, b.proj_w, e->OCX, b.oc_bx[3], b.proj_b, M, D, D, s));
+                } else
                     CK(e, launch_gemm_et(prec, e->AO, b.proj_w, e->X, b.proj_b, nullptr, 0, M, D, D, true, false, true, s));
             }
             if (ln_tail && !sp_attn) {
@@ -1019,6 +1077,11 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
             (void)swap_gelu_form(prev_form);
             CK(e, le);
         }
+        // outlier columns of lin2 (plain launches only): the pre-activations of those <= 32 hidden units once more, in fp32, from the
+        // LayerNorm output that still sits in Y (rows of stride ldy2) -> exact GELU -> lo | hi = A_x
+        const int nol2 = (oc_any && (e->outlier_on & 2) && lin1_plain && b.oc_n[2] && b.oc_bx[2] && e->OCX && e->OCF && b.lin2_ws[ldl ? 1 : 0] &&
+                          // the side weights carry lin1's own extension columns: Y must hold them in this launch (else they are stale)
+                          (b.oc_n[1] == 0 || nol > 0) && (ldl || ldy2 == D + (nol ? 64 : 0))) ? b.oc_n[2] : 0;
         if (e->timing) {
             CK(e, hipEventRecord(t1, s));
             e->tev.emplace_back(t0, t1);
@@ -1045,6 +1108,13 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                     const EncBlock& nb = e->blocks[i + 1];
                     CK(e, launch_gemm_et_lntail(prec, e->H, b.lin2_w, e->X, b.lin2_b, M, D, 4 * D, nb.ln1w, nb.ln1b, 1e-6f, e->Y, e->ln_counters, s));
                     y_ready = true;
+                } else if (nol2) {
+                    {
+                        GemmVariantScope base_kernel(1);        // N = 128: the 128 x 128 kernel (any K % 64 == 0; no operand stride involved: rows of Y are read whole)
+                        CK(e, launch_gemm_et(prec, e->Y, b.lin2_ws[ldl ? 1 : 0], e->OCF, b.lin2_sb, nullptr, 0, M, 128, ldy2, true, false, false, s));
+                    }
+                    CK(e, launch_outlier_hidden_ext(prec, e->OCF, e->OCX, M, s));
+                    CK(e, resid_gemm_ext(e, prec, e->H, b.lin2_w, e->OCX, b.oc_bx[2], b.lin2_b, M, D, 4 * D, s));
                 } else
                     CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));
             }
@@ -1475,7 +1545,7 @@ int samrs_set_option(samrs_engine_t* e, const char* name, int value) {
     else if (n == "gelu_fast") e->gelu_fast = value < 0 ? -1 : (value != 0);
     else if (n == "ln_tail") e->ln_tail = value > 0;
     else if (n == "operand_pad") e->operand_pad_on = value != 0;
-    else if (n == "outlier_cols") e->outlier_on = value != 0;
+    else if (n == "outlier_cols") e->outlier_on = value & 7;
     else if (n == "outlier_ratio_pct") {
         if (e->finalized) return fail(e, SAMRS_ERR_BAD_ARG, "outlier_ratio_pct: the columns are picked when the weights are finalized; set it before");
         if (value < 101) return fail(e, SAMRS_ERR_BAD_ARG, "outlier_ratio_pct must exceed 100 (a column's score as a percentage of the median score)");

@@ -961,13 +961,19 @@ struct LnTail {
     float eps = 0.f;
 };
 
-template <int PREC, bool OUT_F32, bool GELU, int NI = 4, int MODE = 0, int ABL = 0, bool SPLIT3 = false, bool LNT = false>
+// EXT (round 6, the outlier-column extension of proj / lin2: engine.hip EncBlock::oc_*): ONE more pair stage behind the K axis whose
+// 64 k come from two dense side operands A_x [M][64], B_x [N][64] (the hi + lo split of up to 32 outlier columns: A_lo | A_hi against
+// B_hi | B_lo) -- the operand A is written by another kernel with its own row stride, so the extra columns cannot simply be appended
+// to its rows as for qkv / lin1.  Only the DMA source of that one stage differs (row stride 64 instead of K); passed in the A_lo /
+// B_lo parameters (EXT and SPLIT3 exclude each other).
+template <int PREC, bool OUT_F32, bool GELU, int NI = 4, int MODE = 0, int ABL = 0, bool SPLIT3 = false, bool LNT = false, bool EXT = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv,
     const float* __restrict__ bias, const float* __restrict__ add2d, int add2d_period,
     int M, int N, int K, int accumulate, int skew,
     const uint16_t* __restrict__ A_lo = nullptr, const uint16_t* __restrict__ B_lo = nullptr, LnTail ln = LnTail()) {
     static_assert(!LNT || (OUT_F32 && !GELU), "the LayerNorm tail follows the fp32 residual outputs");
+    static_assert(!(EXT && SPLIT3), "the side operands of EXT travel in the A_lo / B_lo parameters");
     constexpr int XBN = 64 * NI;
     constexpr int XROWS = QBM + XBN;                       // 512 / 576 rows per stage
     constexpr int XSTAGE_ELEMS = XROWS * XBK;              // 64 / 72 KiB
@@ -1011,13 +1017,23 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     const uint16_t* sBl = SPLIT3 ? B_lo + (size_t)n0 * K : nullptr;
     const int nst1 = K / XBK;                              // pair stages per K segment
     const size_t rs64 = (size_t)64 * K;
+    // EXT: the side operands' tile bases and the per-lane offset on their 64-element rows
+    const uint16_t* sAx = EXT ? A_lo + (size_t)m0 * XBK : nullptr;
+    const uint16_t* sBx = EXT ? B_lo + (size_t)n0 * XBK : nullptr;
+    const uint32_t voffx = ((uint32_t)prow * (uint32_t)XBK + (uint32_t)(lane >> 5) * 32u + (uint32_t)qswz(prow, lane & 3) * 8u) * 2u;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
     // piece q_ (literal) of pair stage st_ into the buffer at byte offset wr_
 #define X64_PIECE(st_, wr_, q_)                                                                            \
-    if constexpr (!(ABL & 1)) glds16_s(voff, ((q_) < 4 ? seg_src_a<SPLIT3>(sA, sAl, (st_), nst1) + (size_t)(q_) * rs64                  \
-                                                        : seg_src_b<SPLIT3>(sB, sBl, (st_), nst1) + (size_t)((q_) - 4) * rs64),          \
-             lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u))
+    if constexpr (!(ABL & 1)) {                                                                            \
+        if (EXT && (st_) == nst1)                                                                          \
+            glds16_s(voffx, ((q_) < 4 ? sAx + (size_t)(q_) * (64 * XBK) : sBx + (size_t)((q_) - 4) * (64 * XBK)),                        \
+                     lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u));                         \
+        else                                                                                               \
+            glds16_s(voff, ((q_) < 4 ? seg_src_a<SPLIT3>(sA, sAl, (st_), nst1) + (size_t)(q_) * rs64                                    \
+                                      : seg_src_b<SPLIT3>(sB, sBl, (st_), nst1) + (size_t)((q_) - 4) * rs64),                            \
+                     lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u));                         \
+    }
 #define X64_ISSUE(st_, wr_)                                                                                \
     do {                                                                                                   \
         X64_PIECE(st_, wr_, 0); X64_PIECE(st_, wr_, 1); X64_PIECE(st_, wr_, 2); X64_PIECE(st_, wr_, 3);    \
@@ -1031,7 +1047,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nst = (SPLIT3 ? 3 : 1) * nst1;
+    const int nst = (SPLIT3 ? 3 : 1) * nst1 + (EXT ? 1 : 0);
     const int fr = lane & 15, fq = lane >> 4;
     // fragment BYTE offsets inside a stage for k-half 0; k-half 1 is +512
     uint32_t offA[8], offB[NI];
@@ -2405,6 +2421,17 @@ hipError_t launch_gemm_x64(const void* A, const void* B, void* C, const float* b
     return hipGetLastError();
 }
 
+// proj / lin2 with the outlier-column stage (gemm_et_x64_kernel EXT): C (fp32) += A B^T + A_x B_x^T + bias
+template <int PREC>
+hipError_t launch_gemm_x64_ext(const void* A, const void* B, const void* Ax, const void* Bx, void* C, const float* bias,
+                               int M, int N, int K, hipStream_t s) {
+    dim3 grid((M / QBM) * (N / WBN)), block(QTHREADS);
+    gemm_et_x64_kernel<PREC, true, false, 5, 3, 0, false, false, true><<<grid, block, 0, s>>>(
+        reinterpret_cast<const uint16_t*>(A), reinterpret_cast<const uint16_t*>(B), C, bias, nullptr, 0, M, N, K, 1, g_x64_skew,
+        reinterpret_cast<const uint16_t*>(Ax), reinterpret_cast<const uint16_t*>(Bx));
+    return hipGetLastError();
+}
+
 template <int PREC, int NI = 4>
 hipError_t launch_gemm_big(const void* A, const void* B, void* C, const float* bias, const float* add2d, int period,
                            int M, int N, int K, bool out_f32, bool gelu, bool accumulate, hipStream_t s) {
@@ -3261,6 +3288,20 @@ bool gemm_ld_ok(int M, int N, int K, bool gelu) {
 }
 int swap_gemm_ld(int ld) { const int old = tl_gemm_ld; tl_gemm_ld = ld; return old; }
 
+// fp32 residual outputs with the outlier-column stage: the shapes the 256 x 320 pair-stage kernel takes by the automatic rule
+bool gemm_ext_ok(int M, int N, int K) {
+    gemm_env_once();
+    const int gv = tl_gemm_variant >= 0 ? tl_gemm_variant : g_gemm_variant;
+    return gv == 8 && M > 0 && M % QBM == 0 && N % WBN == 0 && K % XBK == 0 && K >= 2 * XBK && (long)(M / QBM) * (N / WBN) >= 256;
+}
+hipError_t launch_gemm_et_ext(int prec, const void* A, const void* B, const void* Ax, const void* Bx, float* C, const float* bias,
+                              int M, int N, int K, hipStream_t s) {
+    if (!A || !B || !Ax || !Bx || !C || !gemm_ext_ok(M, N, K)) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) return launch_gemm_x64_ext<PREC_BF16>(A, B, Ax, Bx, C, bias, M, N, K, s);
+    if (prec == PREC_F16) return launch_gemm_x64_ext<PREC_F16>(A, B, Ax, Bx, C, bias, M, N, K, s);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const float* bias,
                           const float* add2d, int add2d_period, int M, int N, int K, bool out_f32,
                           bool gelu, bool accumulate, hipStream_t s) {
@@ -3375,7 +3416,8 @@ hipError_t launch_gemm_et(int prec, const void* A, const void* B, void* C, const
     // bit 2 = one tile per block instead of persistent, bit 3 = spread pieces
 #ifdef SAMRS_EXPERIMENTS
     static const int m32_mask = [] { const char* v = getenv("SAMRS_GEMM_M32"); return v ? atoi(v) : 0; }();
-    if ((variant == 27 || variant == 28) && m32_ok(M, N, K, add2d) && (m32_mask & (out_f32 ? 2 : 1)))
+    if ((variant == 27 || variant == 28) && tl_gemm_ld == 0 /* the m32 / w4 kernels take no operand stride */ && m32_ok(M, N, K, add2d) &&
+        (m32_mask & (out_f32 ? 2 : 1)))
         variant = (m32_mask & 16) ? 34 : 30 + ((m32_mask & 4) ? 1 : 0) + ((m32_mask & 8) ? 2 : 0);
     if (variant >= 30 && variant <= 33 && !m32_ok(M, N, K, add2d)) variant = add2d ? 27 : 28;
     if (variant >= 30 && variant <= 33) {     // 30 / 31: all pieces in step 3; 32 / 33: pieces spread over two steps

@@ -40,6 +40,12 @@ int swap_gelu_form(int v);                // thread-local erf form of lin1's GEL
 // it (gemm.hip tl_gemm_ld).  gemm_ld_ok: a launch of this shape runs on one of them (anything else refuses a stride).
 int swap_gemm_ld(int ld);
 bool gemm_ld_ok(int M, int N, int K, bool gelu);
+// C (fp32 [M][N], the residual stream) += A B^T + A_x B_x^T + bias: proj / lin2 with ONE more 64-k stage read from two dense side operands
+// A_x [M][64], B_x [N][64] (hi + lo of the outlier columns, engine.hip EncBlock::oc_*).  gemm_ext_ok: the shapes of the 256 x 320
+// pair-stage kernel (ViT-H at >= 2 tiles); other shapes add the side product with an accumulating launch of their own.
+bool gemm_ext_ok(int M, int N, int K);
+hipError_t launch_gemm_et_ext(int prec, const void* A, const void* B, const void* Ax, const void* Bx, float* C, const float* bias,
+                              int M, int N, int K, hipStream_t s);
 int swap_gemm_variant_override(int v);   // thread-local override (-1 = none) used by engine handles; returns the previous value
 void set_gemm_skew(int xcd_units, int cu_units);   // first-round start skew of the pair-stage GEMM (1024-cycle units)
 hipError_t launch_gemm_f32(const float* A, int lda, const float* W, const float* bias, float* C,
@@ -77,8 +83,13 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
                             // optional (plain row order, ld_out >= D + 64): hi + lo of n_oc <= 32 outlier columns as 64 more K columns
                             // of the row: [D + j] = lo of column oc_idx[j], [D + 32 + j] = its hi, zeros in unused slots
                             const int* oc_idx = nullptr, int n_oc = 0);
-// weight side of that extension: out[r][K + j] = ET(W[r][idx[j]]), out[r][K + 32 + j] = ET(W - hi), W fp32 [N][K], out rows of stride ld
-hipError_t launch_outlier_weight_ext(int prec, const float* W, int N, int K, const int* idx, int n_oc, void* out, int ld, hipStream_t s);
+// weight side of that extension: out[r][col0 + j] = ET(W[r][idx[j]]), out[r][col0 + 32 + j] = ET(W - hi), W fp32 [N][K], out rows of stride ld
+hipError_t launch_outlier_weight_ext(int prec, const float* W, int N, int K, const int* idx, int n_oc, void* out, int ld, int col0, hipStream_t s);
+// the producers of the side operands of proj / lin2 (launch_gemm_et_ext): see the kernels in encoder_kernels.hip
+hipError_t launch_outlier_side_weight(int prec, const float* W1, const float* b1, int D, const int* idx2, int n2, const int* idx1, int n1,
+                                      void* out, int Ks, float* bias_out, hipStream_t s);
+hipError_t launch_outlier_gather(const void* hi, const void* lo, int D, const int* idx, int n_oc, void* out, int rows, hipStream_t s);
+hipError_t launch_outlier_hidden_ext(int prec, const float* pre, void* out, int rows, hipStream_t s);
 // squared L2 norms of the columns / rows of an fp32 matrix [N][K] (either output may be null); load-time scoring of outlier columns
 hipError_t launch_weight_norms(const float* W, int N, int K, float* col_sq, float* row_sq, hipStream_t s);
 // out_lo (optional, both attention kernels): the split remainder of `out` (reference-grade mode: proj on hi + lo operands)

@@ -44,7 +44,7 @@ def test_outlier_columns_are_picked_from_the_weights_and_cut_the_error():
         sam = samrs_amd.sam_model_registry[name](state_dict=sd, precision="f16", max_prompts=8, max_points=1, max_images=n_img,
                                                  options={"split": 15}).to("cuda")
         eng = sam.engine
-        assert eng.get_option("outlier_cols") == 1
+        assert eng.get_option("outlier_cols") == 7                                # bit 0: qkv / lin1, bit 1: lin2, bit 2: proj
         assert eng.get_option("outlier_blocks") == cfg.depth                      # heavy_tailed's default blocks: first, middle, last = both
         assert eng.get_option("outlier_columns") == 4 * 4 * cfg.depth             # 4 planted columns x 4 block GEMMs x blocks
         never = samrs_amd.sam_model_registry[name](state_dict=sd, precision="f16", max_prompts=8, max_points=1, max_images=n_img,
@@ -57,17 +57,17 @@ def test_outlier_columns_are_picked_from_the_weights_and_cut_the_error():
             so.image_encoder(sd, cfg, so.preprocess(imgs[0]), taps=taps)
         for nb in range(1, cfg.depth + 1):
             ref = taps[f"block{nb - 1}"][0]
-            eng.set_option("outlier_cols", 1)
-            x_on = eng.debug_encoder_prefix(t, nb).cpu()
-            eng.set_option("outlier_cols", 0)
-            x_off = eng.debug_encoder_prefix(t, nb).cpu()
-            x_never = never.engine.debug_encoder_prefix(t, nb).cpu()
-            assert torch.equal(x_off, x_never), (name, nb)
-            r_on = ((x_on[0] - ref).norm() / ref.norm()).item()
-            r_off = ((x_off[0] - ref).norm() / ref.norm()).item()
-            print(f"{name} x{n_img} after {nb} blocks, heavy-tailed weights: residual-stream rel L2 vs oracle {r_off:.3e} (off) -> {r_on:.3e} (outlier columns)")
-            assert r_on < 0.75 * r_off, (name, nb, r_on, r_off)
-        eng.set_option("outlier_cols", 1)
+            rel = {}
+            for mask in (7, 1, 0):
+                eng.set_option("outlier_cols", mask)
+                x = eng.debug_encoder_prefix(t, nb).cpu()
+                rel[mask] = ((x[0] - ref).norm() / ref.norm()).item()
+                if mask == 0:
+                    assert torch.equal(x, never.engine.debug_encoder_prefix(t, nb).cpu()), (name, nb)
+            print(f"{name} x{n_img} after {nb} blocks, heavy-tailed weights: residual-stream rel L2 vs oracle {rel[0]:.3e} (off) -> "
+                  f"{rel[1]:.3e} (qkv / lin1 columns) -> {rel[7]:.3e} (+ lin2 / proj columns)")
+            assert rel[1] < 0.75 * rel[0] and rel[7] < rel[1], (name, nb, rel)
+        eng.set_option("outlier_cols", 7)
         eng.close()
         never.engine.close()
 
@@ -115,11 +115,11 @@ def test_heavy_tailed_vit_h_holds_the_iou_bar_in_modes_15_and_79(every):
            "n_masks": 32, "outlier_blocks": n_blocks}
     for mode in (15, 79):
         eng.set_option("split", mode)
-        for on in (0, 1):
-            eng.set_option("outlier_cols", on)
+        for tag, mask in (("off", 0), ("qkv_lin1", 1), ("on", 7)):
+            eng.set_option("outlier_cols", mask)
             imin, imean, rel = _c2_compare(pred, m0, low0, img, inp["boxes"])
-            out[f"mode{mode}_{'on' if on else 'off'}"] = {"iou_min": imin, "iou_mean": imean, "low_res_rel_l2": rel}
-            print(f"heavy-tailed ViT-H ({'every block' if every else '3 blocks'}), mode {mode}, outlier columns {'on ' if on else 'off'}: "
+            out[f"mode{mode}_{tag}"] = {"iou_min": imin, "iou_mean": imean, "low_res_rel_l2": rel}
+            print(f"heavy-tailed ViT-H ({'every block' if every else '3 blocks'}), mode {mode}, outlier columns {tag:8s}: "
                   f"C2 IoU min {imin:.5f} mean {imean:.5f}, low-res rel L2 {rel:.2e}")
     # cost of the extension: 8-tile encoder passes in mode 15, alternated
     tiles = torch.as_tensor(np.stack([synth.make_noise_image(i) for i in range(8)]), device="cuda").contiguous()
@@ -137,11 +137,11 @@ def test_heavy_tailed_vit_h_holds_the_iou_bar_in_modes_15_and_79(every):
 
     t_off, t_on = [], []
     for _ in range(3):
-        t_off.append(enc_ms(0)); t_on.append(enc_ms(1))
+        t_off.append(enc_ms(0)); t_on.append(enc_ms(7))
     out["encoder_ms_8_tiles"] = {"off": min(t_off), "on": min(t_on), "cost": min(t_on) / min(t_off) - 1.0}
     print(f"8-tile encoder pass, mode 15: {min(t_off):.2f} ms off -> {min(t_on):.2f} ms with the outlier columns "
           f"({100 * (min(t_on) / min(t_off) - 1):+.1f} %; {n_blocks} of 32 blocks carry them)")
-    eng.set_option("outlier_cols", 1)
+    eng.set_option("outlier_cols", 7)
     if os.path.isdir("gpurun_out"):
         path = "gpurun_out/heavy_tailed_parity.json"
         blob = json.load(open(path)) if os.path.exists(path) else {}
@@ -152,6 +152,7 @@ def test_heavy_tailed_vit_h_holds_the_iou_bar_in_modes_15_and_79(every):
     for mode in (15, 79):
         assert out[f"mode{mode}_on"]["iou_min"] >= 0.999, out
         assert out[f"mode{mode}_on"]["low_res_rel_l2"] < out[f"mode{mode}_off"]["low_res_rel_l2"], out
-    if not every:
-        assert out["encoder_ms_8_tiles"]["cost"] < 0.03, out                # <= 3 % step cost
+    # <= 3 % step cost on synth.heavy_tailed as it is (three blocks); with outlier columns in EVERY block of all
+    # four GEMMs it is one more K stage in each of 128 launches + the side operands: bounded, reported
+    assert out["encoder_ms_8_tiles"]["cost"] < (0.08 if every else 0.03), out
     eng.close()

@@ -252,14 +252,14 @@ __global__ __launch_bounds__(256) void outlier_weight_ext_kernel(const float* __
     out[(size_t)r * ld + col0 + 32 + j] = lo;
 }
 
-// Side weights of lin2's outlier columns (hidden units idx2[0 .. n2)): rows j < n2 of out [128][Ks] = row idx2[j] of lin1's weight in the
+// Side weights of lin2's outlier columns (hidden units idx2[0 .. n2)): rows j < n2 of out [32][Ks] = row idx2[j] of lin1's weight in the
 // operand type, followed -- when lin1 itself carries outlier columns idx1[0 .. n1) -- by the same 64-column extension its own launch
-// reads (hi at D + t, lo at D + 32 + t), zeros up to Ks; rows >= n2 are zero.  bias_out [128] = lin1's bias at idx2, zeros behind.
+// reads (hi at D + t, lo at D + 32 + t), zeros up to Ks; rows >= n2 are zero.  bias_out [32] = lin1's bias at idx2, zeros behind.
 template <int PREC>
 __global__ __launch_bounds__(256) void outlier_side_weight_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int D,
                                                                    const int* __restrict__ idx2, int n2, const int* __restrict__ idx1, int n1,
                                                                    uint16_t* __restrict__ out, int Ks, float* __restrict__ bias_out) {
-    const int j = blockIdx.x;                         // 0 .. 127
+    const int j = blockIdx.x;                         // 0 .. 31
     const float* src = j < n2 ? W1 + (size_t)idx2[j] * D : nullptr;
     for (int k = threadIdx.x; k < Ks; k += 256) {
         uint16_t v = 0;
@@ -289,17 +289,47 @@ __global__ __launch_bounds__(256) void outlier_gather_kernel(const uint16_t* __r
     out[(size_t)r * 64 + j] = v;
 }
 
-// A_x of lin2: pre[r][0 .. 32) = the outlier hidden units' pre-activations (fp32, bias included; row stride 128) -> exact-erf GELU ->
-// lo | hi of the result
+// A_x of lin2: GELU(lin1) of the <= 32 outlier hidden units BEFORE its rounding, recomputed from the LayerNorm output -- a skinny GEMM
+// Y [M][K] (row stride lda) x Ws [32][K]^T + bias, fp32 accumulate on v_mfma_f32_16x16x32, exact-erf GELU, hi + lo split, written as
+// lo | hi into out [M][64].  HBM-bound on the one pass over Y (92 MB at 8 tiles); one wave = 16 rows, both operands straight from
+// global memory (the 86 KB of side weights stay in the L2 / L1), eight waves per SIMD hide the latency.  M % 64 == 0, K % 32 == 0.
 template <int PREC>
-__global__ __launch_bounds__(256) void outlier_hidden_ext_kernel(const float* __restrict__ pre, uint16_t* __restrict__ out, int rows) {
-    const int r = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
-    if (r >= rows) return;
-    const float x = pre[(size_t)r * 128 + j];
-    const float g = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-    const uint16_t hi = ET<PREC>::from_float(g);
-    out[(size_t)r * 64 + j] = ET<PREC>::from_float(g - ET<PREC>::to_float(hi));
-    out[(size_t)r * 64 + 32 + j] = hi;
+__global__ __launch_bounds__(256) void outlier_side_gemm_kernel(const uint16_t* __restrict__ Y, int lda, const uint16_t* __restrict__ Ws,
+                                                                 const float* __restrict__ bias, int K, uint16_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const size_t row0 = (size_t)blockIdx.x * 64 + wave * 16;
+    const uint16_t* a = Y + (row0 + fr) * (size_t)lda + fq * 8;
+    const uint16_t* b0 = Ws + (size_t)fr * K + fq * 8;
+    const uint16_t* b1 = b0 + (size_t)16 * K;
+    f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < K; k += 32) {
+        const uint4 fa = *reinterpret_cast<const uint4*>(a + k);
+        const uint4 f0 = *reinterpret_cast<const uint4*>(b0 + k);
+        const uint4 f1 = *reinterpret_cast<const uint4*>(b1 + k);
+        // D = A B: A = 16 rows of Y (lane: row fr, k 8 fq ..), B[k][n] = Ws[n][k] (lane: n = fr, k 8 fq ..); D[m = 4 fq + i][n = fr]
+        if (PREC == PREC_F16) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa), __builtin_bit_cast(f16x8_t, f0), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, fa), __builtin_bit_cast(f16x8_t, f1), acc1, 0, 0, 0);
+        } else {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, f0), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, f1), acc1, 0, 0, 0);
+        }
+    }
+    const float bs0 = bias[fr], bs1 = bias[16 + fr];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint16_t* o = out + (row0 + 4 * fq + i) * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float x = (t ? acc1[i] : acc0[i]) + (t ? bs1 : bs0);
+            const float g = 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+            const uint16_t hi = ET<PREC>::from_float(g);
+            o[16 * t + fr] = ET<PREC>::from_float(g - ET<PREC>::to_float(hi));
+            o[32 + 16 * t + fr] = hi;
+        }
+    }
 }
 
 // Squared L2 norms of the columns (col_sq[K], must be zero on entry) and of the rows (row_sq[N]) of an fp32 matrix W[N][K]: what the
@@ -1485,8 +1515,8 @@ hipError_t launch_outlier_weight_ext(int prec, const float* W, int N, int K, con
 hipError_t launch_outlier_side_weight(int prec, const float* W1, const float* b1, int D, const int* idx2, int n2, const int* idx1, int n1,
                                       void* out, int Ks, float* bias_out, hipStream_t s) {
     if (!W1 || !b1 || !out || !idx2 || n2 < 1 || n2 > 32 || n1 < 0 || n1 > 32 || (n1 && !idx1) || Ks < D + (n1 ? 64 : 0)) return hipErrorInvalidValue;
-    if (prec == PREC_BF16) outlier_side_weight_kernel<PREC_BF16><<<128, 256, 0, s>>>(W1, b1, D, idx2, n2, idx1, n1, (uint16_t*)out, Ks, bias_out);
-    else outlier_side_weight_kernel<PREC_F16><<<128, 256, 0, s>>>(W1, b1, D, idx2, n2, idx1, n1, (uint16_t*)out, Ks, bias_out);
+    if (prec == PREC_BF16) outlier_side_weight_kernel<PREC_BF16><<<32, 256, 0, s>>>(W1, b1, D, idx2, n2, idx1, n1, (uint16_t*)out, Ks, bias_out);
+    else outlier_side_weight_kernel<PREC_F16><<<32, 256, 0, s>>>(W1, b1, D, idx2, n2, idx1, n1, (uint16_t*)out, Ks, bias_out);
     return hipGetLastError();
 }
 hipError_t launch_outlier_gather(const void* hi, const void* lo, int D, const int* idx, int n_oc, void* out, int rows, hipStream_t s) {
@@ -1494,10 +1524,10 @@ hipError_t launch_outlier_gather(const void* hi, const void* lo, int D, const in
     outlier_gather_kernel<<<(rows + 3) / 4, 256, 0, s>>>((const uint16_t*)hi, (const uint16_t*)lo, D, idx, n_oc, (uint16_t*)out, rows);
     return hipGetLastError();
 }
-hipError_t launch_outlier_hidden_ext(int prec, const float* pre, void* out, int rows, hipStream_t s) {
-    if (!pre || !out || rows < 1) return hipErrorInvalidValue;
-    if (prec == PREC_BF16) outlier_hidden_ext_kernel<PREC_BF16><<<(rows + 7) / 8, 256, 0, s>>>(pre, (uint16_t*)out, rows);
-    else outlier_hidden_ext_kernel<PREC_F16><<<(rows + 7) / 8, 256, 0, s>>>(pre, (uint16_t*)out, rows);
+hipError_t launch_outlier_side_gemm(int prec, const void* Y, int lda, const void* Ws, const float* bias, int M, int K, void* out, hipStream_t s) {
+    if (!Y || !Ws || !bias || !out || M < 64 || M % 64 || K < 32 || K % 32 || lda < K || lda % 8) return hipErrorInvalidValue;
+    if (prec == PREC_BF16) outlier_side_gemm_kernel<PREC_BF16><<<M / 64, 256, 0, s>>>((const uint16_t*)Y, lda, (const uint16_t*)Ws, bias, K, (uint16_t*)out);
+    else outlier_side_gemm_kernel<PREC_F16><<<M / 64, 256, 0, s>>>((const uint16_t*)Y, lda, (const uint16_t*)Ws, bias, K, (uint16_t*)out);
     return hipGetLastError();
 }
 

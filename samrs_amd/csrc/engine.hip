@@ -91,11 +91,11 @@ struct EncBlock {
     // lin2 / proj: their A operands (GELU(lin1), the attention output) are written by other kernels, so the 64 columns travel as a
     // dense side operand A_x [M][64] (engine OCX) against oc_bx [D][64] = W_hi[:, S] | W_lo[:, S], one more K stage of the same
     // launch (gemm.hip EXT).  lin2's A_x needs GELU(lin1) of the outlier hidden units BEFORE its rounding: a side GEMM of the
-    // LayerNorm output against those <= 32 rows of lin1's weight (lin2_ws [128][K]: [0] for dense rows of Y, [1] for ldk-element
-    // rows; lin2_sb the matching bias), then exact GELU + split (encoder_kernels.hip outlier_hidden_ext_kernel).
+    // LayerNorm output against those <= 32 rows of lin1's weight (lin2_ws, lin2_sb the matching bias) with the exact GELU and the split in
+    // its epilogue (encoder_kernels.hip outlier_side_gemm_kernel).
     uint16_t* oc_bx[4] = {nullptr, nullptr, nullptr, nullptr};      // [2] lin2, [3] proj
-    uint16_t* lin2_ws[2] = {nullptr, nullptr};
-    float* lin2_sb = nullptr;
+    uint16_t* lin2_ws = nullptr;       // [32][D (+ 64 when lin1 carries outlier columns of its own)]
+    float* lin2_sb = nullptr;          // [32]
     // LayerNorm folded into qkv / lin1 (ViT-H): W diag(gamma) in ET, its row sums, b + W beta
     uint16_t *qkv_wf = nullptr, *lin1_wf = nullptr;
     float *qkv_c = nullptr, *qkv_bf = nullptr, *lin1_c = nullptr, *lin1_bf = nullptr;
@@ -179,7 +179,6 @@ struct samrs_engine {
     int outlier_on = 7 /* bit 0: qkv / lin1, bit 1: lin2, bit 2: proj */, outlier_ratio_pct = 400, outlier_blocks = 0, outlier_columns = 0;
     float* oc_scratch = nullptr;   // load-time scratch: column / row norms
     uint16_t* OCX = nullptr;       // [M][64]: side operand A_x of the running proj / lin2 launch
-    float* OCF = nullptr;          // [M][128]: pre-activations of lin2's outlier hidden units (side GEMM output)
     bool oc_resid = false;         // some block has outlier columns in lin2 / proj
     int gelu_fast = -1;            // option "gelu_fast": -1 automatic (on in the 1x-rate modes: no block-GEMM bit in "split"), 0 off, 1 on
     int range_check = 0;
@@ -679,16 +678,11 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
         if (b.oc_n[2]) {          // lin2: weight side [D][64] + the side weights / bias of the hidden units' recomputation
             CK(e, dalloc(e, &b.oc_bx[2], (size_t)D * 64));
             CK(e, launch_outlier_weight_ext(e->prec, W(e, p + ".mlp.lin2.weight"), D, 4 * D, b.oc_idx[2], b.oc_n[2], b.oc_bx[2], 64, 0, s));
-            CK(e, dalloc(e, &b.lin2_sb, (size_t)128));
+            CK(e, dalloc(e, &b.lin2_sb, (size_t)32));
             const int k0 = D + (b.oc_n[1] ? 64 : 0);
-            CK(e, dalloc(e, &b.lin2_ws[0], (size_t)128 * k0));
+            CK(e, dalloc(e, &b.lin2_ws, (size_t)32 * k0));
             CK(e, launch_outlier_side_weight(e->prec, W(e, p + ".mlp.lin1.weight"), W(e, p + ".mlp.lin1.bias"), D, b.oc_idx[2], b.oc_n[2],
-                                             b.oc_idx[1], b.oc_n[1], b.lin2_ws[0], k0, b.lin2_sb, s));
-            if (e->ldk) {
-                CK(e, dalloc(e, &b.lin2_ws[1], (size_t)128 * e->ldk));
-                CK(e, launch_outlier_side_weight(e->prec, W(e, p + ".mlp.lin1.weight"), W(e, p + ".mlp.lin1.bias"), D, b.oc_idx[2], b.oc_n[2],
-                                                 b.oc_idx[1], b.oc_n[1], b.lin2_ws[1], e->ldk, b.lin2_sb, s));
-            }
+                                             b.oc_idx[1], b.oc_n[1], b.lin2_ws, k0, b.lin2_sb, s));
             e->oc_resid = true;
         }
         if (b.oc_n[3]) {          // proj
@@ -791,7 +785,7 @@ int samrs_finalize_weights(samrs_engine_t* e, void* stream) {
     CK(e, dalloc(e, &e->AO, M * D));
     CK(e, dalloc(e, &e->VTG, M * D));
     if (e->oc_resid) {
-        CK(e, dalloc(e, &e->OCX, M * 64)); CK(e, dalloc(e, &e->OCF, M * 128));
+        CK(e, dalloc(e, &e->OCX, M * 64));
         if (!(e->split & SPLIT_ATTN_ANY)) CK(e, dalloc(e, &e->AOlo, M * D));       // proj's outlier columns take the attention output's lo half
     }
     e->split_ready = SPLIT_DEFAULT | (e->split & SPLIT_MLP) | ((e->split & SPLIT_ATTN_ANY) ? SPLIT_ATTN_ANY : 0) | (e->mx_mlp_ready ? SPLIT_LIN2 : 0);
@@ -1079,9 +1073,9 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         }
         // outlier columns of lin2 (plain launches only): the pre-activations of those <= 32 hidden units once more, in fp32, from the
         // LayerNorm output that still sits in Y (rows of stride ldy2) -> exact GELU -> lo | hi = A_x
-        const int nol2 = (oc_any && (e->outlier_on & 2) && lin1_plain && b.oc_n[2] && b.oc_bx[2] && e->OCX && e->OCF && b.lin2_ws[ldl ? 1 : 0] &&
+        const int nol2 = (oc_any && (e->outlier_on & 2) && lin1_plain && b.oc_n[2] && b.oc_bx[2] && e->OCX && b.lin2_ws &&
                           // the side weights carry lin1's own extension columns: Y must hold them in this launch (else they are stale)
-                          (b.oc_n[1] == 0 || nol > 0) && (ldl || ldy2 == D + (nol ? 64 : 0))) ? b.oc_n[2] : 0;
+                          (b.oc_n[1] == 0 || nol > 0)) ? b.oc_n[2] : 0;
         if (e->timing) {
             CK(e, hipEventRecord(t1, s));
             e->tev.emplace_back(t0, t1);
@@ -1109,11 +1103,7 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
                     CK(e, launch_gemm_et_lntail(prec, e->H, b.lin2_w, e->X, b.lin2_b, M, D, 4 * D, nb.ln1w, nb.ln1b, 1e-6f, e->Y, e->ln_counters, s));
                     y_ready = true;
                 } else if (nol2) {
-                    {
-                        GemmVariantScope base_kernel(1);        // N = 128: the 128 x 128 kernel (any K % 64 == 0; no operand stride involved: rows of Y are read whole)
-                        CK(e, launch_gemm_et(prec, e->Y, b.lin2_ws[ldl ? 1 : 0], e->OCF, b.lin2_sb, nullptr, 0, M, 128, ldy2, true, false, false, s));
-                    }
-                    CK(e, launch_outlier_hidden_ext(prec, e->OCF, e->OCX, M, s));
+                    CK(e, launch_outlier_side_gemm(prec, e->Y, ldy2, b.lin2_ws, b.lin2_sb, M, Kl, e->OCX, s));
                     CK(e, resid_gemm_ext(e, prec, e->H, b.lin2_w, e->OCX, b.oc_bx[2], b.lin2_b, M, D, 4 * D, s));
                 } else
                     CK(e, launch_gemm_et(prec, e->H, b.lin2_w, e->X, b.lin2_b, nullptr, 0, M, D, 4 * D, true, false, true, s));

@@ -89,7 +89,8 @@ hipError_t launch_outlier_weight_ext(int prec, const float* W, int N, int K, con
 hipError_t launch_outlier_side_weight(int prec, const float* W1, const float* b1, int D, const int* idx2, int n2, const int* idx1, int n1,
                                       void* out, int Ks, float* bias_out, hipStream_t s);
 hipError_t launch_outlier_gather(const void* hi, const void* lo, int D, const int* idx, int n_oc, void* out, int rows, hipStream_t s);
-hipError_t launch_outlier_hidden_ext(int prec, const float* pre, void* out, int rows, hipStream_t s);
+// lin2's A_x: out [M][64] = lo | hi of GELU(Y Ws^T + bias), Y [M][K] with row stride lda, Ws [32][K], bias [32]; M % 64 == 0, K % 32 == 0
+hipError_t launch_outlier_side_gemm(int prec, const void* Y, int lda, const void* Ws, const float* bias, int M, int K, void* out, hipStream_t s);
 // squared L2 norms of the columns / rows of an fp32 matrix [N][K] (either output may be null); load-time scoring of outlier columns
 hipError_t launch_weight_norms(const float* W, int N, int K, float* col_sq, float* row_sq, hipStream_t s);
 // out_lo (optional, both attention kernels): the split remainder of `out` (reference-grade mode: proj on hi + lo operands)

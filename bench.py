@@ -104,6 +104,21 @@ def parity_of_mode(split: int, workload: str, model: str = "vit_h"):
            "c4_n_masks": sum(t["n_masks"] for t in c4), "c4_served_in_this_mode": bool(split & (64 | 16)),
            "n_masks": sum(t["n_masks"] for t in m.values()), "flips_outside_tau": sum(t["flips_outside_tau"] for t in m.values()),
            "tau_frac": st.get("tau_frac"), "csrc_sha16": st.get("csrc_sha16"), "device": st.get("device")}
+    # round 6: (a) the floor -- the fp32 oracle itself on two backends (torch eager on the MI355X vs the host CPU, same 8 C2 tiles);
+    # (b) checkpoint-like weights -- synth.heavy_tailed at ViT-H on the C2 fixture inputs (tests/test_outlier_gpu.py)
+    fl = st.get("reference_backend_floor", {}).get("c2")
+    if fl:
+        out["reference_backend_floor_px"] = {"classmap_px_mean": fl["classmap_diff_mean"], "classmap_px_max": fl["classmap_diff_max"],
+                                             "mask_flips_max": fl["flips_max"], "iou_min": round(fl["iou_min"], 6), "n_masks": fl["n_masks"],
+                                             "what": "oracle fp32 in torch eager on this GPU vs on the host CPU"}
+        out["classmap_px_over_floor"] = round(out["classmap_px_mean"] / max(fl["classmap_diff_mean"], 1e-9), 1)
+    ht = st.get("heavy_tailed", {})
+    key = f"mode{split}_on"
+    if ht.get("csrc_sha16") == st.get("csrc_sha16") and key in ht.get("three_blocks", {}):
+        out["heavy_tailed_iou_min"] = round(ht["three_blocks"][key]["iou_min"], 5)
+        if key in ht.get("every_block", {}):
+            out["heavy_tailed_every_block_iou_min"] = round(ht["every_block"][key]["iou_min"], 5)
+        out["heavy_tailed_encoder_cost"] = {k: round(ht[k]["encoder_ms_8_tiles"]["cost"], 4) for k in ("three_blocks", "every_block") if k in ht}
     if workload == "c4":
         out["headline_workload_iou_min"] = out["c4_iou_min"]
     else:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SAMRS_ABI_VERSION 4
+#define SAMRS_ABI_VERSION 5
 
 enum samrs_status {
     SAMRS_OK = 0,
@@ -275,6 +275,15 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value);
  * out: device fp32 [n][out_size][out_size] = the `mask_input` of samrs_predict (out_size = 256). */
 int samrs_rbox_mask_prompt(const int32_t* pts, int n, int n_vertices, int h, int w, int th, int tw,
                            int img_size, int out_size, float* out, void* stream);
+/* The same with the polygon fill rule named.  cv2.fillPoly's scanline spans changed in OpenCV 4.5.2 (modules/imgproc/src/drawing.cpp
+ * FillEdgeCollection): up to 4.5.1 a span covers ceil(x_left) .. floor(x_right) of the 16.16 fixed-point edge crossings, since 4.5.2
+ * both ends are rounded half up; the 8-connected boundary lines drawn on top are the same.  The reference pins no OpenCV version
+ * (`Generate Dataset/main_sam_rbox_mask_instance.py:126-129`), and on FAIR1M-shaped boxes ~18 % of the polygons differ by 1 - 8
+ * boundary pixels between the two, so the caller says which cv2 it replaces (samrs_amd.transforms picks by cv2.__version__ when
+ * cv2 is importable).  samrs_rbox_mask_prompt == fill_rule SAMRS_FILL_CV2_LE_451. */
+enum samrs_fill_rule { SAMRS_FILL_CV2_LE_451 = 0, SAMRS_FILL_CV2_GE_452 = 1 };
+int samrs_rbox_mask_prompt_rule(const int32_t* pts, int n, int n_vertices, int h, int w, int th, int tw,
+                                int img_size, int out_size, int fill_rule, float* out, void* stream);
 
 /* The kernel-level entry points (samrs_k_*) and the test / measurement hooks (samrs_debug_*) that the parity tests, bench.py's
  * in-situ kernel timer and the tools/ scripts use are declared in samrs_hip_internal.h: exported by the same library, NOT part of

@@ -89,3 +89,77 @@ def train_steps(dataset: SegmentationDataset, n_classes: int, rank: int, world: 
         losses.append(float(loss))
     w = torch.cat([p.detach().flatten() for p in model.parameters()])
     return losses, w, drawn, hist
+
+
+# ------------------------------------------------------------------------------------------------
+# Pinning (round 6): the reader above against the reference's OWN SegmentationDataset on the product's files
+# ------------------------------------------------------------------------------------------------
+SAMPLE_CLASSES, SAMPLE_IMAGES, SAMPLE_SIDE = 18, 6, 64
+
+
+def make_sample_dataset(root: str):
+    """A small dataset in the layout main_pretrain.py:186-190 expects, written by the PRODUCT's writers (samrs_amd.generate.write_outputs,
+    samrs_amd.tile_io: gray / color PNG + ins pickles; the class maps are synthetic rectangles so that it can be made without a GPU):
+    6 tiles of 64 x 64, 18 classes, train.txt = 4 stems, valid.txt = 2.  Returns (image dir, label dir)."""
+    from samrs_amd import generate, tile_io
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    out = os.path.join(root, "hbox_segs_init")
+    palette = generate.default_palette(SAMPLE_CLASSES)
+    names = [str(i) for i in range(SAMPLE_CLASSES)]
+    stems = []
+    for i in range(SAMPLE_IMAGES):
+        rng = np.random.default_rng(70 + i)
+        img = rng.integers(0, 256, (SAMPLE_SIDE, SAMPLE_SIDE, 3), dtype=np.uint8)
+        seg = np.full((SAMPLE_SIDE, SAMPLE_SIDE), 255, np.uint8)                    # main_sam_hbox_semantic.py:162
+        boxes, labels, areas = [], [], []
+        for _ in range(4):
+            x0, y0 = rng.integers(0, SAMPLE_SIDE - 8, 2)
+            w, h = rng.integers(4, 24, 2)
+            lab = int(rng.integers(0, SAMPLE_CLASSES))
+            seg[y0:y0 + h, x0:x0 + w] = lab
+            boxes.append(np.array([x0, y0, x0 + w, y0 + h], np.float32)); labels.append(lab); areas.append(int(w * h))
+        stem = f"P{i:04d}"
+        tile_io.write_rgb(os.path.join(root, "images", stem + ".png"), img)
+        generate.write_outputs(out, stem, seg, None, np.stack(boxes), np.asarray(labels), np.asarray(areas), palette, names)
+        stems.append(stem)
+    with open(os.path.join(root, "train.txt"), "w") as f:
+        f.write("\n".join(stems[:4]) + "\n")
+    with open(os.path.join(root, "valid.txt"), "w") as f:
+        f.write("\n".join(stems[4:]) + "\n")
+    return os.path.join(root, "images"), os.path.join(out, "gray")
+
+
+def reference_dataset(root: str, flag: str):
+    """The REFERENCE's SegmentationDataset (datasets.py:182-273, imported through oracle/ref_import.py) on `root`, as
+    main_pretrain.py:186-202 constructs it for an UperNet decoder; the albumentations pipeline is the identity (not installable)."""
+    import types
+    from oracle import ref_import
+    ds = ref_import.import_reference_consumer()
+    args = types.SimpleNamespace(decoder="upernet")
+    return ds.SegmentationDataset(args, SAMPLE_SIDE, root, os.path.join(root, "images"), os.path.join(root, "hbox_segs_init", "gray"),
+                                  ext_img=".png", ext_lbl=".png", flag=flag, transform=lambda image, mask: {"image": image, "mask": mask})
+
+
+def make_golden(path: str) -> None:
+    """tests/golden/consumer_ref.npz: what the reference's SegmentationDataset returns for every item of the sample dataset
+    (flags trn / val / tes): the file lists it built and the (image tensor, label tensor) pairs.  Run where /root/reference exists:
+        python -m oracle.consumer_check tests/golden/consumer_ref.npz"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as root:
+        make_sample_dataset(root)
+        blob = {}
+        for flag in ("trn", "val", "tes"):
+            ds = reference_dataset(root, flag)
+            blob[f"{flag}_files"] = np.array([os.path.relpath(f, root) for f in ds.files])
+            blob[f"{flag}_targets"] = np.array([os.path.relpath(f, root) for f in ds.targets])
+            xs, ys = zip(*(ds[i] for i in range(len(ds))))
+            blob[f"{flag}_x"] = torch.stack(xs).numpy()
+            blob[f"{flag}_y"] = torch.stack(ys).numpy()
+        np.savez_compressed(path, **blob)
+        print({k: v.shape for k, v in blob.items()})
+
+
+if __name__ == "__main__":
+    import sys
+    make_golden(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                                                   "consumer_ref.npz"))

@@ -18,7 +18,9 @@ paper next to each answer (`derivation` in the JSON):
     is one where BOTH rules give the same picture (the pixels they disagree on are covered by the boundary lines); the script
     asserts it.
 
-Run:  python oracle/derive_fillpoly_cases.py   (rewrites the four `rotated_*` entries of the JSON in place).
+Round 6 adds three `differs_*` cases on which the two rules DISAGREE, with one expected picture per rule (CASES_DIFFER below).
+
+Run:  python oracle/derive_fillpoly_cases.py   (rewrites the `rotated_*` and `differs_*` entries of the JSON in place).
 """
 from __future__ import annotations
 
@@ -59,7 +61,7 @@ def line_walk(p1, p2):
     return pixels, errs
 
 
-def derive(h: int, w: int, pts):
+def derive(h: int, w: int, pts, must_agree: bool = True):
     lines, edges, pix = [], [], set()
     for i in range(len(pts)):
         p0, p1 = pts[i - 1], pts[i]
@@ -82,14 +84,24 @@ def derive(h: int, w: int, pts):
                               "span_round_round": list(new)})
                 for name, (a, b) in (("ceil_floor", old), ("round_round", new)):
                     filled[name] |= {(x, y) for x in range(max(a, 0), min(b, w - 1) + 1)}
-    assert filled["ceil_floor"] == filled["round_round"], "pick a case on which the two published span rules agree"
-    rows = {}
-    for y in range(h):
-        xs = sorted(x for (x, yy) in filled["ceil_floor"] if yy == y)
-        if xs:
-            assert xs == list(range(xs[0], xs[-1] + 1)), "convex: one run per row"
-            rows[str(y)] = [xs[0], xs[-1]]
-    return rows, {"boundary_lines": lines, "scanlines": spans}
+    def as_rows(pixels):
+        rows = {}
+        for y in range(h):
+            xs = sorted(x for (x, yy) in pixels if yy == y)
+            if xs:
+                assert xs == list(range(xs[0], xs[-1] + 1)), "convex: one run per row"
+                rows[str(y)] = [xs[0], xs[-1]]
+        return rows
+
+    if must_agree:
+        assert filled["ceil_floor"] == filled["round_round"], "pick a case on which the two published span rules agree"
+        return as_rows(filled["ceil_floor"]), {"boundary_lines": lines, "scanlines": spans}
+    assert filled["ceil_floor"] != filled["round_round"], "pick a case on which the two published span rules DISAGREE"
+    only_new = sorted(filled["round_round"] - filled["ceil_floor"])
+    only_old = sorted(filled["ceil_floor"] - filled["round_round"])
+    return (as_rows(filled["ceil_floor"]), as_rows(filled["round_round"]),
+            {"boundary_lines": lines, "scanlines": spans, "pixels_only_under_cv2_ge_452": [list(p) for p in only_new],
+             "pixels_only_under_cv2_le_451": [list(p) for p in only_old]})
 
 
 CASES = [
@@ -105,14 +117,36 @@ CASES = [
 ]
 
 
+# Round 6 (VERDICT r05 "next round" 8): cases on which the two span rules give DIFFERENT pictures -- the rasteriser now takes the rule as
+# a parameter (`fill_rule` = "cv2_le_451" | "cv2_ge_452"), so each rule needs known answers of its own where it matters.  Found by
+# a search over small rotated rectangles (this script's own derive(), not the module under test); the extra pixels of the newer
+# rule sit on the right-hand edge where x_right's fraction is >= 0.5 and the boundary line has stepped inwards.
+CASES_DIFFER = [
+    # 3.2 x 4.1 at 23 degrees: two pixels differ
+    ("differs_rectangle_23_degrees", 12, 12, [[3, 4], [6, 5], [4, 9], [2, 8]]),
+    # 6.7 x 1.4 at 60 degrees: three pixels differ
+    ("differs_rectangle_60_degrees", 12, 12, [[3, 1], [6, 7], [5, 8], [1, 2]]),
+    # 8.9 x 2.2 at 118 degrees (one horizontal edge after the int32 truncation): four pixels differ
+    ("differs_rectangle_118_degrees", 12, 12, [[7, 0], [3, 8], [1, 7], [5, 0]]),
+]
+
+
 def main() -> None:
     path = os.path.join(ROOT, "tests", "golden", "opencv_known_answers.json")
     known = json.load(open(path))
-    keep = [c for c in known["fill_poly"] if not c["name"].startswith("rotated_")]
+    keep = [c for c in known["fill_poly"] if not c["name"].startswith(("rotated_", "differs_"))]
     for name, h, w, pts in CASES:
         rows, derivation = derive(h, w, [tuple(p) for p in pts])
         keep.append({"name": name, "h": h, "w": w, "pts": pts, "rows": rows, "derivation": derivation})
+    for name, h, w, pts in CASES_DIFFER:
+        rows_old, rows_new, derivation = derive(h, w, [tuple(p) for p in pts], must_agree=False)
+        keep.append({"name": name, "h": h, "w": w, "pts": pts, "rows": rows_old, "rows_cv2_ge_452": rows_new, "derivation": derivation})
     known["fill_poly"] = keep
+    known["_doc_differs"] = (
+        "Round 6: the three differs_* cases are rotated rectangles on which OpenCV's two published span rules give different pictures: "
+        "`rows` is the picture under ceil(x_left) .. floor(x_right) (OpenCV <= 4.5.1, fill_rule cv2_le_451), `rows_cv2_ge_452` the one "
+        "with both crossings rounded half up (OpenCV >= 4.5.2).  Every other case has one picture: both rules agree on it.  The "
+        "derivation lists both spans per scanline and the pixels that exist under one rule only.")
     known["_doc_rotated"] = (
         "Round 5: the four rotated_* cases have edges at arbitrary slopes (18.4, 21.8, 71.6 degrees and a sub-pixel sliver at 14 "
         "degrees).  Each carries its derivation: the cv::LineIterator walk of every edge (err before each step; a minor-axis step "
@@ -122,8 +156,8 @@ def main() -> None:
     with open(path, "w") as f:
         json.dump(known, f, indent=1)
         f.write("\n")
-    for c in keep[-len(CASES):]:
-        print(c["name"], c["rows"])
+    for c in keep[-len(CASES) - len(CASES_DIFFER):]:
+        print(c["name"], c["rows"], c.get("rows_cv2_ge_452", ""))
 
 
 if __name__ == "__main__":

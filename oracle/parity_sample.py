@@ -115,13 +115,23 @@ def _engine_call(pred, kw, multimask, hw):
     return pred.predict_torch(pc, pl, boxes, mi, multimask_output=multimask)
 
 
-def run(pred, orc, modes: Sequence[int], tile_iter: Iterable[dict] = None, tau_frac: float = TAU_FRAC, log=print):
+REF_BACKEND = "ref_fp32_other_backend"      # pseudo-mode of `run`: the SAME fp32 oracle code on a second backend (torch eager on the GPU)
+
+
+def run(pred, orc, modes: Sequence[int], tile_iter: Iterable[dict] = None, tau_frac: float = TAU_FRAC, log=print, orc_other=None):
     """Engine (`pred`: samrs_amd.SamPredictor on a ViT-H engine whose block-weight lo copies exist) against the oracle
-    predictor `orc` for every mode in `modes` (the engine's "split" option).  Returns {mode: {tag: {field: list}}}."""
+    predictor `orc` for every mode in `modes` (the engine's "split" option).  Returns {mode: {tag: {field: list}}}.
+
+    `orc_other` (optional): the same oracle code with its state dict on another device -- torch eager fp32 on the MI355X (rocBLAS /
+    MIOpen) against torch fp32 on the host CPU.  Its c2 workloads are recorded under the pseudo-mode REF_BACKEND: the class-map
+    pixels and mask pixels that differ between two fp32 evaluations of the REFERENCE algorithm, i.e. the floor below which "bit-identical
+    argmax class map" (BASELINE.json north_star) is not defined by the reference itself (VERDICT r05 "next round" 2)."""
     from oracle import sam_oracle as so
     from oracle.make_golden import unstable_class_map
     eng = pred.model.engine
     rec: Dict[int, Dict[str, Dict[str, List]]] = {m: defaultdict(lambda: defaultdict(list)) for m in modes}
+    if orc_other is not None:
+        rec[REF_BACKEND] = defaultdict(lambda: defaultdict(list))
     for tile in (tile_iter if tile_iter is not None else tiles()):
         img = tile["image"]
         hw = img.shape[:2]
@@ -139,6 +149,33 @@ def run(pred, orc, modes: Sequence[int], tile_iter: Iterable[dict] = None, tau_f
                 ref[tag]["unstable"] = unstable_class_map(lg[:, 0], tau).numpy()
             del lg
         t_or = time.time() - t0
+        if orc_other is not None:
+            odev = next(iter(orc_other.sd.values())).device
+            orc_other.set_image(img)
+            for tag, kw, mm in workloads(tile, None):
+                if "seg" not in ref[tag]:
+                    continue
+                R, r = ref[tag], rec[REF_BACKEND][tag]
+                tb = so.apply_boxes(torch.from_numpy(kw["boxes"]), hw, orc_other.cfg.img_size).to(odev)
+                lg, q, low = orc_other.predict_torch(None, None, tb, None, multimask_output=False, return_logits=True)
+                mc = (lg > orc_other.mask_threshold).cpu()
+                flip = mc != R["masks"]
+                inter = (mc & R["masks"]).flatten(2).sum(-1).double()
+                union = (mc | R["masks"]).flatten(2).sum(-1).double().clamp(min=1)
+                r["iou"] += (inter / union).flatten().tolist()
+                r["area"] += R["masks"].flatten(2).sum(-1).flatten().tolist()
+                r["flips"] += flip.flatten(2).sum(-1).flatten().tolist()
+                r["flips_outside_tau"] += (flip & ~R["near"]).flatten(2).sum(-1).flatten().tolist()
+                r["near"] += R["near"].flatten(2).sum(-1).flatten().tolist()
+                r["low_err_over_std"].append(((low.cpu() - R["low"]).abs().max() / R["std"]).item())
+                r["low_rel_l2"].append(((low.cpu() - R["low"]).norm() / R["low"].norm()).item())
+                r["q_err"].append((q.cpu() - R["q"]).abs().max().item())
+                seg1, _ = so.paint_semantic(mc[:, 0].numpy(), tile["c2"][1], hw)
+                diff = seg1 != R["seg"]
+                r["classmap_diff"].append(int(diff.sum()))
+                r["classmap_unstable"].append(int(R["unstable"].sum()))
+                r["classmap_diff_outside"].append(int((diff & ~R["unstable"]).sum()))
+                del lg
         for mode in modes:
             # a mode is the engine's "split" option, or "<split>:<lo_format>" (lo_format 0 = f16 lo terms, 4 = MXFP4 lo terms)
             split, _, lo = str(mode).partition(":")

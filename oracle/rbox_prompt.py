@@ -26,9 +26,11 @@ horizontal pass then vertical pass).  They could not be checked against cv2 here
     down-scaling with clamped ends) -- tests/test_rbox_prompt.py::test_fill_poly_and_resize_known_answers.
   * round 5: rotated rectangles at arbitrary angles (18.4 / 21.8 / 71.6 degrees) and a sub-pixel sliver, with the derivation
     of every line pixel and scanline crossing committed next to the answer (oracle/derive_fillpoly_cases.py, independent of
-    this module).  OpenCV changed the span rule in 4.5.2 (ceil..floor -> round..round on edge x + 0.5); `fill_poly` below
-    restates the older rule, and the pinned cases are ones where both rules give the same picture.  For a general polygon
-    the two can differ by boundary pixels the 8-connected edge line does not cover -- the reference pins no version.
+    this module).  OpenCV changed the span rule in 4.5.2 (ceil..floor -> round..round on edge x + 0.5); the pinned cases of round 5
+    are ones where both rules give the same picture.  For a general polygon the two can differ by boundary pixels the 8-connected
+    edge line does not cover -- the reference pins no version.
+  * round 6: `fill_poly(rule=...)` restates BOTH rules, and three more derived cases (`differs_*` in the JSON) are ones where the
+    rules give DIFFERENT pictures, with one expected picture per rule.
 One known deviation is documented in `line8`: cv2 clips a boundary line to the image before walking it.
 """
 from __future__ import annotations
@@ -83,14 +85,23 @@ def line8(mask: np.ndarray, p1: Tuple[int, int], p2: Tuple[int, int]) -> None:
             y += ystep if neg else 0
 
 
-def fill_poly(h: int, w: int, pts: np.ndarray) -> np.ndarray:
+FILL_RULES = ("cv2_le_451", "cv2_ge_452")
+
+
+def fill_poly(h: int, w: int, pts: np.ndarray, rule: str = "cv2_le_451") -> np.ndarray:
     """cv2.fillPoly(zeros(h, w), [pts int32 [V, 2]], 255) != 0, lineType = LINE_8, shift = 0.
+
+    ``rule``: the scanline span rule -- "cv2_le_451": pixels ceil(x_left) .. floor(x_right) (OpenCV 2.4 - 4.5.1, the text below);
+    "cv2_ge_452": both crossings rounded half up, (x + XY_ONE / 2) >> XY_SHIFT (OpenCV >= 4.5.2: CollectPolyEdges adds XY_ONE >> 1
+    to the edge x and FillEdgeCollection's delta is 0).  The boundary lines are identical under both.
 
     CollectPolyEdges: every edge is drawn with Line(); non-horizontal edges are collected as
     (y0 < y1, x at y0 in 16.16 fixed point, dx = ((x1 - x0) << 16) / (y1 - y0), C++ truncating division).
     FillEdgeCollection: for every scanline y in [y0, y1) of the active edges, sorted by x and paired,
     pixels ceil(x_left) .. floor(x_right) are set; x advances by dx per scanline.
     """
+    if rule not in FILL_RULES:
+        raise ValueError(rule)
     pts = np.asarray(pts, dtype=np.int64).reshape(-1, 2)
     mask = np.zeros((h, w), dtype=bool)
     edges = []
@@ -113,8 +124,12 @@ def fill_poly(h: int, w: int, pts: np.ndarray) -> np.ndarray:
     for y in range(max(ymin, 0), min(ymax, h)):
         xs = sorted(e[2] + (y - e[0]) * e[3] for e in edges if e[0] <= y < e[1])
         for k in range(0, len(xs) - 1, 2):
-            xa = (xs[k] + XY_ONE - 1) >> XY_SHIFT
-            xb = xs[k + 1] >> XY_SHIFT
+            if rule == "cv2_le_451":
+                xa = (xs[k] + XY_ONE - 1) >> XY_SHIFT
+                xb = xs[k + 1] >> XY_SHIFT
+            else:
+                xa = (xs[k] + (XY_ONE >> 1)) >> XY_SHIFT
+                xb = (xs[k + 1] + (XY_ONE >> 1)) >> XY_SHIFT
             if xa < w and xb >= 0:
                 xa, xb = max(xa, 0), min(xb, w - 1)
                 if xa <= xb:
@@ -158,9 +173,9 @@ def preprocess_shape(h: int, w: int, long_side: int) -> Tuple[int, int]:
     return int(h * scale + 0.5), int(w * scale + 0.5)
 
 
-def rbox_mask_prompt(pts: np.ndarray, h: int, w: int, img_size: int = 1024, out: int = 256) -> np.ndarray:
-    """main_sam_rbox_mask_instance.py:125-141 for one rotated box; returns float32 [out, out]."""
-    inside = fill_poly(h, w, np.asarray(pts).astype(np.int32))
+def rbox_mask_prompt(pts: np.ndarray, h: int, w: int, img_size: int = 1024, out: int = 256, rule: str = "cv2_le_451") -> np.ndarray:
+    """main_sam_rbox_mask_instance.py:125-141 for one rotated box; returns float32 [out, out].  ``rule``: see fill_poly."""
+    inside = fill_poly(h, w, np.asarray(pts).astype(np.int32), rule)
     m = np.where(inside, 1000.0, -1000.0)
     th, tw = preprocess_shape(h, w, img_size)
     m = resize_linear_f64(m, th, tw)

@@ -84,3 +84,89 @@ def build_reference_sam(cfg, state_dict):
     sam.load_state_dict(state_dict, strict=True)
     sam.eval()
     return sa, sam
+
+
+# ------------------------------------------------------------------------------------------------
+# The downstream consumer: `Pretraining and Finetuning/End_to_End/datasets.py`
+# ------------------------------------------------------------------------------------------------
+PF_ROOT = "/root/reference/Pretraining and Finetuning/End_to_End"
+
+
+def consumer_available() -> bool:
+    return os.path.isfile(os.path.join(PF_ROOT, "datasets.py"))
+
+
+def import_reference_consumer():
+    """The reference's ``datasets`` module (``SegmentationDataset``, datasets.py:182-273) imported read-only.
+
+    It imports cv2, skimage, torchvision.transforms, mmcv, mmengine and mmseg at module import (datasets.py:2-17); none of them is
+    installable here.  What ``SegmentationDataset`` itself USES of them for a non-mask2former decoder is
+    ``T.Compose([T.ToPILImage(), T.ToTensor(), T.Normalize(mean, std)])`` (:233-238) -- stubbed below with torchvision's documented
+    semantics (uint8 HWC -> float CHW / 255; (x - mean) / std) -- everything else (file lists from train.txt / valid.txt, the
+    ``val[-500:]`` rule, PIL reads, the order of the calls, the label pass-through) is the reference's own code running."""
+    if not consumer_available():
+        raise RuntimeError("reference tree not present on this machine")
+    sys.dont_write_bytecode = True
+    import numpy as np
+    import torch
+    from PIL import Image
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToPILImage:
+        def __call__(self, a):
+            return Image.fromarray(np.asarray(a))
+
+    class ToTensor:
+        def __call__(self, pic):
+            a = np.asarray(pic)
+            return torch.from_numpy(np.array(a, copy=True)).permute(2, 0, 1).to(torch.float32).div(255)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = torch.tensor(mean)[:, None, None], torch.tensor(std)[:, None, None]
+
+        def __call__(self, t):
+            return (t - self.mean) / self.std
+
+    class _Base:
+        def __init__(self, *a, **k):
+            pass
+
+    keep = {k: sys.modules.get(k) for k in ("torchvision", "torchvision.transforms")}
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms", Compose=Compose, ToPILImage=ToPILImage, ToTensor=ToTensor, Normalize=Normalize)
+    mod("cv2")
+    sk = mod("skimage")
+    sk.io = mod("skimage.io")
+    mod("mmcv")
+    mt = mod("mmcv.transforms", to_tensor=torch.as_tensor)
+    mt.base = mod("mmcv.transforms.base", BaseTransform=_Base)
+    mod("mmengine")
+    mod("mmengine.structures", PixelData=_Base, BaseDataElement=_Base)
+    mod("mmseg")
+    mod("mmseg.structures", SegDataSample=_Base)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("samrs_reference_pf_datasets", os.path.join(PF_ROOT, "datasets.py"))
+    ds = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ds)
+    for k, v in keep.items():                       # the SAM-side stub (import_reference) must find its own torchvision again
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+    return ds

@@ -1065,6 +1065,9 @@ __global__ void resample_pass_kernel(const uint8_t* __restrict__ in, uint8_t* __
 // FP contraction is off: the products of the second stage are not exact, an fma would round differently.
 constexpr int RBOX_MAXV = 8;
 struct RboxPoly {
+    // fill rule of FillEdgeCollection's spans: 0 = OpenCV <= 4.5.1 (ceil(x_left) .. floor(x_right)), 1 = OpenCV >= 4.5.2 (round half up on
+    // both sides: the edge x gets XY_ONE >> 1 added).  The boundary lines are the same under both.
+    int rule;
     int x[RBOX_MAXV], y[RBOX_MAXV];
     long long ex[RBOX_MAXV], edx[RBOX_MAXV];      // per edge (v-1 -> v): x at y0 (16.16), dx per scanline
     int ey0[RBOX_MAXV], ey1[RBOX_MAXV];           // scanline range [y0, y1); y0 == y1 for horizontal edges
@@ -1100,7 +1103,8 @@ __device__ bool rbox_inside(const RboxPoly& P, int px, int py) {
         }
     }
     for (int k = 0; k + 1 < na; k += 2) {
-        const long long xa = (xs[k] + 65535) >> 16, xb = xs[k + 1] >> 16;
+        const long long xa = P.rule ? (xs[k] + 32768) >> 16 : (xs[k] + 65535) >> 16;
+        const long long xb = P.rule ? (xs[k + 1] + 32768) >> 16 : xs[k + 1] >> 16;
         if (xa <= px && px <= xb) in = true;
     }
     return in;
@@ -1126,12 +1130,13 @@ __device__ __forceinline__ RTap rbox_tap(int d, int n_in, int n_out) {
 
 // grid (out*out / 256, n_boxes); pts int32 [n][nv][2] (x, y)
 __global__ __launch_bounds__(256) void rbox_prompt_kernel(const int32_t* __restrict__ pts, int nv, int h, int w, int th, int tw,
-                                                          int img_size, int out_size, float* __restrict__ out) {
+                                                          int img_size, int out_size, float* __restrict__ out, int fill_rule) {
 #pragma clang fp contract(off)
     __shared__ RboxPoly P;
     const int b = blockIdx.y;
     if (threadIdx.x == 0) {
         P.nv = nv;
+        P.rule = fill_rule;
         for (int e = 0; e < nv; ++e) { P.x[e] = pts[((size_t)b * nv + e) * 2]; P.y[e] = pts[((size_t)b * nv + e) * 2 + 1]; }
         for (int e = 0; e < nv; ++e) {
             const int a = e == 0 ? nv - 1 : e - 1;
@@ -1336,10 +1341,11 @@ hipError_t launch_select_best(const uint8_t* masks, const float* iou, int n, int
 }
 
 hipError_t launch_rbox_prompt(const int32_t* pts, int n, int nv, int h, int w, int th, int tw, int img_size, int out_size,
-                              float* out, hipStream_t s) {
-    if (n < 1 || nv < 3 || nv > RBOX_MAXV || h < 1 || w < 1 || th < 1 || tw < 1 || th > img_size || tw > img_size || out_size < 1)
+                              float* out, hipStream_t s, int fill_rule) {
+    if (n < 1 || nv < 3 || nv > RBOX_MAXV || h < 1 || w < 1 || th < 1 || tw < 1 || th > img_size || tw > img_size || out_size < 1 ||
+        fill_rule < 0 || fill_rule > 1)
         return hipErrorInvalidValue;
     dim3 g((out_size * out_size + 255) / 256, n), b(256);
-    rbox_prompt_kernel<<<g, b, 0, s>>>(pts, nv, h, w, th, tw, img_size, out_size, out);
+    rbox_prompt_kernel<<<g, b, 0, s>>>(pts, nv, h, w, th, tw, img_size, out_size, out, fill_rule);
     return hipGetLastError();
 }

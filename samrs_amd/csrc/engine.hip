@@ -1778,7 +1778,12 @@ int samrs_resample_pass_u8(const uint8_t* in, uint8_t* out, const int32_t* bound
 int samrs_rbox_mask_prompt(const int32_t* pts, int n, int n_vertices, int h, int w, int th, int tw, int img_size, int out_size,
                            float* out, void* stream) {
     if (!pts || !out) return SAMRS_ERR_BAD_ARG;
-    KRET(launch_rbox_prompt(pts, n, n_vertices, h, w, th, tw, img_size, out_size, out, (hipStream_t)stream));
+    KRET(launch_rbox_prompt(pts, n, n_vertices, h, w, th, tw, img_size, out_size, out, (hipStream_t)stream, SAMRS_FILL_CV2_LE_451));
+}
+int samrs_rbox_mask_prompt_rule(const int32_t* pts, int n, int n_vertices, int h, int w, int th, int tw, int img_size, int out_size,
+                                int fill_rule, float* out, void* stream) {
+    if (!pts || !out || (fill_rule != SAMRS_FILL_CV2_LE_451 && fill_rule != SAMRS_FILL_CV2_GE_452)) return SAMRS_ERR_BAD_ARG;
+    KRET(launch_rbox_prompt(pts, n, n_vertices, h, w, th, tw, img_size, out_size, out, (hipStream_t)stream, fill_rule));
 }
 int samrs_k_neck_im2col(const void* in, void* A, int n_images, int grid, int C, void* stream) {
     if (!in || !A || n_images < 1 || grid < 1 || C < 8 || C % 8) return SAMRS_ERR_BAD_ARG;

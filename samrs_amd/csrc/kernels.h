@@ -170,7 +170,8 @@ hipError_t launch_resample_pass(const uint8_t* in, uint8_t* out, const int32_t* 
                                 int in_len, int out_len, int other, int horizontal, hipStream_t s);
 // rotated-box polygons (int32 [n][nv][2]) -> mask prompts [n][out][out] fp32 (main_sam_rbox_mask_instance.py:125-141)
 hipError_t launch_rbox_prompt(const int32_t* pts, int n, int nv, int h, int w, int th, int tw, int img_size, int out_size,
-                              float* out, hipStream_t s);
+                              float* out, hipStream_t s,
+                              int fill_rule = 0 /* 0: OpenCV <= 4.5.1 spans (ceil .. floor), 1: OpenCV >= 4.5.2 (round .. round) */);
 // fused transformer.py:176-181: keys = LayerNorm(resid + out_proj(attention(q_i2t, k_tokens, v_tokens))) -> outF (fp32) and outE (ET)
 hipError_t launch_i2t_fused(int prec, const void* qi, int ld, long q_bstride, const float* kt, const float* vt, const void* w,
                             const void* w_lo /* null: un-split out-projection */, const float* bias, const float* resid,

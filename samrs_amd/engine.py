@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsamrs_hip.so")
 PREC_BF16, PREC_F16 = 0, 1
 PRECISIONS = {"bf16": PREC_BF16, "f16": PREC_F16, "fp16": PREC_F16}
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 # "split" option bits (include/samrs_hip.h): rounding points that run as a two-term operand split
 SPLIT_PATCH, SPLIT_NECK, SPLIT_OI, SPLIT_UP, SPLIT_DEFAULT = 1, 2, 4, 8, 15
 SPLIT_ATTN, SPLIT_MLP, SPLIT_ATTN_V, SPLIT_LIN2, SPLIT_ALL = 16, 32, 64, 128, 255          # reference-grade bits: set before the weights are loaded

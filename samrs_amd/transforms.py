@@ -150,15 +150,41 @@ class ResizeLongestSide:
         return int(newh + 0.5), int(neww + 0.5)
 
 
+FILL_RULES = {"cv2_le_451": 0, "cv2_ge_452": 1}
+
+
+def resolve_fill_rule(fill_rule: str = "auto") -> str:
+    """Which of the two scanline span rules OpenCV has published for ``cv2.fillPoly`` the rasteriser reproduces: ``"cv2_le_451"``
+    (ceil(x_left) .. floor(x_right); OpenCV 2.4 - 4.5.1) or ``"cv2_ge_452"`` (both ends rounded half up; OpenCV >= 4.5.2).  The
+    reference pins no OpenCV version (`Generate Dataset/main_sam_rbox_mask_instance.py:126-129`); ``"auto"`` takes the rule of the
+    cv2 that is installed beside this package -- the one the reference script would have called -- and, when none is importable,
+    ``SAMRS_FILL_RULE`` or the older rule (what every fixture of this repository was generated with)."""
+    if fill_rule != "auto":
+        if fill_rule not in FILL_RULES:
+            raise ValueError(f"fill_rule must be 'auto' or one of {sorted(FILL_RULES)}, got {fill_rule!r}")
+        return fill_rule
+    import os
+    env = os.environ.get("SAMRS_FILL_RULE")
+    if env:
+        return resolve_fill_rule(env)
+    try:
+        import cv2                                   # noqa: F401  (absent from the build and GPU images)
+        ver = tuple(int(x) for x in cv2.__version__.split(".")[:3])
+        return "cv2_ge_452" if ver >= (4, 5, 2) else "cv2_le_451"
+    except Exception:
+        return "cv2_le_451"
+
+
 def rbox_mask_prompts(polys, original_size: Tuple[int, int], img_size: int = 1024, out_size: int = 256,
-                      device: Optional["torch.device"] = None) -> torch.Tensor:
+                      device: Optional["torch.device"] = None, fill_rule: str = "auto") -> torch.Tensor:
     """Rotated boxes -> SAM mask prompts on the GPU, replacing the cv2 pre-step of
     `Generate Dataset/main_sam_rbox_mask_instance.py:125-141` (fillPoly -> +-1000 -> resize to the
     ResizeLongestSide shape -> pad with -1000 -> resize to 256x256).
 
     polys: [n, V, 2] (x, y) vertices in original-image pixels (float or int; truncated like the reference's
     `.astype(np.int32)`), 3 <= V <= 8.  Returns fp32 [n, out_size, out_size] on the device; feed
-    `prompts[:, None]` as `mask_input` of `SamPredictor.predict_torch` (main_sam_rbox_mask_instance.py:159-164)."""
+    `prompts[:, None]` as `mask_input` of `SamPredictor.predict_torch` (main_sam_rbox_mask_instance.py:159-164).
+    ``fill_rule``: see ``resolve_fill_rule``."""
     if not torch.cuda.is_available():
         raise RuntimeError("rbox_mask_prompts needs the HIP device (no CPU fallback)")
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -166,20 +192,21 @@ def rbox_mask_prompts(polys, original_size: Tuple[int, int], img_size: int = 102
     if p.ndim != 3 or p.shape[2] != 2 or not (3 <= p.shape[1] <= 8):
         raise ValueError(f"polys must be [n, V, 2] with 3 <= V <= 8, got {p.shape}")
     pts = torch.from_numpy(np.ascontiguousarray(p.astype(np.int32))).to(dev)
-    return _rbox_prompts_from_int_points(pts, original_size, img_size, out_size)
+    return _rbox_prompts_from_int_points(pts, original_size, img_size, out_size, fill_rule)
 
 
 def rbox_mask_prompts_device(polys: torch.Tensor, original_size: Tuple[int, int], img_size: int = 1024, out_size: int = 256,
-                             device: Optional["torch.device"] = None) -> torch.Tensor:
+                             device: Optional["torch.device"] = None, fill_rule: str = "auto") -> torch.Tensor:
     """Same as ``rbox_mask_prompts`` for vertices that already live on the GPU ([n, V, 2] float or int tensor);
     float coordinates are truncated toward zero like the reference's ``.astype(np.int32)``."""
     if polys.dim() != 3 or polys.shape[2] != 2 or not (3 <= polys.shape[1] <= 8):
         raise ValueError(f"polys must be [n, V, 2] with 3 <= V <= 8, got {tuple(polys.shape)}")
     assert polys.is_cuda
-    return _rbox_prompts_from_int_points(polys.to(torch.int32).contiguous(), original_size, img_size, out_size)
+    return _rbox_prompts_from_int_points(polys.to(torch.int32).contiguous(), original_size, img_size, out_size, fill_rule)
 
 
-def _rbox_prompts_from_int_points(pts: torch.Tensor, original_size: Tuple[int, int], img_size: int, out_size: int) -> torch.Tensor:
+def _rbox_prompts_from_int_points(pts: torch.Tensor, original_size: Tuple[int, int], img_size: int, out_size: int,
+                                  fill_rule: str = "auto") -> torch.Tensor:
     from . import engine as _engine
     lib = _engine.load_library()
     dev = pts.device
@@ -190,8 +217,8 @@ def _rbox_prompts_from_int_points(pts: torch.Tensor, original_size: Tuple[int, i
     if n == 0:
         return out
     with torch.cuda.device(dev):
-        rc = lib.samrs_rbox_mask_prompt(pts.data_ptr(), n, nv, h, w, th, tw, img_size, out_size, out.data_ptr(),
-                                        torch.cuda.current_stream(dev).cuda_stream)
+        rc = lib.samrs_rbox_mask_prompt_rule(pts.data_ptr(), n, nv, h, w, th, tw, img_size, out_size, FILL_RULES[resolve_fill_rule(fill_rule)],
+                                             out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
-        raise RuntimeError(f"samrs_rbox_mask_prompt failed with code {rc}")
+        raise RuntimeError(f"samrs_rbox_mask_prompt_rule failed with code {rc}")
     return out

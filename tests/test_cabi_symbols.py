@@ -46,7 +46,7 @@ def test_library_exports_every_declared_symbol(lib_path):
         missing = [n for n in declared_functions(header) if not hasattr(lib, n)]
         assert not missing, f"declared in {header} but not exported: {missing}"
     lib.samrs_abi_version.restype = ctypes.c_int
-    assert lib.samrs_abi_version() == 4
+    assert lib.samrs_abi_version() == 5
 
 
 def test_config_struct_layout_matches_header(lib_path):

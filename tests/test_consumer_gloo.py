@@ -12,43 +12,20 @@ import torch.multiprocessing as mp
 
 from samrs_amd import generate, tile_io
 
-N_CLASSES, N_IMAGES, SIDE = 18, 6, 64
+from oracle import consumer_check as _cc
+
+N_CLASSES, N_IMAGES, SIDE = _cc.SAMPLE_CLASSES, _cc.SAMPLE_IMAGES, _cc.SAMPLE_SIDE
+_make_dataset = _cc.make_sample_dataset
 
 
-def _make_dataset(root):
-    """Synthetic tiles + class maps written by the PRODUCT's writers (the class maps are synthetic: no GPU here)."""
-    os.makedirs(os.path.join(root, "images"), exist_ok=True)
-    out = os.path.join(root, "hbox_segs_init")
-    palette = generate.default_palette(N_CLASSES)
-    names = [str(i) for i in range(N_CLASSES)]
-    stems = []
-    for i in range(N_IMAGES):
-        rng = np.random.default_rng(70 + i)
-        img = rng.integers(0, 256, (SIDE, SIDE, 3), dtype=np.uint8)
-        seg = np.full((SIDE, SIDE), 255, np.uint8)                                  # main_sam_hbox_semantic.py:162
-        boxes, labels, areas = [], [], []
-        for _ in range(4):
-            x0, y0 = rng.integers(0, SIDE - 8, 2)
-            w, h = rng.integers(4, 24, 2)
-            lab = int(rng.integers(0, N_CLASSES))
-            seg[y0:y0 + h, x0:x0 + w] = lab
-            boxes.append(np.array([x0, y0, x0 + w, y0 + h], np.float32)); labels.append(lab); areas.append(int(w * h))
-        stem = f"P{i:04d}"
-        tile_io.write_rgb(os.path.join(root, "images", stem + ".png"), img)
-        generate.write_outputs(out, stem, seg, None, np.stack(boxes), np.asarray(labels), np.asarray(areas), palette, names)
-        stems.append(stem)
-    with open(os.path.join(root, "train.txt"), "w") as f:
-        f.write("\n".join(stems[:4]) + "\n")
-    with open(os.path.join(root, "valid.txt"), "w") as f:
-        f.write("\n".join(stems[4:]) + "\n")
-    return os.path.join(root, "images"), os.path.join(out, "gray")
-
-
-def _worker(rank, world, port, root, out):
+def _worker(rank, world, port, root, out, use_reference=False):
     from oracle import consumer_check as cc
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ds = cc.SegmentationDataset(root, os.path.join(root, "images"), os.path.join(root, "hbox_segs_init", "gray"), flag="trn")
+    if use_reference:        # the REFERENCE's own SegmentationDataset class (datasets.py:182-273) reads the product's files
+        ds = cc.reference_dataset(root, "trn")
+    else:
+        ds = cc.SegmentationDataset(root, os.path.join(root, "images"), os.path.join(root, "hbox_segs_init", "gray"), flag="trn")
     losses, w, drawn, hist = cc.train_steps(ds, N_CLASSES, rank, world, steps=2, batch_size=2)
     out[rank] = (losses, w.numpy().copy(), drawn, hist)
     dist.barrier()
@@ -83,3 +60,50 @@ def test_generated_labels_train_under_ddp(tmp_path):
         raise AssertionError("an RGB label map must be refused")
     except ValueError:
         pass
+
+
+def test_restated_reader_equals_the_reference_dataset_fixture(tmp_path):
+    """Round 6: the reader of oracle/consumer_check.py is pinned to the reference's OWN SegmentationDataset --
+    tests/golden/consumer_ref.npz holds what `Pretraining and Finetuning/End_to_End/datasets.py:182-273` (imported in the authoring
+    container by oracle/ref_import.import_reference_consumer) returned for every item of the sample dataset the product's writers
+    produce: file lists per flag (train.txt / valid.txt, the val[-500:] rule), image tensors and label tensors.  The restated
+    reader must build the same lists and return the same tensors from freshly written files (the writers are deterministic)."""
+    root = str(tmp_path)
+    _make_dataset(root)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "consumer_ref.npz"))
+    for flag in ("trn", "val", "tes"):
+        ds = _cc.SegmentationDataset(root, os.path.join(root, "images"), os.path.join(root, "hbox_segs_init", "gray"), flag=flag)
+        assert [os.path.relpath(f, root) for f in ds.files] == list(gold[f"{flag}_files"])
+        assert [os.path.relpath(f, root) for f in ds.targets] == list(gold[f"{flag}_targets"])
+        for i in range(len(ds)):
+            x, y = ds[i]
+            assert np.array_equal(y.numpy(), gold[f"{flag}_y"][i])                      # labels: bit for bit
+            assert np.allclose(x.numpy(), gold[f"{flag}_x"][i], rtol=0, atol=1e-6)      # images: fp32 (x / 255 - mean) / std
+
+
+def test_reference_dataset_class_trains_on_generated_files_under_ddp(tmp_path):
+    """Where the reference tree is present (the authoring container): two DDP-gloo iterations with the REFERENCE's SegmentationDataset
+    itself over the files the product's writers wrote, and item-by-item equality with the restated reader.  (UperNet-ViT-B needs
+    mmseg / mmengine / timm, which cannot be installed: the model stays the one-layer stand-in.)"""
+    import pytest
+    from oracle import ref_import
+    if not ref_import.consumer_available():
+        pytest.skip("/root/reference is not on this machine")
+    root = str(tmp_path)
+    _make_dataset(root)
+    ref = _cc.reference_dataset(root, "trn")
+    mine = _cc.SegmentationDataset(root, os.path.join(root, "images"), os.path.join(root, "hbox_segs_init", "gray"), flag="trn")
+    assert ref.files == mine.files and ref.targets == mine.targets and len(ref) == 4
+    for i in range(len(ref)):
+        (xr, yr), (xm, ym) = ref[i], mine[i]
+        assert torch.equal(yr, ym) and torch.allclose(xr, xm, rtol=0, atol=1e-6)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, root, out, True), nprocs=2, join=True)
+    (l0, w0, d0, h0), (l1, w1, d1, h1) = out[0], out[1]
+    assert sorted(d0 + d1) == [0, 1, 2, 3] and all(np.isfinite(l0 + l1)) and np.allclose(w0, w1)
+    hist = h0 + h1
+    assert hist[N_CLASSES:255].sum() == 0 and hist[255] > 0 and hist[:N_CLASSES].sum() > 0

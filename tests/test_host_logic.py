@@ -166,3 +166,23 @@ def test_bench_gpus_n_without_a_launcher_becomes_the_launcher(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
     i = cmd.index(os.path.abspath(bench.__file__))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]                  # same arguments, verbatim
+
+
+def test_fill_rule_resolution(monkeypatch):
+    """the rbox rasteriser reproduces one of the two cv2.fillPoly span rules by name; "auto" follows the cv2 that is
+    installed (none here: the older rule, or SAMRS_FILL_RULE), an unknown name is refused."""
+    import sys
+    import types
+    from samrs_amd import transforms
+    monkeypatch.delenv("SAMRS_FILL_RULE", raising=False)
+    monkeypatch.setitem(sys.modules, "cv2", None)                      # "import cv2" raises ImportError
+    assert transforms.resolve_fill_rule("auto") == "cv2_le_451"
+    assert transforms.resolve_fill_rule("cv2_ge_452") == "cv2_ge_452"
+    monkeypatch.setenv("SAMRS_FILL_RULE", "cv2_ge_452")
+    assert transforms.resolve_fill_rule("auto") == "cv2_ge_452"
+    monkeypatch.delenv("SAMRS_FILL_RULE")
+    for ver, want in (("4.5.1", "cv2_le_451"), ("4.5.2", "cv2_ge_452"), ("4.10.0.84", "cv2_ge_452"), ("3.4.18", "cv2_le_451")):
+        monkeypatch.setitem(sys.modules, "cv2", types.SimpleNamespace(__version__=ver))
+        assert transforms.resolve_fill_rule("auto") == want, ver
+    with pytest.raises(ValueError):
+        transforms.resolve_fill_rule("cv2_5")

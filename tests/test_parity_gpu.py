@@ -575,14 +575,26 @@ def test_vit_h_statistical_parity_sample():
     assert sam.engine.get_option("split") == 79            # built WITHOUT options: 15 and 79 are the modes its weights support
     sam.engine.set_option("allow_reduced", 1)              # the sample also runs the multimask workloads in mode 15, to report them
     pred = samrs_amd.SamPredictor(sam)
-    rec = ps.run(pred, so.OraclePredictor(sd, cfg), [15, 79])
+    # round 6: the floor.  The SAME fp32 oracle code in torch eager on this GPU (rocBLAS / MIOpen behind torch) against the host CPU:
+    # what two fp32 backends of the reference algorithm disagree on is what "bit-identical class map" cannot be asked to beat
+    orc_gpu = so.OraclePredictor({k: v.cuda() for k, v in sd.items()}, cfg)
+    rec = ps.run(pred, so.OraclePredictor(sd, cfg), [15, 79], orc_other=orc_gpu)
     summ = ps.summarise(rec)
     print(ps.table(summ))
+    floor = summ.pop(ps.REF_BACKEND)
+    fc2 = floor["c2"]
+    print(f"reference-backend floor (fp32 oracle, torch eager on {torch.cuda.get_device_name(0)} vs host CPU), 8 C2 tiles: class-map pixels "
+          f"differing mean {fc2['classmap_diff_mean']:.1f} max {fc2['classmap_diff_max']}, mask flips max {fc2['flips_max']}, IoU min "
+          f"{fc2['iou_min']:.6f}; the engine: {summ[15]['c2']['classmap_diff_mean']:.0f} (mode 15) / {summ[79]['c2']['classmap_diff_mean']:.0f} (mode 79) "
+          f"= {summ[15]['c2']['classmap_diff_mean'] / max(fc2['classmap_diff_mean'], 1e-9):.0f}x / "
+          f"{summ[79]['c2']['classmap_diff_mean'] / max(fc2['classmap_diff_mean'], 1e-9):.0f}x that floor")
     if os.path.isdir("gpurun_out"):
         # what bench.py's `parity` object reads (copied to profiles/parity_stats.json): pinned to a hash of the device sources
         import bench
         json.dump({"tau_frac": ps.TAU_FRAC, "csrc_sha16": bench.csrc_sha(), "device": torch.cuda.get_device_name(0),
-                   "summary": {str(k): v for k, v in summ.items()}}, open("gpurun_out/parity_stats_test.json", "w"))
+                   "summary": {str(k): v for k, v in summ.items()}, "reference_backend_floor": floor},
+                  open("gpurun_out/parity_stats_test.json", "w"))
+    assert fc2["n_masks"] == 256 and fc2["flips_outside_tau"] == 0 and fc2["classmap_diff_outside_unstable"] == 0
     for mode, tags in summ.items():
         for tag, s in tags.items():
             assert s["flips_outside_tau"] == 0, (mode, tag)
@@ -1150,3 +1162,37 @@ def test_f16_operand_range_stress_and_saturation_counter():
     print(f"the same weights on bf16 operands: embedding rel L2 {rel:.3e}, box-mask IoU min {iou:.5f}, saturated {sam.engine.get_option('saturated')}")
     assert sam.engine.get_option("saturated") == 0 and rel < 3e-2 and iou >= 0.99, (rel, iou)
     sam.engine.close()
+
+
+def test_checkpoint_argument_round_trip(tmp_path):
+    """VERDICT r05 "missing" 5: ``sam_model_registry[...](checkpoint=path)`` -- what the reference's drivers call
+    (main_sam_hbox_semantic.py:83-87; build_sam.py:103-106: torch.load + strict load_state_dict).  A reference-shaped state dict saved
+    with torch.save and loaded through that argument must give the engine built from the in-memory dict, bit for bit; a file with
+    a wrong key, a missing key or a wrong shape must raise like the strict load does (RuntimeError naming the tensor)."""
+    import samrs_amd
+    cfg = synth.CONFIGS["vit_tiny"]
+    sd = synth.make_state_dict(cfg, 3)
+    path = tmp_path / "sam_vit_tiny_seed3.pth"
+    torch.save(sd, path)
+    img = synth.make_image(5)
+    embs = []
+    for kw in (dict(checkpoint=str(path)), dict(state_dict=sd)):
+        sam = samrs_amd.sam_model_registry["vit_tiny"](precision="f16", max_prompts=4, max_points=1, **kw).to(device="cuda")
+        pred = samrs_amd.SamPredictor(sam)
+        pred.set_image(img)
+        embs.append(pred.get_image_embedding().cpu())
+        tb = pred.transform.apply_boxes_torch(torch.from_numpy(synth.C1_BOXES).cuda(), img.shape[:2])
+        embs.append(pred.predict_torch(None, None, tb, None, multimask_output=False)[2].cpu())
+        sam.engine.close()
+    assert torch.equal(embs[0], embs[2]) and torch.equal(embs[1], embs[3])
+    k = "image_encoder.blocks.0.attn.qkv.weight"
+    bad_key = {("module." + n if n == k else n): v for n, v in sd.items()}                  # the classic DataParallel prefix
+    missing = {n: v for n, v in sd.items() if n != "mask_decoder.iou_token.weight"}
+    bad_shape = dict(sd); bad_shape[k] = sd[k][:, :-1].contiguous()
+    for name, blob, what in (("bad_key", bad_key, "unexpected tensor module." + k + "|missing tensor " + k),
+                             ("missing", missing, "missing tensor mask_decoder.iou_token.weight"),
+                             ("bad_shape", bad_shape, "shape mismatch for " + k)):
+        f = tmp_path / (name + ".pth")
+        torch.save(blob, f)
+        with pytest.raises(RuntimeError, match=what):
+            samrs_amd.sam_model_registry["vit_tiny"](checkpoint=str(f), precision="f16", max_prompts=4, max_points=1).to(device="cuda")

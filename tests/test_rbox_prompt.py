@@ -54,12 +54,18 @@ def test_fill_poly_and_resize_known_answers():
     derivation in the JSON (LineIterator error terms, 16.16 crossings, the span under both span rules OpenCV has published),
     produced by oracle/derive_fillpoly_cases.py without importing the module under test."""
     k = _known()
+    n_differ = 0
     for c in k["fill_poly"]:
-        want = np.zeros((c["h"], c["w"]), bool)
-        for y, (a, b) in c["rows"].items():
-            want[int(y), a:b + 1] = True
-        got = rp.fill_poly(c["h"], c["w"], np.asarray(c["pts"]))
-        assert np.array_equal(got, want), c["name"]
+        # round 6: both span rules OpenCV has published (fill_rule); `rows_cv2_ge_452` exists where the newer rule's picture differs
+        for rule in rp.FILL_RULES:
+            rows = c.get("rows_cv2_ge_452", c["rows"]) if rule == "cv2_ge_452" else c["rows"]
+            want = np.zeros((c["h"], c["w"]), bool)
+            for y, (a, b) in rows.items():
+                want[int(y), a:b + 1] = True
+            got = rp.fill_poly(c["h"], c["w"], np.asarray(c["pts"]), rule)
+            assert np.array_equal(got, want), (c["name"], rule)
+        n_differ += "rows_cv2_ge_452" in c
+    assert n_differ >= 3
     for c in k["resize_linear"]:
         got = rp.resize_linear_f64(np.asarray(c["src"], dtype=np.float64), c["out_h"], c["out_w"])
         assert np.allclose(got, np.asarray(c["dst"]), atol=1e-4, rtol=0), c["name"]
@@ -69,7 +75,7 @@ def test_fill_poly_and_resize_known_answers():
 def test_hip_rbox_prompts_on_the_known_answer_polygons():
     """The HIP rasteriser on the known-answer polygons (scaled onto a 1024^2 canvas, where every edge is still horizontal,
     vertical or at 45 degrees): bit-exact with the oracle, whose fill rule the CPU test above pins."""
-    from samrs_amd import transforms
+    from samrs_amd import synth, transforms
     k = _known()
     polys = [np.asarray(c["pts"], dtype=np.float32) * 100.0 for c in k["fill_poly"] if len(c["pts"]) == 4]
     got = transforms.rbox_mask_prompts(np.stack(polys), (1024, 1024), img_size=1024).cpu().numpy()
@@ -84,11 +90,26 @@ def test_hip_rbox_prompts_on_the_known_answer_polygons():
         p = np.asarray(c["pts"], dtype=np.float32)
         if len(p) != 4:
             continue
-        got1 = transforms.rbox_mask_prompts(p[None], (c["h"], c["w"]), img_size=64, out_size=16).cpu().numpy()[0]
-        want1 = rp.rbox_mask_prompt(p.astype(np.int32), c["h"], c["w"], img_size=64, out=16).astype(np.float32)
-        assert np.array_equal(got1, want1), c["name"]
+        per_rule = {}
+        for rule in rp.FILL_RULES:              # round 6: the kernel takes the span rule as a parameter (samrs_rbox_mask_prompt_rule)
+            got1 = transforms.rbox_mask_prompts(p[None], (c["h"], c["w"]), img_size=64, out_size=16, fill_rule=rule).cpu().numpy()[0]
+            want1 = rp.rbox_mask_prompt(p.astype(np.int32), c["h"], c["w"], img_size=64, out=16, rule=rule).astype(np.float32)
+            assert np.array_equal(got1, want1), (c["name"], rule)
+            per_rule[rule] = got1
         if c["name"].startswith("rotated_"):
             assert (got1 > 0).any() and (got1 < 0).any(), c["name"]
+        # the rules must give different prompts exactly on the cases whose known answers differ
+        assert np.array_equal(per_rule["cv2_le_451"], per_rule["cv2_ge_452"]) == ("rows_cv2_ge_452" not in c), c["name"]
+    # FAIR1M-shaped rotated boxes at full size under both rules: bit-exact with the oracle, and the rules do differ on some of them
+    polys, _ = synth.make_rboxes(77, 24)
+    n_diff = 0
+    for rule in rp.FILL_RULES:
+        got = transforms.rbox_mask_prompts(polys, (1024, 1024), fill_rule=rule).cpu().numpy()
+        for j in range(len(polys)):
+            assert np.array_equal(got[j], rp.rbox_mask_prompt(polys[j].astype(np.int32), 1024, 1024, rule=rule)), (rule, j)
+        per_rule[rule] = got
+    n_diff = int(sum(not np.array_equal(a, b) for a, b in zip(per_rule["cv2_le_451"], per_rule["cv2_ge_452"])))
+    print(f"24 FAIR1M-shaped rboxes: {n_diff} prompts differ between the two fill rules")
 
 
 def test_line8_closed_form_matches_walk():

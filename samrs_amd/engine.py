@@ -82,6 +82,8 @@ def load_library() -> C.CDLL:
     lib.samrs_resample_pass_u8.restype = ip
     lib.samrs_rbox_mask_prompt.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, ip, vp, vp]
     lib.samrs_rbox_mask_prompt.restype = ip
+    lib.samrs_rbox_mask_prompt_rule.argtypes = [vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp, vp]
+    lib.samrs_rbox_mask_prompt_rule.restype = ip
     lib.samrs_k_gemm.argtypes = [ip, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_gemm_f32.argtypes = [vp, ip, vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
     lib.samrs_k_gemm_stats.argtypes = [ip, vp, vp, vp, vp, vp, vp, ip, ip, ip, vp]

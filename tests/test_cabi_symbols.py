@@ -70,3 +70,13 @@ def test_create_fails_loudly_without_gpu(lib_path):
     err = ctypes.create_string_buffer(256)
     h = lib.samrs_create(ctypes.byref(c), 0, err, 256)
     assert not h and b"no CPU fallback" in err.value
+
+
+def test_ctypes_binding_declares_argtypes_for_the_public_surface(lib_path):
+    """A ctypes function without argtypes passes every Python int as a C int: a 64-bit device pointer is silently truncated
+    (round 6: the first GPU run of samrs_rbox_mask_prompt_rule returned SAMRS_ERR_HIP for exactly that reason).  Every entry
+    point of the public header that takes arguments must be declared in samrs_amd/engine.py."""
+    from samrs_amd import engine
+    lib = engine.load_library()
+    missing = [n for n in declared_functions() if n != "samrs_abi_version" and getattr(lib, n).argtypes is None]
+    assert not missing, f"no argtypes in samrs_amd/engine.py for: {missing}"

@@ -1730,24 +1730,24 @@ int samrs_k_window_attention(int prec, const void* qkv, const float* qkv_bias, c
     KRET(launch_window_attention(prec, qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, window, heads, head_dim, (hipStream_t)stream));
 }
 // V^T workspace of the two global-attention TEST / BENCH hooks below (the engine owns its own: e->VTG).  One grow-only buffer per
-// DEVICE, looked up under a lock; before a buffer is replaced the device is synchronized, so no launch of an earlier call (on any
-// stream) can still be reading it.  Never released: these entry points exist for tests/ and tools/ only (samrs_hip.h says so).
+// DEVICE, looked up under a lock.  A buffer that is outgrown is RETIRED, never freed: another thread of the same device may hold the
+// old pointer between this function's return and its own kernel launch (the pointer leaves the lock), and a device synchronisation
+// only covers launches that are already enqueued.  Buffers at least double, so the retired ones sum to less than the live
+// one; these entry points exist for tests/ and tools/ only (samrs_hip_internal.h says so).
 static void* kernel_hook_workspace(size_t need) {
     static std::mutex mu;
     static std::map<int, std::pair<void*, size_t>> per_dev;
+    static std::vector<void*> retired;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
     auto& w = per_dev[dev];
     if (need > w.second) {
-        if (w.first) {
-            (void)hipDeviceSynchronize();
-            (void)hipFree(w.first);
-        }
-        w = {nullptr, 0};
+        const size_t want = need > 2 * w.second ? need : 2 * w.second;
         void* p = nullptr;
-        if (hipMalloc(&p, need) != hipSuccess) return nullptr;
-        w = {p, need};
+        if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+        if (w.first) retired.push_back(w.first);
+        w = {p, want};
     }
     return w.first;
 }

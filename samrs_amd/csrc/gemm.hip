@@ -2147,7 +2147,8 @@ hipError_t launch_gemm_w4(const void* A, const void* B, void* C, const float* bi
 //     whole stage earlier) and has finished reading stage t (its k-half 1 fragments were read during step 0); after it stage t + 2
 //     goes into the buffer of stage t.  The stage stream runs on across tiles (persistent, one block per CU): the next tile's
 //     stages 0 and 1 land under the last stage and the epilogue, which bounces through 17 KiB of LDS of its own.
-// Same LDS image, swizzle and k order as gemm_et_x64_kernel: bit-identical output.  M % 256 == 0, N % 256 == 0, K % 128 == 0.
+// Same LDS image, swizzle and k order as gemm_et_x64_kernel: bit-identical output.  M % 256 == 0, N % 256 == 0, K % 64 == 0 (round 6: an
+// odd number of stages per tile is fine -- the buffer parity simply carries over to the next tile).
 // ---------------------------------------------------------------------------------------------
 template <int PREC, bool ZERO>
 __device__ __forceinline__ void mfma16_asm(f32x4_t& c, const uint4& a, const uint4& b) {
@@ -2286,6 +2287,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amd
 #pragma unroll
     for (int j = 0; j < NJ; ++j) W4X_RDA(fa0, 0u, 0, j);
     __builtin_amdgcn_sched_barrier(0);
+    uint32_t rd = 0;
     for (;;) {
         const int Ln = L + (int)gridDim.x;
         const bool more = Ln < ntiles;
@@ -2293,7 +2295,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amd
         if (more) W4X_TILE(Ln, m1, n1);
         const uint16_t* nA = A + (size_t)m1 * LD;
         const uint16_t* nB = B + (size_t)n1 * LD;
-        uint32_t rd = 0;
+        // (rd lives across tiles: with an EVEN number of stages per tile it is back at 0 here -- the round-5 behaviour, bit for bit --, with
+        // an odd number (K = 1344: the K = 1280 operands + the 64-column outlier extension, engine.hip) the next tile starts in buffer 1)
         // stage t feeds stage t + 2 into its own buffer; past the end of this tile that is stage t + 2 - nst of the NEXT tile
         const uint16_t* pa = sA + 2 * XBK;
         const uint16_t* pb = sB + 2 * XBK;
@@ -2340,7 +2343,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(W4THREADS, W4THREADS), amd
 }
 
 static bool w4x_ok(int M, int N, int K, const float* add2d, bool out_f32) {
-    return M % QBM == 0 && N % W4X_BN == 0 && K % (2 * XBK) == 0 && K >= 4 * XBK && !add2d && !out_f32;
+    return M % QBM == 0 && N % W4X_BN == 0 && K % XBK == 0 && K >= 4 * XBK && !add2d && !out_f32;
 }
 
 template <int PREC>

@@ -438,6 +438,27 @@ def main() -> None:
                        "number is the headline and bf16 is reported here only"}
         del sam2, pipe2
 
+    # ---- the mode closest to the reference's own fp32 floor (VERDICT r05 "next round" 2): EVERY block GEMM on hi + lo operands (split 63,
+    # MXFP4 lo terms).  Needs the lo copies of all block weights, i.e. an engine of its own; same loop, same tiles. ----
+    all_split = None
+    if rank == 0 and world == 1 and not args.no_fast_leg and args.model == "vit_h" and args.workload == "c2" and args.dtype == "f16":
+        try:
+            pipe = None
+            torch.cuda.empty_cache()
+            sam3 = samrs_amd.sam_model_registry[args.model](state_dict=sd, precision="f16", max_images=2 * B, max_prompts=box_batch, max_points=1,
+                                                            options={"split": 63}).to(dev)
+            pipe3 = make_pipe(sam3, True)
+            pipe3.split_mode, pipe3.allow_reduced = 63, True
+            n_s = max(2, args.steps // 2)
+            dts, ts_, _ = timed(pipe3, dev_tiles, n_s, 1, shared_queue=False)
+            all_split = {"value": round(ts_ / dts, 3), "unit": "images/s", "steps": n_s, "split": 63, "vs_value": round(ts_ / dts / value, 4),
+                         "parity": parity_of_mode(63, args.workload, args.model),
+                         "note": "same loop with all four block GEMMs of every block on hi + lo operands (MXFP4 lo terms): the mode closest to the "
+                                 "fp32 backend floor; not the headline"}
+            del sam3, pipe3
+        except Exception as ex:
+            all_split = {"value": None, "note": f"failed: {type(ex).__name__}: {ex}"}
+
     # ---- the generation CLI end to end: PNG tiles on disk -> samrs_amd.generate.run (reader pool over libsamrs_io.so,
     # TilePipeline with device RLE, writer pool) -> gray + color PNG + ins/*.pkl on disk.  The rate is that of generate's loop
     # (first read to last file written; its model build is outside).  Host-side work on this box's CPU slice is part of it. ----
@@ -562,7 +583,7 @@ def main() -> None:
                                  "(BASELINE.md 4.3: H2D + D2H inside) -- the transfers are hidden, the two agree within noise",
                        "accumulate": "f32", "operand_split": split_used},
             "flops_per_image": F, "roofline": roofline, "cpu_baseline": cpu_baseline, "alt_dtype": alt, "pcie_inclusive": pcie,
-            "rle_inclusive": rle_leg, "cli_inclusive": cli, "other_precision_mode": other_mode,
+            "rle_inclusive": rle_leg, "cli_inclusive": cli, "other_precision_mode": other_mode, "all_split_mode": all_split,
             "parity": parity_of_mode(int(split_used), args.workload, args.model), "reference_chunking": chunk_leg,
             "boxes_per_s": round(boxes_done / dt, 1),
             "stats_allreduce": {"total_pixels": int(tot_pix.sum().item()), "total_instances": int(tot_ins.sum().item()),

@@ -138,8 +138,12 @@ class InstancePrompter:
 
     MODES = ("point", "rbox_mask", "box")
 
-    def __init__(self, predictor):
+    def __init__(self, predictor, fill_rule: str = "auto"):
+        """fill_rule: which cv2.fillPoly span rule the rbox rasteriser reproduces (transforms.resolve_fill_rule: "auto" = that of the
+        cv2 installed beside this package, else the older one)."""
+        from . import transforms
         self.predictor = predictor
+        self.fill_rule = transforms.resolve_fill_rule(fill_rule)
 
     @torch.no_grad()
     def predict(self, image: np.ndarray, mode: str, hboxes=None, rboxes=None, points=None, already_set: bool = False,
@@ -167,7 +171,7 @@ class InstancePrompter:
                 m, q, _ = p.predict_torch(point_coords=pc, point_labels=pl, boxes=None, mask_input=None, multimask_output=multimask_output)
             elif mode == "rbox_mask":
                 prompts = transforms.rbox_mask_prompts(np.asarray(rboxes[s:e]), (h, w), img_size=p.model.image_encoder.img_size,
-                                                       device=dev)
+                                                       device=dev, fill_rule=self.fill_rule)
                 m, q, _ = p.predict_torch(point_coords=None, point_labels=None, boxes=None, mask_input=prompts[:, None],
                                           multimask_output=multimask_output)
             else:
@@ -667,7 +671,7 @@ class InstancePipeline(TilePipeline):
 
     BOX_WIDTH = 8          # four (x, y) corners
 
-    def __init__(self, sam, n_classes: int, prompt: str = "box", multimask: bool = True, **kw):
+    def __init__(self, sam, n_classes: int, prompt: str = "box", multimask: bool = True, fill_rule: str = "auto", **kw):
         """prompt: "box" / "rbox_mask" (annotations = rotated boxes [n, 4, 2]) or "point"
         (main_sam_hbox_mask_instance.py:160-165: annotations = one foreground point [n, 2] per object, handed to the prompt
         encoder AS IS -- the reference does not run them through apply_coords -- labels all 1, no box, no mask;
@@ -676,6 +680,8 @@ class InstancePipeline(TilePipeline):
             raise ValueError("prompt must be 'box', 'rbox_mask' or 'point'")
         if prompt == "point":
             self.BOX_WIDTH = 2
+        from . import transforms
+        self.fill_rule = transforms.resolve_fill_rule(fill_rule)       # prompt="rbox_mask": the cv2.fillPoly span rule to reproduce
         super().__init__(sam, n_classes, precision=kw.pop("precision", "auto"), _multimask=bool(multimask), **kw)
         self.prompt, self.multimask = prompt, bool(multimask)
         self.qual_dev = [torch.zeros(self.batch, self.max_boxes, dtype=torch.float32, device=self.dev) for _ in range(2)]
@@ -698,7 +704,7 @@ class InstancePipeline(TilePipeline):
                 hb = torch.cat([polys.amin(1), polys.amax(1)], dim=1)                                   # :125-130
                 m, q, _ = eng.predict(slot, self._input_frame_boxes(hb, (H, W), in_size), None, None, None, mm, False, in_size, (H, W))
             elif self.prompt == "rbox_mask":
-                pr = transforms.rbox_mask_prompts_device(ann.view(-1, 4, 2), (H, W), self.side, device=self.dev)
+                pr = transforms.rbox_mask_prompts_device(ann.view(-1, 4, 2), (H, W), self.side, device=self.dev, fill_rule=self.fill_rule)
                 m, q, _ = eng.predict(slot, None, None, None, pr[:, None], mm, False, in_size, (H, W))
             else:
                 pl = torch.ones(e - s, 1, dtype=torch.int32, device=self.dev)

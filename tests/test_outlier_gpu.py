@@ -112,6 +112,13 @@ def test_heavy_tailed_vit_h_holds_the_iou_bar_in_modes_15_and_79(every):
         m, _, low = orc.predict_torch(None, None, tb[s0:s1], None, multimask_output=False)
         ms.append(m); lows.append(low)
     m0, low0 = torch.cat(ms), torch.cat(lows)
+    # C4 (BASELINE configs[3]): the fixture's four rotated boxes -> enclosing hbox / +-1000 mask prompt, multimask_output=True (12 + 12 masks)
+    from oracle import rbox_prompt
+    from samrs_amd import transforms
+    hb = so.apply_boxes(torch.as_tensor(inp["hboxes"]), (1024, 1024))
+    c4box0 = orc.predict_torch(None, None, hb, None, multimask_output=True)[0]
+    pr0 = torch.from_numpy(np.stack([rbox_prompt.rbox_mask_prompt(p.astype(np.int32), 1024, 1024) for p in inp["polys"]]).astype(np.float32))[:, None]
+    c4mask0 = orc.predict_torch(None, None, None, pr0, multimask_output=True)[0]
     print(f"oracle on heavy-tailed ViT-H weights: {time.time() - t0:.0f} s")
     sam = samrs_amd.sam_model_registry["vit_h"](state_dict=sd, precision="f16", max_prompts=32, max_points=1, max_images=8).to("cuda")
     eng = sam.engine
@@ -135,6 +142,19 @@ def test_heavy_tailed_vit_h_holds_the_iou_bar_in_modes_15_and_79(every):
         out[f"mode{mode}_on_single_tile"] = {"iou_min": imin, "iou_mean": imean, "low_res_rel_l2": rel}
         print(f"   ... one tile (set_image), mode {mode}, outlier columns on: C2 IoU min {imin:.5f}, low-res rel L2 {rel:.2e}")
         assert imin >= 0.999 and rel < 1.25 * out[f"mode{mode}_on"]["low_res_rel_l2"], (mode, imin, rel)
+        # the multimask outputs (three smaller masks per object: the thin side of the parity statement) on the same embedding
+        eng.set_option("allow_reduced", 1)
+        for tag, mask in (("off", 0), ("on", 7)):
+            eng.set_option("outlier_cols", mask)
+            pred.set_image(img)
+            tb4 = pred.transform.apply_boxes_torch(torch.from_numpy(inp["hboxes"]).cuda(), img.shape[:2])
+            mb = pred.predict_torch(None, None, tb4, None, multimask_output=True)[0].cpu()
+            pm = transforms.rbox_mask_prompts(inp["polys"], (1024, 1024), fill_rule="cv2_le_451")[:, None]
+            mm = pred.predict_torch(None, None, None, pm, multimask_output=True)[0].cpu()
+            i_box, i_mask = float(_iou(mb.flatten(0, 1), c4box0.flatten(0, 1)).min()), float(_iou(mm.flatten(0, 1), c4mask0.flatten(0, 1)).min())
+            out[f"mode{mode}_{tag}_c4"] = {"hbox_iou_min": i_box, "mask_prompt_iou_min": i_mask, "n_masks": 24}
+            print(f"   ... C4 multimask (12 + 12 masks), mode {mode}, outlier columns {tag:3s}: IoU min hbox {i_box:.5f} / mask prompt {i_mask:.5f}")
+        eng.set_option("outlier_cols", 7)
     # cost of the extension: 8-tile encoder passes in mode 15, alternated
     eng.set_option("split", 15)
 

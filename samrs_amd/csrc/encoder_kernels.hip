@@ -1716,7 +1716,7 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
                             const int* oc_idx, int n_oc) {
     if (D % 4 || D > LN_MAXV * 256) return hipErrorInvalidValue;
     if (ld_out == 0) ld_out = D;
-    if (ld_out < D || ld_out % 4 || (ld_out != D && (out_lo || mx_q_hi))) return hipErrorInvalidValue;
+    if (ld_out < D || ld_out % 4 || (ld_out != D && out_lo)) return hipErrorInvalidValue;      // (the MX rows and out_lo stay dense)
     if (n_oc < 0 || n_oc > 32 || (n_oc && (!oc_idx || !out_et || window_mode || ld_out < D + 64))) return hipErrorInvalidValue;
     MxOut mx;
     if (mx_q_hi) {       // MX outputs: whole stages per row, rows in plain order, an ET output to take hi from, no partial lane passes

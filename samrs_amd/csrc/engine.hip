@@ -944,11 +944,16 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         if (fold) {
             CK(e, launch_gemm_et_fold(prec, e->Y, b.qkv_wf, e->QKV, b.qkv_bf, b.qkv_c, e->ROWSTAT, M, 3 * D, D, false, s));
         } else if (sp_attn && mx_attn) {
-            // lo terms on MXFP4 operands: the LayerNorm emits the fp4 codes + scales of its output's hi and lo (no ET lo copy)
+            // lo terms on MXFP4 operands: the LayerNorm emits the fp4 codes + scales of its output's hi and lo (no ET lo copy).
+            // Outlier columns of norm1's output: the v third is covered by its fp4 correction segments (they span every column); the q and k
+            // tiles of the v-third form run plain f16 and read the 64-column extension of the padded rows as one more stage
+            const int nocx = (oc_ok && !attn_full && b.oc_n[0] && e->ldk && b.qkv_wp) ? b.oc_n[0] : 0;
             CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, nullptr,
-                                   e->Y4[0], e->Y4[1], e->SY4[0], e->SY4[1]));
-            CK(e, launch_gemm_et_mx(prec, e->Y, b.qkv_w, e->QKV, b.qkv_b, M, 3 * D, D, D, e->Y4[1], e->Y4[0], e->SY4[1], e->SY4[0],
-                                    b.qkv_w4[0], b.qkv_w4[1], b.qkv_s4[0], b.qkv_s4[1], false, false, attn_full ? 0 : 2 * D, s));
+                                   e->Y4[0], e->Y4[1], e->SY4[0], e->SY4[1], nocx ? e->ldk : 0, nocx ? b.oc_idx[0] : nullptr, nocx));
+            if (nocx) { y_ld = e->ldk; y_live = D + 64; }
+            CK(e, launch_gemm_et_mx(prec, e->Y, nocx ? b.qkv_wp : b.qkv_w, e->QKV, b.qkv_b, M, 3 * D, D, D, e->Y4[1], e->Y4[0], e->SY4[1], e->SY4[0],
+                                    b.qkv_w4[0], b.qkv_w4[1], b.qkv_s4[0], b.qkv_s4[1], false, false, attn_full ? 0 : 2 * D, s,
+                                    false, nullptr, nullptr, nullptr, nullptr, nocx ? e->ldk : 0, nocx != 0));
         } else if (sp_attn) {
             CK(e, launch_layernorm(prec, e->X, b.ln1w, b.ln1b, 1e-6f, e->Y, nullptr, M, D, 0, g, 0, s, e->Ylo));
             if (one3 && gemm_split3_ok(M, 3 * D, D)) {     // one launch, ET output rounded once from the register accumulators

@@ -2977,13 +2977,18 @@ __device__ __forceinline__ f32x4_t mfma_mx4(const uint4& a, const uint4& b, f32x
 template <int PREC, bool OUT_F32, bool GELU = false, bool MXO = false>
 __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
     const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, void* __restrict__ Cv, const float* __restrict__ bias,
-    int M, int N, int K, int accumulate, MxOperands mx, MxOut mxo = MxOut()) {
+    int M, int N, int K, int accumulate, MxOperands mx, MxOut mxo = MxOut(),
+    int ld = 0 /* row stride of A and B in elements, 0 = K */,
+    int ext = 0 /* round 6: the rows carry the 64-column outlier extension behind their K live columns (engine.hip EncBlock::oc_*): the tiles
+                   that take NO lo terms (n0 < split_from_n: q and k of the v-third split) read it as one more f16 stage; the tiles that do
+                   take them are covered by their fp4 correction segments, which span every column */) {
     constexpr int NI = 5;
     constexpr int XBN = 64 * NI;
     constexpr int XROWS = QBM + XBN;
     constexpr int XSTAGE_ELEMS = XROWS * XBK;
     constexpr uint32_t XSB = XSTAGE_ELEMS * 2;             // stage bytes (f16 and MX alike: rows x 128 B)
     __shared__ __attribute__((aligned(16))) uint16_t lds[2 * XSTAGE_ELEMS + MX_S_BYTES];   // ring (144 KiB) + 2 x 6 KiB of scales
+    const int LD = ld > 0 ? ld : K;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -3013,14 +3018,15 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
     const int nst1 = K / XBK;                              // f16 stages
     const int nst4 = mx.Kp / MXK;                          // MX stages per correction segment
     int nmx = n0 >= mx.split_from_n ? 2 * nst4 : 0;        // MX stages of the tile being fed (wave-uniform): A_lo B_hi, then A_hi B_lo
+    int nf16 = nst1 + ((ext && n0 < mx.split_from_n) ? 1 : 0);   // ... and its f16 stages (+ the outlier extension where no lo terms run)
 
     // DMA map as in gemm_et_x64_kernel; the per-lane byte offset depends on the row stride of the source (2 K vs Kp / 2)
     const int prow = 8 * wave + ((lane >> 2) & 7);
     const uint32_t lane_off = (uint32_t)(lane >> 5) * 64u + (uint32_t)qswz(prow, lane & 3) * 16u;
-    const uint32_t voff16 = (uint32_t)prow * (uint32_t)K * 2u + lane_off;
+    const uint32_t voff16 = (uint32_t)prow * (uint32_t)LD * 2u + lane_off;
     const uint32_t voff4 = (uint32_t)prow * (uint32_t)(mx.Kp >> 1) + lane_off;
-    const unsigned char* A16 = reinterpret_cast<const unsigned char*>(A) + (size_t)m0 * K * 2;     // of the tile being fed
-    const unsigned char* B16 = reinterpret_cast<const unsigned char*>(B) + (size_t)n0 * K * 2;
+    const unsigned char* A16 = reinterpret_cast<const unsigned char*>(A) + (size_t)m0 * LD * 2;     // of the tile being fed
+    const unsigned char* B16 = reinterpret_cast<const unsigned char*>(B) + (size_t)n0 * LD * 2;
     int fm0 = m0, fn0 = n0;                                // rows of the tile being fed (the fp4 sources)
     const size_t row4 = (size_t)(mx.Kp >> 1);
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
@@ -3041,7 +3047,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
                                                    : (seg__ ? mx.b4_lo : mx.b4_hi) + ((size_t)fn0 + ((q_) - 4) * 64) * row4; \
             glds16_s(voff4, src__ + (size_t)s__ * 128, dst__);                                                       \
         } else {                                                                                                     \
-            const unsigned char* src__ = (q_) < 4 ? A16 + (size_t)(q_) * 64 * K * 2 : B16 + (size_t)((q_) - 4) * 64 * K * 2; \
+            const unsigned char* src__ = (q_) < 4 ? A16 + (size_t)(q_) * 64 * LD * 2 : B16 + (size_t)((q_) - 4) * 64 * LD * 2; \
             glds16_s(voff16, src__ + (size_t)(st__ - nmx) * 128, dst__);                                             \
         }                                                                                                            \
     } while (0)
@@ -3154,7 +3160,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
         rd = wr;                                                                                           \
     }
     for (;;) {
-        const int nst = nmx + nst1;                        // stages of THIS tile (the feed variables still are its own here)
+        const int nst = nmx + nf16;                        // stages of THIS tile (the feed variables still are its own here)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -3180,9 +3186,10 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_mx_kernel(
         if (more) {
             MX_TILE(Ln, tile_m, tile_n);
             fm0 = tile_m * QBM; fn0 = tile_n * XBN;
-            A16 = reinterpret_cast<const unsigned char*>(A) + (size_t)fm0 * K * 2;
-            B16 = reinterpret_cast<const unsigned char*>(B) + (size_t)fn0 * K * 2;
+            A16 = reinterpret_cast<const unsigned char*>(A) + (size_t)fm0 * LD * 2;
+            B16 = reinterpret_cast<const unsigned char*>(B) + (size_t)fn0 * LD * 2;
             nmx = fn0 >= mx.split_from_n ? 2 * nst4 : 0;
+            nf16 = nst1 + ((ext && fn0 < mx.split_from_n) ? 1 : 0);
             MX_ISSUE(0, 0u);
         }
         {   // epilogue of tile (em0, en0); bounce scratch = ring buffer 1 only (72 KiB: 9 KiB per wave / 18 KiB per pair)
@@ -3643,8 +3650,9 @@ hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, co
                              const void* a4_lo, const void* a4_hi, const void* sa_lo, const void* sa_hi,
                              const void* b4_hi, const void* b4_lo, const void* sb_hi, const void* sb_lo,
                              bool out_f32, bool accumulate, int split_from_n, hipStream_t s, bool gelu, void* o4_hi, void* o4_lo,
-                             void* so_hi, void* so_lo) {
+                             void* so_hi, void* so_lo, int ld, bool ext) {
     if ((gelu || o4_hi) && out_f32) return hipErrorInvalidValue;
+    if (ld < 0 || (ld && ld < K + (ext ? XBK : 0)) || (ext && (!ld || o4_hi || out_f32 || split_from_n <= 0))) return hipErrorInvalidValue;
     // the MX-row epilogue goes with lo terms on every tile or (split_from_n == N) on none
     if (o4_hi && (!o4_lo || !so_hi || !so_lo || N % 80 || ((N / 80) * 96) % MXK || (split_from_n && split_from_n != N))) return hipErrorInvalidValue;
     if (!gemm_mx_ok(M, N, K, Kp) || !A || !B || !C || !a4_lo || !a4_hi || !sa_lo || !sa_hi || !b4_hi || !b4_lo || !sb_hi || !sb_lo)
@@ -3680,11 +3688,11 @@ hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, co
     mxo.q_hi = (unsigned char*)o4_hi; mxo.q_lo = (unsigned char*)o4_lo; mxo.s_hi = (unsigned char*)so_hi; mxo.s_lo = (unsigned char*)so_lo;
 #define MXL(P_)                                                                                                          \
     do {                                                                                                                 \
-        if (out_f32) gemm_et_mx_kernel<P_, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);                \
-        else if (o4_hi && gelu) gemm_et_mx_kernel<P_, false, true, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx, mxo);  \
-        else if (o4_hi) gemm_et_mx_kernel<P_, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx, mxo);         \
-        else if (gelu) gemm_et_mx_kernel<P_, false, true, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);               \
-        else gemm_et_mx_kernel<P_, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx);                       \
+        if (out_f32) gemm_et_mx_kernel<P_, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx, MxOut(), ld, ext ? 1 : 0);                \
+        else if (o4_hi && gelu) gemm_et_mx_kernel<P_, false, true, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx, mxo, ld, ext ? 1 : 0);  \
+        else if (o4_hi) gemm_et_mx_kernel<P_, false, false, true><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx, mxo, ld, ext ? 1 : 0);         \
+        else if (gelu) gemm_et_mx_kernel<P_, false, true, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx, MxOut(), ld, ext ? 1 : 0);               \
+        else gemm_et_mx_kernel<P_, false><<<grid, block, 0, s>>>(a, b, C, bias, M, N, K, acc, mx, MxOut(), ld, ext ? 1 : 0);                       \
     } while (0)
     if (prec == PREC_F16) MXL(PREC_F16);
     else if (prec == PREC_BF16) MXL(PREC_BF16);

@@ -192,7 +192,10 @@ hipError_t launch_gemm_et_mx(int prec, const void* A, const void* B, void* C, co
                              // ET outputs only: GELU in the epilogue, and (o4_*: all four or none) the output ALSO as MXFP4 hi / lo on a K
                              // axis padded per 80-column wave tile to 96 ([M][N / 80 * 48] bytes, A-operand scale tiles, block-internal
                              // order = launch_mx4_pack perm 2): lin1 -> lin2 of the all-split mode
-                             bool gelu = false, void* o4_hi = nullptr, void* o4_lo = nullptr, void* so_hi = nullptr, void* so_lo = nullptr);
+                             bool gelu = false, void* o4_hi = nullptr, void* o4_lo = nullptr, void* so_hi = nullptr, void* so_lo = nullptr,
+                             // round 6: operand rows of stride ld (0 = K); ext: they carry the 64-column outlier extension behind their K
+                             // live columns, which the tiles WITHOUT lo terms (n0 < split_from_n) read as one more f16 stage
+                             int ld = 0, bool ext = false);
 // x (fp32 [rows][K]) or the ET pair (hi_in, lo_in) -> fp4 codes of hi and lo [rows][Kp / 2] + E8M0 scale tiles (A layout, or the
 // B layout when is_b); optional out_hi = ET(x).  Padded axis: every group of G source elements becomes GP (zeros behind it);
 // Kp = K / G * GP must be a multiple of 256.  Plain: G = GP = K.

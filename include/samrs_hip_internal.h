@@ -20,6 +20,10 @@ extern "C" {
 int samrs_debug_encoder_prefix(samrs_engine_t* e, const uint8_t* images, int n_images, int in_h,
                                int in_w, int n_blocks, float* x_out, void* stream);
 
+/* -- test hook: the outlier K-columns (option "outlier_cols") picked at samrs_finalize_weights for block GEMM `gemm` (0 qkv, 1 lin1,
+ * 2 lin2, 3 proj) of encoder block `block`: returns their number (<= 32) and writes the ascending indices to the HOST array out32. */
+int samrs_debug_outlier_columns(samrs_engine_t* e, int block, int gemm, int32_t* out32);
+
 /* -- process-wide test / tuning hooks of the KERNEL-LEVEL entry points below (samrs_k_gemm has no handle): GEMM tile variant,
  * and the start skew of the first round of GEMM blocks, per XCD / per CU group, in 1024-cycle units (0, 0 = off). */
 void samrs_debug_set_gemm_variant(int variant);

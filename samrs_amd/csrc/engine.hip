@@ -1780,6 +1780,17 @@ int samrs_resample_pass_u8(const uint8_t* in, uint8_t* out, const int32_t* bound
     if (!in || !out || !bounds || !coef || ksize < 1 || in_len < 1 || out_len < 1 || other < 1) return SAMRS_ERR_BAD_ARG;
     KRET(launch_resample_pass(in, out, bounds, coef, ksize, in_len, out_len, other, horizontal, (hipStream_t)stream));
 }
+// test hook: the outlier K-columns picked for block GEMM `gemm` (0 qkv, 1 lin1, 2 lin2, 3 proj) of encoder block `block`; returns the count
+// (<= 32) and copies the indices (ascending) to the HOST array `out32`, or a negative status
+int samrs_debug_outlier_columns(samrs_engine_t* e, int block, int gemm, int32_t* out32) {
+    if (!e || !out32 || gemm < 0 || gemm > 3 || block < 0 || block >= (int)e->blocks.size()) return SAMRS_ERR_BAD_ARG;
+    const EncBlock& b = e->blocks[block];
+    if (b.oc_n[gemm] > 0) {
+        ON_DEVICE(e);
+        CK(e, hipMemcpy(out32, b.oc_idx[gemm], sizeof(int32_t) * b.oc_n[gemm], hipMemcpyDeviceToHost));
+    }
+    return b.oc_n[gemm];
+}
 int samrs_rbox_mask_prompt(const int32_t* pts, int n, int n_vertices, int h, int w, int th, int tw, int img_size, int out_size,
                            float* out, void* stream) {
     if (!pts || !out) return SAMRS_ERR_BAD_ARG;

@@ -279,6 +279,16 @@ class Engine:
                                                             out.data_ptr(), _stream()))
         return out
 
+    def outlier_columns(self, block: int, gemm: int):
+        """Test hook: the outlier K-columns the engine picked for block GEMM `gemm` (0 qkv, 1 lin1, 2 lin2, 3 proj) of encoder block `block`."""
+        buf = (C.c_int32 * 32)()
+        self.lib.samrs_debug_outlier_columns.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32)]
+        self.lib.samrs_debug_outlier_columns.restype = C.c_int
+        n = self.lib.samrs_debug_outlier_columns(self.handle, block, gemm, buf)
+        if n < 0:
+            self._check(n)
+        return [int(buf[i]) for i in range(n)]
+
     def time_dominant_kernel(self, enable: bool) -> None:
         self._check(self.lib.samrs_debug_time_dominant_kernel(self.handle, int(enable)))
 

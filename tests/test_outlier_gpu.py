@@ -47,6 +47,13 @@ def test_outlier_columns_are_picked_from_the_weights_and_cut_the_error():
         assert eng.get_option("outlier_cols") == 7                                # bit 0: qkv / lin1, bit 1: lin2, bit 2: proj
         assert eng.get_option("outlier_blocks") == cfg.depth                      # heavy_tailed's default blocks: first, middle, last = both
         assert eng.get_option("outlier_columns") == 4 * 4 * cfg.depth             # 4 planted columns x 4 block GEMMs x blocks
+        # ... and they are the SAME columns the CPU restatement of the rule picks (oracle/outlier_budget.py: what lets that tool price the
+        # engine's behaviour on a new checkpoint before a GPU sees it)
+        from oracle.outlier_budget import outlier_columns
+        want = outlier_columns(sd, cfg)
+        for blk in range(cfg.depth):
+            for gi, point in enumerate(("enc.qkv_in", "enc.lin1_in", "enc.lin2_in", "enc.proj_in")):
+                assert eng.outlier_columns(blk, gi) == want[(blk, point)].tolist(), (name, blk, point)
         never = samrs_amd.sam_model_registry[name](state_dict=sd, precision="f16", max_prompts=8, max_points=1, max_images=n_img,
                                                    options={"split": 15, "outlier_cols": 0}).to("cuda")
         assert never.engine.get_option("outlier_columns") == 0

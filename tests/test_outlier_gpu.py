@@ -197,3 +197,42 @@ def test_heavy_tailed_vit_h_holds_the_iou_bar_in_modes_15_and_79(every):
     # output, the side GEMM, the gather: ~130 us per block) it is bounded and reported
     assert out["encoder_ms_8_tiles"]["cost"] < (0.12 if every else 0.03), out
     eng.close()
+
+
+def test_heavy_tailed_statistical_sample():
+    """The parity sample of oracle/parity_sample.py (what the N(0, sigma) claims rest on) on CHECKPOINT-LIKE weights: synth.heavy_tailed with
+    outlier channels in every block (the harsher variant), 4 tiles x 32 hboxes (128 single masks, 4 painted class maps) and 4 x 8
+    FAIR1M-shaped rboxes (96 + 96 multimask masks, the three scripted instance recipes), engine (outlier columns on) against the fp32 oracle on
+    the SAME weights, modes 15 and 79.  Asserted: every single-mask workload >= 0.9995 in both modes; the multimask outputs >= 0.999 in
+    mode 15 -- on these weights the 1x-rate mode clears the bar the N(0, sigma) weights need mode 79 for, because the error sits in columns
+    the extension reaches; zero flips outside the tau band."""
+    import samrs_amd
+    from oracle import parity_sample as ps
+    from oracle import sam_oracle as so
+    cfg = synth.CONFIGS["vit_h"]
+    base = synth.make_state_dict(cfg, 0, logit_scale=synth.MARGIN_LOGIT_SCALE)
+    sd = synth.heavy_tailed(base, cfg, 0, blocks=list(range(cfg.depth)), **HEAVY)
+    sam = samrs_amd.sam_model_registry["vit_h"](state_dict=sd, precision="f16", max_prompts=32, max_points=1).to("cuda")
+    eng = sam.engine
+    assert eng.get_option("outlier_cols") == 7 and eng.get_option("outlier_blocks") == cfg.depth
+    eng.set_option("allow_reduced", 1)
+    pred = samrs_amd.SamPredictor(sam)
+    rec = ps.run(pred, so.OraclePredictor(sd, cfg), [15, 79], tile_iter=ps.tiles(n_c2=4, n_c4=4, odd=False, long_tail=False))
+    summ = ps.summarise(rec)
+    print(ps.table(summ))
+    if os.path.isdir("gpurun_out"):
+        path = "gpurun_out/heavy_tailed_parity.json"
+        blob = json.load(open(path)) if os.path.exists(path) else {}
+        import bench
+        blob["csrc_sha16"] = bench.csrc_sha()
+        blob["sample_every_block"] = {str(k): v for k, v in summ.items()}
+        json.dump(blob, open(path, "w"), indent=1)
+    for mode, tags in summ.items():
+        for tag, s in tags.items():
+            assert s["flips_outside_tau"] == 0 and s.get("classmap_diff_outside_unstable", 0) == 0, (mode, tag)
+            if tag in ("c2", "inst_point", "inst_mask", "inst_rhbox"):
+                assert s["iou_min"] >= 0.9995, (mode, tag, s["iou_min"])
+    assert summ[15]["c2"]["n_masks"] == 128 and summ[15]["c4box"]["n_masks"] == 96
+    for tag in ("c4box", "c4mask"):
+        assert summ[15][tag]["iou_min"] >= 0.999, (tag, summ[15][tag])
+    eng.close()

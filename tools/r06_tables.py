@@ -67,6 +67,17 @@ from each launch's neighbours on its queue; durations under the profiler and und
 | role | kernel | per step | avg µs in situ (min) | algorithmic rate |
 |---|---|---|---|---|
 """ + "\n".join(rows) + "\n| decoder token side | `gemm_f32_kernel` | ≈ 160 | 35 – 116 in situ, 5 – 9 alone | one to 64 blocks each: they wait for CUs, not for data |"
+    readme = f"""| | round 6 (`profiles/r06_bench.json`, one MI355X) |
+|---|---|
+| ViT-H, 8 × 1024² tiles per step, 32 boxes per tile, f16 operands / fp32 accumulate, the production pipeline | **{d['value']:.1f} images/s** ({d['ms_per_step']:.1f} ms per step); {r['whole_path_frac'] * 100:.1f} % of the dense MFMA roofline for the whole path, dominant kernel (lin1 + GELU) **{r['frac'] * 100:.1f} %** ({r['achieved']:.0f} TFLOP/s, MFMA busy {100 * pmc['mfma_busy_frac']:.1f} %); {d['pcie_inclusive']['value']:.1f} with the tiles starting in host memory, {d['rle_inclusive']['value']:.1f} with every instance's COCO RLE string (encoded on the device) |
+| DOTA-shaped stream / instance path (multimask, best of 3) / the generation CLI files → files | {c3['value']:.1f} / {c4['value']:.1f} / {cli['value']:.1f} images/s |
+| The reference algorithm on the GPU box's CPU (fp32, {cb['cores']} threads, {cb['cpu_model']}) / in torch eager fp32 on the MI355X | {cb['value']:.2f} / {cb['eager_gpu']['value']:.1f} images/s |
+| Parity vs the pinned oracle (256 single masks, 96 + 96 multimask masks, instance recipes, odd shapes: `profiles/parity_stats.json`) | C2 IoU min {p['c2_iou_min']}; multimask ≥ 0.9991 in the ViT-H default mode; painted class map differs on {p['classmap_px_mean']:.0f} of 1 048 576 pixels per tile — **not** bit-identical: {p['classmap_px_over_floor']:.0f}× what the reference's own fp32 disagrees with itself across backends (MI355X rocBLAS vs host CPU: {p['reference_backend_floor_px']['classmap_px_mean']} px, measured), all of it inside the band where the reference's logit is within 0.25 % of the spread from the threshold; with every block GEMM on hi + lo operands: {ap.get('classmap_px_mean', float('nan')):.0f} px at {a.get('value', float('nan')):.1f} images/s |
+| Checkpoint-like weights (`synth.heavy_tailed`: outlier LayerNorm gammas / hidden units / v channels; round 6) | the engine finds the outlier K-columns from the weights at load time and carries their hi + lo terms as one more K stage of the same GEMM launches: IoU min {p['heavy_tailed_iou_min']} (outliers in every block: {p['heavy_tailed_every_block_iou_min']}) at + {100 * p['heavy_tailed_encoder_cost']['three_blocks']:.1f} % (+ {100 * p['heavy_tailed_encoder_cost']['every_block']:.1f} %) encoder time; seeded-normal weights: no columns, bit-identical, zero cost |"""
+    rp = os.path.join(ROOT, "README.md")
+    rs = open(rp).read()
+    rs2 = re.sub(r"<!-- R06:BEGIN -->.*?<!-- R06:END -->", lambda m: "<!-- R06:BEGIN -->\n" + readme + "\n<!-- R06:END -->", rs, flags=re.S)
+    open(rp, "w").write(rs2)
     path = os.path.join(ROOT, "DESIGN.md")
     s = open(path).read()
     s2 = re.sub(r"<!-- R06:BEGIN -->.*?<!-- R06:END -->", lambda m: "<!-- R06:BEGIN -->\n" + table + "\n<!-- R06:END -->", s, flags=re.S)

@@ -263,8 +263,10 @@ int samrs_resample_pass_u8(const uint8_t* in, uint8_t* out, const int32_t* bound
  *                    in fp32 by a 128-column side GEMM, exact GELU, split) and enter as one more K stage of the same launch.
  *                    Weights without outliers (seeded-normal test models) pick nothing: bit-identical output, zero cost.
  *   "outlier_ratio_pct" [SAMRS_OUTLIER_RATIO_PCT, default 400; before samrs_finalize_weights only]
- *   "outlier_blocks" / "outlier_columns"  read-only: encoder blocks with at least one outlier column in qkv / lin1, and the number
- *                    of columns picked over all four block GEMMs. */
+ *   "outlier_blocks" / "outlier_columns" / "outlier_dominant_blocks"  read-only: encoder blocks with at least one outlier column in
+ *                    qkv / lin1; the number of columns picked over all four block GEMMs; blocks in which the picked columns carry more
+ *                    than half of the qkv or proj operand-error mass -- in the v-third modes (79 / 207) those blocks run the plain
+ *                    launches with the exact lo terms of their outlier columns instead of the MXFP4 lo terms of all columns. */
 int samrs_set_option(samrs_engine_t* e, const char* name, int value);
 int samrs_get_option(const samrs_engine_t* e, const char* name, int* value);
 

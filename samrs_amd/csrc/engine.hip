@@ -87,6 +87,10 @@ struct EncBlock {
     // padded-stride route the same 64 columns sit in the pad region of qkv_wp / lin1_wp instead).
     int oc_n[4] = {0, 0, 0, 0};
     int* oc_idx[4] = {nullptr, nullptr, nullptr, nullptr};
+    // share of the picked columns in the GEMM's squared-score mass (sum over S of score^2 / sum over all columns): > 1/2 = the operand error
+    // of this GEMM is dominated by its outlier columns.  Decides between the exact f16 lo terms of those columns and the MXFP4 lo terms of
+    // ALL columns in the v-third modes (run_encoder: oc_dominant)
+    float oc_share[4] = {0.f, 0.f, 0.f, 0.f};
     uint16_t *qkv_wx = nullptr, *lin1_wx = nullptr;
     // lin2 / proj: their A operands (GELU(lin1), the attention output) are written by other kernels, so the 64 columns travel as a
     // dense side operand A_x [M][64] (engine OCX) against oc_bx [D][64] = W_hi[:, S] | W_lo[:, S], one more K stage of the same
@@ -177,6 +181,7 @@ struct samrs_engine {
     // Read-only: "outlier_blocks" (blocks with at least one such column in qkv / lin1), "outlier_columns" (their total over the
     // four block GEMMs).  Weights without outliers (every seeded-normal test model) pick nothing: bit-identical, zero cost.
     int outlier_on = 7 /* bit 0: qkv / lin1, bit 1: lin2, bit 2: proj */, outlier_ratio_pct = 400, outlier_blocks = 0, outlier_columns = 0;
+    int outlier_dominant_blocks = 0;   // blocks whose qkv or proj operand error is dominated by outlier columns (EncBlock::oc_share > 1/2)
     float* oc_scratch = nullptr;   // load-time scratch: column / row norms
     uint16_t* OCX = nullptr;       // [M][64]: side operand A_x of the running proj / lin2 launch
     bool oc_resid = false;         // some block has outlier columns in lin2 / proj
@@ -450,6 +455,10 @@ int pick_outlier_columns(samrs_engine* e, int i, hipStream_t s) {
         }
         b.oc_n[g] = (int)idx.size();
         e->outlier_columns += b.oc_n[g];
+        double all2 = 0.0, sel2 = 0.0;
+        for (float v : sc[g]) all2 += (double)v * v;
+        for (int c : idx) sel2 += (double)sc[g][c] * sc[g][c];
+        b.oc_share[g] = all2 > 0.0 ? (float)(sel2 / all2) : 0.f;
         if (b.oc_n[g]) {
             CK(e, dalloc(e, &b.oc_idx[g], 32));
             idx.resize(32, 0);
@@ -457,6 +466,7 @@ int pick_outlier_columns(samrs_engine* e, int i, hipStream_t s) {
         }
     }
     if (b.oc_n[0] || b.oc_n[1]) e->outlier_blocks += 1;
+    if (b.oc_share[0] > 0.5f || b.oc_share[3] > 0.5f) e->outlier_dominant_blocks += 1;
     return SAMRS_OK;
 }
 
@@ -933,7 +943,12 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         const EncBlock& b = e->blocks[i];
         y_ld = D; y_live = D;
         const bool attn_full = (e->split & SPLIT_ATTN) && i < depth_full;
-        const bool sp_attn = attn_full || ((e->split & SPLIT_ATTN_V) && i < depth_v), sp_mlp = any_mlp && i < depth_full;
+        // v-third modes (79 / 207): where the outlier columns carry more than half of this block's qkv or proj operand-error mass, the block
+        // runs the plain launches with the EXACT f16 lo terms of those columns instead of the MXFP4 lo terms of all columns -- an outlier
+        // column shares its fp4 block scale with 31 neighbours (their lo terms quantise to zero, its own keeps ~2 bits).  Measured on
+        // heavy-tailed weights (tests/test_outlier_gpu.py): multimask IoU min 0.99848 -> the 1x-rate mode's 0.99906 with the columns treated.
+        const bool oc_dominant = oc_any && (e->outlier_on & 5) == 5 && !attn_full && (b.oc_share[0] > 0.5f || b.oc_share[3] > 0.5f);
+        const bool sp_attn = attn_full || ((e->split & SPLIT_ATTN_V) && i < depth_v && !oc_dominant), sp_mlp = any_mlp && i < depth_full;
         // v third only: needs the tile mask of the one-launch kernel; other shapes split all of qkv
         const int v_from = (sp_attn && !attn_full && one3 && gemm_split3_ok(M, 3 * D, D) && (2 * D) % 320 == 0) ? 2 * D : 0;
         const bool mx_mlp = e->lo_format == 4 && e->mx_mlp_ready && !e->split_passes && gemm_mx_ok(M, 4 * D, D, D) && gemm_mx_ok(M, D, 4 * D, e->mx_kp_lin2);
@@ -1597,6 +1612,7 @@ int samrs_get_option(const samrs_engine_t* e, const char* name, int* value) {
     else if (n == "outlier_ratio_pct") *value = e->outlier_ratio_pct;
     else if (n == "outlier_blocks") *value = e->outlier_blocks;       // read-only
     else if (n == "outlier_columns") *value = e->outlier_columns;     // read-only
+    else if (n == "outlier_dominant_blocks") *value = e->outlier_dominant_blocks;   // read-only
     else if (n == "range_check") *value = e->range_check;
     else if (n == "saturated") {                    // synchronizes the device: a diagnostic, not a hot-path call
         unsigned long long c = 0;

@@ -203,9 +203,10 @@ def test_heavy_tailed_statistical_sample():
     """The parity sample of oracle/parity_sample.py (what the N(0, sigma) claims rest on) on CHECKPOINT-LIKE weights: synth.heavy_tailed with
     outlier channels in every block (the harsher variant), 4 tiles x 32 hboxes (128 single masks, 4 painted class maps) and 4 x 8
     FAIR1M-shaped rboxes (96 + 96 multimask masks, the three scripted instance recipes), engine (outlier columns on) against the fp32 oracle on
-    the SAME weights, modes 15 and 79.  Asserted: every single-mask workload >= 0.9995 in both modes; the multimask outputs >= 0.999 in
-    mode 15 -- on these weights the 1x-rate mode clears the bar the N(0, sigma) weights need mode 79 for, because the error sits in columns
-    the extension reaches; zero flips outside the tau band."""
+    the SAME weights, modes 15 and 79.  Asserted: every single-mask workload >= 0.9995 (the mask-only recipe >= 0.999) in both modes; the
+    multimask outputs >= 0.999 on all 96 + 96 masks in BOTH modes -- on these weights the 1x-rate mode clears the bar the N(0, sigma) weights
+    need mode 79 for, because the error sits in columns the extension reaches, and mode 79 hands its outlier-dominated blocks to the same
+    exact lo terms (before that rule: 0.99848, 16 masks under 0.999); zero flips outside the tau band."""
     import samrs_amd
     from oracle import parity_sample as ps
     from oracle import sam_oracle as so
@@ -215,6 +216,9 @@ def test_heavy_tailed_statistical_sample():
     sam = samrs_amd.sam_model_registry["vit_h"](state_dict=sd, precision="f16", max_prompts=32, max_points=1).to("cuda")
     eng = sam.engine
     assert eng.get_option("outlier_cols") == 7 and eng.get_option("outlier_blocks") == cfg.depth
+    # every block's qkv / proj operand error is dominated by its outlier columns: in mode 79 these blocks take the exact lo terms of those
+    # columns (plain launches + the extension) instead of the MXFP4 lo terms of all columns (engine.hip oc_dominant)
+    assert eng.get_option("outlier_dominant_blocks") == cfg.depth
     eng.set_option("allow_reduced", 1)
     pred = samrs_amd.SamPredictor(sam)
     rec = ps.run(pred, so.OraclePredictor(sd, cfg), [15, 79], tile_iter=ps.tiles(n_c2=4, n_c4=4, odd=False, long_tail=False))
@@ -230,9 +234,12 @@ def test_heavy_tailed_statistical_sample():
     for mode, tags in summ.items():
         for tag, s in tags.items():
             assert s["flips_outside_tau"] == 0 and s.get("classmap_diff_outside_unstable", 0) == 0, (mode, tag)
-            if tag in ("c2", "inst_point", "inst_mask", "inst_rhbox"):
+            if tag in ("c2", "inst_point", "inst_rhbox"):
                 assert s["iou_min"] >= 0.9995, (mode, tag, s["iou_min"])
+            if tag == "inst_mask":                      # the mask-only recipe: the weakest single-mask workload on the seeded-normal weights too (floor 0.999 there)
+                assert s["iou_min"] >= 0.999, (mode, tag, s["iou_min"])
     assert summ[15]["c2"]["n_masks"] == 128 and summ[15]["c4box"]["n_masks"] == 96
-    for tag in ("c4box", "c4mask"):
-        assert summ[15][tag]["iou_min"] >= 0.999, (tag, summ[15][tag])
+    for mode in (15, 79):
+        for tag in ("c4box", "c4mask"):
+            assert summ[mode][tag]["iou_min"] >= 0.999 and summ[mode][tag]["n_below_0999"] == 0, (mode, tag, summ[mode][tag])
     eng.close()

@@ -119,6 +119,13 @@ def parity_of_mode(split: int, workload: str, model: str = "vit_h"):
         if key in ht.get("every_block", {}):
             out["heavy_tailed_every_block_iou_min"] = round(ht["every_block"][key]["iou_min"], 5)
         out["heavy_tailed_encoder_cost"] = {k: round(ht[k]["encoder_ms_8_tiles"]["cost"], 4) for k in ("three_blocks", "every_block") if k in ht}
+        smp = ht.get("sample_every_block", {}).get(str(split))
+        if smp:          # the statistical sample on the every-block weights (tests/test_outlier_gpu.py::test_heavy_tailed_statistical_sample)
+            out["heavy_tailed_sample"] = {"c2_iou_min": round(smp["c2"]["iou_min"], 5), "c2_n_masks": smp["c2"]["n_masks"],
+                                          "c4_iou_min": round(min(smp["c4box"]["iou_min"], smp["c4mask"]["iou_min"]), 5),
+                                          "c4_n_masks": smp["c4box"]["n_masks"] + smp["c4mask"]["n_masks"],
+                                          "c4_below_0999": smp["c4box"]["n_below_0999"] + smp["c4mask"]["n_below_0999"],
+                                          "classmap_px_mean": smp["c2"]["classmap_diff_mean"]}
     if workload == "c4":
         out["headline_workload_iou_min"] = out["c4_iou_min"]
     else:

@@ -507,6 +507,28 @@ def main() -> None:
                            "RLE on the device, gray + color PNG (one parse, two streams) + ins/*.pkl written; reader / writer threads "
                            "sized from this rank's share of the container's CPUs; first-call warm-up inside the timed loop",
                    "host_thread_ms_per_image": per}
+            # The PNG pair is the largest host item (write.gray_color_png) and its cost is a function of the class map's RUNS: masks of
+            # random-init weights are noise-like.  The same encoder call on class maps shaped like real annotations (32 filled ellipses
+            # per tile), timed on this box's host: what the 8-rank CPU budget of a real job looks like.
+            lut = tile_io.class_lut(generate.default_palette(18))
+            yy, xx = np.mgrid[0:1024, 0:1024]
+            blob_ms = []
+            for k in range(3):
+                rng = np.random.default_rng(9000 + k)
+                seg = np.full((1024, 1024), 255, np.uint8)
+                for _ in range(32):
+                    cy, cx = rng.uniform(0, 1024, 2)
+                    a, b2 = rng.uniform(8, 200, 2)
+                    th = rng.uniform(0, np.pi)
+                    u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+                    v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+                    seg[(u / a) ** 2 + (v / b2) ** 2 <= 1] = rng.integers(0, 18)
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    tile_io.write_label_pair(os.path.join(root, "g.png"), os.path.join(root, "c.png"), seg, lut)
+                blob_ms.append((time.perf_counter() - t0) / 4 * 1e3)
+            cli["png_pair_ms_on_blob_shaped_class_maps"] = round(float(np.median(blob_ms)), 2)
+            cli["read_plus_png_pair_ms_with_blob_shaped_maps"] = round(per.get("read.decode", 0.0) + float(np.median(blob_ms)), 1)
             shutil.rmtree(root, ignore_errors=True)
         except Exception as ex:                                      # a secondary leg must not take the bench line down
             cli = {"value": None, "note": f"failed: {type(ex).__name__}: {ex}"}

@@ -27,7 +27,8 @@ def _iou(m, m0):
     return ((m & m0).sum(1).double() / (m | m0).sum(1).double().clamp(min=1))
 
 
-def test_outlier_columns_are_picked_from_the_weights_and_cut_the_error():
+@pytest.mark.parametrize("precision", ["f16", "bf16"])
+def test_outlier_columns_are_picked_from_the_weights_and_cut_the_error(precision):
     """vit_tiny / vit_tiny1280 (the padded-stride route needs width 1280), heavy-tailed weights, a batch of 4 tiles so that the 1280-wide
     model runs the persistent 256 x 320 kernels: (1) the load-time rule finds exactly the planted columns -- 4 per block GEMM and
     block, none on the seeded-normal weights; (2) the residual stream after every block is closer to the oracle's with the
@@ -38,10 +39,10 @@ def test_outlier_columns_are_picked_from_the_weights_and_cut_the_error():
         cfg = synth.CONFIGS[name]
         base = synth.make_state_dict(cfg, 0)
         sd = synth.heavy_tailed(base, cfg, 0, **HEAVY)
-        sam0 = samrs_amd.sam_model_registry[name](state_dict=base, precision="f16", max_prompts=8, max_points=1, max_images=n_img).to("cuda")
+        sam0 = samrs_amd.sam_model_registry[name](state_dict=base, precision=precision, max_prompts=8, max_points=1, max_images=n_img).to("cuda")
         assert sam0.engine.get_option("outlier_blocks") == 0 and sam0.engine.get_option("outlier_columns") == 0
         sam0.engine.close()
-        sam = samrs_amd.sam_model_registry[name](state_dict=sd, precision="f16", max_prompts=8, max_points=1, max_images=n_img,
+        sam = samrs_amd.sam_model_registry[name](state_dict=sd, precision=precision, max_prompts=8, max_points=1, max_images=n_img,
                                                  options={"split": 15}).to("cuda")
         eng = sam.engine
         assert eng.get_option("outlier_cols") == 7                                # bit 0: qkv / lin1, bit 1: lin2, bit 2: proj
@@ -54,7 +55,7 @@ def test_outlier_columns_are_picked_from_the_weights_and_cut_the_error():
         for blk in range(cfg.depth):
             for gi, point in enumerate(("enc.qkv_in", "enc.lin1_in", "enc.lin2_in", "enc.proj_in")):
                 assert eng.outlier_columns(blk, gi) == want[(blk, point)].tolist(), (name, blk, point)
-        never = samrs_amd.sam_model_registry[name](state_dict=sd, precision="f16", max_prompts=8, max_points=1, max_images=n_img,
+        never = samrs_amd.sam_model_registry[name](state_dict=sd, precision=precision, max_prompts=8, max_points=1, max_images=n_img,
                                                    options={"split": 15, "outlier_cols": 0}).to("cuda")
         assert never.engine.get_option("outlier_columns") == 0
         imgs = [synth.make_image(i) for i in range(n_img)]
@@ -71,7 +72,7 @@ def test_outlier_columns_are_picked_from_the_weights_and_cut_the_error():
                 rel[mask] = ((x[0] - ref).norm() / ref.norm()).item()
                 if mask == 0:
                     assert torch.equal(x, never.engine.debug_encoder_prefix(t, nb).cpu()), (name, nb)
-            print(f"{name} x{n_img} after {nb} blocks, heavy-tailed weights: residual-stream rel L2 vs oracle {rel[0]:.3e} (off) -> "
+            print(f"{name} {precision} x{n_img} after {nb} blocks, heavy-tailed weights: residual-stream rel L2 vs oracle {rel[0]:.3e} (off) -> "
                   f"{rel[1]:.3e} (qkv / lin1 columns) -> {rel[7]:.3e} (+ lin2 / proj columns)")
             assert rel[1] < 0.75 * rel[0] and rel[7] < rel[1], (name, nb, rel)
         eng.set_option("outlier_cols", 7)

@@ -74,7 +74,8 @@ def test_outlier_columns_are_picked_from_the_weights_and_cut_the_error(precision
                     assert torch.equal(x, never.engine.debug_encoder_prefix(t, nb).cpu()), (name, nb)
             print(f"{name} {precision} x{n_img} after {nb} blocks, heavy-tailed weights: residual-stream rel L2 vs oracle {rel[0]:.3e} (off) -> "
                   f"{rel[1]:.3e} (qkv / lin1 columns) -> {rel[7]:.3e} (+ lin2 / proj columns)")
-            assert rel[1] < 0.75 * rel[0] and rel[7] < rel[1], (name, nb, rel)
+            # (bf16: 8 significand bits everywhere, so the non-outlier columns' rounding is a larger share of the error than at f16)
+            assert rel[1] < (0.75 if precision == "f16" else 0.9) * rel[0] and rel[7] < rel[1], (name, precision, nb, rel)
         eng.set_option("outlier_cols", 7)
         eng.close()
         never.engine.close()

@@ -97,11 +97,12 @@ def train_steps(dataset: SegmentationDataset, n_classes: int, rank: int, world: 
 SAMPLE_CLASSES, SAMPLE_IMAGES, SAMPLE_SIDE = 18, 6, 64
 
 
-def make_sample_dataset(root: str):
+def make_sample_dataset(root: str, side: int = 0):
     """A small dataset in the layout main_pretrain.py:186-190 expects, written by the PRODUCT's writers (samrs_amd.generate.write_outputs,
     samrs_amd.tile_io: gray / color PNG + ins pickles; the class maps are synthetic rectangles so that it can be made without a GPU):
     6 tiles of 64 x 64, 18 classes, train.txt = 4 stems, valid.txt = 2.  Returns (image dir, label dir)."""
     from samrs_amd import generate, tile_io
+    SAMPLE_SIDE = side or globals()["SAMPLE_SIDE"]          # (side: other tile sizes, e.g. 224 for the reference's ViT-B + UperNet)
     os.makedirs(os.path.join(root, "images"), exist_ok=True)
     out = os.path.join(root, "hbox_segs_init")
     palette = generate.default_palette(SAMPLE_CLASSES)
@@ -138,6 +139,61 @@ def reference_dataset(root: str, flag: str):
     args = types.SimpleNamespace(decoder="upernet")
     return ds.SegmentationDataset(args, SAMPLE_SIDE, root, os.path.join(root, "images"), os.path.join(root, "hbox_segs_init", "gray"),
                                   ext_img=".png", ext_lbl=".png", flag=flag, transform=lambda image, mask: {"image": image, "mask": mask})
+
+
+def reference_upernet_vit_b(n_classes: int, image_size: int = 224):
+    """The reference's OWN segmentation model for BASELINE.json configs[4]: ViT-B + RVSA backbone and UPerHead, assembled as
+    `Pretraining and Finetuning/Encoder_Decoder/models.py:81-82,174-186` does (`vit_b_rvsa(args)`; `UPerHead(in_channels =
+    encoder.out_channels[1:], channels = encoder.out_channels[2], in_index = (0, 1, 2, 3), dropout_ratio = 0.1, norm_cfg = SyncBN)`;
+    head = `Dropout2d(0.1)` + `Conv2d(channels, classes, 1)`) with its forward (`:277-280`: `head(decoder(*encoder(x)))`).  Both classes are
+    imported from the reference tree (oracle/ref_import.import_reference_upernet); only where that tree exists."""
+    import types
+    from oracle import ref_import
+    bb, up = ref_import.import_reference_upernet()
+    args = types.SimpleNamespace(image_size=image_size, use_ckpt="False")
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = bb.vit_b_rvsa(args, inchannels=3)                                                     # models.py:81-82
+            self.decoder = up.UPerHead(in_channels=self.encoder.out_channels[1:], channels=self.encoder.out_channels[2],
+                                       in_index=(0, 1, 2, 3), dropout_ratio=0.1, norm_cfg=dict(type="SyncBN", requires_grad=True))   # :176-182
+            self.semseghead_1 = torch.nn.Sequential(torch.nn.Dropout2d(0.1),
+                                                    torch.nn.Conv2d(self.encoder.out_channels[2], n_classes, kernel_size=1))     # :184-187
+
+        def forward(self, x):
+            return self.semseghead_1(self.decoder(*self.encoder(x)))                                            # :277-280
+
+    return Net()
+
+
+def train_steps_model(model, dataset, rank: int, world: int, steps: int = 2, batch_size: int = 1, lr: float = 0.01):
+    """`train_steps` with a given model (the reference's UperNet-ViT-B): DistributedSampler + CrossEntropyLoss(ignore_index=255) + DDP."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+    # find_unused_parameters=True: as the reference wraps it (Encoder_Decoder/main_pretrain.py:445, End_to_End/main_pretrain.py:464)
+    ddp = DDP(model, find_unused_parameters=True) if (dist.is_available() and dist.is_initialized() and world > 1) else model
+    sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=False)
+    loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=0, drop_last=False)
+    criterion = torch.nn.CrossEntropyLoss(ignore_index=IGNORE_LABEL)
+    opt = torch.optim.SGD(ddp.parameters(), lr=lr)
+    losses, it = [], iter(loader)
+    for _ in range(steps):
+        try:
+            x, y = next(it)
+        except StopIteration:
+            it = iter(loader)
+            x, y = next(it)
+        out = ddp(x)
+        loss = criterion(out, y.long())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    probe = torch.cat([p.detach().flatten()[:64] for p in list(model.parameters())[:8]])
+    return losses, probe, tuple(out.shape)
 
 
 def make_golden(path: str) -> None:

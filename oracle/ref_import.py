@@ -170,3 +170,97 @@ def import_reference_consumer():
         else:
             sys.modules[k] = v
     return ds
+
+
+# ------------------------------------------------------------------------------------------------
+# UperNet + ViT-B (RVSA) of the reference's segmentation training: `Pretraining and Finetuning/Encoder_Decoder`
+# ------------------------------------------------------------------------------------------------
+ED_ROOT = "/root/reference/Pretraining and Finetuning/Encoder_Decoder"
+
+
+def upernet_available() -> bool:
+    return os.path.isfile(os.path.join(ED_ROOT, "upernet_mmseg_30.py"))
+
+
+def import_reference_upernet():
+    """(backbone module, head module): the reference's OWN `backbone/vit_win_rvsa_v3_wsz7.py` (ViT-B + RVSA, `vit_b_rvsa`) and
+    `upernet_mmseg_30.py` (`UPerHead`), imported read-only, file by file (`models.py` itself imports every backbone of the repository, incl.
+    CUDA-only ops).  What they need from packages that cannot be installed here, and what stands in:
+      timm.models.layers  drop_path / to_2tuple / trunc_normal_      -> their documented one-liners (torch.nn.init.trunc_normal_)
+      mmengine.dist.get_dist_info                                    -> (rank, world) of torch.distributed
+      mmengine.model.BaseModule                                      -> torch.nn.Module
+      mmcv.cnn.ConvModule                                            -> conv -> norm -> activation with mmcv's `bias='auto'` rule;
+                                                                        norm_cfg type 'SyncBN' becomes BatchNorm2d (SyncBatchNorm has no
+                                                                        CPU / gloo implementation: the statistics stay per rank)
+      mmseg.structures.build_pixel_sampler, mmseg.utils types        -> unused by the forward pass
+    The model code -- attention with rotated varied-size windows, the FPN neck, PPM, the UPerNet fusion -- is the reference's, unmodified."""
+    if not upernet_available():
+        raise RuntimeError("reference tree not present on this machine")
+    sys.dont_write_bytecode = True
+    import importlib.util
+    import torch
+    import torch.nn as nn
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    def drop_path(x, drop_prob: float = 0., training: bool = False):
+        if not drop_prob or not training:
+            return x
+        keep = 1 - drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        return x.div(keep) * mask
+
+    def to_2tuple(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+    def get_dist_info():
+        import torch.distributed as dist
+        return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+    class BaseModule(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+            self.init_cfg = init_cfg
+
+    class ConvModule(nn.Module):
+        def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias="auto",
+                     conv_cfg=None, norm_cfg=None, act_cfg=dict(type="ReLU"), inplace=True, **kw):
+            super().__init__()
+            with_norm = norm_cfg is not None
+            self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                                  bias=(not with_norm) if bias == "auto" else bias)
+            self.bn = nn.BatchNorm2d(out_channels) if with_norm else None
+            if with_norm and not norm_cfg.get("requires_grad", True):
+                for p in self.bn.parameters():
+                    p.requires_grad = False
+            self.activate = nn.ReLU(inplace=inplace) if act_cfg is not None else None
+
+        def forward(self, x):
+            x = self.conv(x)
+            if self.bn is not None:
+                x = self.bn(x)
+            return self.activate(x) if self.activate is not None else x
+
+    mod("timm")
+    mod("timm.models")
+    mod("timm.models.layers", drop_path=drop_path, to_2tuple=to_2tuple, trunc_normal_=nn.init.trunc_normal_)
+    mod("mmengine")
+    mod("mmengine.dist", get_dist_info=get_dist_info)
+    mod("mmengine.model", BaseModule=BaseModule)
+    mod("mmcv")
+    mod("mmcv.cnn", ConvModule=ConvModule)
+    mod("mmseg")
+    mod("mmseg.structures", build_pixel_sampler=lambda *a, **k: None)
+    mod("mmseg.utils", ConfigType=dict, SampleList=list)
+    out = []
+    for name, rel in (("samrs_reference_vit_rvsa", "backbone/vit_win_rvsa_v3_wsz7.py"), ("samrs_reference_upernet", "upernet_mmseg_30.py")):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ED_ROOT, rel))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        out.append(m)
+    return tuple(out)

@@ -107,3 +107,43 @@ def test_reference_dataset_class_trains_on_generated_files_under_ddp(tmp_path):
     assert sorted(d0 + d1) == [0, 1, 2, 3] and all(np.isfinite(l0 + l1)) and np.allclose(w0, w1)
     hist = h0 + h1
     assert hist[N_CLASSES:255].sum() == 0 and hist[255] > 0 and hist[:N_CLASSES].sum() > 0
+
+
+def _upernet_worker(rank, world, port, root, out):
+    from oracle import consumer_check as cc
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)                                             # the same initial weights on both ranks (DDP broadcasts rank 0's anyway)
+    ds = cc.reference_dataset(root, "trn")
+    model = cc.reference_upernet_vit_b(N_CLASSES, image_size=224)
+    losses, probe, shape = cc.train_steps_model(model, ds, rank, world, steps=2, batch_size=2)     # (BatchNorm over the 1 x 1 PPM bin needs > 1 sample)
+    out[rank] = (losses, probe.numpy().copy(), shape)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_upernet_vit_b_trains_on_generated_files_under_ddp(tmp_path):
+    """BASELINE.json configs[4] / SURVEY 8f N4 with the reference's OWN model: where the reference tree exists (the authoring container),
+    `Pretraining and Finetuning/Encoder_Decoder`'s ViT-B + RVSA backbone and UPerHead (imported file by file through
+    oracle/ref_import.import_reference_upernet; mmcv / mmengine / timm are replaced by the few lines those files use of them) are
+    assembled as models.py:81-82,174-187 does, fed by the reference's own SegmentationDataset reading the files the PRODUCT's writers
+    wrote (224 x 224 tiles: the ViT's 7 x 7 windows need a 14 x 14 token grid), and trained for two iterations under DDP on two gloo
+    ranks with the reference's loss (`CrossEntropyLoss(ignore_index=255)`, main_pretrain.py:321): finite losses, logits of the
+    label map's size, identical weights on both ranks afterwards.  (8 GPUs / RCCL / mmseg's training loop: not available here.)"""
+    import pytest
+    from oracle import ref_import
+    if not (ref_import.upernet_available() and ref_import.consumer_available()):
+        pytest.skip("/root/reference is not on this machine")
+    root = str(tmp_path)
+    _cc.make_sample_dataset(root, side=224)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_upernet_worker, args=(2, port, root, out), nprocs=2, join=True)
+    (l0, p0, s0), (l1, p1, s1) = out[0], out[1]
+    assert s0 == s1 == (2, N_CLASSES, 224, 224)
+    assert all(np.isfinite(l0 + l1)) and 0.5 < l0[0] < 10.0           # ~ log(18) at initialisation
+    assert np.allclose(p0, p1)                                        # DDP: the same weights on both ranks after the two steps

@@ -186,6 +186,10 @@ def main() -> None:
                     help="c3: boxes per predict call (default 64 = the product's chunking, samrs_amd.generate --box-batch; the masks do "
                          "not depend on it: test_predict_batches_beyond_max_prompts.  The reference's 20, main_sam_hbox_semantic.py:91, "
                          "is timed beside it as `reference_chunking`)")
+    ap.add_argument("--weights", default="normal", choices=["normal", "heavy_tailed", "heavy_tailed_every_block"],
+                    help="normal: seeded N(0, sigma) weights (the headline).  heavy_tailed: synth.heavy_tailed on top (outlier LayerNorm gammas / "
+                         "hidden units / v channels in the first, middle and last block, or in every block): what the engine's outlier-column "
+                         "extension costs in the product loop (DESIGN.md 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-dtype", action="store_true", help="skip the second (bf16) timing leg")
     ap.add_argument("--no-pcie-leg", action="store_true", help="skip the PCIe-inclusive measurement")
@@ -224,6 +228,9 @@ def main() -> None:
 
     cfg = synth.CONFIGS[args.model]
     sd = synth.make_state_dict(cfg, 0)
+    if args.weights != "normal":
+        sd = synth.heavy_tailed(sd, cfg, 0, hidden_scale=3e3, v_scale=3e3, gamma_scale=30.0,
+                                blocks=list(range(cfg.depth)) if args.weights == "heavy_tailed_every_block" else None)
     B = args.batch
     n_classes = 37 if args.workload == "c4" else 18
     # a pool of distinct synthetic tiles per rank (host, pinned) and their device copies: the timed region walks through all of
@@ -323,6 +330,7 @@ def main() -> None:
     shared_q = args.workload == "c3"
     sam, pipe = make_pipeline(args.dtype, device_inputs=True)
     eng = sam.engine
+    eng_info = {k: eng.get_option(k) for k in ("outlier_cols", "outlier_blocks", "outlier_columns")}
     # the engine brackets every launch of the dominant kernel (MLP lin1+GELU GEMM) with hipEvents on its
     # launch stream; warm-up launches are discarded, so the average below is over the timed region
     eng.time_dominant_kernel(True)
@@ -604,7 +612,10 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": wl, "tiles_per_step": world * B, "boxes_per_tile": round(boxes_per_tile, 2),
-                       "parallelism": f"image-parallel x{world}", "weights": "seeded random init (no checkpoint available)",
+                       "parallelism": f"image-parallel x{world}",
+                       "weights": "seeded random init (no checkpoint available)" if args.weights == "normal" else
+                                  f"seeded random init + synth.heavy_tailed ({args.weights}): outlier columns "
+                                  f"{eng_info.get('outlier_columns')} in {eng_info.get('outlier_blocks')} blocks, option outlier_cols = {eng_info.get('outlier_cols')}",
                        "loop": "samrs_amd.driver.TilePipeline (the product loop of samrs_amd.generate): H2D / encoder / decoder+paint+D2H "
                                "on three HIP streams, two embedding slot sets",
                        "inputs": f"{n_pool} distinct tiles per rank rotated through the timed region, resident in HBM when it starts (the bench "

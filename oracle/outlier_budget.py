@@ -40,29 +40,11 @@ MAX_COLS = 32          # at most this many per GEMM: 32 lo + 32 hi columns = one
 
 
 def outlier_columns(sd, cfg, ratio: float = RATIO, max_cols: int = MAX_COLS):
-    """{(block, point): LongTensor of K-columns} from the weights alone (see the module docstring)."""
-    D = cfg.embed_dim
-    out = {}
-    for i in range(cfg.depth):
-        p = f"image_encoder.blocks.{i}"
-        g1, b1 = sd[p + ".norm1.weight"].abs(), sd[p + ".norm1.bias"].abs()
-        g2, b2 = sd[p + ".norm2.weight"].abs(), sd[p + ".norm2.bias"].abs()
-        wqkv, bqkv = sd[p + ".attn.qkv.weight"], sd[p + ".attn.qkv.bias"]
-        w1, bb1 = sd[p + ".mlp.lin1.weight"], sd[p + ".mlp.lin1.bias"]
-        w2, wp = sd[p + ".mlp.lin2.weight"], sd[p + ".attn.proj.weight"]
-        rms1, rms2 = float(g1.square().mean().sqrt()), float(g2.square().mean().sqrt())
-        scores = {
-            "enc.qkv_in": (g1 + b1) * wqkv.norm(dim=0),
-            "enc.lin1_in": (g2 + b2) * w1.norm(dim=0),
-            "enc.lin2_in": (w1.norm(dim=1) * rms2 + bb1.abs()) * w2.norm(dim=0),
-            "enc.proj_in": (wqkv[2 * D:].norm(dim=1) * rms1 + bqkv[2 * D:].abs()) * wp.norm(dim=0),
-        }
-        for k, s in scores.items():
-            idx = torch.nonzero(s > ratio * s.median()).flatten()
-            if len(idx) > max_cols:
-                idx = idx[torch.argsort(s[idx], descending=True)[:max_cols]]
-            out[(i, k)] = torch.sort(idx).values
-    return out
+    """{(block, point): LongTensor of K-columns} from the weights alone: the host-side statement of the engine's rule lives in the product
+    package (samrs_amd/outliers.py, usable on a checkpoint without a GPU); this is that function under the oracle's rounding-point names."""
+    from samrs_amd import outliers
+    names = {"qkv": "enc.qkv_in", "lin1": "enc.lin1_in", "lin2": "enc.lin2_in", "proj": "enc.proj_in"}
+    return {(i, names[g]): idx for (i, g), (idx, _share) in outliers.outlier_columns(sd, cfg, ratio, max_cols).items()}
 
 
 class ColSplit:

@@ -186,3 +186,29 @@ def test_fill_rule_resolution(monkeypatch):
         assert transforms.resolve_fill_rule("auto") == want, ver
     with pytest.raises(ValueError):
         transforms.resolve_fill_rule("cv2_5")
+
+
+def test_outlier_rule_on_the_host_finds_the_planted_columns(tmp_path, capsys):
+    """samrs_amd/outliers.py -- the host-side statement of the rule the engine applies on the device when it loads weights (the GPU suite
+    asserts that the two pick the same columns): nothing on seeded-normal weights, exactly the planted channels on synth.heavy_tailed
+    (LayerNorm gammas -> qkv / lin1 columns, hidden units -> lin2, v channels -> proj), each block outlier-dominated; and the CLI a user
+    points at a checkpoint file."""
+    from samrs_amd import outliers
+    cfg = synth.CONFIGS["vit_tiny"]
+    base = synth.make_state_dict(cfg, 0)
+    assert all(len(idx) == 0 for idx, _ in outliers.outlier_columns(base, cfg).values())
+    sd = synth.heavy_tailed(base, cfg, 0, hidden_scale=3e3, v_scale=3e3, gamma_scale=30.0)
+    oc = outliers.outlier_columns(sd, cfg)
+    gen = torch.Generator().manual_seed(424242)                   # synth.heavy_tailed's own draw order: hidden, v, gamma per block
+    for i in range(cfg.depth):
+        hid = torch.randperm(4 * cfg.embed_dim, generator=gen)[:4]
+        vch = torch.randperm(cfg.embed_dim, generator=gen)[:4]
+        gch = torch.randperm(cfg.embed_dim, generator=gen)[:4]
+        assert oc[(i, "qkv")][0].tolist() == sorted(gch.tolist()) == oc[(i, "lin1")][0].tolist()
+        assert oc[(i, "lin2")][0].tolist() == sorted(hid.tolist()) and oc[(i, "proj")][0].tolist() == sorted(vch.tolist())
+        assert all(oc[(i, g)][1] > 0.5 for g in outliers.GEMMS)
+    path = tmp_path / "heavy.pth"
+    torch.save(sd, path)
+    assert outliers.main([str(path), "--model", "vit_tiny"]) == 0
+    out = capsys.readouterr().out
+    assert "32 outlier columns in all; 2 of 2 blocks outlier-dominated" in out

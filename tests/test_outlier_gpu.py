@@ -55,6 +55,9 @@ def test_outlier_columns_are_picked_from_the_weights_and_cut_the_error(precision
         for blk in range(cfg.depth):
             for gi, point in enumerate(("enc.qkv_in", "enc.lin1_in", "enc.lin2_in", "enc.proj_in")):
                 assert eng.outlier_columns(blk, gi) == want[(blk, point)].tolist(), (name, blk, point)
+        from samrs_amd import outliers
+        host = outliers.outlier_columns(sd, cfg)
+        assert eng.get_option("outlier_dominant_blocks") == sum(host[(b_, "qkv")][1] > 0.5 or host[(b_, "proj")][1] > 0.5 for b_ in range(cfg.depth))
         never = samrs_amd.sam_model_registry[name](state_dict=sd, precision=precision, max_prompts=8, max_points=1, max_images=n_img,
                                                    options={"split": 15, "outlier_cols": 0}).to("cuda")
         assert never.engine.get_option("outlier_columns") == 0

@@ -332,22 +332,30 @@ __global__ __launch_bounds__(256) void outlier_side_gemm_kernel(const uint16_t* 
     }
 }
 
-// Squared L2 norms of the columns (col_sq[K], must be zero on entry) and of the rows (row_sq[N]) of an fp32 matrix W[N][K]: what the
-// weights-only outlier rule scores columns with (engine.hip pick_outlier_columns).  Load-time only.
-__global__ __launch_bounds__(256) void weight_norms_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ col_sq,
-                                                           float* __restrict__ row_sq) {
+// Squared L2 norms of the columns (col_sq[K]) and of the rows (row_sq[N]) of an fp32 matrix W[N][K]: what the weights-only outlier rule
+// scores columns with (engine.hip pick_outlier_columns).  Load-time only, and DETERMINISTIC (no atomics: which columns sit above the threshold
+// must not depend on the order in which blocks happen to finish): a thread walks its column top to bottom, a wave sums its row in the
+// fixed order of wave_sum.
+__global__ __launch_bounds__(256) void weight_col_norms_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ col_sq) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * 64, r1 = min(N, r0 + 64);
+    if (c >= K) return;
     float acc = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        const float w = c < K ? W[(size_t)r * K + c] : 0.f;
+    for (int r = 0; r < N; ++r) {
+        const float w = W[(size_t)r * K + c];
         acc += w * w;
-        if (row_sq) {
-            float t = wave_sum(w * w);
-            if ((threadIdx.x & 63) == 0) atomicAdd(row_sq + r, t);
-        }
     }
-    if (col_sq && c < K) atomicAdd(col_sq + c, acc);
+    col_sq[c] = acc;
+}
+__global__ __launch_bounds__(256) void weight_row_norms_kernel(const float* __restrict__ W, int N, int K, float* __restrict__ row_sq) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= N) return;
+    float acc = 0.f;
+    for (int c = lane; c < K; c += 64) {
+        const float w = W[(size_t)r * K + c];
+        acc += w * w;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) row_sq[r] = acc;
 }
 
 // -----------------------------------------------------------------------------------------
@@ -1533,9 +1541,8 @@ hipError_t launch_outlier_side_gemm(int prec, const void* Y, int lda, const void
 
 hipError_t launch_weight_norms(const float* W, int N, int K, float* col_sq, float* row_sq, hipStream_t s) {
     if (!W || N < 1 || K < 1) return hipErrorInvalidValue;
-    if (col_sq) HIP_CHECK_RET(hipMemsetAsync(col_sq, 0, sizeof(float) * K, s));
-    if (row_sq) HIP_CHECK_RET(hipMemsetAsync(row_sq, 0, sizeof(float) * N, s));
-    weight_norms_kernel<<<dim3((K + 255) / 256, (N + 63) / 64), 256, 0, s>>>(W, N, K, col_sq, row_sq);
+    if (col_sq) weight_col_norms_kernel<<<(K + 255) / 256, 256, 0, s>>>(W, N, K, col_sq);
+    if (row_sq) weight_row_norms_kernel<<<(N + 3) / 4, 256, 0, s>>>(W, N, K, row_sq);
     return hipGetLastError();
 }
 

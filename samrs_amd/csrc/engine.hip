@@ -423,13 +423,16 @@ int pick_outlier_columns(samrs_engine* e, int i, hipStream_t s) {
     if ((rc = norms(p + ".mlp.lin1.weight", H, D, l1_col.data(), l1_row.data()))) return rc;
     if ((rc = norms(p + ".mlp.lin2.weight", D, H, l2_col.data(), nullptr))) return rc;
     if ((rc = norms(p + ".attn.proj.weight", D, D, pj_col.data(), nullptr))) return rc;
+    hipError_t copy_err = hipSuccess;
     auto host = [&](const std::string& name, size_t n) {
         std::vector<float> v(n);
-        (void)hipMemcpy(v.data(), W(e, name), sizeof(float) * n, hipMemcpyDeviceToHost);
+        const hipError_t r = hipMemcpy(v.data(), W(e, name), sizeof(float) * n, hipMemcpyDeviceToHost);
+        if (r != hipSuccess) copy_err = r;
         return v;
     };
     const std::vector<float> g1 = host(p + ".norm1.weight", D), b1 = host(p + ".norm1.bias", D), g2 = host(p + ".norm2.weight", D),
                              b2 = host(p + ".norm2.bias", D), bq = host(p + ".attn.qkv.bias", 3 * D), bl = host(p + ".mlp.lin1.bias", H);
+    CK(e, copy_err);
     double r1 = 0, r2 = 0;
     for (int c = 0; c < D; ++c) { r1 += (double)g1[c] * g1[c]; r2 += (double)g2[c] * g2[c]; }
     const float rms1 = (float)std::sqrt(r1 / D), rms2 = (float)std::sqrt(r2 / D);

@@ -147,7 +147,9 @@ def import_reference_consumer():
         def __init__(self, *a, **k):
             pass
 
-    keep = {k: sys.modules.get(k) for k in ("torchvision", "torchvision.transforms")}
+    stub_names = ("torchvision", "torchvision.transforms", "cv2", "skimage", "skimage.io", "mmcv", "mmcv.transforms", "mmcv.transforms.base",
+                  "mmengine", "mmengine.structures", "mmseg", "mmseg.structures")
+    keep = {k: sys.modules.get(k) for k in stub_names}
     tv = mod("torchvision")
     tv.transforms = mod("torchvision.transforms", Compose=Compose, ToPILImage=ToPILImage, ToTensor=ToTensor, Normalize=Normalize)
     mod("cv2")
@@ -164,8 +166,8 @@ def import_reference_consumer():
     spec = importlib.util.spec_from_file_location("samrs_reference_pf_datasets", os.path.join(PF_ROOT, "datasets.py"))
     ds = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ds)
-    for k, v in keep.items():                       # the SAM-side stub (import_reference) must find its own torchvision again
-        if v is None:
+    for k, v in keep.items():       # the stand-ins must not outlive the import: the SAM-side stub (import_reference) wants its own torchvision
+        if v is None:               # back, and `import cv2` elsewhere (samrs_amd.transforms.resolve_fill_rule) must keep failing honestly
             sys.modules.pop(k, None)
         else:
             sys.modules[k] = v
@@ -246,6 +248,9 @@ def import_reference_upernet():
                 x = self.bn(x)
             return self.activate(x) if self.activate is not None else x
 
+    stub_names = ("timm", "timm.models", "timm.models.layers", "mmengine", "mmengine.dist", "mmengine.model", "mmcv", "mmcv.cnn", "mmseg",
+                  "mmseg.structures", "mmseg.utils")
+    keep = {k: sys.modules.get(k) for k in stub_names}
     mod("timm")
     mod("timm.models")
     mod("timm.models.layers", drop_path=drop_path, to_2tuple=to_2tuple, trunc_normal_=nn.init.trunc_normal_)
@@ -263,4 +268,9 @@ def import_reference_upernet():
         m = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(m)
         out.append(m)
+    for k, v in keep.items():       # (the imported files hold what they imported; the stand-ins leave sys.modules again)
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
     return tuple(out)

@@ -45,7 +45,7 @@ def main():
     rows.append(f"| LayerNorm, decoder rows | `layernorm_kernel` other grids | {n_ld} | {s_ld} | |")
     a = d.get("all_split_mode") or {}
     ap = a.get("parity") or {}
-    table = f"""| | round 6 (`profiles/r06_bench.json`; one box; the pool's boxes differ by ± 2 – 3 %) |
+    table = f"""| | round 6 (`profiles/r06_bench.json`; ONE box of the pool — the same loop on this round's boxes: 141.3 / 143.3 / 144.6 / 145.5 / 146.9 / 147.9 images/s; it runs at the socket power cap) |
 |---|---|
 | `value`: c2 = BASELINE configs[1], ViT-H, 8 × 1024² tiles per step, 32 hboxes per tile, f16 operands / fp32 accumulate, mode 15, tiles resident in HBM, 64 distinct tiles through 50 timed steps, the product loop (`driver.TilePipeline`) | **{d['value']:.1f} images/s** ({d['ms_per_step']:.2f} ms per step; round 5: 144.0, round 4: 142.3) |
 | dominant kernel lin1 + GELU (`gemm_et_w4x_kernel`, 429.5 GFLOP per launch), hipEvents on its launch stream over the timed region ({r['launches_timed']} launches) | {r['avg_launch_ms']:.4f} ms → {r['achieved']:.0f} TFLOP/s = **{r['frac']:.3f}** of the 2.5 PFLOP/s dense f16 roof; rocprofv3 kernel trace of the same command: {k('lin1 + GELU', 'gemm_et_w4x_kernel')[1]:.1f} µs (`profiles/r06_trace_summary.md`) |
@@ -67,7 +67,7 @@ from each launch's neighbours on its queue; durations under the profiler and und
 | role | kernel | per step | avg µs in situ (min) | algorithmic rate |
 |---|---|---|---|---|
 """ + "\n".join(rows) + "\n| decoder token side | `gemm_f32_kernel` | ≈ 160 | 35 – 116 in situ, 5 – 9 alone | one to 64 blocks each: they wait for CUs, not for data |"
-    readme = f"""| | round 6 (`profiles/r06_bench.json`, one MI355X) |
+    readme = f"""| | round 6 (`profiles/r06_bench.json`: ONE MI355X of the pool; the same loop on this round's boxes: 141.3 … 147.9 images/s) |
 |---|---|
 | ViT-H, 8 × 1024² tiles per step, 32 boxes per tile, f16 operands / fp32 accumulate, the production pipeline | **{d['value']:.1f} images/s** ({d['ms_per_step']:.1f} ms per step); {r['whole_path_frac'] * 100:.1f} % of the dense MFMA roofline for the whole path, dominant kernel (lin1 + GELU) **{r['frac'] * 100:.1f} %** ({r['achieved']:.0f} TFLOP/s, MFMA busy {100 * pmc['mfma_busy_frac']:.1f} %); {d['pcie_inclusive']['value']:.1f} with the tiles starting in host memory, {d['rle_inclusive']['value']:.1f} with every instance's COCO RLE string (encoded on the device) |
 | DOTA-shaped stream / instance path (multimask, best of 3) / the generation CLI files → files | {c3['value']:.1f} / {c4['value']:.1f} / {cli['value']:.1f} images/s |

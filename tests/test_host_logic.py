@@ -212,3 +212,17 @@ def test_outlier_rule_on_the_host_finds_the_planted_columns(tmp_path, capsys):
     assert outliers.main([str(path), "--model", "vit_tiny"]) == 0
     out = capsys.readouterr().out
     assert "32 outlier columns in all; 2 of 2 blocks outlier-dominated" in out
+
+
+def test_outlier_rule_caps_at_32_columns_per_gemm():
+    """More candidates than one 64-wide K stage can carry (32 lo + 32 hi columns): the 32 largest scores are kept, ascending."""
+    from samrs_amd import outliers
+    cfg = synth.CONFIGS["vit_tiny"]
+    sd = synth.heavy_tailed(synth.make_state_dict(cfg, 0), cfg, 0, gamma_scale=30.0, n_channels=40, blocks=[0])
+    sc = outliers.block_scores(sd, cfg, 0)["qkv"]
+    idx, share = outliers.pick(sc)
+    assert len(idx) == 32 and idx.tolist() == sorted(idx.tolist()) and share > 0.5
+    assert int((sc > 4 * sc.median()).sum()) == 40
+    kept = set(idx.tolist())
+    dropped = [c for c in torch.nonzero(sc > 4 * sc.median()).flatten().tolist() if c not in kept]
+    assert len(dropped) == 8 and max(float(sc[c]) for c in dropped) <= min(float(sc[c]) for c in kept)

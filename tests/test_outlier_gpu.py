@@ -248,3 +248,32 @@ def test_heavy_tailed_statistical_sample():
         for tag in ("c4box", "c4mask"):
             assert summ[mode][tag]["iou_min"] >= 0.999 and summ[mode][tag]["n_below_0999"] == 0, (mode, tag, summ[mode][tag])
     eng.close()
+
+
+def test_more_outlier_candidates_than_a_stage_holds():
+    """40 LayerNorm gammas x 30 in one block of the two-block model: 40 candidate columns for qkv / lin1, one 64-wide K stage carries 32 -- the
+    engine keeps the 32 largest scores (the same ones the host rule keeps) and still improves on the untreated arithmetic."""
+    import samrs_amd
+    from oracle import sam_oracle as so
+    from samrs_amd import outliers
+    cfg = synth.CONFIGS["vit_tiny"]
+    sd = synth.heavy_tailed(synth.make_state_dict(cfg, 0), cfg, 0, gamma_scale=30.0, n_channels=40, blocks=[0])
+    sam = samrs_amd.sam_model_registry["vit_tiny"](state_dict=sd, precision="f16", max_prompts=8, max_points=1, options={"split": 15}).to("cuda")
+    eng = sam.engine
+    host = outliers.outlier_columns(sd, cfg)
+    assert len(host[(0, "qkv")][0]) == 32
+    for gi, g in enumerate(outliers.GEMMS):
+        assert eng.outlier_columns(0, gi) == host[(0, g)][0].tolist(), g
+    img = synth.make_image(0)
+    taps = {}
+    with torch.no_grad():
+        so.image_encoder(sd, cfg, so.preprocess(img), taps=taps)
+    t = torch.as_tensor(img, device="cuda")[None].contiguous()
+    rel = {}
+    for mask in (7, 0):
+        eng.set_option("outlier_cols", mask)
+        x = eng.debug_encoder_prefix(t, cfg.depth).cpu()[0]
+        rel[mask] = ((x - taps[f"block{cfg.depth - 1}"][0]).norm() / taps[f"block{cfg.depth - 1}"][0].norm()).item()
+    print(f"40 hot LayerNorm channels, 32 carried: residual stream rel L2 vs oracle {rel[0]:.3e} -> {rel[7]:.3e}")
+    assert rel[7] < 0.8 * rel[0], rel
+    eng.close()

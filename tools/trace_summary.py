@@ -39,7 +39,7 @@ def load_db(path):
     tabs = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
     kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
     ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-    q = (f"select s.kernel_name, d.start, d.end, d.grid_size_x * d.grid_size_y * d.grid_size_z, d.workgroup_size_x, d.queue_id, d.stream_id "
+    q = (f"select s.kernel_name, d.start, d.end, d.grid_size_x * d.grid_size_y * d.grid_size_z, d.workgroup_size_x * d.workgroup_size_y * d.workgroup_size_z, d.queue_id, d.stream_id "
          f"from {kd} d join {ks} s on d.kernel_id = s.id order by d.start")
     return [dict(name=r[0], start=r[1], end=r[2], grid=r[3] // max(1, r[4]), queue=(r[5], r[6])) for r in db.execute(q)]
 
@@ -47,8 +47,9 @@ def load_db(path):
 def load_csv(path):
     rows = []
     for r in csv.DictReader(open(path)):
-        wg = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1)
-        gx = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
+        geti = lambda k, d: int(r.get(k, d) or d)
+        wg = geti("Workgroup_Size_X", geti("Workgroup_Size", 1)) * geti("Workgroup_Size_Y", 1) * geti("Workgroup_Size_Z", 1)
+        gx = geti("Grid_Size_X", geti("Grid_Size", 0)) * geti("Grid_Size_Y", 1) * geti("Grid_Size_Z", 1)      # work items, all three axes
         rows.append(dict(name=r["Kernel_Name"], start=int(r["Start_Timestamp"]), end=int(r["End_Timestamp"]), grid=gx // max(1, wg),
                          queue=(r.get("Queue_Id", "0"), r.get("Stream_Id", "0"))))
     rows.sort(key=lambda x: x["start"])

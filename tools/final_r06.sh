@@ -41,3 +41,5 @@ timeout 400 python bench.py --workload c4 --steps 12 --warmup 2 $BQ > gpurun_out
 # the driver's N > 1 command form on this ONE-GPU box: bench.py launches its own ranks; both share cuda:0 over gloo
 SAMRS_BENCH_SHARE_GPU=1 timeout 600 env -u WORLD_SIZE -u RANK -u LOCAL_RANK python bench.py --gpus 2 --steps 6 --warmup 2 $BQ > gpurun_out/x2_shared.log 2>&1; tail -1 gpurun_out/x2_shared.log | cut -c1-300
 { echo "# c3"; tail -1 gpurun_out/c3.log; echo "# c4"; tail -1 gpurun_out/c4.log; echo "# python bench.py --gpus 2 (self-launched; both ranks on ONE GPU over gloo: control flow, not a scaling number)"; tail -1 gpurun_out/x2_shared.log; } > profiles/r06_bench_other_workloads.txt
+# only gpurun_out/ travels back from the GPU box: hand over what this run wrote into profiles/
+cp profiles/r06_* profiles/parity_stats.json profiles/dominant_kernel_pmc.json gpurun_out/ 2>/dev/null

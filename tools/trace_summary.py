@@ -99,6 +99,8 @@ def roles(rows, enc_rows):
             elif any(k in n for k in ("t2i_", "i2t_", "upscaler", "token_self_attn", "k256", "prompt_tokens", "make_keys", "postprocess", "paint_area",
                                       "class_stats", "select_best", "rle_")):
                 role = "decoder / output side"
+            elif any(k in n for k in ("weight_col_norms", "weight_row_norms", "outlier_weight_ext", "outlier_side_weight", "mx4_pack_kernel")):
+                role = "engine load (once per handle)"
             elif "outlier_" in n:
                 role = "outlier-column side operands"
             out[i] = role

@@ -645,7 +645,9 @@ template <int PREC, int HD, int LO = 0 /* 0: out only; 1: + its f16 split remain
 __global__ __launch_bounds__(512) void window_attention_kernel(
     const uint16_t* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ rel_h,
     const float* __restrict__ rel_w, uint16_t* __restrict__ out, int grid, int heads, int n_items,
-    uint16_t* __restrict__ out_lo = nullptr /* LO == 1: the split remainder of out (reference-grade mode) */, MxOut mx = MxOut()) {
+    uint16_t* __restrict__ out_lo = nullptr /* LO == 1: the split remainder of out (reference-grade mode) */, MxOut mx = MxOut(),
+    uint32_t lo_heads = 0xffffffffu /* LO == 1: bit h set = head h writes its remainder (the outlier extension of proj needs the
+                                       heads that hold its columns only: engine.hip EncBlock::oc_heads) */) {
     using C = WinCfg<HD>;
     constexpr int KS = HD / 16;
     constexpr bool PL = (PIPE & 1) != 0;          // software-pipelined tile loop
@@ -1023,10 +1025,12 @@ __global__ __launch_bounds__(512) void window_attention_kernel(
                         o.y = pack2_fast<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv);
                         *reinterpret_cast<uint2*>(orow + d0) = o;
                         if constexpr (LO == 1) {
-                            uint2 h, l;
-                            split2_pack<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv, h.x, l.x);
-                            split2_pack<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv, h.y, l.y);
-                            *reinterpret_cast<uint2*>(out_lo + obase + d0) = l;
+                            if ((lo_heads >> (head & 31)) & 1u) {          // wave-uniform (head comes from the block's item)
+                                uint2 h, l;
+                                split2_pack<PREC>(O[dt][4 * g + 0] * inv, O[dt][4 * g + 1] * inv, h.x, l.x);
+                                split2_pack<PREC>(O[dt][4 * g + 2] * inv, O[dt][4 * g + 3] * inv, h.y, l.y);
+                                *reinterpret_cast<uint2*>(out_lo + obase + d0) = l;
+                            }
                         }
                     }
                 }
@@ -1750,7 +1754,7 @@ hipError_t launch_layernorm(int prec, const float* X, const float* gamma, const 
 
 template <int PREC, int HD, int LO = 0>
 static hipError_t launch_win(const void* qkv, const float* qb, const float* rh, const float* rw, void* out, int n_images,
-                             int grid, int heads, hipStream_t s, void* out_lo = nullptr, MxOut mx = MxOut()) {
+                             int grid, int heads, hipStream_t s, void* out_lo = nullptr, MxOut mx = MxOut(), uint32_t lo_heads = 0xffffffffu) {
     using C = WinCfg<HD>;
     // SAMRS_WIN_PIPE=1 / 3: the software-pipelined tile loop (/ + static priority for the younger waves); A/B runs
     // measured (profiles/r05_attention_pipelining.txt): no faster, and the rel-pos row terms take one more rounding on their way through
@@ -1772,14 +1776,15 @@ static hipError_t launch_win(const void* qkv, const float* qb, const float* rh, 
         return n > 0 ? n : 256;
     }();
     dim3 g(n_items < n_cu ? n_items : n_cu), b(C::THREADS);      // persistent: one block per CU (LDS-limited)
-    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, qb, rh, rw, (uint16_t*)out, grid, heads, n_items, (uint16_t*)out_lo, mx);
+    k<<<g, b, C::LDS_BYTES, s>>>((const uint16_t*)qkv, qb, rh, rw, (uint16_t*)out, grid, heads, n_items, (uint16_t*)out_lo, mx, lo_heads);
     return hipGetLastError();
 }
 
 hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_bias, const float* rel_h, const float* rel_w, void* out,
                                    int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo,
-                                   void* mx_q_hi, void* mx_q_lo, void* mx_s_hi, void* mx_s_lo) {
+                                   void* mx_q_hi, void* mx_q_lo, void* mx_s_hi, void* mx_s_lo, uint32_t lo_heads) {
     if (window != 14) return hipErrorInvalidValue;
+    if (heads > 32) lo_heads = 0xffffffffu;            // the mask has one bit per head
     MxOut mx;
     if (mx_q_hi) {
         if (!mx_q_lo || !mx_s_hi || !mx_s_lo || (heads * ((head_dim + 31) / 32) * 32) % MXK) return hipErrorInvalidValue;
@@ -1787,7 +1792,7 @@ hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_b
     }
 #define WIN_CALL(P, H)                                                                                                          \
     return mx_q_hi ? launch_win<P, H, 2>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s, nullptr, mx)               \
-         : out_lo ? launch_win<P, H, 1>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s, out_lo)                     \
+         : out_lo ? launch_win<P, H, 1>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s, out_lo, MxOut(), lo_heads)  \
                   : launch_win<P, H, 0>(qkv, qkv_bias, rel_h, rel_w, out, n_images, grid, heads, s)
     if (prec == PREC_BF16) {
         if (head_dim == 64) WIN_CALL(PREC_BF16, 64);

@@ -91,6 +91,7 @@ struct EncBlock {
     // of this GEMM is dominated by its outlier columns.  Decides between the exact f16 lo terms of those columns and the MXFP4 lo terms of
     // ALL columns in the v-third modes (run_encoder: oc_dominant)
     float oc_share[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t oc_heads = 0;         // bit h: attention head h holds an outlier column of proj (the only heads whose output remainder is needed)
     uint16_t *qkv_wx = nullptr, *lin1_wx = nullptr;
     // lin2 / proj: their A operands (GELU(lin1), the attention output) are written by other kernels, so the 64 columns travel as a
     // dense side operand A_x [M][64] (engine OCX) against oc_bx [D][64] = W_hi[:, S] | W_lo[:, S], one more K stage of the same
@@ -458,6 +459,10 @@ int pick_outlier_columns(samrs_engine* e, int i, hipStream_t s) {
         }
         b.oc_n[g] = (int)idx.size();
         e->outlier_columns += b.oc_n[g];
+        if (g == 3) {
+            b.oc_heads = 0;
+            for (int c : idx) b.oc_heads |= (e->hd > 0 && c / e->hd < 32) ? (1u << (c / e->hd)) : 0xffffffffu;
+        }
         double all2 = 0.0, sel2 = 0.0;
         for (float v : sc[g]) all2 += (double)v * v;
         for (int c : idx) sel2 += (double)sc[g][c] * sc[g][c];
@@ -1006,7 +1011,9 @@ static int encode(samrs_engine_t* e, const uint8_t* const* images, const int* in
         if (!b.global)
             CK(e, launch_window_attention(prec, e->QKV, b.qkv_b, b.rel_h, b.rel_w, e->AO, n, g, c.window_size, c.num_heads, e->hd, s,
                                           ao_lo ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,
-                                          mx_ao ? e->SAO4[0] : nullptr, mx_ao ? e->SAO4[1] : nullptr));
+                                          mx_ao ? e->SAO4[0] : nullptr, mx_ao ? e->SAO4[1] : nullptr,
+                                          // the remainder only feeds the gather of proj's outlier columns: the heads that hold them
+                                          (nop && !sp_attn) ? b.oc_heads : 0xffffffffu));
         else
             CK(e, launch_global_attention(prec, e->QKV, b.rel_h, b.rel_w, e->AO, n, g, c.num_heads, e->hd, e->VTG, s,
                                           ao_lo ? e->AOlo : nullptr, mx_ao ? e->AO4[0] : nullptr, mx_ao ? e->AO4[1] : nullptr,

@@ -1024,10 +1024,24 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
         (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds + (uint32_t)wave * 1024u);
     // piece q_ (literal) of pair stage st_ into the buffer at byte offset wr_
+    // EXT: where the pieces of a stage come from is chosen ONCE per stage (X64_SEL: wave-uniform selects into xpa / xpb / xprs and one
+    // v_cndmask for the lane offset), not by a branch in front of each of its nine pieces inside the MFMA stream (the first form: lin2
+    // + 17 us for 1 / 80 more work).  The other instantiations never see these variables.
+    const uint16_t *xpa = sA, *xpb = sB;
+    size_t xprs = rs64;
+    uint32_t xvo = voff;
+#define X64_SEL(st_)                                                                                       \
+    if constexpr (EXT) {                                                                                   \
+        const bool xs_ = (st_) == nst1;                                                                    \
+        xpa = xs_ ? sAx : sA + (size_t)(st_) * XBK;                                                        \
+        xpb = xs_ ? sBx : sB + (size_t)(st_) * XBK;                                                        \
+        xprs = xs_ ? (size_t)(64 * XBK) : rs64;                                                            \
+        xvo = xs_ ? voffx : voff;                                                                          \
+    }
 #define X64_PIECE(st_, wr_, q_)                                                                            \
     if constexpr (!(ABL & 1)) {                                                                            \
-        if (EXT && (st_) == nst1)                                                                          \
-            glds16_s(voffx, ((q_) < 4 ? sAx + (size_t)(q_) * (64 * XBK) : sBx + (size_t)((q_) - 4) * (64 * XBK)),                        \
+        if constexpr (EXT)                                                                                 \
+            glds16_s(xvo, ((q_) < 4 ? xpa + (size_t)(q_) * xprs : xpb + (size_t)((q_) - 4) * xprs),                                      \
                      lds0 + (wr_) + ((q_) < 4 ? (q_) * 8192u : (uint32_t)(QBM * XBK * 2) + ((q_) - 4) * 8192u));                         \
         else                                                                                               \
             glds16_s(voff, ((q_) < 4 ? seg_src_a<SPLIT3>(sA, sAl, (st_), nst1) + (size_t)(q_) * rs64                                    \
@@ -1036,6 +1050,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     }
 #define X64_ISSUE(st_, wr_)                                                                                \
     do {                                                                                                   \
+        X64_SEL(st_)                                                                                       \
         X64_PIECE(st_, wr_, 0); X64_PIECE(st_, wr_, 1); X64_PIECE(st_, wr_, 2); X64_PIECE(st_, wr_, 3);    \
         X64_PIECE(st_, wr_, 4); X64_PIECE(st_, wr_, 5); X64_PIECE(st_, wr_, 6); X64_PIECE(st_, wr_, 7);    \
         if constexpr (NPIECE == 9) X64_PIECE(st_, wr_, 8);                                                 \
@@ -1099,6 +1114,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
     // or one per m-tile row of MFMAs (SPREAD).  The accumulators never sit inside a conditional region.
 #define X64_MFMA(dma_, st_, wr_)                                                                           \
     if (!SPREAD) { if (dma_) X64_ISSUE(st_, wr_); }                                                        \
+    if (SPREAD) { X64_SEL(st_) }                                                                           \
     _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                        \
         if constexpr (!(ABL & 4)) {                                                                        \
         _Pragma("unroll") for (int i = 0; i < NI; ++i) acc[i][j] = ET<PREC>::mfma16(fb[i], fa[j], acc[i][j]); \
@@ -1266,6 +1282,7 @@ __global__ __launch_bounds__(QTHREADS) void gemm_et_x64_kernel(
 #undef LNT_LOAD
     }
 #undef X64_PIECE
+#undef X64_SEL
 #undef X64_ISSUE
 #undef X64_READ
 #undef X64_MFMA

@@ -98,7 +98,9 @@ hipError_t launch_window_attention(int prec, const void* qkv, const float* qkv_b
                                    int n_images, int grid, int window, int heads, int head_dim, hipStream_t s, void* out_lo = nullptr,
                                    // optional (instead of out_lo): hi / lo of the output as MXFP4 on the per-head padded K axis
                                    // [rows][heads * ceil32(head_dim) / 2], block-internal order of store_attention_row_mx
-                                   void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr);
+                                   void* mx_q_hi = nullptr, void* mx_q_lo = nullptr, void* mx_s_hi = nullptr, void* mx_s_lo = nullptr,
+                                   // out_lo only: bit h set = head h writes its remainder (default: every head)
+                                   uint32_t lo_heads = 0xffffffffu);
 hipError_t launch_gelu_split(int prec, const float* in, void* hi, void* lo, long n, hipStream_t s);
 // operand-range check: adds to *counter the elements of an ET tensor that sit at the operand type's saturation value or beyond (n % 8 == 0)
 hipError_t launch_range_scan(int prec, const void* x, long n, unsigned long long* counter, hipStream_t s,
